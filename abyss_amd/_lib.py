@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI in include/abyss_amd.h (libabyss_amd.so)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build
+
+ABG_OK = 0
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32), ("num_hashes", C.c_uint32), ("min_cov", C.c_uint32), ("trim", C.c_uint32),
+        ("bloom_bytes", C.c_uint64), ("counters", C.c_uint64), ("spaced_seed", C.c_char_p),
+        ("device", C.c_int32), ("verbose", C.c_int32), ("insert_batch_kmers", C.c_uint64),
+        ("claim_log2", C.c_uint32), ("walk_slots", C.c_uint32), ("wtab_log2", C.c_uint32),
+        ("reserved_", C.c_uint32 * 7),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("solid_reads", "visited_reads", "reads_processed", "bases_assembled", "next_contig_id")]
+
+
+class Contig(C.Structure):
+    _fields_ = [
+        ("contig_id", C.c_uint64), ("read_index", C.c_uint64), ("seq", C.c_char_p),
+        ("length", C.c_uint32), ("coverage", C.c_uint32), ("redundant", C.c_int32),
+        ("left_ext", C.c_uint32), ("right_ext", C.c_uint32), ("left_code", C.c_int32),
+        ("right_code", C.c_int32), ("seed_pos", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("insert_rounds", "walk_rounds", "candidates", "walked", "rewalked", "commit_breaks")]
+
+
+CONTIG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Contig))
+
+_lib = None
+
+
+def symbols():
+    """Every entry point include/abyss_amd.h declares."""
+    return [
+        "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_filter_size",
+        "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
+        "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
+        "abg_assemble_packed", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
+        "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
+    ]
+
+
+def load(path: str | None = None):
+    """Load libabyss_amd.so (building it in-tree first if it is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if path is None:
+        path = build.LIB
+        if not os.path.exists(path):
+            build.build_lib()
+    lib = C.CDLL(path)
+    vp, u64p, u8p = C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p
+    lib.abg_params_init.argtypes = [C.POINTER(Params)]
+    lib.abg_params_init.restype = None
+    lib.abg_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    lib.abg_destroy.argtypes = [vp]
+    lib.abg_destroy.restype = None
+    lib.abg_last_error.argtypes = [vp]
+    lib.abg_last_error.restype = C.c_char_p
+    lib.abg_filter_size.argtypes = [vp, u64p]
+    lib.abg_load_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
+    lib.abg_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    lib.abg_counting_stats.argtypes = [vp, u64p, u64p]
+    lib.abg_counters_export.argtypes = [vp, u8p]
+    lib.abg_counters_import.argtypes = [vp, u8p]
+    lib.abg_visited_export.argtypes = [vp, u8p]
+    lib.abg_visited_import.argtypes = [vp, u8p]
+    lib.abg_assemble_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64, vp, CONTIG_CB, vp]
+    lib.abg_assemble_packed.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, CONTIG_CB, vp]
+    lib.abg_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.abg_set_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.abg_hash_seq.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint64, u64p]
+    lib.abg_profile_enable.argtypes = [vp, C.c_int]
+    lib.abg_profile_reset.argtypes = [vp]
+    lib.abg_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
+    lib.abg_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    _lib = lib
+    return lib

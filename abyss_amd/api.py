@@ -1,0 +1,232 @@
+"""Python mirror of the abyss-bloom-dbg unitig stage over the C ABI.
+
+Names follow the reference: a counting Bloom filter of solid k-mers is loaded from reads
+(PASS 1, BloomDBG/BloomIO.h), then reads are extended into unitigs (PASS 2,
+BloomDBG/bloom-dbg.h ``assemble``), and contigs are printed as
+``>ID LEN COV read:READID`` FASTA records (bloom-dbg.h:455-487).  All compute happens in
+libabyss_amd.so on the GPU; this module only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+READ_RESULT_NAMES = ["NA", "SHORTER_THAN_K", "NON_ACGT", "BLUNT_END", "NOT_SOLID", "ALL_KMERS_VISITED",
+                     "ALL_BRANCH_KMERS_VISITED", "GENERATED_CONTIGS"]  # bloom-dbg.h:268-293
+EXT_CODE_NAMES = ["AMBI_IN", "AMBI_OUT", "DEAD_END", "CYCLE", "LENGTH_LIMIT"]  # ExtendPath.h:62-79
+NO_CONTIG = 2 ** 64 - 1
+
+
+class AbyssAmdError(RuntimeError):
+    pass
+
+
+@dataclass
+class ContigRecord:  # ContigRecord, bloom-dbg.h:186-254
+    contig_id: int
+    read_index: int
+    seq: bytes
+    coverage: int
+    redundant: bool
+    left_ext: int
+    right_ext: int
+    left_code: int
+    right_code: int
+    seed_pos: int
+
+
+def concat_seqs(seqs: Sequence[bytes]) -> Tuple[bytes, np.ndarray]:
+    """Concatenate sequences into (buffer, offsets[n+1]) as the C ABI takes them."""
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    return b"".join(seqs), off
+
+
+def matrix_to_seqs(ascii_matrix: np.ndarray) -> Tuple[bytes, np.ndarray]:
+    """An [n, L] uint8 ASCII matrix as (buffer, offsets)."""
+    n, L = ascii_matrix.shape
+    return np.ascontiguousarray(ascii_matrix).tobytes(), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+
+
+class BloomDBG:
+    """One assembly: solid counting filter + visited filter + counters on one GPU."""
+
+    def __init__(self, k: int, bloom_bytes: int = 0, counters: int = 0, num_hashes: int = 4, min_cov: int = 2,
+                 trim: Optional[int] = None, device: int = 0, verbose: int = 0, **tuning):
+        self._lib = _lib.load()
+        p = _lib.Params()
+        self._lib.abg_params_init(C.byref(p))
+        p.k, p.num_hashes, p.min_cov = k, num_hashes, min_cov
+        p.trim = 0xFFFFFFFF if trim is None else trim
+        p.bloom_bytes, p.counters, p.device, p.verbose = bloom_bytes, counters, device, verbose
+        for key, val in tuning.items():
+            setattr(p, key, val)
+        self._ctx = C.c_void_p()
+        rc = self._lib.abg_create(C.byref(p), C.byref(self._ctx))
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_last_error(None)
+            self._ctx = None
+            raise AbyssAmdError("abg_create failed (%d): %s" % (rc, msg.decode() if msg else ""))
+        self.k = k
+        self.num_hashes = num_hashes
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.abg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_last_error(self._ctx)
+            raise AbyssAmdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    # ---- filter
+    @property
+    def size(self) -> int:
+        n = C.c_uint64()
+        self._check(self._lib.abg_filter_size(self._ctx, C.byref(n)), "abg_filter_size")
+        return n.value
+
+    def load(self, buf: bytes, offsets: np.ndarray) -> None:
+        """PASS 1: loadSeq over every sequence in order (BloomIO.h:32-41)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._lib.abg_load_seqs(self._ctx, buf, offsets.ctypes.data, len(offsets) - 1), "abg_load_seqs")
+
+    def load_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int) -> None:
+        self._check(self._lib.abg_load_packed(self._ctx, words_ptr, woff_ptr, len_ptr, n), "abg_load_packed")
+
+    def counting_stats(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.abg_counting_stats(self._ctx, C.byref(a), C.byref(b)), "abg_counting_stats")
+        return a.value, b.value
+
+    def counters(self) -> np.ndarray:
+        out = np.empty(self.size, dtype=np.uint8)
+        self._check(self._lib.abg_counters_export(self._ctx, out.ctypes.data), "abg_counters_export")
+        return out
+
+    def set_counters_array(self, arr: np.ndarray) -> None:
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        assert arr.size == self.size
+        self._check(self._lib.abg_counters_import(self._ctx, arr.ctypes.data), "abg_counters_import")
+
+    def visited(self) -> np.ndarray:
+        out = np.empty(self.size // 8, dtype=np.uint8)
+        self._check(self._lib.abg_visited_export(self._ctx, out.ctypes.data), "abg_visited_export")
+        return out
+
+    def set_visited_array(self, arr: np.ndarray) -> None:
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        assert arr.size == self.size // 8
+        self._check(self._lib.abg_visited_import(self._ctx, arr.ctypes.data), "abg_visited_import")
+
+    # ---- assembly
+    def _collector(self, out: List[ContigRecord]):
+        def cb(_user, c):
+            c = c.contents
+            out.append(ContigRecord(c.contig_id, c.read_index, c.seq, c.coverage, bool(c.redundant), c.left_ext,
+                                    c.right_ext, c.left_code, c.right_code, c.seed_pos))
+        return _lib.CONTIG_CB(cb)
+
+    def assemble(self, buf: bytes, offsets: np.ndarray) -> Tuple[np.ndarray, List[ContigRecord]]:
+        """PASS 2: processRead over every read in order (bloom-dbg.h:781-882)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        results = np.zeros(n, dtype=np.uint8)
+        contigs: List[ContigRecord] = []
+        cb = self._collector(contigs)
+        self._check(self._lib.abg_assemble_seqs(self._ctx, buf, offsets.ctypes.data, n, results.ctypes.data, cb, None),
+                    "abg_assemble_seqs")
+        return results, contigs
+
+    def assemble_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int,
+                        want_results: bool = True) -> Tuple[Optional[np.ndarray], List[ContigRecord]]:
+        results = np.zeros(n, dtype=np.uint8) if want_results else None
+        contigs: List[ContigRecord] = []
+        cb = self._collector(contigs)
+        self._check(self._lib.abg_assemble_packed(self._ctx, words_ptr, woff_ptr, len_ptr, n,
+                                                  results.ctypes.data if want_results else None, cb, None),
+                    "abg_assemble_packed")
+        return results, contigs
+
+    def assembly_counters(self) -> dict:
+        c = _lib.Counters()
+        self._check(self._lib.abg_get_counters(self._ctx, C.byref(c)), "abg_get_counters")
+        return {n: getattr(c, n) for n, _ in c._fields_}
+
+    def stats(self) -> dict:
+        s = _lib.Stats()
+        self._check(self._lib.abg_get_stats(self._ctx, C.byref(s)), "abg_get_stats")
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    # ---- probes / profiling
+    def hash_seq(self, seq: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        cap = max(len(seq), 1)
+        pos = np.zeros(cap, dtype=np.uint32)
+        hashes = np.zeros((cap, self.num_hashes), dtype=np.uint64)
+        n = C.c_uint64()
+        self._check(self._lib.abg_hash_seq(self._ctx, seq, len(seq), pos.ctypes.data, hashes.ctypes.data, cap,
+                                           C.byref(n)), "abg_hash_seq")
+        return pos[:n.value], hashes[:n.value]
+
+    def profile_enable(self, on: bool = True) -> None:
+        self._check(self._lib.abg_profile_enable(self._ctx, int(on)), "abg_profile_enable")
+
+    def profile_reset(self) -> None:
+        self._check(self._lib.abg_profile_reset(self._ctx), "abg_profile_reset")
+
+    def profile_get(self, name: str) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._lib.abg_profile_get(self._ctx, name.encode(), C.byref(ms), C.byref(n)), "abg_profile_get")
+        return ms.value, n.value
+
+
+def format_fasta(contigs: Iterable[ContigRecord], read_ids: Sequence[bytes]) -> bytes:
+    """printContig (bloom-dbg.h:455-487): ``>ID LEN COV read:READID`` + sequence, non-redundant only."""
+    out = []
+    for c in contigs:
+        if c.redundant:
+            continue
+        out.append(b">%d %d %d read:%s\n%s\n" % (c.contig_id, len(c.seq), c.coverage, read_ids[c.read_index], c.seq))
+    return b"".join(out)
+
+
+def format_trace(contigs: Iterable[ContigRecord], read_ids: Sequence[bytes], reads: Sequence[bytes], k: int,
+                 with_length: bool = True) -> bytes:
+    """-T trace rows (ContigRecord operator<<, bloom-dbg.h:229-254).  The reference leaves `length`
+    uninitialised for redundant contigs, so parity checks drop that column (with_length=False)."""
+    rows = [b"contig_id\tlength\tredundant\tread_id\tleft_result\tleft_extension\tright_result\t"
+            b"right_extension\tseed_type\tseed_length\tseed\n" if with_length else
+            b"contig_id\tredundant\tread_id\tleft_result\tleft_extension\tright_result\t"
+            b"right_extension\tseed_type\tseed_length\tseed\n"]
+    for c in contigs:
+        f = [b"NA" if c.redundant else b"%d" % c.contig_id]
+        if with_length:
+            f.append(b"%d" % len(c.seq))
+        f += [b"%d" % int(c.redundant), read_ids[c.read_index]]
+        f += [EXT_CODE_NAMES[c.left_code].encode(), b"%d" % c.left_ext] if c.left_ext > 0 else [b"NA", b"NA"]
+        f += [EXT_CODE_NAMES[c.right_code].encode(), b"%d" % c.right_ext] if c.right_ext > 0 else [b"NA", b"NA"]
+        seed = reads[c.read_index][c.seed_pos:c.seed_pos + k].upper()
+        f += [b"READ", b"%d" % k, seed]
+        rows.append(b"\t".join(f) + b"\n")
+    return b"".join(rows)
+
+
+def format_read_log(results: np.ndarray, read_ids: Sequence[bytes]) -> bytes:
+    """--read-log rows (ReadRecord, bloom-dbg.h:300-334)."""
+    rows = [b"read_id\tresult\n"]
+    for rid, r in zip(read_ids, results):
+        rows.append(rid + b"\t" + READ_RESULT_NAMES[int(r)].encode() + b"\n")
+    return b"".join(rows)

@@ -1,0 +1,102 @@
+"""Build helpers: compile the HIP library (product) and the checkers (test infrastructure).
+
+The product is one shared library, ``abyss_amd/lib/libabyss_amd.so``, built in-tree with
+``hipcc --offload-arch=gfx950`` from ``abyss_amd/csrc/abg_kernels.hip``; hipcc
+cross-compiles without a GPU.  The checkers (``oracle/liboracle.so``, ``oracle/abg_oracle``,
+``oracle/_ref/*`` when /root/reference is present, ``tests/hostcheck/libhostcheck.so``) are
+only ever loaded by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "abyss_amd", "csrc")
+LIB = os.path.join(ROOT, "abyss_amd", "lib", "libabyss_amd.so")
+BIN_DIR = os.path.join(ROOT, "abyss_amd", "bin")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+HOSTCHECK = os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so")
+REFERENCE = "/root/reference"
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build step failed: %s" % " ".join(cmd))
+    return r.stdout
+
+
+def hipcc() -> str:
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        p = shutil.which(c)
+        if p:
+            return p
+    raise RuntimeError("hipcc not found")
+
+
+def csrc_files():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "abyss_amd.h")]
+
+
+def build_lib(force: bool = False) -> str:
+    """libabyss_amd.so: the gfx950 kernels + C ABI."""
+    if force or _newer(LIB, csrc_files()):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+              "-o", LIB, os.path.join(CSRC, "abg_kernels.hip")])
+    return LIB
+
+
+def build_cli(force: bool = False) -> str:
+    """abyss_amd/bin/abyss-bloom-dbg: the drop-in host binary (C++ over the C ABI)."""
+    src = os.path.join(CSRC, "host", "bloom_dbg_main.cc")
+    out = os.path.join(BIN_DIR, "abyss-bloom-dbg")
+    if not os.path.exists(src):
+        return ""
+    deps = [src] + [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+    if force or _newer(out, deps + [LIB]):
+        os.makedirs(BIN_DIR, exist_ok=True)
+        build_lib()
+        _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+              "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
+    return out
+
+
+def build_oracle(force: bool = False) -> None:
+    """C restatement (always) and the unmodified reference (when its sources are present)."""
+    targets = ["oracle"]
+    if os.path.isdir(REFERENCE):
+        targets.append("ref")
+    if force:
+        _run(["make", "-C", ORACLE_DIR, "clean"])
+    _run(["make", "-C", ORACLE_DIR, "-j8"] + targets)
+
+
+def build_hostcheck(force: bool = False) -> str:
+    src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cc")
+    if force or _newer(HOSTCHECK, [src] + csrc_files()):
+        _run(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", HOSTCHECK, src])
+    return HOSTCHECK
+
+
+def build_all(force: bool = False) -> None:
+    build_lib(force)
+    build_cli(force)
+    build_oracle(force)
+    build_hostcheck(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)
+    print("built:", LIB)

@@ -1,0 +1,605 @@
+// abg_core.h -- device-side building blocks of the MI355X Bloom-filter de Bruijn
+// graph unitig stage: ntHash, 2-bit k-mers, counting/bit Bloom probes and the
+// bounded graph searches (lookAhead / trueBranch / successor) that drive unitig
+// extension.  Every function is ABG_HD (__host__ __device__) and free of global
+// state, so the kernels in abg_kernels.hip are thin grid-stride wrappers around
+// them, and tests/hostcheck can execute the very same code serially on a CPU.
+// The product library only ever runs them on the GPU.
+//
+// Reference behaviour restated here (ABySS 2.3.10, paths relative to the repo):
+//   vendor/nthash/nthash.hpp                 ntHash v1 (NTF64/NTR64/NTC64/NTC64L/NTE64)
+//   BloomDBG/RollingHash.h                   canonical hash + H derived hashes
+//   vendor/btl_bloomfilter/CountingBloomFilter.hpp   uint8 counters, minCount/contains
+//   vendor/btl_bloomfilter/BloomFilter.hpp           bit filter (visited k-mers)
+//   BloomDBG/RollingBloomDBG.h               implicit graph: neighbours in A,C,G,T order
+//   Graph/ExtendPath.h                       lookAhead, trueBranch, successor, extendPath
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ABG_HD __host__ __device__ __forceinline__
+#define ABG_HDN __host__ __device__
+#else
+#define ABG_HD inline
+#define ABG_HDN
+#endif
+
+namespace abg {
+
+// ----------------------------------------------------------------- constants
+constexpr int MAX_NW = 6;             // 6 x 32 bases = MAX_KMER 192 (configure.ac:151)
+constexpr int MAX_HASHES = 32;        // configure.ac:156
+constexpr unsigned FP_TRIM = 5;       // fpTrim / fpLookAhead, bloom-dbg.h:494,548,848
+
+enum Dir : int { FORWARD = 0, REVERSE = 1 };       // Graph/Path.h:37
+enum Sense : int { SENSE = 0, ANTISENSE = 1 };     // Common/Sense.h
+
+// PathExtensionResultCode, Graph/ExtendPath.h:46-57
+enum ExtCode : int { ER_AMBI_IN = 0, ER_AMBI_OUT, ER_DEAD_END, ER_CYCLE, ER_LENGTH_LIMIT };
+
+// ReadResult, BloomDBG/bloom-dbg.h:256-266
+enum ReadResult : int {
+	RR_UNINITIALIZED = 0, RR_SHORTER_THAN_K, RR_NON_ACGT, RR_BLUNT_END, RR_NOT_SOLID,
+	RR_ALL_KMERS_VISITED, RR_ALL_BRANCH_KMERS_VISITED, RR_GENERATED_CONTIGS
+};
+
+// nthash.hpp:18-29
+constexpr uint64_t MULTISEED = 0x90b45d39fb6da1faULL;
+constexpr int MULTISHIFT = 27;
+constexpr uint64_t SEED_A = 0x3c8bfbb395c60474ULL;
+constexpr uint64_t SEED_C = 0x3193c18562a02b4cULL;
+constexpr uint64_t SEED_G = 0x20323ed082572324ULL;
+constexpr uint64_t SEED_T = 0x295549f54be24456ULL;
+
+// ------------------------------------------------------------------ ntHash
+// rol1 + swapbits033 (nthash.hpp:186-207): rotate low 33 and high 31 bits left by 1.
+ABG_HD uint64_t srol1(uint64_t v)
+{
+	uint64_t h = (v << 1) | (v >> 63);
+	uint64_t x = (h ^ (h >> 33)) & 1;
+	return h ^ (x | (x << 33));
+}
+// ror1 + swapbits3263 (nthash.hpp:191-217)
+ABG_HD uint64_t sror1(uint64_t v)
+{
+	uint64_t h = (v >> 1) | (v << 63);
+	uint64_t x = ((h >> 32) ^ (h >> 63)) & 1;
+	return h ^ ((x << 32) | (x << 63));
+}
+// msTab31l[c][n%31] | msTab33r[c][n%33] (nthash.hpp:66-183)
+ABG_HD uint64_t srol_n(uint64_t v, unsigned n)
+{
+	uint64_t lo = v & 0x1FFFFFFFFULL, hi = v >> 33;
+	unsigned a = n % 33, b = n % 31;
+	if (a) lo = ((lo << a) | (lo >> (33 - a))) & 0x1FFFFFFFFULL;
+	if (b) hi = ((hi << b) | (hi >> (31 - b))) & 0x7FFFFFFFULL;
+	return (hi << 33) | lo;
+}
+// seed of base code 0..3 = A,C,G,T (seedTab, nthash.hpp:31-64)
+ABG_HD uint64_t seed_of(unsigned b)
+{
+	return b == 0 ? SEED_A : b == 1 ? SEED_C : b == 2 ? SEED_G : SEED_T;
+}
+
+// Exact h % m for a 64-bit h and runtime divisor m (CountingBloomFilter.hpp:56-58,
+// BloomFilter.hpp:187,252).  Round-up magic-number division (65-bit magic, the
+// "branch-free" scheme of Granlund-Montgomery / libdivide): q = floor(h / m) for
+// every 64-bit h; verified against the hardware % in tests for edge values.
+struct Mod64 {
+	uint64_t m;
+	uint64_t magic;
+	uint32_t shift;
+	uint32_t pow2; // m is a power of two
+};
+ABG_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __umul64hi(a, b);
+#else
+	return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+ABG_HD uint64_t mod64(const Mod64& d, uint64_t h)
+{
+	if (d.pow2)
+		return h & (d.m - 1);
+	uint64_t q = mulhi64(d.magic, h);
+	uint64_t t = ((h - q) >> 1) + q;
+	q = t >> d.shift;
+	return h - q * d.m;
+}
+inline Mod64 make_mod64(uint64_t m)
+{
+	Mod64 d;
+	d.m = m;
+	d.magic = 0;
+	d.shift = 0;
+	d.pow2 = (m & (m - 1)) == 0;
+	if (d.pow2)
+		return d;
+	unsigned fl = 63 - (unsigned)__builtin_clzll(m);
+	// proposed = floor(2^(64+fl) / m), rem = 2^(64+fl) mod m
+	unsigned __int128 num = (unsigned __int128)1 << (64 + fl);
+	uint64_t proposed = (uint64_t)(num / m);
+	uint64_t rem = (uint64_t)(num % m);
+	proposed += proposed;
+	uint64_t twice_rem = rem + rem;
+	if (twice_rem >= m || twice_rem < rem)
+		proposed += 1;
+	d.magic = 1 + proposed;
+	d.shift = fl;
+	return d;
+}
+
+// -------------------------------------------------------------- parameters
+struct Params {
+	uint32_t k;        // k-mer size
+	uint32_t nh;       // number of hash functions (H)
+	uint32_t kc;       // minimum count threshold (--kc)
+	uint32_t trim;     // max branch length to trim (-t)
+	uint32_t nw;       // ceil(k / 32)
+	uint32_t pad_;
+	Mod64 mod;         // counters == visited bits (bloom-dbg.h:910)
+	uint64_t kmul;     // k * multiSeed, for NTE64 (nthash.hpp:337-342)
+	uint64_t seed_k[4];     // srol^k(seed[b])
+	uint64_t seedrc_k[4];   // srol^k(seed[3-b])
+	uint64_t seedrc_km1[4]; // srol^(k-1)(seed[3-b])
+	uint64_t seed_km1[4];   // srol^(k-1)(seed[b])
+};
+inline Params make_params(uint32_t k, uint32_t nh, uint32_t kc, uint32_t trim, uint64_t m)
+{
+	Params p;
+	p.k = k; p.nh = nh; p.kc = kc; p.trim = trim; p.nw = (k + 31) / 32; p.pad_ = 0;
+	p.mod = make_mod64(m);
+	p.kmul = (uint64_t)k * MULTISEED;
+	for (unsigned b = 0; b < 4; b++) {
+		p.seed_k[b] = srol_n(seed_of(b), k);
+		p.seedrc_k[b] = srol_n(seed_of(3 - b), k);
+		p.seedrc_km1[b] = srol_n(seed_of(3 - b), k - 1);
+		p.seed_km1[b] = srol_n(seed_of(b), k - 1);
+	}
+	return p;
+}
+
+// NTE64 (nthash.hpp:337-342; note precedence i ^ (k * multiSeed)); hash 0 is the
+// canonical hash itself (RollingHash::getHashes, RollingHash.h:141-146).
+ABG_HD uint64_t hash_i(const Params& p, uint64_t h, unsigned i)
+{
+	if (i == 0) return h;
+	uint64_t t = h * ((uint64_t)i ^ p.kmul);
+	t ^= t >> MULTISHIFT;
+	return t;
+}
+ABG_HD uint64_t pos_i(const Params& p, uint64_t h, unsigned i)
+{
+	return mod64(p.mod, hash_i(p, h, i));
+}
+
+// ------------------------------------------------------------ 2-bit k-mers
+// Base i lives in bits [2*(i%32), 2*(i%32)+2) of word i/32; bits past 2k are zero.
+template <int NW>
+struct Kmer {
+	uint64_t w[NW];
+};
+template <int NW>
+ABG_HD unsigned kmer_get(const Kmer<NW>& s, unsigned i)
+{
+	unsigned r = 0;
+#pragma unroll
+	for (int j = 0; j < NW; j++)
+		if ((int)(i >> 5) == j) r = (unsigned)(s.w[j] >> (2 * (i & 31))) & 3u;
+	return r;
+}
+template <int NW>
+ABG_HD void kmer_set(Kmer<NW>& s, unsigned i, unsigned b)
+{
+#pragma unroll
+	for (int j = 0; j < NW; j++)
+		if ((int)(i >> 5) == j) {
+			unsigned sh = 2 * (i & 31);
+			s.w[j] = (s.w[j] & ~(3ULL << sh)) | ((uint64_t)b << sh);
+		}
+}
+// LightweightKmer::shift (LightweightKmer.h:52-62)
+template <int NW>
+ABG_HD void kmer_shift(Kmer<NW>& s, unsigned k, int sense, unsigned b)
+{
+	if (sense == SENSE) {
+#pragma unroll
+		for (int j = 0; j < NW; j++) {
+			uint64_t hi = (j + 1 < NW) ? s.w[j + 1] : 0;
+			s.w[j] = (s.w[j] >> 2) | (hi << 62);
+		}
+		kmer_set(s, k - 1, b);
+	} else {
+#pragma unroll
+		for (int j = NW - 1; j >= 0; j--) {
+			uint64_t lo = (j > 0) ? s.w[j - 1] : 0;
+			s.w[j] = (s.w[j] << 2) | (lo >> 62);
+		}
+		s.w[0] = (s.w[0] & ~3ULL) | b;
+		// clear the base shifted past position k-1
+		unsigned top = k & 31;
+#pragma unroll
+		for (int j = 0; j < NW; j++) {
+			if (j == (int)(k >> 5)) s.w[j] = top ? (s.w[j] & ((1ULL << (2 * top)) - 1)) : 0;
+			else if (j > (int)(k >> 5)) s.w[j] = 0;
+		}
+	}
+}
+// LightweightKmer::reverseComplement (LightweightKmer.h:114-129)
+template <int NW>
+ABG_HD Kmer<NW> kmer_revcomp(const Kmer<NW>& s, unsigned k)
+{
+	Kmer<NW> r;
+#pragma unroll
+	for (int j = 0; j < NW; j++) r.w[j] = 0;
+	for (unsigned i = 0; i < k; i++)
+		kmer_set(r, k - 1 - i, 3u - kmer_get(s, i));
+	return r;
+}
+// LightweightKmer::isCanonical (LightweightKmer.h:88-101): compares only the first
+// k/2 bases with the complement of the mirrored ones; ties count as canonical.
+template <int NW>
+ABG_HD bool kmer_is_canonical(const Kmer<NW>& s, unsigned k)
+{
+	for (unsigned i = 0; i < k / 2; i++) {
+		unsigned c1 = kmer_get(s, i), c2 = 3u - kmer_get(s, k - 1 - i);
+		if (c1 > c2) return false;
+		if (c1 < c2) return true;
+	}
+	return true;
+}
+// true when isCanonical() holds for both the k-mer and its reverse complement,
+// which happens only for odd k with a reverse-palindromic flank; such a k-mer
+// and its reverse complement are DIFFERENT vertices for the reference
+// (RollingBloomDBGVertex::compare, RollingBloomDBG.h:114-159).
+template <int NW>
+ABG_HD bool kmer_is_tie(const Kmer<NW>& s, unsigned k)
+{
+	if ((k & 1) == 0) return false;
+	for (unsigned i = 0; i < k / 2; i++)
+		if (kmer_get(s, i) != 3u - kmer_get(s, k - 1 - i)) return false;
+	return true;
+}
+template <int NW>
+ABG_HD bool kmer_equal(const Kmer<NW>& a, const Kmer<NW>& b)
+{
+	bool e = true;
+#pragma unroll
+	for (int j = 0; j < NW; j++) e = e && (a.w[j] == b.w[j]);
+	return e;
+}
+
+// ------------------------------------------------------------------ vertex
+// RollingBloomDBGVertex (RollingBloomDBG.h:33-38) with value semantics: the k-mer
+// and the forward / reverse-complement ntHash state of RollingHash (RollingHash.h:211-219).
+template <int NW>
+struct Vtx {
+	Kmer<NW> s;
+	uint64_t fh, rh;
+};
+template <int NW>
+ABG_HD uint64_t vtx_hash(const Vtx<NW>& v) { return v.rh < v.fh ? v.rh : v.fh; } // RollingHash.h:28-31
+
+// RollingHash::reset (RollingHash.h:69-80): NTF64 / NTR64 base forms, nthash.hpp:220-239
+template <int NW>
+ABG_HD void vtx_rehash(const Params& p, Vtx<NW>& v)
+{
+	uint64_t fh = 0, rh = 0;
+	unsigned k = p.k;
+	for (unsigned i = 0; i < k; i++) {
+		fh = srol1(fh) ^ seed_of(kmer_get(v.s, i));
+		rh = srol1(rh) ^ seed_of(3u - kmer_get(v.s, k - 1 - i));
+	}
+	v.fh = fh;
+	v.rh = rh;
+}
+// Vertex::shift (RollingBloomDBG.h:55-63): RollingHash::rollRight / rollLeft
+// (RollingHash.h:88-124; NTC64 nthash.hpp:242-257,275-279; NTC64L :282-304).
+template <int NW>
+ABG_HD void vtx_shift(const Params& p, Vtx<NW>& v, int sense, unsigned in)
+{
+	unsigned k = p.k;
+	if (sense == SENSE) {
+		unsigned out = kmer_get(v.s, 0);
+		v.fh = srol1(v.fh) ^ seed_of(in) ^ p.seed_k[out];
+		v.rh = sror1(v.rh ^ p.seedrc_k[in] ^ seed_of(3u - out));
+	} else {
+		unsigned out = kmer_get(v.s, k - 1);
+		v.fh = sror1(v.fh ^ p.seed_k[in] ^ seed_of(out));
+		v.rh = srol1(v.rh) ^ seed_of(3u - in) ^ p.seedrc_k[out];
+	}
+	kmer_shift(v.s, k, sense, in);
+}
+// Vertex::reverseComplement (RollingBloomDBG.h:71-75)
+template <int NW>
+ABG_HD void vtx_revcomp(const Params& p, Vtx<NW>& v)
+{
+	v.s = kmer_revcomp(v.s, p.k);
+	uint64_t t = v.fh; v.fh = v.rh; v.rh = t;
+}
+// RollingBloomDBGVertex::operator== (RollingBloomDBG.h:92-99): equal canonical hash and
+// RC-invariant k-mer comparison.  Two k-mers with equal (fh, rh) are the same string;
+// with swapped (fh, rh) they are reverse complements, which the reference treats as
+// the same vertex unless the k-mer is in the odd-k tie class (kmer_is_tie).
+template <int NW>
+ABG_HD bool vtx_equal(const Params& p, const Vtx<NW>& a, const Vtx<NW>& b)
+{
+	if (a.fh == b.fh && a.rh == b.rh) return true;
+	if (a.fh == b.rh && a.rh == b.fh) return !kmer_is_tie(a.s, p.k);
+	return false;
+}
+
+// --------------------------------------------------------- Bloom filter probes
+// CountingBloomFilter::contains (CountingBloomFilter.hpp:190-196): min over the H
+// counters >= threshold.  All H loads are issued before any is tested.
+ABG_HD bool solid_contains(const Params& p, const uint8_t* __restrict__ cnt, uint64_t h)
+{
+	bool ok = true;
+	for (unsigned i = 0; i < p.nh; i++)
+		ok = ok & (cnt[pos_i(p, h, i)] >= p.kc);
+	return ok;
+}
+// CountingBloomFilter::minCount (CountingBloomFilter.hpp:53-64)
+ABG_HD unsigned solid_min_count(const Params& p, const uint8_t* __restrict__ cnt, uint64_t h)
+{
+	unsigned mn = 255;
+	for (unsigned i = 0; i < p.nh; i++) {
+		unsigned c = cnt[pos_i(p, h, i)];
+		mn = c < mn ? c : mn;
+	}
+	return mn;
+}
+// BloomFilter::contains (BloomFilter.hpp:249-259)
+ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, uint64_t h)
+{
+	bool ok = true;
+	for (unsigned i = 0; i < p.nh; i++) {
+		uint64_t q = pos_i(p, h, i);
+		ok = ok & (((vis[q >> 3] >> (q & 7)) & 1u) != 0);
+	}
+	return ok;
+}
+
+// Neighbour enumeration of out_edge_iterator / in_edge_iterator
+// (RollingBloomDBG.h:302-427): the k-mer shifted by one base with last (first) base
+// A,C,G,T in that order, present iff the solid filter contains it (vertex_exists,
+// :436-446).  The four neighbours' hashes are XOR deltas off one shifted state.
+// Returns a 4-bit mask (bit b = base b exists) and the hash pairs.
+template <int NW>
+ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
+    const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
+{
+	unsigned k = p.k;
+	if (sense == SENSE) {
+		unsigned out = kmer_get(u.s, 0);
+		uint64_t fb = srol1(u.fh) ^ p.seed_k[out];
+		uint64_t rb = sror1(u.rh ^ seed_of(3u - out));
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++) {
+			fh4[b] = fb ^ seed_of(b);
+			rh4[b] = rb ^ p.seedrc_km1[b];
+		}
+	} else {
+		unsigned out = kmer_get(u.s, k - 1);
+		uint64_t fb = sror1(u.fh ^ seed_of(out));
+		uint64_t rb = srol1(u.rh) ^ p.seedrc_k[out];
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++) {
+			fh4[b] = fb ^ p.seed_km1[b];
+			rh4[b] = rb ^ seed_of(3u - b);
+		}
+	}
+	unsigned mask = 0;
+#pragma unroll
+	for (unsigned b = 0; b < 4; b++) {
+		uint64_t h = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
+		mask |= (solid_contains(p, cnt, h) ? 1u : 0u) << b;
+	}
+	return mask;
+}
+template <int NW>
+ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsigned b,
+    uint64_t fh, uint64_t rh)
+{
+	Vtx<NW> v = u;
+	kmer_shift(v.s, p.k, sense, b);
+	v.fh = fh;
+	v.rh = rh;
+	return v;
+}
+
+// ------------------------------------------------------------ search scratch
+// Explicit stacks for the reference's recursive searches.  One SearchScratch per
+// concurrently running searcher (GPU thread); capacities are fixed at launch and
+// overflow is reported (never silently truncated).
+struct VKey { uint64_t fh, rh; };
+template <int NW>
+struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
+	Vtx<NW> v;          // the vertex this call inserted into `visited`
+	uint64_t ufh, urh;  // the vertex we came from (skipped when changing direction)
+	uint16_t depth;
+	uint8_t dir;        // direction of this call
+	uint8_t stage;      // 0: same-direction children, 1: other-direction children
+	uint8_t next;       // next base to try in the current stage
+	uint8_t mask_same, mask_other;
+	uint8_t have_other; // mask_other computed
+	uint64_t nfh[4], nrh[4]; // neighbour hashes of the current stage
+};
+template <int NW>
+struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
+	Vtx<NW> v;
+	uint64_t nfh[4], nrh[4];
+	uint8_t mask, next;
+};
+constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
+template <int NW>
+struct SearchScratch {
+	TBFrame<NW>* tb;       // [tb_cap]
+	uint32_t tb_cap;
+	uint32_t overflow;     // set when a stack capacity was exceeded
+	LAFrame<NW> la[FP_TRIM + 1];
+	VKey* la_visited;      // [LA_MAX_VISITED]
+};
+
+// lookAhead (ExtendPath.h:100-161): is there a path of >= `limit` further vertices
+// from `start` in direction `dir`?  Depth-first, `visited` shared by the whole search
+// and never erased, neighbours tried in A,C,G,T order.
+template <int NW>
+ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start,
+    int dir, unsigned limit, SearchScratch<NW>& sc)
+{
+	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
+	unsigned nv = 0;
+	VKey* vis = sc.la_visited;
+	vis[nv].fh = start.fh; vis[nv].rh = start.rh; nv++;
+	if (limit == 0) return true;
+	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
+	int depth = 0;
+	sc.la[0].v = start;
+	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, sc.la[0].nfh, sc.la[0].nrh);
+	sc.la[0].next = 0;
+	while (depth >= 0) {
+		LAFrame<NW>& f = sc.la[depth];
+		if (f.next >= 4) { depth--; continue; }
+		unsigned b = f.next++;
+		if (!((f.mask >> b) & 1u)) continue;
+		Vtx<NW> w = make_neighbour(p, f.v, sense, b, f.nfh[b], f.nrh[b]);
+		bool seen = false;
+		for (unsigned i = 0; i < nv; i++) {
+			Vtx<NW> t; t.s = w.s; t.fh = vis[i].fh; t.rh = vis[i].rh;
+			// vtx_equal needs the k-mer only for the tie test, which is a property of
+			// either orientation of the same k-mer
+			if (vtx_equal(p, w, t)) { seen = true; break; }
+		}
+		if (seen) continue;
+		// recursive call lookAhead(w, depth + 1)
+		if (nv < (unsigned)LA_MAX_VISITED) { vis[nv].fh = w.fh; vis[nv].rh = w.rh; nv++; }
+		else sc.overflow = 1;
+		if ((unsigned)(depth + 1) >= limit) return true;
+		depth++;
+		sc.la[depth].v = w;
+		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, sc.la[depth].nfh, sc.la[depth].nrh);
+		sc.la[depth].next = 0;
+	}
+	return false;
+}
+
+// trueBranch (ExtendPath.h:174-261).  Edge (u -> v) walked in direction `dir`.  Every
+// `return true` of the recursion propagates to the root, and `visited` holds exactly the
+// vertices of the active calls (inserted on entry, erased on a false return), so the
+// recursion is a depth-first search over an explicit frame stack that stops at the first
+// call that would return true.
+template <int NW>
+ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
+    const Vtx<NW>& v0, int dir0, unsigned trim, SearchScratch<NW>& sc)
+{
+	TBFrame<NW>* st = sc.tb;
+	int top = -1;
+	// "call" trueBranch(u0 -> v0, depth 0, dir0)
+	Vtx<NW> cu = u0, cv = v0;
+	unsigned cdepth = 0;
+	int cdir = dir0;
+	for (;;) {
+		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
+		bool on_stack = false;
+		for (int i = 0; i <= top; i++)
+			if (vtx_equal(p, cv, st[i].v)) { on_stack = true; break; }
+		if (on_stack) return true;
+		if (cdepth >= trim) return true;
+		if (top + 1 >= (int)sc.tb_cap) { sc.overflow = 1; return true; }
+		top++;
+		{
+			TBFrame<NW>& f = st[top];
+			f.v = cv; f.ufh = cu.fh; f.urh = cu.rh;
+			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
+			f.have_other = 0; f.mask_other = 0;
+			f.mask_same = (uint8_t)neighbour_mask(p, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE,
+			    f.nfh, f.nrh);
+		}
+		// ---- resume frames until one of them makes a new call
+		bool called = false;
+		while (top >= 0 && !called) {
+			TBFrame<NW>& f = st[top];
+			int fdir = f.dir;
+			int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
+			if (f.stage == 0) {
+				while (f.next < 4 && !((f.mask_same >> f.next) & 1u)) f.next++;
+				if (f.next < 4) {
+					unsigned b = f.next++;
+					cu = f.v;
+					cv = make_neighbour(p, f.v, sense, b, f.nfh[b], f.nrh[b]);
+					cdepth = f.depth + 1u;
+					cdir = fdir;
+					called = true;
+					break;
+				}
+				// same-direction children exhausted: may we change direction?
+				// (depth >= fpTrim || lookAhead(v, dir, fpTrim), ExtendPath.h:208,230)
+				bool flip = f.depth >= FP_TRIM;
+				if (!flip) flip = look_ahead(p, cnt, f.v, fdir, FP_TRIM, sc);
+				if (!flip) { top--; continue; } // visited.erase(v); return false
+				f.stage = 1;
+				f.next = 0;
+				f.mask_other = (uint8_t)neighbour_mask(p, cnt, f.v,
+				    fdir == FORWARD ? ANTISENSE : SENSE, f.nfh, f.nrh);
+				f.have_other = 1;
+			}
+			// stage 1: other-direction children, skipping the vertex we came from
+			{
+				int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
+				int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
+				bool made = false;
+				while (f.next < 4) {
+					unsigned b = f.next++;
+					if (!((f.mask_other >> b) & 1u)) continue;
+					Vtx<NW> w = make_neighbour(p, f.v, osense, b, f.nfh[b], f.nrh[b]);
+					Vtx<NW> uu; uu.s = w.s; uu.fh = f.ufh; uu.rh = f.urh;
+					if (vtx_equal(p, w, uu)) continue; // source(*iei) == u
+					cu = f.v; cv = w; cdepth = 0; cdir = odir;
+					made = true;
+					break;
+				}
+				if (made) { called = true; break; }
+				top--; // visited.erase(v); return false
+			}
+		}
+		if (!called) return false; // root call returned false
+	}
+}
+
+// successor (ExtendPath.h:314-362): iterative deepening over the branch-length
+// threshold i = 0,1,2,4,...,trim.  Returns the code and (for LENGTH_LIMIT) the unique
+// successor; for AMBI_OUT the last true branch found, for DEAD_END `u` itself.
+template <int NW>
+ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
+    unsigned trim, Vtx<NW>& vout, SearchScratch<NW>& sc)
+{
+	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
+	uint64_t nfh[4], nrh[4];
+	unsigned mask = neighbour_mask(p, cnt, u, sense, nfh, nrh);
+	vout = u;
+	for (unsigned i = 0;; i = (i == 0) ? 1u : (trim < 2 * i ? trim : 2 * i)) {
+		unsigned tb = 0;
+		for (unsigned b = 0; b < 4; b++) {
+			if (!((mask >> b) & 1u)) continue;
+			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
+			// trueBranch(e, dir, g, i, fpTrim) with a fresh visited set; at i == 0 every
+			// existing edge is a true branch (depth 0 >= trim 0)
+			bool t = (i == 0) ? true : true_branch(p, cnt, u, w, dir, i, sc);
+			if (t) {
+				vout = w;
+				if (++tb >= 2) break;
+			}
+		}
+		if (tb == 0) return ER_DEAD_END;
+		if (tb == 1) return ER_LENGTH_LIMIT;
+		if (i == trim) return ER_AMBI_OUT;
+	}
+}
+
+} // namespace abg

@@ -1,0 +1,879 @@
+// abg_engine.h -- orchestration of the two passes of abyss-bloom-dbg over device
+// memory: PASS 1 (BloomIO.h:32-41 loadSeq: ntHash every k-mer, conservative-update
+// insert into the uint8 counting filter, in exact read order) and PASS 2
+// (bloom-dbg.h:781-882,972-1089: classify reads, walk unitigs, commit contigs in read
+// order).  The engine is a template over a Backend that allocates memory and runs
+// "for each item" functors; the product instantiates it with the HIP backend only
+// (abg_kernels.hip).  tests/hostcheck instantiates it with a serial backend to check
+// the logic against the oracle on machines without a GPU.
+#pragma once
+#include "abg_walk.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace abg {
+
+struct Config {
+	uint32_t k = 0, nh = 4, kc = 2, trim = 0;
+	uint64_t counters = 0;            // number of uint8 counters == visited bits
+	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
+	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
+	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
+	uint32_t walk_slots = 32768;      // concurrent walkers
+	uint32_t tb_cap = 192;            // trueBranch frames per walker
+	uint32_t buf_cap = 1u << 13;      // extension bases per side per walker
+	uint64_t pool_cap = 1ull << 28;   // contig pool bytes
+	uint32_t rec_cap = 1u << 22;      // contig records per round
+	uint32_t wtab_log2 = 26;          // walker vertex table entries
+	uint32_t wclaim_log2 = 26;        // walker claim slots
+	uint32_t cend_log2 = 20;          // contigEndKmers table entries
+	uint64_t p2_first_batch = 4096;   // PASS 2 read batches grow geometrically from here
+	uint64_t p2_max_batch = 1ull << 21;
+	int verbose = 0;
+};
+
+struct Counters { // AssemblyCounters.h:15-31
+	uint64_t solid_reads = 0, visited_reads = 0, reads_processed = 0, bases_assembled = 0,
+	         contig_id = 0;
+};
+
+// Host-side staging of pure-ACGT sequences in the device layout (see Batch).
+struct HostBatch {
+	std::vector<uint32_t> words;
+	std::vector<uint64_t> woff{ 0 };
+	std::vector<uint32_t> len;
+	std::vector<uint64_t> koff{ 0 };
+	void clear() { words.clear(); woff.assign(1, 0); len.clear(); koff.assign(1, 0); }
+	uint64_t n() const { return len.size(); }
+	// append one sequence of codes 0..3 given as ASCII ACGT (upper case); caller guarantees len >= k
+	void add_ascii(const char* s, uint32_t L, uint32_t k)
+	{
+		size_t w0 = words.size();
+		words.resize(w0 + (L + 15) / 16, 0);
+		for (uint32_t i = 0; i < L; i++) {
+			char ch = s[i];
+			uint32_t b = (ch == 'A') ? 0u : (ch == 'C') ? 1u : (ch == 'G') ? 2u : 3u;
+			words[w0 + (i >> 4)] |= b << (2 * (i & 15));
+		}
+		woff.push_back(words.size());
+		len.push_back(L);
+		koff.push_back(koff.back() + (L - k + 1));
+	}
+};
+
+struct ContigOut {
+	uint64_t contig_id;   // UINT64_MAX if redundant
+	uint64_t read_index;  // index of the seeding read within the assemble call
+	std::string seq;
+	uint32_t coverage;
+	bool redundant;
+	uint32_t left_ext, right_ext;
+	int left_code, right_code;
+	uint32_t seed_pos;
+};
+
+// ============================================================ PASS 1 functors
+// claim value: newer epochs compare lower so stale entries never win
+ABG_HD uint64_t claim_val(uint32_t epoch, uint32_t t) { return ((uint64_t)(0xFFFFFFFFu - epoch) << 32) | t; }
+
+struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
+	Params p; Batch b; uint64_t* h0;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		uint64_t r = find_seq(b.koff, b.n, t);
+		uint32_t j = (uint32_t)(t - b.koff[r]);
+		uint64_t fh = 0, rh = 0;
+		unsigned k = p.k;
+		for (unsigned i = 0; i < k; i++) {
+			fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
+			rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
+		}
+		h0[t] = rh < fh ? rh : fh;
+	}
+};
+struct FClaim { // first round: every op claims its H counters
+	Params p; const uint64_t* h0; uint64_t* claim; uint64_t cmask; uint32_t epoch;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		uint64_t h = h0[t];
+		uint64_t v = claim_val(epoch, (uint32_t)t);
+		for (unsigned i = 0; i < p.nh; i++)
+			atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
+	}
+};
+// One round of the deterministic-reservation insert: an op that holds the claim on all
+// of its counters is the earliest pending op touching them, so applying it now is what
+// the sequential loop of the reference would do (CountingBloomFilter::incrementMin,
+// CountingBloomFilter.hpp:135-162); the others re-claim in the other table for the next
+// round.  pend == NULL means "all ops 0..n-1".
+struct FInsertRound {
+	Params p; const uint64_t* h0; uint8_t* cnt;
+	const uint32_t* pend; uint32_t* next; uint32_t* next_n;
+	const uint64_t* claim_cur; uint64_t* claim_next; uint64_t cmask; uint32_t epoch;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t t = pend ? pend[i] : (uint32_t)i;
+		uint64_t h = h0[t];
+		uint64_t v = claim_val(epoch, t);
+		bool win = true;
+		for (unsigned j = 0; j < p.nh; j++)
+			win = win & (claim_cur[pos_i(p, h, j) & cmask] == v);
+		if (win) {
+			unsigned mn = 255;
+			for (unsigned j = 0; j < p.nh; j++) { unsigned c = cnt[pos_i(p, h, j)]; mn = c < mn ? c : mn; }
+			if (mn < 255)
+				for (unsigned j = 0; j < p.nh; j++) {
+					uint64_t q = pos_i(p, h, j);
+					if (cnt[q] == mn) cnt[q] = (uint8_t)(mn + 1);
+				}
+		} else {
+			uint32_t slot = atomic_add_u32(next_n, 1);
+			next[slot] = t;
+			uint64_t v2 = claim_val(epoch + 1, t);
+			for (unsigned j = 0; j < p.nh; j++)
+				atomic_min_u64(&claim_next[pos_i(p, h, j) & cmask], v2);
+		}
+	}
+};
+struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219-242), 8 counters per item
+	const uint64_t* cnt8; uint32_t kc; uint64_t* out; // out[0] non-zero, out[1] >= kc
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint64_t w = cnt8[i];
+		uint32_t nz = 0, ge = 0;
+		for (int b = 0; b < 8; b++) { unsigned c = (unsigned)(w >> (8 * b)) & 0xFF; nz += c != 0; ge += c >= kc; }
+		if (nz) atomic_add_u64(&out[0], nz);
+		if (ge) atomic_add_u64(&out[1], ge);
+	}
+};
+
+// ============================================================ PASS 2 functors
+// provisional per-read result of the classify step
+constexpr uint8_t RES_CANDIDATE = 0x80;
+
+template <int NW>
+struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
+	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
+	VKey* la_pool; // [slots][LA_MAX_VISITED]
+	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
+	{
+		uint64_t r = first + i;
+		uint32_t L = b.len[r];
+		unsigned k = p.k;
+		uint32_t nk = L - k + 1;
+		SearchScratch<NW> sc;
+		sc.tb = nullptr; sc.tb_cap = 0; sc.overflow = 0;
+		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
+		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
+		// the read and from the first k-mer of its reverse complement
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		Vtx<NW> first_v = v;
+		if (!look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		Vtx<NW> lastv;
+		lastv.s = batch_kmer<NW>(b, r, nk - 1, k);
+		vtx_rehash(p, lastv);
+		vtx_revcomp(p, lastv);
+		if (!look_ahead(p, cnt, lastv, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		// allKmersInBloom(seq, solidKmerSet) (bloom-dbg.h:58-77)
+		v = first_v;
+		bool solid = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!solid_contains(p, cnt, vtx_hash(v))) { solid = false; break; }
+		}
+		if (!solid) { result[r] = RR_NOT_SOLID; return; }
+		// allKmersInBloom(seq, assembledKmerSet) against the snapshot
+		v = first_v;
+		bool visited = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!visited_contains(p, vis, vtx_hash(v))) { visited = false; break; }
+		}
+		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
+	}
+};
+
+template <int NW>
+struct FRefilter { // is a remaining candidate now entirely visited? (monotone => final)
+	Params p; Batch b; const uint32_t* cand_read; const uint8_t* vis; uint8_t* now_visited;
+	ABG_HDN void operator()(uint64_t c, uint32_t) const
+	{
+		uint64_t r = cand_read[c];
+		unsigned k = p.k;
+		uint32_t nk = b.len[r] - k + 1;
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		bool visited = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!visited_contains(p, vis, vtx_hash(v))) { visited = false; break; }
+		}
+		now_visited[c] = visited;
+	}
+};
+
+template <int NW>
+struct FWalk { // one walker per item; `list` selects the candidates to walk
+	WalkEnv<NW> e; const uint32_t* list;
+	ABG_HDN void operator()(uint64_t i, uint32_t slot)
+	{
+		WalkEnv<NW> env = e;
+		walk_read<NW>(env, list[i], slot);
+	}
+};
+
+template <int NW>
+struct FPredict { // which deferred candidates will still be needed at their turn?
+	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint8_t* vis;
+	const uint32_t* claims; uint32_t claim_mask; uint32_t* need_list; uint32_t* need_n;
+	const uint32_t* list;
+	ABG_HDN void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t c = list[i];
+		if (status[c] != WS_DEFERRED) return;
+		uint64_t r = cand_read[c];
+		unsigned k = p.k;
+		uint32_t nk = b.len[r] - k + 1;
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		bool covered = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			uint64_t hm = vtx_hash(v);
+			if (visited_contains(p, vis, hm)) continue;
+			if (claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask] < c) continue;
+			covered = false;
+			break;
+		}
+		if (!covered) need_list[atomic_add_u32(need_n, 1)] = c;
+	}
+};
+
+// ---- ordered commit (outputContig, bloom-dbg.h:538-620), cooperative over T threads
+struct CommitState {
+	Counters counters;
+	uint32_t break_at;   // first candidate that could not be committed
+	uint32_t pad_;
+};
+template <int NW>
+struct CommitEnv {
+	Params p; Batch b; const uint8_t* cnt; uint32_t* vis32;
+	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
+	ContigRec* recs; const uint8_t* pool; uint8_t* result;
+	WalkTab cend;        // contigEndKmers (bloom-dbg.h:992), owner 0
+	CommitState* st;
+	uint32_t* order;     // [rec_cap] records in commit order
+	uint32_t* order_n;
+};
+ABG_HD bool visited_contains_coherent(const Params& p, const uint32_t* vis32, uint64_t h)
+{
+	bool ok = true;
+	for (unsigned i = 0; i < p.nh; i++) {
+		uint64_t q = pos_i(p, h, i);
+		ok = ok & (((ld_coherent(&vis32[q >> 5]) >> (q & 31)) & 1u) != 0);
+	}
+	return ok;
+}
+template <int NW>
+ABG_HDN uint64_t seq_kmer_hash(const Params& p, const uint8_t* seq, uint64_t j)
+{
+	uint64_t fh = 0, rh = 0;
+	unsigned k = p.k;
+	for (unsigned i = 0; i < k; i++) {
+		fh = srol1(fh) ^ seed_of(seq[j + i]);
+		rh = srol1(rh) ^ seed_of(3u - seq[j + k - 1 - i]);
+	}
+	return rh < fh ? rh : fh;
+}
+template <int NW>
+ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uint32_t j)
+{
+	uint64_t fh = 0, rh = 0;
+	unsigned k = p.k;
+	for (unsigned i = 0; i < k; i++) {
+		fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
+		rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
+	}
+	return rh < fh ? rh : fh;
+}
+// Sync policy: tid(), nthreads(), barrier(), all(bool), sum(uint32_t), bcast(uint32_t from tid 0)
+template <int NW, class Sync>
+ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_end, Sync& sy)
+{
+	const Params& p = e.p;
+	const unsigned k = p.k;
+	const uint32_t tid = sy.tid(), T = sy.nthreads();
+	uint32_t c = c_begin;
+	for (; c < c_end; c++) {
+		uint64_t r = e.cand_read[c];
+		uint32_t nk = e.b.len[r] - k + 1;
+		// allKmersInBloom(seq, assembledKmerSet) at this read's turn (bloom-dbg.h:823)
+		bool mine = true;
+		for (uint32_t j = tid; j < nk; j += T)
+			mine = mine & visited_contains_coherent(p, e.vis32, read_kmer_hash<NW>(p, e.b, r, j));
+		if (sy.all(mine)) {
+			if (tid == 0) { e.result[r] = RR_ALL_KMERS_VISITED; e.st->counters.visited_reads++; }
+			continue;
+		}
+		if (sy.bcast(e.status[c]) != WS_COMPLETE) break;
+		if (tid == 0) e.result[r] = RR_GENERATED_CONTIGS;
+		for (uint32_t ri = sy.bcast(e.first_rec[c]); ri != REC_END; ri = sy.bcast(e.recs[ri].next)) {
+			ContigRec& rec = e.recs[ri];
+			const uint8_t* seq = e.pool + rec.seq_off;
+			uint32_t len = rec.len, cnk = len - k + 1;
+			uint32_t redundant = 0;
+			if (len < k + FP_TRIM - 1) {
+				// short contigs: exact set of canonical end k-mers (bloom-dbg.h:576-584)
+				if (tid == 0) {
+					Vtx<NW> v1 = canonical_end_vertex<NW>(p, seq);
+					Vtx<NW> v2 = canonical_end_vertex<NW>(p, seq + len - k);
+					VKey k1 = vtx_key(p, v1), k2 = vtx_key(p, v2);
+					if (wt_find(e.cend, k1, 0) != WT_EMPTY && wt_find(e.cend, k2, 0) != WT_EMPTY) {
+						redundant = 1;
+					} else {
+						int a = wt_insert(e.cend, k1, 0, 0), bb = wt_insert(e.cend, k2, 0, 0);
+						if (a == WT_FULL || bb == WT_FULL) redundant = 2; // table overflow: reported
+					}
+				}
+				redundant = sy.bcast(redundant);
+			} else {
+				bool all = true;
+				for (uint32_t j = tid; j < cnk; j += T)
+					all = all & visited_contains_coherent(p, e.vis32, seq_kmer_hash<NW>(p, seq, j));
+				redundant = sy.all(all) ? 1u : 0u;
+			}
+			if (redundant == 2) { if (tid == 0) e.st->pad_ = 1; redundant = 0; }
+			uint32_t cov = 0;
+			if (!redundant) {
+				// addKmersToBloom + getSeqAbsoluteKmerCoverage (bloom-dbg.h:79-109)
+				for (uint32_t j = tid; j < cnk; j += T) {
+					uint64_t h = seq_kmer_hash<NW>(p, seq, j);
+					for (unsigned i = 0; i < p.nh; i++) {
+						uint64_t q = pos_i(p, h, i);
+						atomic_or_u32(&e.vis32[q >> 5], 1u << (q & 31));
+					}
+					cov += solid_min_count(p, e.cnt, h);
+				}
+			}
+			cov = sy.sum(cov); // also the barrier that publishes the inserted bits
+			if (tid == 0) {
+				rec.redundant = (uint8_t)redundant;
+				if (!redundant) {
+					rec.coverage = cov;
+					rec.contig_id = e.st->counters.contig_id++;
+					e.st->counters.bases_assembled += len;
+				}
+				e.order[(*e.order_n)++] = ri;
+			}
+		}
+	}
+	if (tid == 0) e.st->break_at = c;
+	sy.barrier();
+}
+
+// ================================================================== Engine
+// Backend concept:
+//   void* alloc(size_t); void free(void*); void memset(void*, int, size_t);
+//   void h2d(void*, const void*, size_t); void d2h(void*, const void*, size_t);
+//   uint32_t max_slots();                       // upper bound on concurrent items of launch()
+//   template<class F> void launch(uint64_t n, F f, const char* name);               // f(i, slot)
+//   template<class F> void launch_slots(uint64_t n, F f, uint32_t slots, const char* name);
+//   template<int NW> void launch_commit(CommitEnv<NW>, uint32_t c_begin, uint32_t c_end);
+template <class BE>
+class Engine {
+  public:
+	Engine(BE& be, const Config& cfg) : be_(be), cfg_(cfg)
+	{
+		uint64_t rem = cfg_.counters % 8; // CountingBloomFilter ctor, hpp:40-50
+		m_ = rem ? cfg_.counters + 8 - rem : cfg_.counters;
+		p_ = make_params(cfg_.k, cfg_.nh, cfg_.kc, cfg_.trim, m_);
+		cnt_ = (uint8_t*)be_.alloc(m_);
+		be_.memset(cnt_, 0, m_);
+		vis_bytes_ = (m_ / 8 + 4 + 3) & ~3ull;
+		vis_ = (uint8_t*)be_.alloc(vis_bytes_);
+		be_.memset(vis_, 0, vis_bytes_);
+		cstate_ = (CommitState*)be_.alloc(sizeof(CommitState));
+		be_.memset(cstate_, 0, sizeof(CommitState));
+		scal_ = (uint64_t*)be_.alloc(64);
+	}
+	~Engine()
+	{
+		be_.free(cnt_); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
+		free_insert();
+		free_walk();
+	}
+	const Params& params() const { return p_; }
+	uint64_t size() const { return m_; }
+	uint8_t* counters_dev() { return cnt_; }
+	uint8_t* visited_dev() { return vis_; }
+	uint64_t visited_bytes() const { return m_ / 8; }
+	Counters counters() const { return counters_; }
+	void set_counters(const Counters& c) { counters_ = c; }
+	uint64_t last_insert_rounds() const { return last_rounds_; }
+
+	void popcounts(uint64_t* nonzero, uint64_t* filtered)
+	{
+		be_.memset(scal_, 0, 16);
+		FPopcount f{ (const uint64_t*)cnt_, p_.kc, scal_ };
+		be_.launch(m_ / 8, f, "popcount");
+		uint64_t out[2];
+		be_.d2h(out, scal_, 16);
+		*nonzero = out[0];
+		*filtered = out[1];
+	}
+
+	// ---- PASS 1 on a device-resident packed batch (ops are inserted in batch order).
+	// koff_h is the host copy of b.koff.
+	void load_packed(const Batch& b, const uint64_t* koff_h)
+	{
+		ensure_insert();
+		last_rounds_ = 0;
+		// op ranges of at most insert_batch_kmers along sequence boundaries
+		uint64_t s = 0;
+		while (s < b.n) {
+			uint64_t e = s;
+			while (e < b.n && (e == s || koff_h[e + 1] - koff_h[s] <= cfg_.insert_batch_kmers)) e++;
+			insert_range(b, s, e, koff_h);
+			s = e;
+		}
+	}
+
+	// ---- PASS 2 on a device-resident packed batch of reads.  results_host (b.n bytes,
+	// may be NULL) receives a ReadResult per read; contigs are delivered in commit order.
+	void assemble_packed(const Batch& b, uint8_t* results_host,
+	    const std::function<void(const ContigOut&)>& sink)
+	{
+		ensure_walk();
+		uint64_t done = 0;
+		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
+		while (done < b.n) {
+			uint64_t bs = std::min<uint64_t>(p2_batch_, b.n - done);
+			assemble_range(b, done, bs, result_d, results_host, sink);
+			done += bs;
+			counters_.reads_processed += bs;
+			p2_batch_ = std::min<uint64_t>(p2_batch_ * 2, cfg_.p2_max_batch);
+		}
+		be_.free(result_d);
+	}
+
+	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0; };
+	Stats stats() const { return stats_; }
+
+  private:
+	BE& be_;
+	Config cfg_;
+	Params p_;
+	uint64_t m_ = 0, vis_bytes_ = 0;
+	uint8_t* cnt_ = nullptr;
+	uint8_t* vis_ = nullptr;
+	CommitState* cstate_ = nullptr;
+	uint64_t* scal_ = nullptr;
+	Counters counters_;
+	Stats stats_;
+	uint64_t last_rounds_ = 0;
+	uint64_t p2_batch_ = 0;
+	// PASS 1 resources
+	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
+	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
+	// PASS 2 resources
+	bool walk_ready_ = false;
+	WalkTab wtab_{}, cend_{};
+	uint32_t wtab_log2_ = 0;
+	uint32_t* wclaims_ = nullptr;
+	void* tb_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
+	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
+	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
+	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
+	uint32_t walk_tb_cap_ = 0, walk_buf_cap_ = 0, wslots_ = 0, cslots_ = 0;
+	std::vector<uint32_t> visited_now_;
+
+	void ensure_insert()
+	{
+		if (h0_) return;
+		uint64_t nb = cfg_.insert_batch_kmers;
+		h0_ = (uint64_t*)be_.alloc(nb * 8);
+		for (int i = 0; i < 2; i++) {
+			claim_[i] = (uint64_t*)be_.alloc((8ull << cfg_.claim_log2));
+			be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
+			pend_[i] = (uint32_t*)be_.alloc(nb * 4);
+		}
+		pend_n_ = (uint32_t*)be_.alloc(8);
+	}
+	void free_insert()
+	{
+		if (!h0_) return;
+		be_.free(h0_);
+		for (int i = 0; i < 2; i++) { be_.free(claim_[i]); be_.free(pend_[i]); }
+		be_.free(pend_n_);
+		h0_ = nullptr;
+	}
+	void insert_range(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h)
+	{
+		uint64_t T = koff_h[e] - koff_h[s];
+		if (T == 0) return;
+		if (T > cfg_.insert_batch_kmers || T >= 0xFFFFFFFFull) {
+			fprintf(stderr, "abyss_amd: a single sequence has more k-mers (%llu) than insert_batch_kmers\n",
+			    (unsigned long long)T);
+			abort();
+		}
+		// a view of sequences [s, e) whose op ids start at 0
+		Batch v = b;
+		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s;
+		std::vector<uint64_t> kv(e - s + 1);
+		for (uint64_t i = 0; i <= e - s; i++) kv[i] = koff_h[s + i] - koff_h[s];
+		uint64_t* kv_d = (uint64_t*)be_.alloc(kv.size() * 8);
+		be_.h2d(kv_d, kv.data(), kv.size() * 8);
+		v.koff = kv_d;
+		FHash fh{ p_, v, h0_ };
+		be_.launch(T, fh, "hash");
+		uint64_t cmask = (1ull << cfg_.claim_log2) - 1;
+		if (epoch_ > 0xFFFFFF00u) { // claim epochs exhausted: start over
+			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
+			epoch_ = 1;
+		}
+		uint64_t* ccur = claim_[0];
+		uint64_t* cnext = claim_[1];
+		FClaim fc{ p_, h0_, ccur, cmask, epoch_ };
+		be_.launch(T, fc, "claim");
+		uint64_t npend = T;
+		const uint32_t* pin = nullptr; // NULL: all ops 0..T-1
+		uint32_t* pout = pend_[0];
+		while (npend) {
+			be_.memset(pend_n_, 0, 4);
+			FInsertRound fr{ p_, h0_, cnt_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_ };
+			be_.launch(npend, fr, pin ? "insert_retry" : "insert_round");
+			uint32_t nn = 0;
+			be_.d2h(&nn, pend_n_, 4);
+			npend = nn;
+			// losers claimed in `cnext` under epoch + 1; stale older-epoch values lose to them
+			std::swap(ccur, cnext);
+			pin = pout;
+			pout = (pout == pend_[0]) ? pend_[1] : pend_[0];
+			epoch_++;
+			last_rounds_++;
+			stats_.insert_rounds++;
+		}
+		epoch_++;
+		be_.free(kv_d);
+	}
+
+	void ensure_walk()
+	{
+		if (walk_ready_) return;
+		p2_batch_ = cfg_.p2_first_batch;
+		wslots_ = std::min<uint32_t>(be_.max_slots(), cfg_.walk_slots);
+		cslots_ = std::min<uint32_t>(be_.max_slots(), 65536u);
+		alloc_tab(cend_, cfg_.cend_log2);
+		wtab_log2_ = cfg_.wtab_log2;
+		alloc_tab(wtab_, wtab_log2_);
+		wclaims_ = (uint32_t*)be_.alloc(4ull << cfg_.wclaim_log2);
+		la_pool_ = (VKey*)be_.alloc((uint64_t)std::max(wslots_, cslots_) * LA_MAX_VISITED * sizeof(VKey));
+		walk_tb_cap_ = cfg_.tb_cap;
+		walk_buf_cap_ = cfg_.buf_cap;
+		alloc_walk_scratch();
+		pool_cap_ = cfg_.pool_cap;
+		pool_ = (uint8_t*)be_.alloc(pool_cap_);
+		pool_used_ = (uint64_t*)be_.alloc(8);
+		rec_cap_ = cfg_.rec_cap;
+		recs_ = (ContigRec*)be_.alloc((uint64_t)rec_cap_ * sizeof(ContigRec));
+		rec_used_ = (uint32_t*)be_.alloc(8);
+		order_ = (uint32_t*)be_.alloc((uint64_t)rec_cap_ * 4);
+		order_n_ = (uint32_t*)be_.alloc(8);
+		walk_ready_ = true;
+	}
+	void alloc_walk_scratch()
+	{
+		tb_pool_ = be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(TBFrame<MAX_NW>));
+		lbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
+		rbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
+	}
+	void free_walk_scratch() { be_.free(tb_pool_); be_.free(lbuf_); be_.free(rbuf_); }
+	void alloc_tab(WalkTab& t, uint32_t log2)
+	{
+		uint64_t cap = 1ull << log2;
+		t.hmin = (uint64_t*)be_.alloc(cap * 8);
+		t.hmax = (uint64_t*)be_.alloc(cap * 8);
+		t.meta = (uint64_t*)be_.alloc(cap * 8);
+		t.mask = cap - 1;
+		be_.memset(t.hmin, 0xFF, cap * 8);
+		be_.memset(t.meta, 0xFF, cap * 8);
+	}
+	void free_tab(WalkTab& t) { be_.free(t.hmin); be_.free(t.hmax); be_.free(t.meta); }
+	void free_walk()
+	{
+		if (!walk_ready_) return;
+		free_tab(cend_); free_tab(wtab_);
+		be_.free(wclaims_); be_.free(la_pool_);
+		free_walk_scratch();
+		be_.free(pool_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
+		be_.free(order_); be_.free(order_n_);
+		walk_ready_ = false;
+	}
+	// A round made no progress because its first candidate ran out of some capacity:
+	// enlarge everything a single walk can exhaust.
+	void grow_walk_resources()
+	{
+		free_walk_scratch();
+		walk_tb_cap_ *= 4;
+		walk_buf_cap_ *= 8;
+		if (walk_buf_cap_ > (1u << 28) || wtab_log2_ > 31) {
+			fprintf(stderr, "abyss_amd: a unitig exceeds the walker limits\n");
+			abort();
+		}
+		// fewer walkers when each needs a lot of scratch
+		while ((uint64_t)wslots_ * walk_buf_cap_ > (8ull << 30) && wslots_ > 64) wslots_ /= 2;
+		alloc_walk_scratch();
+		free_tab(wtab_);
+		wtab_log2_++;
+		alloc_tab(wtab_, wtab_log2_);
+		be_.free(pool_);
+		pool_cap_ *= 2;
+		pool_ = (uint8_t*)be_.alloc(pool_cap_);
+		if (cfg_.verbose)
+			fprintf(stderr, "abyss_amd: walker resources grown: %u frames, %u bases, 2^%u table, %llu pool\n",
+			    walk_tb_cap_, walk_buf_cap_, wtab_log2_, (unsigned long long)pool_cap_);
+	}
+
+	template <int NW>
+	WalkEnv<NW> make_env(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d)
+	{
+		WalkEnv<NW> e;
+		e.p = p_; e.cnt = cnt_; e.batch = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
+		e.tab = wtab_; e.claims = nullptr; e.claim_mask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1); e.owner_base = 0;
+		// scratch strides are sized for TBFrame<MAX_NW>; a smaller NW fits more frames in them
+		e.tb_pool = (TBFrame<NW>*)tb_pool_;
+		e.tb_cap = (uint32_t)((uint64_t)walk_tb_cap_ * sizeof(TBFrame<MAX_NW>) / sizeof(TBFrame<NW>));
+		e.la_pool = la_pool_;
+		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
+		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
+		e.recs = recs_; e.rec_cap = rec_cap_; e.rec_used = rec_used_;
+		return e;
+	}
+
+	template <int NW>
+	uint32_t commit(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d,
+	    uint8_t* result_d, uint32_t c_begin, uint32_t c_end)
+	{
+		CommitState cs;
+		cs.counters = counters_;
+		cs.break_at = c_begin; cs.pad_ = 0;
+		be_.h2d(cstate_, &cs, sizeof cs);
+		CommitEnv<NW> e;
+		e.p = p_; e.b = b; e.cnt = cnt_; e.vis32 = (uint32_t*)vis_;
+		e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
+		e.recs = recs_; e.pool = pool_; e.result = result_d; e.cend = cend_; e.st = cstate_;
+		e.order = order_; e.order_n = order_n_;
+		be_.template launch_commit<NW>(e, c_begin, c_end);
+		be_.d2h(&cs, cstate_, sizeof cs);
+		counters_ = cs.counters;
+		if (cs.pad_) { fprintf(stderr, "abyss_amd: contigEndKmers table is full (raise cend_log2)\n"); abort(); }
+		return cs.break_at;
+	}
+
+	// One batch of reads: rounds of {walk everything, re-walk what lower reads do not
+	// cover, commit in read order} until every candidate is accounted for.
+	template <int NW>
+	void run_rounds(const Batch& b, std::vector<uint32_t>& cand_h, uint8_t* result_d,
+	    uint64_t read_base, const std::function<void(const ContigOut&)>& sink)
+	{
+		while (!cand_h.empty()) {
+			const uint32_t nc = (uint32_t)cand_h.size();
+			stats_.rounds++;
+			uint32_t* cand_d = (uint32_t*)be_.alloc(nc * 4ull);
+			uint32_t* status_d = (uint32_t*)be_.alloc(nc * 4ull);
+			uint32_t* first_d = (uint32_t*)be_.alloc(nc * 4ull);
+			uint32_t* list_d = (uint32_t*)be_.alloc(nc * 4ull);
+			uint32_t* need_d = (uint32_t*)be_.alloc(nc * 4ull);
+			uint32_t* need_n = (uint32_t*)be_.alloc(8);
+			be_.h2d(cand_d, cand_h.data(), nc * 4ull);
+			be_.memset(status_d, 0, nc * 4ull);
+			be_.memset(first_d, 0xFF, nc * 4ull);
+			{
+				std::vector<uint32_t> ident(nc);
+				for (uint32_t i = 0; i < nc; i++) ident[i] = i;
+				be_.h2d(list_d, ident.data(), nc * 4ull);
+			}
+			// fresh per-round walker state
+			be_.memset(wtab_.hmin, 0xFF, (wtab_.mask + 1) * 8);
+			be_.memset(wtab_.meta, 0xFF, (wtab_.mask + 1) * 8);
+			be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
+			be_.memset(pool_used_, 0, 8);
+			be_.memset(rec_used_, 0, 4);
+			be_.memset(order_n_, 0, 4);
+
+			WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
+			// stage 1: every candidate walks; a walker that meets the territory of a
+			// lower-numbered read stops (its read is almost always visited by its turn)
+			env.claims = wclaims_;
+			env.owner_base = 0;
+			{
+				FWalk<NW> fw{ env, list_d };
+				be_.launch_slots(nc, fw, wslots_, "walk");
+			}
+			stats_.walked += nc;
+			// stage 2: deferred candidates that lower reads do not cover are walked privately
+			be_.memset(need_n, 0, 4);
+			{
+				FPredict<NW> fp{ p_, b, cand_d, status_d, vis_, wclaims_,
+					(uint32_t)((1ull << cfg_.wclaim_log2) - 1), need_d, need_n, list_d };
+				be_.launch(nc, fp, "predict");
+			}
+			uint32_t nneed = 0;
+			be_.d2h(&nneed, need_n, 4);
+			uint32_t owner_next = nc;
+			if (nneed) {
+				env.claims = nullptr;
+				env.owner_base = owner_next; // owner ids distinct from stage 1
+				owner_next += nc;
+				FWalk<NW> fw{ env, need_d };
+				be_.launch_slots(nneed, fw, wslots_, "rewalk");
+				stats_.rewalked += nneed;
+			}
+			// stage 3: ordered commit as far as the results allow.  A candidate that stops it
+			// (deferred but needed after all) is walked on the spot -- it is now the
+			// lowest-numbered read left -- and the commit resumes.
+			uint32_t committed = commit<NW>(b, cand_d, status_d, first_d, result_d, 0, nc);
+			bool overflowed = false;
+			uint32_t spot = 0;
+			while (committed < nc) {
+				uint32_t st = 0;
+				be_.d2h(&st, status_d + committed, 4);
+				if (st == WS_OVERFLOW) { overflowed = true; break; }
+				if (spot >= 256 || owner_next > 0xF0000000u - nc) break; // re-plan the remainder
+				stats_.breaks++;
+				spot++;
+				WalkEnv<NW> env2 = make_env<NW>(b, cand_d, status_d, first_d);
+				env2.claims = nullptr;
+				env2.owner_base = owner_next;
+				owner_next += nc;
+				be_.h2d(need_d, &committed, 4);
+				FWalk<NW> fw{ env2, need_d };
+				be_.launch_slots(1, fw, wslots_, "spotwalk");
+				stats_.rewalked++;
+				be_.d2h(&st, status_d + committed, 4);
+				if (st == WS_OVERFLOW) { overflowed = true; break; }
+				if (st != WS_COMPLETE) { fprintf(stderr, "abyss_amd: walker failed with status %u\n", st); abort(); }
+				uint32_t next = commit<NW>(b, cand_d, status_d, first_d, result_d, committed, nc);
+				if (next == committed) { fprintf(stderr, "abyss_amd: commit made no progress\n"); abort(); }
+				committed = next;
+			}
+			deliver(cand_h, read_base, sink);
+			if (overflowed && committed == 0) grow_walk_resources();
+			// what is left goes to the next round, minus the reads that are entirely visited
+			// by now (the visited set only grows, so that verdict is final)
+			std::vector<uint32_t> rest(cand_h.begin() + committed, cand_h.end());
+			if (!rest.empty()) {
+				uint32_t nr = (uint32_t)rest.size();
+				uint8_t* nowv_d = (uint8_t*)be_.alloc(nr);
+				be_.h2d(cand_d, rest.data(), nr * 4ull);
+				FRefilter<NW> fr{ p_, b, cand_d, vis_, nowv_d };
+				be_.launch(nr, fr, "refilter");
+				std::vector<uint8_t> nowv(nr);
+				be_.d2h(nowv.data(), nowv_d, nr);
+				be_.free(nowv_d);
+				std::vector<uint32_t> keep;
+				for (uint32_t i = 0; i < nr; i++) {
+					// the first one stopped the commit, so it is known not to be visited
+					if (nowv[i] && i > 0) { visited_now_.push_back(rest[i]); counters_.visited_reads++; }
+					else keep.push_back(rest[i]);
+				}
+				rest.swap(keep);
+			}
+			cand_h.swap(rest);
+			be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
+			be_.free(need_d); be_.free(need_n);
+		}
+	}
+
+	void deliver(const std::vector<uint32_t>& cand_h, uint64_t read_base,
+	    const std::function<void(const ContigOut&)>& sink)
+	{
+		uint32_t n = 0;
+		be_.d2h(&n, order_n_, 4);
+		if (!n) return;
+		std::vector<uint32_t> order(n);
+		be_.d2h(order.data(), order_, n * 4ull);
+		uint32_t nrec = 0;
+		be_.d2h(&nrec, rec_used_, 4);
+		nrec = std::min(nrec, rec_cap_);
+		std::vector<ContigRec> recs(nrec);
+		be_.d2h(recs.data(), recs_, nrec * sizeof(ContigRec));
+		uint64_t used = 0;
+		be_.d2h(&used, pool_used_, 8);
+		used = std::min<uint64_t>(used, pool_cap_);
+		std::vector<uint8_t> pool(used);
+		be_.d2h(pool.data(), pool_, used);
+		for (uint32_t i = 0; i < n; i++) {
+			const ContigRec& r = recs[order[i]];
+			ContigOut o;
+			o.contig_id = r.redundant ? ~0ULL : r.contig_id;
+			o.read_index = read_base + cand_h[r.cand];
+			o.seq.resize(r.len);
+			for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGT"[pool[r.seq_off + j] & 3];
+			o.coverage = r.coverage;
+			o.redundant = r.redundant != 0;
+			o.left_ext = r.left_ext; o.right_ext = r.right_ext;
+			o.left_code = r.left_code; o.right_code = r.right_code;
+			o.seed_pos = r.seed_pos;
+			sink(o);
+		}
+	}
+
+	template <int NW>
+	void assemble_range_nw(const Batch& v, uint64_t first, uint64_t n, uint8_t* res_d,
+	    uint8_t* results_host, const std::function<void(const ContigOut&)>& sink)
+	{
+		{
+			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_ };
+			be_.launch_slots(n, f, cslots_, "classify");
+		}
+		std::vector<uint8_t> res(n);
+		be_.d2h(res.data(), res_d, n);
+		std::vector<uint32_t> cand;
+		for (uint64_t i = 0; i < n; i++) {
+			if (res[i] == RES_CANDIDATE) cand.push_back((uint32_t)i);
+			if (res[i] == RES_CANDIDATE || res[i] == RR_ALL_KMERS_VISITED) counters_.solid_reads++;
+			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
+		}
+		stats_.candidates += cand.size();
+		visited_now_.clear();
+		if (!cand.empty()) run_rounds<NW>(v, cand, res_d, first, sink);
+		if (results_host) {
+			be_.d2h(results_host + first, res_d, n);
+			for (uint32_t r : visited_now_) results_host[first + r] = RR_ALL_KMERS_VISITED;
+			for (uint64_t i = 0; i < n; i++)
+				if (results_host[first + i] == RES_CANDIDATE) {
+					fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)(first + i));
+					abort();
+				}
+		}
+	}
+
+	void assemble_range(const Batch& b, uint64_t first, uint64_t n, uint8_t* result_d,
+	    uint8_t* results_host, const std::function<void(const ContigOut&)>& sink)
+	{
+		// view of reads [first, first + n)
+		Batch v = b;
+		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
+		uint8_t* res_d = result_d + first;
+		switch (p_.nw) {
+		case 1: assemble_range_nw<1>(v, first, n, res_d, results_host, sink); break;
+		case 2: assemble_range_nw<2>(v, first, n, res_d, results_host, sink); break;
+		case 3: assemble_range_nw<3>(v, first, n, res_d, results_host, sink); break;
+		case 4: assemble_range_nw<4>(v, first, n, res_d, results_host, sink); break;
+		default: assemble_range_nw<6>(v, first, n, res_d, results_host, sink); break;
+		}
+	}
+};
+
+} // namespace abg

@@ -1,0 +1,256 @@
+// abg_host.h -- host side of the C ABI (include/abyss_amd.h) above the engine:
+// turns the reference's inputs (ASCII sequences as FastaReader hands them to loadSeq /
+// processRead) into packed device batches and maps results back.  Templated over the
+// backend like the engine; the product instantiates it for HIP only.
+#pragma once
+#include "abg_engine.h"
+#include "../../include/abyss_amd.h"
+
+#include <cctype>
+#include <cmath>
+#include <map>
+#include <string>
+
+namespace abg {
+
+struct FExpand { // RollingHash::getHashes (RollingHash.h:141-146) for every op
+	Params p; const uint64_t* h0; uint64_t* out;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		uint64_t h = h0[t];
+		for (unsigned i = 0; i < p.nh; i++) out[t * p.nh + i] = hash_i(p, h, i);
+	}
+};
+
+// roundUpToMultiple(round(B / 1.125 / sizeof(uint8_t)), 64): bloom-dbg.cc:365-367, BloomIO.h:14-24
+inline uint64_t counters_for_budget(uint64_t bloom_bytes)
+{
+	double sz = (double)bloom_bytes / 1.125 / 1.0;
+	uint64_t n = (uint64_t)std::round(sz);
+	uint64_t rem = n % 64;
+	return rem ? n + 64 - rem : n;
+}
+
+template <class BE>
+class Session {
+  public:
+	std::string error;
+	BE be;
+	Engine<BE>* eng = nullptr;
+	Config cfg;
+
+	template <class... A>
+	explicit Session(A&&... a) : be(std::forward<A>(a)...) {}
+	~Session() { delete eng; }
+
+	int create(const abg_params& p)
+	{
+		if (p.k < 2 || p.k > ABG_MAX_KMER) return fail(ABG_EINVAL, "k must be in 2.." + std::to_string(ABG_MAX_KMER));
+		if (p.num_hashes < 1 || p.num_hashes > ABG_MAX_HASHES) return fail(ABG_EINVAL, "num_hashes must be in 1..32");
+		if (p.spaced_seed && p.spaced_seed[0]) return fail(ABG_EINVAL, "spaced seeds (-s/-K/--qr-seed) are not supported yet");
+		cfg.k = p.k; cfg.nh = p.num_hashes; cfg.kc = p.min_cov;
+		cfg.trim = (p.trim == 0xFFFFFFFFu) ? p.k : p.trim;
+		cfg.counters = p.counters ? p.counters : counters_for_budget(p.bloom_bytes);
+		if (!cfg.counters) return fail(ABG_EINVAL, "bloom_bytes / counters must be > 0");
+		cfg.verbose = p.verbose;
+		if (p.insert_batch_kmers) cfg.insert_batch_kmers = p.insert_batch_kmers;
+		if (p.claim_log2) cfg.claim_log2 = p.claim_log2;
+		if (p.walk_slots) cfg.walk_slots = p.walk_slots;
+		if (p.wtab_log2) cfg.wtab_log2 = p.wtab_log2;
+		if (const char* e = getenv("ABG_CLAIM_LOG2")) cfg.claim_log2 = (uint32_t)atoi(e);
+		if (const char* e = getenv("ABG_INSERT_BATCH")) cfg.insert_batch_kmers = strtoull(e, 0, 10);
+		if (const char* e = getenv("ABG_WALK_SLOTS")) cfg.walk_slots = (uint32_t)atoi(e);
+		if (const char* e = getenv("ABG_WTAB_LOG2")) cfg.wtab_log2 = (uint32_t)atoi(e);
+		if (const char* e = getenv("ABG_P2_FIRST_BATCH")) cfg.p2_first_batch = strtoull(e, 0, 10);
+		if (const char* e = getenv("ABG_P2_MAX_BATCH")) cfg.p2_max_batch = strtoull(e, 0, 10);
+		if (!be.ok()) return fail(ABG_ENODEV, be.why());
+		eng = new Engine<BE>(be, cfg);
+		return ABG_OK;
+	}
+
+	// ------------------------------------------------------------------ PASS 1
+	int load_seqs(const char* seqs, const uint64_t* off, uint64_t n)
+	{
+		const uint32_t k = cfg.k;
+		// longest piece handed to the device as one sequence; longer ACGT runs are cut into
+		// pieces overlapping by k-1 bases, which yields the same k-mers in the same order
+		const uint32_t max_piece = (uint32_t)std::min<uint64_t>(1u << 20, cfg.insert_batch_kmers + k - 1);
+		HostBatch hb;
+		std::string up;
+		for (uint64_t i = 0; i < n; i++) {
+			const char* s = seqs + off[i];
+			uint64_t L = off[i + 1] - off[i];
+			if (L < k) continue; // RollingHashIterator.h:37-40
+			up.assign(s, L);
+			for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
+			uint64_t a = 0;
+			while (a < L) {
+				while (a < L && !is_acgt(up[a])) a++;
+				uint64_t b = a;
+				while (b < L && is_acgt(up[b])) b++;
+				if (b - a >= k) {
+					for (uint64_t q = a; q + k <= b;) {
+						uint64_t e = std::min<uint64_t>(b, q + max_piece);
+						hb.add_ascii(up.data() + q, (uint32_t)(e - q), k);
+						if (e == b) break;
+						q = e - (k - 1);
+					}
+				}
+				a = b;
+			}
+			if (hb.koff.back() >= cfg.insert_batch_kmers) { flush_load(hb); hb.clear(); }
+		}
+		if (hb.n()) flush_load(hb);
+		return ABG_OK;
+	}
+	int load_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
+	{
+		if (!n) return ABG_OK;
+		std::vector<uint32_t> len(n);
+		be.d2h(len.data(), d_len, n * 4);
+		std::vector<uint64_t> koff(n + 1, 0);
+		for (uint64_t i = 0; i < n; i++) {
+			if (len[i] < cfg.k) return fail(ABG_EINVAL, "packed sequence shorter than k");
+			koff[i + 1] = koff[i] + (len[i] - cfg.k + 1);
+		}
+		uint64_t* koff_d = (uint64_t*)be.alloc((n + 1) * 8);
+		be.h2d(koff_d, koff.data(), (n + 1) * 8);
+		Batch b{ d_words, d_woff, d_len, koff_d, n };
+		eng->load_packed(b, koff.data());
+		be.free(koff_d);
+		return ABG_OK;
+	}
+
+	// ------------------------------------------------------------------ PASS 2
+	int assemble_seqs(const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
+	    abg_contig_cb cb, void* user)
+	{
+		const uint32_t k = cfg.k;
+		HostBatch hb;
+		std::vector<uint64_t> orig; // packed index -> caller index
+		std::vector<uint8_t> res(n, (uint8_t)RR_UNINITIALIZED);
+		std::string up;
+		for (uint64_t i = 0; i < n; i++) {
+			const char* s = seqs + off[i];
+			uint64_t L = off[i + 1] - off[i];
+			if (L < k) { res[i] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
+			up.assign(s, L);
+			bool ok = true;
+			for (auto& ch : up) { ch = (char)toupper((unsigned char)ch); ok = ok && is_acgt(ch); }
+			if (!ok) { res[i] = RR_NON_ACGT; continue; }            // allACGT, bloom-dbg.h:808
+			hb.add_ascii(up.data(), (uint32_t)L, k);
+			orig.push_back(i);
+		}
+		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
+		// ones rejected above; the engine counts the ones it sees
+		Counters c0 = eng->counters();
+		c0.reads_processed += n - hb.n();
+		eng->set_counters(c0);
+		if (hb.n()) {
+			DevBatch d = upload(hb);
+			std::vector<uint8_t> pres(hb.n());
+			auto sink = [&](const ContigOut& o) {
+				if (!cb) return;
+				abg_contig c;
+				c.contig_id = o.contig_id; c.read_index = orig[o.read_index];
+				c.seq = o.seq.c_str(); c.length = (uint32_t)o.seq.size(); c.coverage = o.coverage;
+				c.redundant = o.redundant; c.left_ext = o.left_ext; c.right_ext = o.right_ext;
+				c.left_code = o.left_code; c.right_code = o.right_code; c.seed_pos = o.seed_pos;
+				cb(user, &c);
+			};
+			eng->assemble_packed(d.b, pres.data(), sink);
+			release(d);
+			for (uint64_t j = 0; j < hb.n(); j++) res[orig[j]] = pres[j];
+		}
+		if (results) memcpy(results, res.data(), n);
+		return ABG_OK;
+	}
+	int assemble_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len,
+	    uint64_t n, uint8_t* results, abg_contig_cb cb, void* user)
+	{
+		if (!n) return ABG_OK;
+		Batch b{ d_words, d_woff, d_len, d_woff /* unused in pass 2 */, n };
+		auto sink = [&](const ContigOut& o) {
+			if (!cb) return;
+			abg_contig c;
+			c.contig_id = o.contig_id; c.read_index = o.read_index;
+			c.seq = o.seq.c_str(); c.length = (uint32_t)o.seq.size(); c.coverage = o.coverage;
+			c.redundant = o.redundant; c.left_ext = o.left_ext; c.right_ext = o.right_ext;
+			c.left_code = o.left_code; c.right_code = o.right_code; c.seed_pos = o.seed_pos;
+			cb(user, &c);
+		};
+		eng->assemble_packed(b, results, sink);
+		return ABG_OK;
+	}
+
+	// ------------------------------------------------------------------ probes
+	int hash_seq(const char* seq, uint64_t len, uint32_t* pos_out, uint64_t* hashes_out,
+	    uint64_t cap, uint64_t* n_out)
+	{
+		const uint32_t k = cfg.k;
+		HostBatch hb;
+		std::vector<uint32_t> start; // start position of each packed piece
+		std::string up(seq, len);
+		for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
+		uint64_t a = 0;
+		while (a < len) {
+			while (a < len && !is_acgt(up[a])) a++;
+			uint64_t b = a;
+			while (b < len && is_acgt(up[b])) b++;
+			if (b - a >= k) { hb.add_ascii(up.data() + a, (uint32_t)(b - a), k); start.push_back((uint32_t)a); }
+			a = b;
+		}
+		uint64_t T = hb.koff.back();
+		*n_out = T;
+		if (!T) return ABG_OK;
+		DevBatch d = upload(hb);
+		uint64_t* h0 = (uint64_t*)be.alloc(T * 8);
+		uint64_t* all = (uint64_t*)be.alloc(T * 8 * cfg.nh);
+		FHash fh{ eng->params(), d.b, h0 };
+		be.launch(T, fh, "hash");
+		FExpand fe{ eng->params(), h0, all };
+		be.launch(T, fe, "expand");
+		std::vector<uint64_t> host(T * cfg.nh);
+		be.d2h(host.data(), all, T * 8 * cfg.nh);
+		uint64_t t = 0;
+		for (uint64_t s = 0; s < hb.n(); s++)
+			for (uint32_t j = 0; j + k <= hb.len[s]; j++, t++) {
+				if (t >= cap) continue;
+				if (pos_out) pos_out[t] = start[s] + j;
+				if (hashes_out) memcpy(hashes_out + t * cfg.nh, host.data() + t * cfg.nh, 8 * cfg.nh);
+			}
+		be.free(h0); be.free(all);
+		release(d);
+		return ABG_OK;
+	}
+
+	int fail(int code, const std::string& msg) { error = msg; return code; }
+
+  private:
+	static bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+	struct DevBatch { Batch b; void* words; void* woff; void* len; void* koff; };
+	DevBatch upload(const HostBatch& hb)
+	{
+		DevBatch d;
+		d.words = be.alloc(std::max<size_t>(hb.words.size(), 1) * 4 + 64);
+		d.woff = be.alloc(hb.woff.size() * 8);
+		d.len = be.alloc(std::max<size_t>(hb.len.size(), 1) * 4);
+		d.koff = be.alloc(hb.koff.size() * 8);
+		be.h2d(d.words, hb.words.data(), hb.words.size() * 4);
+		be.h2d(d.woff, hb.woff.data(), hb.woff.size() * 8);
+		be.h2d(d.len, hb.len.data(), hb.len.size() * 4);
+		be.h2d(d.koff, hb.koff.data(), hb.koff.size() * 8);
+		d.b = Batch{ (const uint32_t*)d.words, (const uint64_t*)d.woff, (const uint32_t*)d.len,
+			(const uint64_t*)d.koff, hb.n() };
+		return d;
+	}
+	void release(DevBatch& d) { be.free(d.words); be.free(d.woff); be.free(d.len); be.free(d.koff); }
+	void flush_load(const HostBatch& hb)
+	{
+		DevBatch d = upload(hb);
+		eng->load_packed(d.b, hb.koff.data());
+		release(d);
+	}
+};
+
+} // namespace abg

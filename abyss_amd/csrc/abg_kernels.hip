@@ -1,0 +1,353 @@
+// abg_kernels.hip -- the gfx950 kernels and the C ABI (include/abyss_amd.h).
+//
+// Kernels are grid-stride wrappers around the functors of abg_engine.h / abg_walk.h:
+//   k_foreach      one item per lane (hash, claim, insert rounds, classify, predict, ...)
+//   k_foreach_w    the same, launched one wave per workgroup so that the <=32768 walkers
+//                  spread over all 256 CUs (each walker is a latency-bound pointer chase)
+//   k_commit       one 1024-thread workgroup: the ordered commit, cooperative per contig
+// Launch geometry: wave = 64 lanes, workgroups of 256 (4 waves), grids capped at
+// 256 CUs x 8 workgroups and grid-strided beyond that.
+//
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
+#include <hip/hip_runtime.h>
+
+#include "abg_host.h"
+
+#include <chrono>
+#include <map>
+#include <mutex>
+
+namespace {
+
+template <class F>
+__global__ void __launch_bounds__(256) k_foreach(F f, uint64_t n)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	const uint32_t slot = (uint32_t)i;
+	for (; i < n; i += stride) f(i, slot);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	const uint32_t slot = (uint32_t)i;
+	for (; i < n; i += stride) f(i, slot);
+}
+
+constexpr int COMMIT_THREADS = 1024;
+struct DeviceSync {
+	uint32_t* sh; // [COMMIT_THREADS / 64 + 2] shared words
+	__device__ uint32_t tid() const { return threadIdx.x; }
+	__device__ uint32_t nthreads() const { return blockDim.x; }
+	__device__ void barrier() { __syncthreads(); }
+	__device__ bool all(bool v) { return __syncthreads_and(v ? 1 : 0) != 0; }
+	__device__ uint32_t sum(uint32_t v)
+	{
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+		__syncthreads();
+		uint32_t t = 0;
+		for (unsigned w = 0; w < blockDim.x / 64; w++) t += sh[w];
+		__syncthreads();
+		return t;
+	}
+	__device__ uint32_t bcast(uint32_t v)
+	{
+		__syncthreads();
+		if (threadIdx.x == 0) sh[COMMIT_THREADS / 64] = v;
+		__syncthreads();
+		uint32_t r = sh[COMMIT_THREADS / 64];
+		__syncthreads();
+		return r;
+	}
+};
+template <int NW>
+__global__ void __launch_bounds__(COMMIT_THREADS) k_commit(abg::CommitEnv<NW> e, uint32_t c_begin, uint32_t c_end)
+{
+	__shared__ uint32_t sh[COMMIT_THREADS / 64 + 2];
+	DeviceSync sy{ sh };
+	abg::commit_candidates<NW>(e, c_begin, c_end, sy);
+}
+
+struct ProfEntry { double ms = 0; uint64_t launches = 0; };
+
+struct HipBackend {
+	int device = 0;
+	bool good = false;
+	std::string reason;
+	hipStream_t stream = nullptr;
+	bool profiling = false;
+	std::map<std::string, ProfEntry> prof;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	uint32_t cus = 256;
+
+	explicit HipBackend(int dev = 0) : device(dev)
+	{
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0) { reason = "no HIP device available (abyss_amd has no CPU fallback)"; return; }
+		if (dev < 0 || dev >= n) { reason = "HIP device ordinal out of range"; return; }
+		if (hipSetDevice(dev) != hipSuccess) { reason = "hipSetDevice failed"; return; }
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint32_t)prop.multiProcessorCount;
+		if (hipStreamCreate(&stream) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		hipEventCreate(&ev0);
+		hipEventCreate(&ev1);
+		good = true;
+	}
+	~HipBackend()
+	{
+		if (ev0) hipEventDestroy(ev0);
+		if (ev1) hipEventDestroy(ev1);
+		if (stream) hipStreamDestroy(stream);
+	}
+	bool ok() const { return good; }
+	std::string why() const { return reason; }
+	static void check(hipError_t e, const char* what)
+	{
+		if (e != hipSuccess) {
+			fprintf(stderr, "abyss_amd: %s failed: %s\n", what, hipGetErrorString(e));
+			abort();
+		}
+	}
+	void* alloc(size_t n)
+	{
+		void* p = nullptr;
+		hipSetDevice(device);
+		check(hipMalloc(&p, n ? n : 1), "hipMalloc");
+		return p;
+	}
+	void free(void* p) { if (p) { hipStreamSynchronize(stream); hipFree(p); } }
+	void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
+	void h2d(void* d, const void* s, size_t n)
+	{
+		if (!n) return;
+		check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
+		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	void d2h(void* d, const void* s, size_t n)
+	{
+		if (!n) return;
+		check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
+		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+	uint32_t max_slots() const { return cus * 8 * 256; }
+
+	void begin(const char*) { if (profiling) hipEventRecord(ev0, stream); }
+	void end(const char* name)
+	{
+		check(hipGetLastError(), name);
+		if (!profiling) return;
+		hipEventRecord(ev1, stream);
+		hipEventSynchronize(ev1);
+		float ms = 0;
+		hipEventElapsedTime(&ms, ev0, ev1);
+		ProfEntry& p = prof[name];
+		p.ms += ms;
+		p.launches++;
+	}
+	template <class F>
+	void launch(uint64_t n, F f, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = (n + 255) / 256;
+		uint64_t cap = (uint64_t)cus * 8;
+		if (blocks > cap) blocks = cap;
+		begin(name);
+		hipLaunchKernelGGL(k_foreach<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
+		end(name);
+	}
+	template <class F>
+	void launch_slots(uint64_t n, F f, uint32_t slots, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = (n + 63) / 64;
+		uint64_t cap = slots / 64 ? slots / 64 : 1;
+		if (blocks > cap) blocks = cap;
+		begin(name);
+		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
+		end(name);
+	}
+	template <int NW>
+	void launch_commit(abg::CommitEnv<NW> e, uint32_t c_begin, uint32_t c_end)
+	{
+		begin("commit");
+		hipLaunchKernelGGL(k_commit<NW>, dim3(1), dim3(COMMIT_THREADS), 0, stream, e, c_begin, c_end);
+		end("commit");
+	}
+};
+
+typedef abg::Session<HipBackend> Sess;
+
+std::mutex g_err_mutex;
+std::string g_create_error;
+
+} // namespace
+
+struct abg_ctx {
+	Sess s;
+	explicit abg_ctx(int dev) : s(dev) {}
+};
+
+extern "C" {
+
+void abg_params_init(abg_params* p)
+{
+	memset(p, 0, sizeof *p);
+	p->num_hashes = 4;
+	p->min_cov = 2;
+	p->trim = 0xFFFFFFFFu;
+}
+
+int abg_create(const abg_params* p, abg_ctx** out)
+{
+	if (!p || !out) return ABG_EINVAL;
+	*out = nullptr;
+	abg_ctx* c = new abg_ctx(p->device);
+	int rc = c->s.create(*p);
+	if (rc != ABG_OK) {
+		std::lock_guard<std::mutex> g(g_err_mutex);
+		g_create_error = c->s.error;
+		delete c;
+		return rc;
+	}
+	*out = c;
+	return ABG_OK;
+}
+void abg_destroy(abg_ctx* ctx) { delete ctx; }
+const char* abg_last_error(const abg_ctx* ctx)
+{
+	if (ctx) return ctx->s.error.c_str();
+	return g_create_error.c_str();
+}
+int abg_filter_size(const abg_ctx* ctx, uint64_t* counters)
+{
+	if (!ctx || !counters) return ABG_EINVAL;
+	*counters = ctx->s.eng->size();
+	return ABG_OK;
+}
+int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n)
+{
+	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
+	return ctx->s.load_seqs(seqs, offsets, n);
+}
+int abg_load_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
+{
+	if (!ctx || (n && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
+	return ctx->s.load_packed(d_words, d_woff, d_len, n);
+}
+int abg_counting_stats(abg_ctx* ctx, uint64_t* popcount, uint64_t* filtered_popcount)
+{
+	if (!ctx) return ABG_EINVAL;
+	uint64_t a = 0, b = 0;
+	ctx->s.eng->popcounts(&a, &b);
+	if (popcount) *popcount = a;
+	if (filtered_popcount) *filtered_popcount = b;
+	return ABG_OK;
+}
+int abg_counters_export(abg_ctx* ctx, uint8_t* host_out)
+{
+	if (!ctx || !host_out) return ABG_EINVAL;
+	ctx->s.be.d2h(host_out, ctx->s.eng->counters_dev(), ctx->s.eng->size());
+	return ABG_OK;
+}
+int abg_counters_import(abg_ctx* ctx, const uint8_t* host_in)
+{
+	if (!ctx || !host_in) return ABG_EINVAL;
+	ctx->s.be.h2d(ctx->s.eng->counters_dev(), host_in, ctx->s.eng->size());
+	return ABG_OK;
+}
+int abg_visited_export(abg_ctx* ctx, uint8_t* host_out)
+{
+	if (!ctx || !host_out) return ABG_EINVAL;
+	ctx->s.be.d2h(host_out, ctx->s.eng->visited_dev(), ctx->s.eng->visited_bytes());
+	return ABG_OK;
+}
+int abg_visited_import(abg_ctx* ctx, const uint8_t* host_in)
+{
+	if (!ctx || !host_in) return ABG_EINVAL;
+	ctx->s.be.h2d(ctx->s.eng->visited_dev(), host_in, ctx->s.eng->visited_bytes());
+	return ABG_OK;
+}
+int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
+    uint8_t* results, abg_contig_cb cb, void* user)
+{
+	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
+	return ctx->s.assemble_seqs(seqs, offsets, n, results, cb, user);
+}
+int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
+    const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user)
+{
+	if (!ctx || (n && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
+	return ctx->s.assemble_packed(d_words, d_woff, d_len, n, results, cb, user);
+}
+int abg_get_counters(const abg_ctx* ctx, abg_counters* out)
+{
+	if (!ctx || !out) return ABG_EINVAL;
+	abg::Counters c = ctx->s.eng->counters();
+	out->solid_reads = c.solid_reads;
+	out->visited_reads = c.visited_reads;
+	out->reads_processed = c.reads_processed;
+	out->bases_assembled = c.bases_assembled;
+	out->next_contig_id = c.contig_id;
+	return ABG_OK;
+}
+int abg_set_counters(abg_ctx* ctx, const abg_counters* in)
+{
+	if (!ctx || !in) return ABG_EINVAL;
+	abg::Counters c;
+	c.solid_reads = in->solid_reads;
+	c.visited_reads = in->visited_reads;
+	c.reads_processed = in->reads_processed;
+	c.bases_assembled = in->bases_assembled;
+	c.contig_id = in->next_contig_id;
+	ctx->s.eng->set_counters(c);
+	return ABG_OK;
+}
+int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out, uint64_t* hashes_out,
+    uint64_t cap, uint64_t* n_out)
+{
+	if (!ctx || !seq || !n_out) return ABG_EINVAL;
+	return ctx->s.hash_seq(seq, len, pos_out, hashes_out, cap, n_out);
+}
+int abg_profile_enable(abg_ctx* ctx, int on)
+{
+	if (!ctx) return ABG_EINVAL;
+	ctx->s.be.profiling = on != 0;
+	return ABG_OK;
+}
+int abg_profile_reset(abg_ctx* ctx)
+{
+	if (!ctx) return ABG_EINVAL;
+	ctx->s.be.prof.clear();
+	return ABG_OK;
+}
+int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* launches)
+{
+	if (!ctx || !name) return ABG_EINVAL;
+	auto it = ctx->s.be.prof.find(name);
+	double ms = 0;
+	uint64_t n = 0;
+	if (it != ctx->s.be.prof.end()) { ms = it->second.ms; n = it->second.launches; }
+	if (total_ms) *total_ms = ms;
+	if (launches) *launches = n;
+	return ABG_OK;
+}
+int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
+{
+	if (!ctx || !out) return ABG_EINVAL;
+	auto s = ctx->s.eng->stats();
+	out->insert_rounds = s.insert_rounds;
+	out->walk_rounds = s.rounds;
+	out->candidates = s.candidates;
+	out->walked = s.walked;
+	out->rewalked = s.rewalked;
+	out->commit_breaks = s.breaks;
+	return ABG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,500 @@
+// abg_walk.h -- PASS 2 of abyss-bloom-dbg on the device: the per-read unitig walk
+// (processRead, BloomDBG/bloom-dbg.h:781-882) as a pure function of the read and the
+// read-only solid filter, and the per-k-mer pieces of the ordered commit
+// (outputContig, bloom-dbg.h:538-620).
+//
+// A "walker" owns one candidate read.  Its vertex sets (extendPath's `visited`,
+// processRead's `assembledKmers`) live in one device-wide open-addressing table keyed
+// by (k-mer identity, owner), so walkers never see each other's entries; a separate
+// lossy claim array lets a walker notice that a lower-numbered read already walks the
+// same unitig and stop early (work avoidance only: results never depend on it).
+#pragma once
+#include "abg_core.h"
+
+namespace abg {
+
+// --------------------------------------------------------------- atomics
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint64_t ld_coherent(const uint64_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD uint32_t ld_coherent(const uint32_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD void st_coherent(uint64_t* p, uint64_t v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
+{
+	return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect,
+	    (unsigned long long)val);
+}
+ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v)
+{
+	return (uint64_t)atomicMin((unsigned long long*)p, (unsigned long long)v);
+}
+ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
+{
+	return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
+}
+ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+#else
+// serial execution (tests/hostcheck): one item at a time, plain memory
+ABG_HD uint64_t ld_coherent(const uint64_t* p) { return *p; }
+ABG_HD uint32_t ld_coherent(const uint32_t* p) { return *p; }
+ABG_HD void st_coherent(uint64_t* p, uint64_t v) { *p = v; }
+ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
+{
+	uint64_t old = *p;
+	if (old == expect) *p = val;
+	return old;
+}
+ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
+ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = o + v; return o; }
+ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+#endif
+
+// ---------------------------------------------------------- packed read batch
+// Sequences are pure ACGT, 2 bits per base, 16 bases per 32-bit word, each sequence
+// starting on a word boundary.
+struct Batch {
+	const uint32_t* words;
+	const uint64_t* woff;   // [n + 1] word offset of each sequence
+	const uint32_t* len;    // [n] length in bases
+	const uint64_t* koff;   // [n + 1] prefix sum of k-mer counts (len - k + 1)
+	uint64_t n;
+};
+ABG_HD unsigned batch_base(const Batch& b, uint64_t r, uint32_t i)
+{
+	uint32_t w = b.words[b.woff[r] + (i >> 4)];
+	return (w >> (2 * (i & 15))) & 3u;
+}
+template <int NW>
+ABG_HD Kmer<NW> batch_kmer(const Batch& b, uint64_t r, uint32_t pos, unsigned k)
+{
+	Kmer<NW> s;
+#pragma unroll
+	for (int j = 0; j < NW; j++) s.w[j] = 0;
+	for (unsigned i = 0; i < k; i++)
+		kmer_set(s, i, batch_base(b, r, pos + i));
+	return s;
+}
+// index of the sequence holding k-mer op t (koff[r] <= t < koff[r+1])
+ABG_HD uint64_t find_seq(const uint64_t* koff, uint64_t n, uint64_t t)
+{
+	uint64_t lo = 0, hi = n; // invariant: koff[lo] <= t < koff[hi]
+	while (hi - lo > 1) {
+		uint64_t mid = (lo + hi) >> 1;
+		if (koff[mid] <= t) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// ---------------------------------------------------------------- vertex table
+constexpr uint64_t WT_EMPTY = ~0ULL;
+constexpr uint32_t WT_TOMB = 0xFFFFFFFEu;      // contig field of a tombstoned entry
+constexpr uint64_t WT_TIE_SALT = 0x9E3779B97F4A7C15ULL;
+struct WalkTab {
+	uint64_t* hmin;   // [cap]  WT_EMPTY when free
+	uint64_t* hmax;   // [cap]
+	uint64_t* meta;   // [cap]  owner << 32 | contig
+	uint64_t mask;    // cap - 1 (cap is a power of two)
+};
+// identity of a vertex under RollingBloomDBGVertex::operator== (see vtx_equal)
+template <int NW>
+ABG_HD VKey vtx_key(const Params& p, const Vtx<NW>& v)
+{
+	VKey key;
+	bool f_lt = v.fh < v.rh;
+	key.fh = f_lt ? v.fh : v.rh; // min
+	key.rh = f_lt ? v.rh : v.fh; // max
+	if ((p.k & 1) && kmer_is_tie(v.s, p.k) && f_lt) key.rh ^= WT_TIE_SALT;
+	if (key.fh == WT_EMPTY) key.fh = WT_EMPTY - 1;
+	return key;
+}
+ABG_HD uint64_t wt_slot(const WalkTab& t, const VKey& key, uint32_t owner)
+{
+	uint64_t x = key.fh ^ ((uint64_t)(owner + 1) * 0xD6E8FEB86659FD93ULL);
+	x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29;
+	return x & t.mask;
+}
+enum { WT_NEW = 0, WT_SAME_CONTIG = 1, WT_EARLIER = 2, WT_FULL = 3 };
+// insert (key, owner) with contig number; returns WT_NEW (also when reviving a
+// tombstone), WT_SAME_CONTIG (already inserted by this contig walk: a cycle),
+// WT_EARLIER (inserted by an earlier contig of the same read; now re-tagged) or WT_FULL.
+ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t contig)
+{
+	uint64_t s = wt_slot(t, key, owner);
+	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
+		uint64_t cur = ld_coherent(&t.hmin[s]);
+		if (cur == WT_EMPTY) {
+			uint64_t old = cas_u64(&t.hmin[s], WT_EMPTY, key.fh);
+			if (old == WT_EMPTY) {
+				st_coherent(&t.hmax[s], key.rh);
+				st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
+				return WT_NEW;
+			}
+			cur = old;
+		}
+		if (cur != key.fh) continue;
+		uint64_t m = ld_coherent(&t.meta[s]);
+		if ((uint32_t)(m >> 32) != owner) continue;
+		if (ld_coherent(&t.hmax[s]) != key.rh) continue;
+		uint32_t c = (uint32_t)m;
+		if (c == contig) return WT_SAME_CONTIG;
+		st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
+		return c == WT_TOMB ? WT_NEW : WT_EARLIER;
+	}
+	return WT_FULL;
+}
+// returns the slot of (key, owner) or WT_EMPTY
+ABG_HD uint64_t wt_find(const WalkTab& t, const VKey& key, uint32_t owner)
+{
+	uint64_t s = wt_slot(t, key, owner);
+	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
+		uint64_t cur = ld_coherent(&t.hmin[s]);
+		if (cur == WT_EMPTY) return WT_EMPTY;
+		if (cur != key.fh) continue;
+		uint64_t m = ld_coherent(&t.meta[s]);
+		if ((uint32_t)(m >> 32) != owner) continue;
+		if (ld_coherent(&t.hmax[s]) != key.rh) continue;
+		return s;
+	}
+	return WT_EMPTY;
+}
+
+// ------------------------------------------------------------- walker output
+enum WalkStatus : uint32_t {
+	WS_NONE = 0,      // not walked yet
+	WS_COMPLETE = 1,  // all contigs of the read recorded
+	WS_DEFERRED = 2,  // ran into a unitig claimed by a lower-numbered read
+	WS_OVERFLOW = 3   // a capacity (stack, path buffer, pool, table, records) was exceeded
+};
+struct ContigRec {
+	uint64_t seq_off;     // offset of the sequence in the contig pool (1 byte per base, 0..3)
+	uint32_t len;         // bases
+	uint32_t cand;        // candidate that produced it
+	uint32_t next;        // next record of the same candidate (UINT32_MAX = end)
+	uint32_t seed_pos;    // read k-mer index that seeded the walk
+	uint32_t left_ext, right_ext;
+	uint8_t left_code, right_code;
+	uint8_t redundant;    // filled by the commit
+	uint8_t pad_;
+	uint32_t coverage;    // filled by the commit
+	uint64_t contig_id;   // filled by the commit
+};
+constexpr uint32_t REC_END = 0xFFFFFFFFu;
+
+template <int NW>
+struct WalkEnv {
+	Params p;
+	const uint8_t* cnt;       // solid filter (read-only in pass 2)
+	Batch batch;
+	const uint32_t* cand_read; // [ncand] read index of each candidate (ascending)
+	uint32_t* status;          // [ncand] WalkStatus
+	uint32_t* first_rec;       // [ncand]
+	WalkTab tab;
+	uint32_t* claims;          // lossy claim array (NULL: private mode, never defer)
+	uint32_t claim_mask;
+	uint32_t owner_base;       // owner ids of this launch are owner_base + candidate index
+	// per-slot scratch
+	TBFrame<NW>* tb_pool; uint32_t tb_cap;
+	VKey* la_pool;
+	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
+	// contig output
+	uint8_t* pool; uint64_t pool_cap; uint64_t* pool_used;
+	ContigRec* recs; uint32_t rec_cap; uint32_t* rec_used;
+};
+
+// The path of one contig walk: reverse(lbuf[0..nl)) + seed + rbuf[0..nr), materialised
+// into the pool (one slack base either side) once both extensions are done.
+template <int NW>
+struct WalkState {
+	Vtx<NW> seed;
+	uint8_t* lbuf; uint8_t* rbuf;
+	uint32_t nl, nr;
+};
+template <int NW>
+ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
+{
+	if (j < w.nl) return w.lbuf[w.nl - 1 - j];
+	j -= w.nl;
+	if (j < p.k) return kmer_get(w.seed.s, j);
+	return w.rbuf[j - p.k];
+}
+template <int NW>
+ABG_HDN Vtx<NW> ws_vertex(const Params& p, const WalkState<NW>& w, uint32_t i)
+{
+	Vtx<NW> v;
+#pragma unroll
+	for (int j = 0; j < NW; j++) v.s.w[j] = 0;
+	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, ws_base(p, w, i + j));
+	vtx_rehash(p, v);
+	return v;
+}
+template <int NW>
+ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i)
+{
+	Vtx<NW> v;
+#pragma unroll
+	for (int j = 0; j < NW; j++) v.s.w[j] = 0;
+	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, seq[i + j]);
+	vtx_rehash(p, v);
+	return v;
+}
+
+// extendPath (ExtendPath.h:620-706) with the ExtendPathParams of processRead
+// (bloom-dbg.h:845-850): trimLen = trim, fpTrim = 5, no length limit, lookBehind = true,
+// lookBehindStartVertex = false; extendPathBySingleVertex (:403-459) inlined.
+// Returns the ExtCode, or -1 when the walker must stop (status written to *abort).
+template <int NW>
+ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owner, uint32_t contig,
+    uint32_t claim_id, SearchScratch<NW>& sc, uint32_t* ext_out, uint32_t* abort, bool* end_earlier)
+{
+	const Params& p = e.p;
+	int other = (dir == FORWARD) ? REVERSE : FORWARD;
+	uint32_t n = w.nl + 1 + w.nr;
+	Vtx<NW> head = (dir == FORWARD) ? ws_vertex(p, w, n - 1) : ws_vertex(p, w, 0);
+	Vtx<NW> prev = head;
+	if (n > 1) prev = (dir == FORWARD) ? ws_vertex(p, w, n - 2) : ws_vertex(p, w, 1);
+	uint32_t ext = 0;
+	bool look_behind = false;
+	int result;
+	for (;;) {
+		Vtx<NW> t, v;
+		if (look_behind) {
+			result = successor(p, e.cnt, head, other, p.trim, t, sc);
+			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
+			if (n > 1) {
+				if (result == ER_DEAD_END) { result = ER_AMBI_IN; break; }
+				if (!vtx_equal(p, prev, t)) { result = ER_AMBI_IN; break; }
+			}
+		}
+		result = successor(p, e.cnt, head, dir, p.trim, v, sc);
+		if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
+		if (result != ER_LENGTH_LIMIT) break;
+		// path.push_back(v) / push_front(v)
+		if (dir == FORWARD) {
+			if (w.nr >= e.buf_cap) { *abort = WS_OVERFLOW; return -1; }
+			w.rbuf[w.nr++] = (uint8_t)kmer_get(v.s, p.k - 1);
+		} else {
+			if (w.nl >= e.buf_cap) { *abort = WS_OVERFLOW; return -1; }
+			w.lbuf[w.nl++] = (uint8_t)kmer_get(v.s, 0);
+		}
+		n++; ext++;
+		// visited.insert(head), ExtendPath.h:650-658
+		int ins = wt_insert(e.tab, vtx_key(p, v), owner, contig);
+		if (ins == WT_FULL) { *abort = WS_OVERFLOW; return -1; }
+		if (ins == WT_SAME_CONTIG) {
+			result = ER_CYCLE;
+			if (dir == FORWARD) w.nr--; else w.nl--;
+			n--; ext--;
+			break;
+		}
+		*end_earlier = (ins == WT_EARLIER);
+		if (e.claims) {
+			uint64_t hm = v.fh < v.rh ? v.fh : v.rh;
+			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
+			if (old < claim_id) { *abort = WS_DEFERRED; return -1; }
+		}
+		prev = head;
+		head = v;
+		look_behind = true;
+	}
+	if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
+	*ext_out = ext;
+	return result;
+}
+
+// isTip (bloom-dbg.h:759-776)
+ABG_HD bool is_tip(unsigned length, int left, int right, unsigned trim)
+{
+	if (length > trim) return false;
+	if (left == ER_DEAD_END && (right == ER_DEAD_END || right == ER_AMBI_IN)) return true;
+	if (right == ER_DEAD_END && (left == ER_DEAD_END || left == ER_AMBI_IN)) return true;
+	return false;
+}
+
+enum { CT_LINEAR = 0, CT_CIRCULAR = 1, CT_HAIRPIN = 2 };
+
+// ambiguous(u, dir) (ExtendPath.h:368-374)
+template <int NW>
+ABG_HDN bool ambiguous1(const Params& p, const uint8_t* cnt, const Vtx<NW>& u, int dir,
+    SearchScratch<NW>& sc)
+{
+	Vtx<NW> v;
+	return successor(p, cnt, u, dir, p.trim, v, sc) == ER_AMBI_OUT;
+}
+// ambiguous(u, expected, dir) (ExtendPath.h:383-397)
+template <int NW>
+ABG_HDN bool ambiguous2(const Params& p, const uint8_t* cnt, const Vtx<NW>& u, const Vtx<NW>& expected,
+    int dir, SearchScratch<NW>& sc)
+{
+	Vtx<NW> v;
+	int r = successor(p, cnt, u, dir, p.trim, v, sc);
+	return r == ER_AMBI_OUT || (r == ER_LENGTH_LIMIT && !vtx_equal(p, v, expected));
+}
+
+// One candidate read: the loop of processRead (bloom-dbg.h:839-879).
+template <int NW>
+ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
+{
+	const Params& p = e.p;
+	const unsigned k = p.k;
+	SearchScratch<NW> sc;
+	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
+	sc.tb_cap = e.tb_cap;
+	sc.overflow = 0;
+	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
+
+	WalkState<NW> w;
+	w.lbuf = e.lbuf_pool + (uint64_t)slot * e.buf_cap;
+	w.rbuf = e.rbuf_pool + (uint64_t)slot * e.buf_cap;
+
+	const uint64_t r = e.cand_read[c];
+	const uint32_t L = e.batch.len[r];
+	const uint32_t nk = L - k + 1;
+	const uint32_t owner = e.owner_base + c;
+	const uint32_t claim_id = c;
+	uint32_t first = REC_END, last = REC_END, contig = 0;
+	uint32_t abort_status = 0;
+
+	Vtx<NW> cur;
+	cur.s = batch_kmer<NW>(e.batch, r, 0, k);
+	vtx_rehash(p, cur);
+	for (uint32_t it = 0; it < nk; it++) {
+		if (it > 0) vtx_shift(p, cur, SENSE, batch_base(e.batch, r, it + k - 1));
+		VKey ckey = vtx_key(p, cur);
+		// assembledKmers.find(*it), bloom-dbg.h:842
+		uint64_t fs = wt_find(e.tab, ckey, owner);
+		if (fs != WT_EMPTY && (uint32_t)ld_coherent(&e.tab.meta[fs]) != WT_TOMB) continue;
+
+		w.seed = cur; w.nl = 0; w.nr = 0;
+		int ins = wt_insert(e.tab, ckey, owner, contig);
+		if (ins == WT_FULL) { abort_status = WS_OVERFLOW; break; }
+		bool seed_earlier = (ins == WT_EARLIER);
+		bool left_earlier = seed_earlier, right_earlier = seed_earlier;
+		if (e.claims) {
+			uint64_t hm = ckey.fh;
+			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
+			if (old < claim_id) { abort_status = WS_DEFERRED; break; }
+		}
+		uint32_t lext = 0, rext = 0;
+		int lcode = walk_extend(e, w, REVERSE, owner, contig, claim_id, sc, &lext, &abort_status, &left_earlier);
+		if (lcode < 0) break;
+		int rcode = walk_extend(e, w, FORWARD, owner, contig, claim_id, sc, &rext, &abort_status, &right_earlier);
+		if (rcode < 0) break;
+		uint32_t n = w.nl + 1 + w.nr;
+
+		if (!is_tip(n, lcode, rcode, p.trim)) {
+			// materialise the path: S = reverse(lbuf) + seed + rbuf, one slack base each side
+			uint64_t need = (uint64_t)n + k - 1 + 2;
+			uint64_t off = atomic_add_u64(e.pool_used, need);
+			if (off + need > e.pool_cap) { abort_status = WS_OVERFLOW; break; }
+			uint8_t* S = e.pool + off + 1;
+			uint64_t slen = (uint64_t)n + k - 1;
+			for (uint64_t j = 0; j < slen; j++) S[j] = (uint8_t)ws_base(p, w, (uint32_t)j);
+			int64_t lo = 0, hi = (int64_t)n; // path = vertices [lo, hi) over S
+			// ---- trimBranchKmers (bloom-dbg.h:723-757)
+			Vtx<NW> popped[2]; bool popped_earlier[2]; int npopped = 0;
+			if (n > 1) {
+				Vtx<NW> front = pool_vertex<NW>(p, S, 0), back = pool_vertex<NW>(p, S, n - 1);
+				// getContigType (bloom-dbg.h:629-645): edge(back, front) via adjacency (RollingBloomDBG.h:558-574)
+				int type = CT_LINEAR;
+				{
+					uint64_t nfh[4], nrh[4];
+					unsigned mask = neighbour_mask(p, e.cnt, back, SENSE, nfh, nrh);
+					bool edge = false;
+					for (unsigned b = 0; b < 4; b++) {
+						if (!((mask >> b) & 1u)) continue;
+						Vtx<NW> x = make_neighbour(p, back, SENSE, b, nfh[b], nrh[b]);
+						if (vtx_equal(p, x, front)) { edge = true; break; }
+					}
+					if (edge) {
+						Vtx<NW> x = front;
+						vtx_shift(p, x, ANTISENSE, kmer_get(back.s, 0));
+						type = kmer_equal(x.s, back.s) ? CT_CIRCULAR : CT_HAIRPIN;
+					}
+				}
+				// preprocessCircularContig (bloom-dbg.h:648-702)
+				if (type != CT_LINEAR && n > 2) {
+					bool bstart = ambiguous1(p, e.cnt, front, FORWARD, sc) || ambiguous1(p, e.cnt, front, REVERSE, sc);
+					bool bend = ambiguous1(p, e.cnt, back, FORWARD, sc) || ambiguous1(p, e.cnt, back, REVERSE, sc);
+					if (bstart && !bend) {
+						// push_back(front) or push_back(rc(front)): one more base on the right
+						unsigned nb = (type == CT_CIRCULAR) ? kmer_get(front.s, k - 1) : 3u - kmer_get(front.s, 0);
+						S[hi + k - 1] = (uint8_t)nb;
+						hi++;
+					} else if (!bstart && bend) {
+						unsigned nb = (type == CT_CIRCULAR) ? kmer_get(back.s, 0) : 3u - kmer_get(back.s, k - 1);
+						S[lo - 1] = (uint8_t)nb;
+						lo--;
+					}
+				}
+				int64_t l = hi - lo;
+				Vtx<NW> p0 = pool_vertex<NW>(p, S, lo), p1 = pool_vertex<NW>(p, S, lo + 1);
+				Vtx<NW> q1 = pool_vertex<NW>(p, S, hi - 1), q2 = pool_vertex<NW>(p, S, hi - 2);
+				(void)l;
+				bool amb1 = ambiguous2(p, e.cnt, p0, p1, FORWARD, sc);
+				bool amb2 = ambiguous2(p, e.cnt, q1, q2, REVERSE, sc);
+				if (amb1) { popped[npopped] = p0; popped_earlier[npopped] = (lo == 0) ? (w.nl ? left_earlier : seed_earlier) : true; npopped++; lo++; }
+				if (amb2) { popped[npopped] = q1; popped_earlier[npopped] = (hi == (int64_t)n) ? (w.nr ? right_earlier : seed_earlier) : true; npopped++; hi--; }
+			}
+			if (sc.overflow) { abort_status = WS_OVERFLOW; break; }
+			// ---- record for outputContig
+			uint32_t ri = atomic_add_u32(e.rec_used, 1);
+			if (ri >= e.rec_cap) { abort_status = WS_OVERFLOW; break; }
+			ContigRec& rec = e.recs[ri];
+			rec.seq_off = off + 1 + (uint64_t)lo;
+			rec.len = (uint32_t)(hi - lo) + k - 1;
+			rec.cand = c; rec.next = REC_END; rec.seed_pos = it;
+			rec.left_ext = lext; rec.right_ext = rext;
+			rec.left_code = (uint8_t)lcode; rec.right_code = (uint8_t)rcode;
+			rec.redundant = 0; rec.pad_ = 0; rec.coverage = 0; rec.contig_id = ~0ULL;
+			if (last == REC_END) first = ri; else e.recs[last].next = ri;
+			last = ri;
+			// ---- assembledKmers.insert(contigPath): vertices trimmed off the ends are not
+			// part of the contig; forget them unless an earlier contig of this read holds them
+			// or the same vertex is still an end of the path (circular / hairpin duplicates)
+			if (npopped) {
+				Vtx<NW> nf = pool_vertex<NW>(p, S, lo), nb = pool_vertex<NW>(p, S, hi - 1);
+				for (int q = 0; q < npopped; q++) {
+					if (popped_earlier[q]) continue;
+					if (hi > lo && (vtx_equal(p, popped[q], nf) || vtx_equal(p, popped[q], nb))) continue;
+					uint64_t s = wt_find(e.tab, vtx_key(p, popped[q]), owner);
+					if (s != WT_EMPTY) st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB);
+				}
+			}
+		}
+		contig++;
+	}
+	e.first_rec[c] = first;
+	e.status[c] = abort_status ? abort_status : (uint32_t)WS_COMPLETE;
+}
+
+// ------------------------------------------------------------ commit helpers
+// canonicalize(Sequence&) (Common/Sequence.h:39-44) applied to the k-mer at seq[0..k):
+// returns the vertex of whichever of the k-mer / its reverse complement is
+// lexicographically smaller as a string.
+template <int NW>
+ABG_HDN Vtx<NW> canonical_end_vertex(const Params& p, const uint8_t* seq)
+{
+	Vtx<NW> v = pool_vertex<NW>(p, seq, 0);
+	// rc < seq ?
+	bool rc_less = false;
+	for (unsigned i = 0; i < p.k; i++) {
+		unsigned a = 3u - kmer_get(v.s, p.k - 1 - i), b = kmer_get(v.s, i);
+		if (a != b) { rc_less = a < b; break; }
+	}
+	if (rc_less) vtx_revcomp(p, v);
+	return v;
+}
+
+} // namespace abg

@@ -1,0 +1,174 @@
+/*
+ * abyss_amd.h -- C ABI of the MI355X-native Bloom-filter de Bruijn graph unitig stage.
+ *
+ * The reference (bcgsc/abyss 2.3.10) has no FFI seam for this path: abyss-bloom-dbg is
+ * header-template C++ instantiated into one binary.  The seam it
+ * does have is (1) the process boundary -- the abyss-bloom-dbg command line, FASTA and
+ * Bloom file formats -- served by abyss_amd/bin/abyss-bloom-dbg, and (2) the in-process
+ * "bloom concept" + assembly entry points that BloomDBG/bloom-dbg.h is templated over.
+ * This header is the batch-granular replacement of (2): each entry point names the
+ * reference interface it stands in for.  Plain pointers and sizes only; the library owns
+ * all device memory; the caller owns every host buffer.  One abg_ctx is not thread-safe;
+ * distinct contexts may be used from distinct threads.
+ *
+ * Every function returns ABG_OK (0) or a negative ABG_E* code; abg_last_error() gives the
+ * message.  The reference reports errors by printing and exit(EXIT_FAILURE)
+ * (Common/IOUtil.h:14-22); the host binary maps non-zero codes to that behaviour.
+ *
+ * The implementation is HIP for gfx950 only: abg_create() fails with ABG_ENODEV when no
+ * GPU is present.  There is no CPU fallback.
+ */
+#ifndef ABYSS_AMD_H
+#define ABYSS_AMD_H 1
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABG_OK 0
+#define ABG_EINVAL (-1)   /* bad argument / unsupported parameter combination */
+#define ABG_ENODEV (-2)   /* no usable HIP device */
+#define ABG_ENOMEM (-3)   /* device or host allocation failed */
+#define ABG_EINTERNAL (-4)
+
+#define ABG_MAX_KMER 192  /* configure.ac:151 (MAX_KMER) */
+#define ABG_MAX_HASHES 32 /* configure.ac:156 (MAX_HASHES) */
+
+/* ReadResult, BloomDBG/bloom-dbg.h:256-266 */
+enum abg_read_result {
+	ABG_RR_UNINITIALIZED = 0,
+	ABG_RR_SHORTER_THAN_K,
+	ABG_RR_NON_ACGT,
+	ABG_RR_BLUNT_END,
+	ABG_RR_NOT_SOLID,
+	ABG_RR_ALL_KMERS_VISITED,
+	ABG_RR_ALL_BRANCH_KMERS_VISITED,
+	ABG_RR_GENERATED_CONTIGS
+};
+
+/* PathExtensionResultCode, Graph/ExtendPath.h:46-57 */
+enum abg_ext_code {
+	ABG_ER_AMBI_IN = 0,
+	ABG_ER_AMBI_OUT,
+	ABG_ER_DEAD_END,
+	ABG_ER_CYCLE,
+	ABG_ER_LENGTH_LIMIT
+};
+
+/* AssemblyParams, BloomDBG/AssemblyParams.h:13-85 (the fields the path uses) */
+typedef struct abg_params {
+	uint32_t k;          /* -k  k-mer size, 2..ABG_MAX_KMER */
+	uint32_t num_hashes; /* -H  Bloom hash functions [4] */
+	uint32_t min_cov;    /* --kc minimum k-mer count [2] */
+	uint32_t trim;       /* -t  max branch length to trim; UINT32_MAX = k (bloom-dbg.cc:507-509) */
+	uint64_t bloom_bytes;/* -b  memory budget; counters = roundUp64(round(B/1.125)) (bloom-dbg.cc:365-367) */
+	uint64_t counters;   /* if non-zero, use exactly this many counters instead of bloom_bytes (-i, tests) */
+	const char* spaced_seed; /* -s / -K / --qr-seed mask; NULL or "" = none.  Not supported yet: ABG_EINVAL */
+	int32_t device;      /* HIP device ordinal */
+	int32_t verbose;
+	/* tuning; 0 = default */
+	uint64_t insert_batch_kmers;
+	uint32_t claim_log2;
+	uint32_t walk_slots;
+	uint32_t wtab_log2;
+	uint32_t reserved_[7];
+} abg_params;
+
+/* AssemblyCounters, BloomDBG/AssemblyCounters.h:15-31 */
+typedef struct abg_counters {
+	uint64_t solid_reads, visited_reads, reads_processed, bases_assembled, next_contig_id;
+} abg_counters;
+
+/* What outputContig hands to printContig and to the -T trace (bloom-dbg.h:186-254,538-620).
+ * Pointers are valid only during the callback. */
+typedef struct abg_contig {
+	uint64_t contig_id;   /* UINT64_MAX when redundant (not printed) */
+	uint64_t read_index;  /* index, within this abg_assemble_* call, of the seeding read */
+	const char* seq;      /* ACGT, NUL-terminated */
+	uint32_t length;
+	uint32_t coverage;    /* getSeqAbsoluteKmerCoverage, bloom-dbg.h:92-109 */
+	int32_t redundant;
+	uint32_t left_ext, right_ext;
+	int32_t left_code, right_code; /* abg_ext_code */
+	uint32_t seed_pos;    /* read k-mer index of the seed k-mer */
+} abg_contig;
+typedef void (*abg_contig_cb)(void* user, const abg_contig* contig);
+
+typedef struct abg_ctx abg_ctx;
+
+/* defaults: num_hashes 4, min_cov 2, trim UINT32_MAX (AssemblyParams.h:78-85) */
+void abg_params_init(abg_params* p);
+/* CountingBloomFilter<uint8_t>(counters, H, k, kc) + BloomFilter(size, H, k)
+ * (bloom-dbg.cc:349-369, bloom-dbg.h:909-911) */
+int abg_create(const abg_params* p, abg_ctx** out);
+void abg_destroy(abg_ctx* ctx);
+const char* abg_last_error(const abg_ctx* ctx); /* ctx may be NULL: error of the last failed abg_create */
+
+/* bloom.size() / sizeInBytes(): number of uint8 counters == number of visited bits */
+int abg_filter_size(const abg_ctx* ctx, uint64_t* counters);
+
+/* PASS 1 -- BloomDBG::loadSeq for each sequence in order (BloomIO.h:32-41; loadFile
+ * :50-94 at -j1).  Sequences are ASCII, offsets has n + 1 entries; characters are
+ * upper-cased and k-mers overlapping a non-ACGT character are skipped exactly like
+ * RollingHashIterator (RollingHashIterator.h:35-97). */
+int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n);
+
+/* PASS 1 on sequences already resident in device memory in the packed layout:
+ * 2 bits per base (A,C,G,T = 0..3), 16 bases per uint32 word, every sequence starting on
+ * a word boundary.  d_words/d_woff/d_len are device pointers (woff has n + 1 entries);
+ * every sequence must be pure ACGT with len >= k. */
+int abg_load_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
+    const uint32_t* d_len, uint64_t n);
+
+/* popCount() / filtered_popcount() of the counting filter (CountingBloomFilter.hpp:219-242) */
+int abg_counting_stats(abg_ctx* ctx, uint64_t* popcount, uint64_t* filtered_popcount);
+
+/* raw arrays, for operator<< / loadFilter (CountingBloomFilter.hpp:262-281,370-379;
+ * BloomFilter.hpp:105-114,283-294), checkpoints (Checkpoint.h) and parity tests.
+ * counters: abg_filter_size() bytes; visited: abg_filter_size()/8 bytes. */
+int abg_counters_export(abg_ctx* ctx, uint8_t* host_out);
+int abg_counters_import(abg_ctx* ctx, const uint8_t* host_in);
+int abg_visited_export(abg_ctx* ctx, uint8_t* host_out);
+int abg_visited_import(abg_ctx* ctx, const uint8_t* host_in);
+
+/* PASS 2 -- processRead for each read in order (bloom-dbg.h:781-882; the batch loop of
+ * assemble() :1012-1066 at -j1).  results (may be NULL) receives one abg_read_result per
+ * read; cb is invoked once per outputContig call, in the reference's order, redundant
+ * contigs included (they appear in the -T trace).  State (visited filter, contigEndKmers,
+ * counters) carries over between calls, so a read stream may be fed in chunks. */
+int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
+    uint8_t* results, abg_contig_cb cb, void* user);
+/* the same on device-resident packed reads (pure ACGT, len >= k) */
+int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
+    const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user);
+
+int abg_get_counters(const abg_ctx* ctx, abg_counters* out);
+int abg_set_counters(abg_ctx* ctx, const abg_counters* in); /* resume, Checkpoint.h:159-228 */
+
+/* ---- probes used by parity tests and tools ------------------------------------- */
+/* ntHash of every valid k-mer of one sequence: positions and num_hashes values each
+ * (RollingHashIterator + RollingHash::getHashes, RollingHash.h:141-146), computed on the
+ * device.  Returns the number of valid k-mers in *n_out; writes at most cap entries. */
+int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
+    uint64_t* hashes_out, uint64_t cap, uint64_t* n_out);
+
+/* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
+ * runs on; abg_profile_get reports total milliseconds and launch count of one kernel
+ * family ("hash", "claim", "insert_round", "insert_retry", "classify", "walk", "rewalk",
+ * "spotwalk", "predict", "refilter", "commit", "popcount"). */
+int abg_profile_enable(abg_ctx* ctx, int on);
+int abg_profile_reset(abg_ctx* ctx);
+int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+/* work statistics of the engine since creation */
+typedef struct abg_stats {
+	uint64_t insert_rounds, walk_rounds, candidates, walked, rewalked, commit_breaks;
+} abg_stats;
+int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

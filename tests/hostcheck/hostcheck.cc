@@ -1,0 +1,102 @@
+// hostcheck.cc -- TEST INFRASTRUCTURE ONLY.
+// Runs the product's device logic (abyss_amd/csrc/abg_core.h, abg_walk.h, abg_engine.h,
+// abg_host.h) on the CPU, one item at a time, through a serial backend, so that the
+// "-m 'not gpu'" test-suite can compare the kernels' logic with the oracle on machines
+// without a GPU.  It is built only by tests/ (g++), never linked into libabyss_amd.so,
+// and is not a fallback: the product library refuses to run without a HIP device.
+#include "../../abyss_amd/csrc/abg_host.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+struct SerialSync {
+	uint32_t tid() const { return 0; }
+	uint32_t nthreads() const { return 1; }
+	void barrier() {}
+	bool all(bool v) { return v; }
+	uint32_t sum(uint32_t v) { return v; }
+	uint32_t bcast(uint32_t v) { return v; }
+};
+
+struct SerialBackend {
+	bool ok() const { return true; }
+	std::string why() const { return ""; }
+	void* alloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
+	void free(void* p) { ::free(p); }
+	void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
+	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+	uint32_t max_slots() const { return 1; }
+	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
+	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
+	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
+	{
+		SerialSync sy;
+		abg::commit_candidates<NW>(e, b, c, sy);
+	}
+};
+
+typedef abg::Session<SerialBackend> Sess;
+
+} // namespace
+
+extern "C" {
+
+void* hc_create(unsigned k, unsigned nh, unsigned kc, unsigned trim, uint64_t counters,
+    uint64_t insert_batch, unsigned claim_log2, uint64_t p2_first_batch)
+{
+	Sess* s = new Sess();
+	abg_params p;
+	memset(&p, 0, sizeof p);
+	p.k = k; p.num_hashes = nh; p.min_cov = kc; p.trim = trim; p.counters = counters;
+	s->cfg.claim_log2 = claim_log2 ? claim_log2 : 16;
+	s->cfg.insert_batch_kmers = insert_batch ? insert_batch : (1u << 16);
+	s->cfg.walk_slots = 1; s->cfg.tb_cap = 4096; s->cfg.buf_cap = 1u << 20;
+	s->cfg.pool_cap = 1ull << 26; s->cfg.rec_cap = 1u << 18; s->cfg.wtab_log2 = 22;
+	s->cfg.wclaim_log2 = 18; s->cfg.cend_log2 = 16;
+	if (p2_first_batch) s->cfg.p2_first_batch = p2_first_batch;
+	p.insert_batch_kmers = 0; p.claim_log2 = 0; p.walk_slots = 0; p.wtab_log2 = 0;
+	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }
+	return s;
+}
+void hc_destroy(void* h) { delete (Sess*)h; }
+uint64_t hc_size(void* h) { return ((Sess*)h)->eng->size(); }
+uint8_t* hc_counters(void* h) { return ((Sess*)h)->eng->counters_dev(); }
+uint8_t* hc_visited(void* h) { return ((Sess*)h)->eng->visited_dev(); }
+int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n) { return ((Sess*)h)->load_seqs(seqs, off, n); }
+uint64_t hc_insert_rounds(void* h) { return ((Sess*)h)->eng->stats().insert_rounds; }
+int hc_popcounts(void* h, uint64_t* a, uint64_t* b) { ((Sess*)h)->eng->popcounts(a, b); return 0; }
+int hc_assemble_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
+    abg_contig_cb cb, void* user)
+{
+	return ((Sess*)h)->assemble_seqs(seqs, off, n, results, cb, user);
+}
+int hc_hash_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint64_t* hashes, uint64_t cap, uint64_t* n)
+{
+	return ((Sess*)h)->hash_seq(seq, len, pos, hashes, cap, n);
+}
+void hc_get_counters(void* h, abg_counters* out)
+{
+	abg::Counters c = ((Sess*)h)->eng->counters();
+	out->solid_reads = c.solid_reads; out->visited_reads = c.visited_reads;
+	out->reads_processed = c.reads_processed; out->bases_assembled = c.bases_assembled;
+	out->next_contig_id = c.contig_id;
+}
+void hc_get_stats(void* h, abg_stats* out)
+{
+	auto s = ((Sess*)h)->eng->stats();
+	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
+	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks;
+}
+// exact modulo check: returns the number of mismatches between mod64 and the hardware %
+uint64_t hc_mod_check(uint64_t m, const uint64_t* hs, uint64_t n)
+{
+	abg::Mod64 d = abg::make_mod64(m);
+	uint64_t bad = 0;
+	for (uint64_t i = 0; i < n; i++) bad += abg::mod64(d, hs[i]) != hs[i] % m;
+	return bad;
+}
+
+} // extern "C"

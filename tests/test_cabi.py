@@ -1,0 +1,53 @@
+"""The C-ABI shared library: loads, exports every symbol of include/abyss_amd.h, and
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from abyss_amd import _lib, api, build
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(build.ROOT, "include", "abyss_amd.h")).read()
+    declared = set(re.findall(r"\b(abg_[a-z_]+)\s*\(", header))
+    declared -= {"abg_contig_cb"}
+    assert declared == set(_lib.symbols())
+    lib = C.CDLL(build.build_lib())
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_params_init_defaults():
+    lib = _lib.load()
+    p = _lib.Params()
+    lib.abg_params_init(C.byref(p))
+    # AssemblyParams defaults, AssemblyParams.h:78-85
+    assert (p.num_hashes, p.min_cov, p.trim) == (4, 2, 0xFFFFFFFF)
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="a GPU is present")
+def test_no_cpu_fallback():
+    with pytest.raises(api.AbyssAmdError) as e:
+        api.BloomDBG(32, counters=4096)
+    assert "no HIP device" in str(e.value)
+
+
+def test_rejects_bad_parameters():
+    lib = _lib.load()
+    for k, h in ((1, 4), (193, 4), (32, 0), (32, 33)):
+        p = _lib.Params()
+        lib.abg_params_init(C.byref(p))
+        p.k, p.num_hashes, p.counters = k, h, 4096
+        ctx = C.c_void_p()
+        assert lib.abg_create(C.byref(p), C.byref(ctx)) == -1
+        assert lib.abg_last_error(None)

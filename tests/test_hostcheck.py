@@ -1,0 +1,197 @@
+"""The product's device logic (abyss_amd/csrc/*.h) executed serially on the CPU through
+tests/hostcheck, against the oracle and the golden fixtures.  This checks the kernels'
+LOGIC without a GPU; the kernels themselves are checked by the -m gpu tests."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from abyss_amd import _lib, api, build, synth
+from util import GOLDEN, GoldenCase, contig_tuple, random_reads
+
+
+class HostCheck:
+    def __init__(self, k, counters, num_hashes=4, min_cov=2, trim=None, insert_batch=0, claim_log2=0, p2_first=0):
+        l = C.CDLL(build.build_hostcheck())
+        l.hc_create.restype = C.c_void_p
+        l.hc_create.argtypes = [C.c_uint] * 4 + [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64]
+        l.hc_destroy.argtypes = [C.c_void_p]
+        l.hc_size.restype = C.c_uint64
+        l.hc_size.argtypes = [C.c_void_p]
+        l.hc_counters.restype = C.POINTER(C.c_uint8)
+        l.hc_counters.argtypes = [C.c_void_p]
+        l.hc_visited.restype = C.POINTER(C.c_uint8)
+        l.hc_visited.argtypes = [C.c_void_p]
+        l.hc_load_seqs.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        l.hc_popcounts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        l.hc_assemble_seqs.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, _lib.CONTIG_CB, C.c_void_p]
+        l.hc_hash_seq.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        l.hc_get_counters.argtypes = [C.c_void_p, C.POINTER(_lib.Counters)]
+        l.hc_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.Stats)]
+        l.hc_mod_check.restype = C.c_uint64
+        l.hc_mod_check.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64]
+        self.l = l
+        self.k, self.num_hashes = k, num_hashes
+        self.h = l.hc_create(k, num_hashes, min_cov, k if trim is None else trim, counters, insert_batch, claim_log2, p2_first)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.hc_destroy(self.h)
+
+    @property
+    def size(self):
+        return self.l.hc_size(self.h)
+
+    def load(self, buf, off):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        assert self.l.hc_load_seqs(self.h, buf, off.ctypes.data, len(off) - 1) == 0
+
+    def counters(self):
+        return np.ctypeslib.as_array(self.l.hc_counters(self.h), (self.size,)).copy()
+
+    def visited(self):
+        return np.ctypeslib.as_array(self.l.hc_visited(self.h), (self.size // 8,)).copy()
+
+    def counting_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.l.hc_popcounts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def assemble(self, buf, off):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        res = np.zeros(n, dtype=np.uint8)
+        out = []
+
+        def cb(_u, c):
+            c = c.contents
+            out.append(api.ContigRecord(c.contig_id, c.read_index, c.seq, c.coverage, bool(c.redundant), c.left_ext,
+                                        c.right_ext, c.left_code, c.right_code, c.seed_pos))
+        assert self.l.hc_assemble_seqs(self.h, buf, off.ctypes.data, n, res.ctypes.data, _lib.CONTIG_CB(cb), None) == 0
+        return res, out
+
+    def hash_seq(self, seq):
+        cap = max(len(seq), 1)
+        pos = np.zeros(cap, dtype=np.uint32)
+        hashes = np.zeros((cap, self.num_hashes), dtype=np.uint64)
+        n = C.c_uint64()
+        assert self.l.hc_hash_seq(self.h, seq, len(seq), pos.ctypes.data, hashes.ctypes.data, cap, C.byref(n)) == 0
+        return pos[:n.value], hashes[:n.value]
+
+    def assembly_counters(self):
+        c = _lib.Counters()
+        self.l.hc_get_counters(self.h, C.byref(c))
+        return {n: getattr(c, n) for n, _ in c._fields_}
+
+    def stats(self):
+        s = _lib.Stats()
+        self.l.hc_get_stats(self.h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+
+def test_exact_modulo():
+    hc = HostCheck(8, 1024)
+    rng = np.random.default_rng(0)
+    edge = np.array([0, 1, 2, 2 ** 32 - 1, 2 ** 32, 2 ** 63 - 1, 2 ** 63, 2 ** 64 - 1, 2 ** 64 - 2], dtype=np.uint64)
+    for m in (1, 2, 3, 64, 1000, 3728320, 93206784, 1908874368, 38177487104, 477218588480, 2 ** 40, 2 ** 63 + 12345,
+              2 ** 64 - 59):
+        hs = np.concatenate([edge, rng.integers(0, 2 ** 64, size=200000, dtype=np.uint64),
+                             np.uint64(m) * rng.integers(0, max(1, (2 ** 64 - 1) // m), size=1000, dtype=np.uint64),
+                             np.uint64(m) * rng.integers(1, max(2, (2 ** 64 - 1) // m), size=1000, dtype=np.uint64) - np.uint64(1)])
+        assert hc.l.hc_mod_check(m, hs.ctypes.data, len(hs)) == 0, m
+
+
+def test_hash_stream_matches_reference_vectors():
+    vectors = json.load(open(os.path.join(GOLDEN, "nthash_vectors.json")))
+    for v in vectors:
+        hc = HostCheck(v["k"], 1024)
+        pos, h = hc.hash_seq(v["seq"].encode())
+        assert list(pos) == v["pos"]
+        assert [[str(int(x)) for x in row] for row in h] == v["hashes"]
+
+
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96"])
+def test_device_logic_reproduces_reference_run(name):
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, p2_first=128)
+    hc.load(g.buf, g.off)
+    assert hc.counting_stats()[1] == g.meta["filtered_popcount"]
+    results, contigs = hc.assemble(g.buf, g.off)
+    assert api.format_fasta(contigs, g.ids) == g.fasta
+    assert api.format_read_log(results, g.ids) == g.readlog
+    assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+    c = hc.assembly_counters()
+    assert (c["reads_processed"], c["solid_reads"], c["visited_reads"]) == (
+        g.meta["reads"], g.meta["solid_reads"], g.meta["visited_reads"])
+
+
+@pytest.mark.parametrize("k,G", [(17, 15000), (33, 15000), (65, 15000), (97, 20000), (129, 15000), (150, 12000)])
+def test_device_logic_matches_oracle(k, G):
+    m1, m2 = synth.make_read_set(G, 25.0)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    counters = 1 << 21
+    o = ob.Oracle(k, counters=counters)
+    hc = HostCheck(k, counters, insert_batch=20000, claim_log2=14, p2_first=64)
+    o.load(buf, off)
+    hc.load(buf, off)
+    assert np.array_equal(o.counters(), hc.counters())
+    assert o.counting_stats() == hc.counting_stats()
+    ro, co = o.assemble(buf, off)
+    rh, ch = hc.assemble(buf, off)
+    assert np.array_equal(ro, rh)
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
+    assert np.array_equal(o.visited(), hc.visited())
+    assert o.assembly_counters() == hc.assembly_counters()
+
+
+def test_saturating_counters_and_duplicate_kmers():
+    # heavy duplication: 300 copies of the same read saturate counters at 255
+    # (CountingBloomFilter.hpp:146-149); homopolymers give runs of identical k-mers
+    reads = [b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAATTTGGCC"] * 300 + [b"A" * 60, b"T" * 60, b"ACAC" * 20]
+    buf, off = api.concat_seqs(reads)
+    o = ob.Oracle(21, counters=4096)
+    hc = HostCheck(21, 4096, insert_batch=1000, claim_log2=8)
+    o.load(buf, off)
+    hc.load(buf, off)
+    a, b = o.counters(), hc.counters()
+    assert a.max() == 255
+    assert np.array_equal(a, b)
+
+
+def test_empty_and_short_inputs():
+    hc = HostCheck(31, 4096)
+    buf, off = api.concat_seqs([])
+    hc.load(buf, off)
+    res, contigs = hc.assemble(buf, off)
+    assert len(res) == 0 and contigs == []
+    buf, off = api.concat_seqs([b"ACGT", b"", b"ACGTNNNN" * 10])
+    hc.load(buf, off)
+    assert hc.counters().sum() == 0
+    res, contigs = hc.assemble(buf, off)
+    assert list(res) == [1, 1, 2] and contigs == []  # SHORTER_THAN_K, SHORTER_THAN_K, NON_ACGT
+
+
+def test_chunked_calls_equal_single_call():
+    g = GoldenCase("k32")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], insert_batch=30000, claim_log2=16, p2_first=100)
+    cut = [0, 1, 777, 2000, g.n]
+    for a, b in zip(cut, cut[1:]):
+        off = g.off[a:b + 1] - g.off[a]
+        hc.load(g.buf[int(g.off[a]):int(g.off[b])], off)
+    contigs_all, results_all = [], []
+    for a, b in zip(cut, cut[1:]):
+        off = g.off[a:b + 1] - g.off[a]
+        r, c = hc.assemble(g.buf[int(g.off[a]):int(g.off[b])], off)
+        for x in c:
+            x.read_index += a
+        contigs_all += c
+        results_all.append(r)
+    assert api.format_fasta(contigs_all, g.ids) == g.fasta
+    assert api.format_read_log(np.concatenate(results_all), g.ids) == g.readlog
