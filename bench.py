@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- Mk-mers/s of the abyss-bloom-dbg unitig stage on MI355X.
+
+One "step" = one whole pass of the hot path over one synthetic read set already resident
+in HBM in the packed 2-bit layout: reset both filters, PASS 1 (ntHash + ordered
+conservative-update insert of every read k-mer into the counting Bloom filter), PASS 2
+(classify reads, walk unitigs, commit contigs in read order).  N = number of read k-mers,
+each counted once although both passes touch it.
+
+Workload at N=1: BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads,
+k=64, B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors).  With --gpus N every
+rank runs that workload on its own read set and filter (weak scaling; the filter is not
+yet partitioned across GPUs -- see DESIGN.md); value is the whole-job aggregate.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from abyss_amd import api, synth  # noqa: E402
+
+METRIC = "Mk-mers/s inserted+extended (abyss-bloom-dbg, k=64); unitig bit-exact"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, seed: int, device):
+    """Synthetic read set generated on the GPU in the packed layout of include/abyss_amd.h:
+    2 bits per base, 16 bases per uint32 word, each read on a word boundary.  File order of
+    the reference: all mate-1 reads, then all mate-2 reads (BloomIO.h:102-115)."""
+    h1, h2 = synth.make_genome(genome_len, seed=seed)
+    g1 = torch.from_numpy(h1).to(device)
+    g2 = torch.from_numpy(h2).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 1000003 + 7)
+    wpr = (read_len + 15) // 16
+    words = torch.empty((2 * n_pairs, wpr), dtype=torch.int32, device=device)
+    shifts = (2 * torch.arange(16, device=device, dtype=torch.int64))
+    ar = torch.arange(read_len, device=device, dtype=torch.int64)
+    chunk = 1 << 19
+    for a in range(0, n_pairs, chunk):
+        b = min(n_pairs, a + chunk)
+        m = b - a
+        frag = torch.randint(350, 451, (m,), generator=gen, device=device)
+        start = torch.randint(0, genome_len - 450, (m,), generator=gen, device=device)
+        hap = torch.randint(0, 2, (m, 1), generator=gen, device=device).bool()
+        strand = torch.randint(0, 2, (m, 1), generator=gen, device=device).bool()
+        idx1 = start[:, None] + ar[None, :]
+        idx2 = (start + frag - 1)[:, None] - ar[None, :]
+        m1 = torch.where(hap, g2[idx1], g1[idx1])
+        m2 = 3 - torch.where(hap, g2[idx2], g1[idx2])
+        ra = torch.where(strand, m2, m1)
+        rb = torch.where(strand, m1, m2)
+        for dst, r in ((a, ra), (n_pairs + a, rb)):
+            e = torch.rand(r.shape, generator=gen, device=device) < err
+            r = torch.where(e, (r + torch.randint(1, 4, r.shape, generator=gen, device=device).to(r.dtype)) & 3, r)
+            pad = wpr * 16 - read_len
+            r64 = torch.nn.functional.pad(r.to(torch.int64), (0, pad)).view(m, wpr, 16)
+            w = (r64 << shifts).sum(dim=2)
+            words[dst:dst + m] = w.to(torch.int32)  # wraps modulo 2^32: same bits as uint32
+    n = 2 * n_pairs
+    woff = torch.arange(n + 1, device=device, dtype=torch.int64) * wpr
+    lens = torch.full((n,), read_len, dtype=torch.int32, device=device)
+    return words.view(-1), woff, lens
+
+
+def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
+    """The unmodified reference binary (oracle/_ref, kind "reference") -- or the oracle's C port
+    when it is not built -- timed on the host cores on a bounded sample of the same workload
+    (same read length, coverage, error rate, k, H; genome and B scaled down together)."""
+    import oracle_binding as ob
+    genome, cov, L = 600_000, 50.0, 150
+    m1, m2 = synth.make_read_set(genome, cov, read_len=L)
+    n_reads = 2 * m1.shape[0]
+    kmers = n_reads * (L - k + 1)
+    sample = "%d x 2x%d bp reads of a %d bp genome (50x, 0.5%% err), k=%d, B=40M, H=4" % (m1.shape[0], L, genome, k)
+    if ob.have_ref():
+        with tempfile.TemporaryDirectory() as td:
+            synth.write_fastq(os.path.join(td, "r1.fq"), m1, "r", 1)
+            synth.write_fastq(os.path.join(td, "r2.fq"), m2, "r", 2)
+            # fixed start-up cost of the reference (contigEndKmers.rehash(2^28), bloom-dbg.h:993)
+            open(os.path.join(td, "one.fq"), "w").write("@x\n%s\n+\n%s\n" % ("A" * L, "I" * L))
+            t0 = time.time()
+            ob.run_ref(["-k%d" % k, "-b1M", "one.fq"], cwd=td, threads=1)
+            startup = time.time() - t0
+            t0 = time.time()
+            out, _ = ob.run_ref(["-k%d" % k, "-b40M", "-H4", "r1.fq", "r2.fq"], cwd=td, threads=cores)
+            wall = time.time() - t0
+        return {"value": kmers / wall / 1e6, "unit": "Mk-mers/s", "cores": cores, "kind": "reference",
+                "sample": sample + "; whole-binary wall %.1f s incl. FASTQ parse and %.1f s fixed start-up" % (wall, startup),
+                "value_excl_startup": kmers / max(wall - startup, 1e-9) / 1e6}
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    o = ob.Oracle(k, bloom_bytes=40 << 20)
+    t0 = time.time()
+    o.load(buf, off)
+    o.assemble(buf, off)
+    wall = time.time() - t0
+    return {"value": kmers / wall / 1e6, "unit": "Mk-mers/s", "cores": 1, "kind": "port", "sample": sample}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=5_000_000, help="read pairs per GPU (configs[1]: 5 M)")
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--bloom", type=str, default="2G")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30}
+    bloom_bytes = int(float(a.bloom[:-1]) * mult[a.bloom[-1].upper()]) if a.bloom[-1].isalpha() else int(a.bloom)
+    read_len, cov, err = 150, 50.0, 0.005
+    genome_len = int(a.pairs * 2 * read_len / cov)
+    words, woff, lens = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42 + rank, device=device)
+    n_reads = 2 * a.pairs
+    kmers = n_reads * (read_len - a.k + 1)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    g = None
+    unitigs = bases = 0
+
+    def step():
+        nonlocal g, unitigs, bases
+        if g is not None:
+            g.close()
+        g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local)
+        g.profile_enable(True)
+        g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
+        _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False)
+        unitigs = sum(not c.redundant for c in contigs)
+        bases = sum(len(c.seq) for c in contigs if not c.redundant)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
+    names = ["hash", "claim", "insert_round", "insert_retry", "classify", "walk", "rewalk", "spotwalk", "predict",
+             "refilter", "commit", "popcount"]
+    prof = {nm: g.profile_get(nm) for nm in names}
+    stats = g.stats()
+    H = 4
+    per_kmer_bases = (read_len / 4.0) / (read_len - a.k + 1)
+    # algorithmic bytes per read k-mer of each streaming kernel (DESIGN.md "Roofline")
+    alg_bytes = {
+        "hash": per_kmer_bases + 8,                 # 2-bit bases in, canonical hash out
+        "claim": 8 + H * 8,                         # hash in, H claim slots
+        "insert_round": 8 + H * 8 + 2 * H,          # hash + H claim slots + H counter reads + H counter writes
+        "classify": per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1),  # solid + visited probes + look-ahead
+    }
+    dom = max(alg_bytes, key=lambda nm: prof[nm][0])
+    dms, dn = prof[dom]
+    # bytes per launch = alg_bytes x (k-mers / launches); duration per launch = dms / launches
+    achieved = (alg_bytes[dom] * kmers / 1e9) / (dms / 1e3) if dms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": dms / max(dn, 1), "launches": dn,
+                "alg_bytes_per_kmer": alg_bytes[dom]}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": world * kmers * a.steps / elapsed / 1e6, "unit": "Mk-mers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d, B=%s, H=4, 1xMI355X per rank"
+                       % (a.pairs, read_len, a.k, a.bloom),
+                       "genome_bp": genome_len, "coverage": cov, "error_rate": err, "read_kmers": kmers,
+                       "parallelism": "replicas x%d (filter not partitioned yet)" % world if world > 1 else "single GPU",
+                       "unitigs": unitigs, "unitig_bp": bases},
+            "roofline": roofline,
+            "kernel_ms": {nm: {"ms": round(v[0], 3), "launches": v[1]} for nm, v in prof.items() if v[1]},
+            "engine_stats": stats,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)
+        print(json.dumps(out))
+    if g is not None:
+        g.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
