@@ -25,7 +25,7 @@ struct Config {
 	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
 	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
 	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
-	uint32_t walk_slots = 32768;      // concurrent walkers
+	uint32_t walk_slots = 8192;       // concurrent walkers (one per wavefront)
 	uint32_t tb_cap = 192;            // trueBranch frames per walker
 	uint32_t buf_cap = 1u << 13;      // extension bases per side per walker
 	uint64_t pool_cap = 1ull << 28;   // contig pool bytes
@@ -388,6 +388,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 //   uint32_t max_slots();                       // upper bound on concurrent items of launch()
 //   template<class F> void launch(uint64_t n, F f, const char* name);               // f(i, slot)
 //   template<class F> void launch_slots(uint64_t n, F f, uint32_t slots, const char* name);
+//   template<class F> void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name); // one item per wave
 //   template<int NW> void launch_commit(CommitEnv<NW>, uint32_t c_begin, uint32_t c_end);
 template <class BE>
 class Engine {
@@ -718,7 +719,7 @@ class Engine {
 			env.owner_base = 0;
 			{
 				FWalk<NW> fw{ env, list_d };
-				be_.launch_slots(nc, fw, wslots_, "walk");
+				be_.launch_walkers(nc, fw, wslots_, "walk");
 			}
 			stats_.walked += nc;
 			// stage 2: deferred candidates that lower reads do not cover are walked privately
@@ -736,7 +737,7 @@ class Engine {
 				env.owner_base = owner_next; // owner ids distinct from stage 1
 				owner_next += nc;
 				FWalk<NW> fw{ env, need_d };
-				be_.launch_slots(nneed, fw, wslots_, "rewalk");
+				be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 				stats_.rewalked += nneed;
 			}
 			// stage 3: ordered commit as far as the results allow.  A candidate that stops it
@@ -758,7 +759,7 @@ class Engine {
 				owner_next += nc;
 				be_.h2d(need_d, &committed, 4);
 				FWalk<NW> fw{ env2, need_d };
-				be_.launch_slots(1, fw, wslots_, "spotwalk");
+				be_.launch_walkers(1, fw, wslots_, "spotwalk");
 				stats_.rewalked++;
 				be_.d2h(&st, status_d + committed, 4);
 				if (st == WS_OVERFLOW) { overflowed = true; break; }

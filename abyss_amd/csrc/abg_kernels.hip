@@ -36,6 +36,16 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 	for (; i < n; i += stride) f(i, slot);
 }
 
+// One walker per wavefront: a unitig walk is a long, branchy, latency-bound pointer chase;
+// 64 of them in one wave would serialise on every divergent branch, so each wave runs a
+// single walker on lane 0 with wave-uniform control flow and the other lanes masked off.
+template <class F>
+__global__ void __launch_bounds__(64) k_foreach_lane0(F f, uint64_t n)
+{
+	if (threadIdx.x != 0) return;
+	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x);
+}
+
 constexpr int COMMIT_THREADS = 1024;
 struct DeviceSync {
 	uint32_t* sh; // [COMMIT_THREADS / 64 + 2] shared words
@@ -170,6 +180,15 @@ struct HipBackend {
 		if (blocks > cap) blocks = cap;
 		begin(name);
 		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
+		end(name);
+	}
+	template <class F>
+	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = n < slots ? n : slots;
+		begin(name);
+		hipLaunchKernelGGL(k_foreach_lane0<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
 		end(name);
 	}
 	template <int NW>
