@@ -365,14 +365,63 @@ ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, u
 	return ok;
 }
 
+// 4-bit mask: which of four canonical hashes does the solid filter contain?  The probe
+// positions of all four k-mers (up to four hash functions at a time) are computed first
+// and their loads issued back to back, so one probe round costs one memory latency
+// instead of sixteen.
+ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[4])
+{
+	unsigned ok = 0xFu;
+	for (unsigned base = 0; base < p.nh; base += 4) {
+		uint8_t c[4][4];
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++) {
+#pragma unroll
+			for (unsigned i = 0; i < 4; i++) {
+				unsigned ii = base + i < p.nh ? base + i : 0; // surplus slots re-probe hash 0
+				c[b][i] = cnt[pos_i(p, h[b], ii)];
+			}
+		}
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++) {
+#pragma unroll
+			for (unsigned i = 0; i < 4; i++)
+				if (c[b][i] < p.kc) ok &= ~(1u << b);
+		}
+	}
+	return ok;
+}
+
+// the same for eight hashes (both neighbourhoods of a vertex in one probe round)
+ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[8])
+{
+	unsigned ok = 0xFFu;
+	for (unsigned base = 0; base < p.nh; base += 4) {
+		uint8_t c[8][4];
+#pragma unroll
+		for (unsigned b = 0; b < 8; b++) {
+#pragma unroll
+			for (unsigned i = 0; i < 4; i++) {
+				unsigned ii = base + i < p.nh ? base + i : 0;
+				c[b][i] = cnt[pos_i(p, h[b], ii)];
+			}
+		}
+#pragma unroll
+		for (unsigned b = 0; b < 8; b++) {
+#pragma unroll
+			for (unsigned i = 0; i < 4; i++)
+				if (c[b][i] < p.kc) ok &= ~(1u << b);
+		}
+	}
+	return ok;
+}
+
 // Neighbour enumeration of out_edge_iterator / in_edge_iterator
 // (RollingBloomDBG.h:302-427): the k-mer shifted by one base with last (first) base
 // A,C,G,T in that order, present iff the solid filter contains it (vertex_exists,
 // :436-446).  The four neighbours' hashes are XOR deltas off one shifted state.
-// Returns a 4-bit mask (bit b = base b exists) and the hash pairs.
 template <int NW>
-ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
-    const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
+ABG_HD void neighbour_hashes(const Params& p, const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
 {
 	unsigned k = p.k;
 	if (sense == SENSE) {
@@ -394,13 +443,17 @@ ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
 			rh4[b] = rb ^ seed_of(3u - b);
 		}
 	}
-	unsigned mask = 0;
+}
+// Returns a 4-bit mask (bit b = neighbour with base b exists) and the hash pairs.
+template <int NW>
+ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
+    const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
+{
+	neighbour_hashes(p, u, sense, fh4, rh4);
+	uint64_t h[4];
 #pragma unroll
-	for (unsigned b = 0; b < 4; b++) {
-		uint64_t h = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
-		mask |= (solid_contains(p, cnt, h) ? 1u : 0u) << b;
-	}
-	return mask;
+	for (unsigned b = 0; b < 4; b++) h[b] = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
+	return solid_mask4(p, cnt, h);
 }
 template <int NW>
 ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsigned b,
@@ -575,13 +628,13 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 // successor (ExtendPath.h:314-362): iterative deepening over the branch-length
 // threshold i = 0,1,2,4,...,trim.  Returns the code and (for LENGTH_LIMIT) the unique
 // successor; for AMBI_OUT the last true branch found, for DEAD_END `u` itself.
+// `mask`, `nfh`, `nrh` are the neighbour mask / hashes of `u` in direction `dir`.
 template <int NW>
-ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
-    unsigned trim, Vtx<NW>& vout, SearchScratch<NW>& sc)
+ABG_HDN int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
+    unsigned trim, unsigned mask, const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout,
+    SearchScratch<NW>& sc)
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
-	uint64_t nfh[4], nrh[4];
-	unsigned mask = neighbour_mask(p, cnt, u, sense, nfh, nrh);
 	vout = u;
 	for (unsigned i = 0;; i = (i == 0) ? 1u : (trim < 2 * i ? trim : 2 * i)) {
 		unsigned tb = 0;
@@ -600,6 +653,14 @@ ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vt
 		if (tb == 1) return ER_LENGTH_LIMIT;
 		if (i == trim) return ER_AMBI_OUT;
 	}
+}
+template <int NW>
+ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
+    unsigned trim, Vtx<NW>& vout, SearchScratch<NW>& sc)
+{
+	uint64_t nfh[4], nrh[4];
+	unsigned mask = neighbour_mask(p, cnt, u, (dir == FORWARD) ? SENSE : ANTISENSE, nfh, nrh);
+	return successor_m(p, cnt, u, dir, trim, mask, nfh, nrh, vout, sc);
 }
 
 } // namespace abg

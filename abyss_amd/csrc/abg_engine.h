@@ -202,26 +202,6 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 };
 
 template <int NW>
-struct FRefilter { // is a remaining candidate now entirely visited? (monotone => final)
-	Params p; Batch b; const uint32_t* cand_read; const uint8_t* vis; uint8_t* now_visited;
-	ABG_HDN void operator()(uint64_t c, uint32_t) const
-	{
-		uint64_t r = cand_read[c];
-		unsigned k = p.k;
-		uint32_t nk = b.len[r] - k + 1;
-		Vtx<NW> v;
-		v.s = batch_kmer<NW>(b, r, 0, k);
-		vtx_rehash(p, v);
-		bool visited = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(v))) { visited = false; break; }
-		}
-		now_visited[c] = visited;
-	}
-};
-
-template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
 	WalkEnv<NW> e; const uint32_t* list;
 	ABG_HDN void operator()(uint64_t i, uint32_t slot)
@@ -231,59 +211,6 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 	}
 };
 
-template <int NW>
-struct FPredict { // which deferred candidates will still be needed at their turn?
-	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint8_t* vis;
-	const uint32_t* claims; uint32_t claim_mask; uint32_t* need_list; uint32_t* need_n;
-	const uint32_t* list;
-	ABG_HDN void operator()(uint64_t i, uint32_t) const
-	{
-		uint32_t c = list[i];
-		if (status[c] != WS_DEFERRED) return;
-		uint64_t r = cand_read[c];
-		unsigned k = p.k;
-		uint32_t nk = b.len[r] - k + 1;
-		Vtx<NW> v;
-		v.s = batch_kmer<NW>(b, r, 0, k);
-		vtx_rehash(p, v);
-		bool covered = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			uint64_t hm = vtx_hash(v);
-			if (visited_contains(p, vis, hm)) continue;
-			if (claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask] < c) continue;
-			covered = false;
-			break;
-		}
-		if (!covered) need_list[atomic_add_u32(need_n, 1)] = c;
-	}
-};
-
-// ---- ordered commit (outputContig, bloom-dbg.h:538-620), cooperative over T threads
-struct CommitState {
-	Counters counters;
-	uint32_t break_at;   // first candidate that could not be committed
-	uint32_t pad_;
-};
-template <int NW>
-struct CommitEnv {
-	Params p; Batch b; const uint8_t* cnt; uint32_t* vis32;
-	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
-	ContigRec* recs; const uint8_t* pool; uint8_t* result;
-	WalkTab cend;        // contigEndKmers (bloom-dbg.h:992), owner 0
-	CommitState* st;
-	uint32_t* order;     // [rec_cap] records in commit order
-	uint32_t* order_n;
-};
-ABG_HD bool visited_contains_coherent(const Params& p, const uint32_t* vis32, uint64_t h)
-{
-	bool ok = true;
-	for (unsigned i = 0; i < p.nh; i++) {
-		uint64_t q = pos_i(p, h, i);
-		ok = ok & (((ld_coherent(&vis32[q >> 5]) >> (q & 31)) & 1u) != 0);
-	}
-	return ok;
-}
 template <int NW>
 ABG_HDN uint64_t seq_kmer_hash(const Params& p, const uint8_t* seq, uint64_t j)
 {
@@ -306,7 +233,95 @@ ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uin
 	}
 	return rh < fh ? rh : fh;
 }
-// Sync policy: tid(), nthreads(), barrier(), all(bool), sum(uint32_t), bcast(uint32_t from tid 0)
+template <int NW>
+struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave per candidate)
+	Params p; Batch b; const uint32_t* cand_read; const uint64_t* rkoff; uint64_t* rkh; uint32_t first;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		uint32_t c = first + (uint32_t)i;
+		uint64_t r = cand_read[c];
+		uint32_t nk = b.len[r] - p.k + 1;
+		for (uint32_t j = lane; j < nk; j += nlanes) rkh[rkoff[c] + j] = read_kmer_hash<NW>(p, b, r, j);
+	}
+};
+template <int NW>
+struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum minCount
+	Params p; const uint8_t* cnt; ContigRec* recs; uint32_t first; const uint8_t* pool; uint64_t* kh;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		ContigRec& rec = recs[first + i];
+		const uint8_t* seq = pool + rec.seq_off;
+		uint32_t cnk = rec.len - p.k + 1;
+		uint32_t cov = 0; // getSeqAbsoluteKmerCoverage (bloom-dbg.h:92-109): a pure function of the solid filter
+		for (uint32_t j = lane; j < cnk; j += nlanes) {
+			uint64_t h = seq_kmer_hash<NW>(p, seq, j);
+			kh[rec.seq_off + j] = h;
+			cov += solid_min_count(p, cnt, h);
+		}
+		if (cov) atomic_add_u32(&rec.coverage, cov);
+	}
+};
+// Which candidates without a result will still be unvisited at their turn?  A read is
+// predicted "covered" when each of its k-mers is already visited or lies in the territory
+// of a lower-numbered walker that completed.  Mispredictions only cost time: the ordered
+// commit stops at a needed candidate without a result and it is then walked (`force`).
+template <int NW>
+struct FPredict {
+	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint8_t* vis;
+	const uint64_t* rkoff; const uint64_t* rkh;
+	const uint32_t* claims; uint32_t claim_mask; uint32_t* need_list; uint32_t* need_n;
+	uint32_t first; uint32_t force;
+	ABG_HDN void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t c = first + (uint32_t)i;
+		if (status[c] == WS_COMPLETE) return;
+		uint64_t r = cand_read[c];
+		uint32_t nk = b.len[r] - p.k + 1;
+		bool covered = c != force;
+		for (uint32_t j = 0; covered && j < nk; j++) {
+			uint64_t hm = rkh[rkoff[c] + j];
+			if (visited_contains(p, vis, hm)) continue;
+			uint32_t owner = claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask];
+			if (owner < c && status[owner] == WS_COMPLETE) continue;
+			covered = false;
+		}
+		if (!covered) need_list[atomic_add_u32(need_n, 1)] = c;
+	}
+};
+
+// ---- ordered commit (outputContig, bloom-dbg.h:538-620), cooperative over T threads
+struct CommitState {
+	Counters counters;
+	uint32_t break_at;   // first candidate that could not be committed
+	uint32_t pad_;
+};
+template <int NW>
+struct CommitEnv {
+	Params p; Batch b; uint32_t* vis32;
+	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
+	ContigRec* recs; const uint8_t* pool; uint8_t* result;
+	const uint64_t* kh;      // hash of the k-mer starting at each pool offset (FContigPrep)
+	const uint64_t* rkh;     // hashes of the candidates' read k-mers (FReadPrep)
+	const uint64_t* rkoff;
+	WalkTab cend;            // contigEndKmers (bloom-dbg.h:992), owner 0
+	CommitState* st;
+	uint32_t* order;         // [rec_cap] records in commit order
+	uint32_t* order_n;
+};
+ABG_HD bool visited_contains_coherent(const Params& p, const uint32_t* vis32, uint64_t h)
+{
+	bool ok = true;
+	for (unsigned i = 0; i < p.nh; i++) {
+		uint64_t q = pos_i(p, h, i);
+		ok = ok & (((ld_coherent(&vis32[q >> 5]) >> (q & 31)) & 1u) != 0);
+	}
+	return ok;
+}
+// The only inherently sequential part of PASS 2: in read order, decide "all k-mers
+// visited?" for the read, then for each of its contigs the redundancy test and the
+// insertion into the visited filter (outputContig, bloom-dbg.h:538-620).  All hashing and
+// the coverage sums were done in parallel beforehand; this loop only tests and sets bits.
+// Sync policy: tid(), nthreads(), barrier(), all(bool), bcast(uint32_t from tid 0)
 template <int NW, class Sync>
 ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_end, Sync& sy)
 {
@@ -319,17 +334,19 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 		uint32_t nk = e.b.len[r] - k + 1;
 		// allKmersInBloom(seq, assembledKmerSet) at this read's turn (bloom-dbg.h:823)
 		bool mine = true;
+		const uint64_t* rh = e.rkh + e.rkoff[c];
 		for (uint32_t j = tid; j < nk; j += T)
-			mine = mine & visited_contains_coherent(p, e.vis32, read_kmer_hash<NW>(p, e.b, r, j));
+			mine = mine & visited_contains_coherent(p, e.vis32, rh[j]);
 		if (sy.all(mine)) {
 			if (tid == 0) { e.result[r] = RR_ALL_KMERS_VISITED; e.st->counters.visited_reads++; }
 			continue;
 		}
-		if (sy.bcast(e.status[c]) != WS_COMPLETE) break;
+		if (e.status[c] != WS_COMPLETE) break;
 		if (tid == 0) e.result[r] = RR_GENERATED_CONTIGS;
-		for (uint32_t ri = sy.bcast(e.first_rec[c]); ri != REC_END; ri = sy.bcast(e.recs[ri].next)) {
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
 			ContigRec& rec = e.recs[ri];
 			const uint8_t* seq = e.pool + rec.seq_off;
+			const uint64_t* ch = e.kh + rec.seq_off;
 			uint32_t len = rec.len, cnk = len - k + 1;
 			uint32_t redundant = 0;
 			if (len < k + FP_TRIM - 1) {
@@ -349,32 +366,29 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 			} else {
 				bool all = true;
 				for (uint32_t j = tid; j < cnk; j += T)
-					all = all & visited_contains_coherent(p, e.vis32, seq_kmer_hash<NW>(p, seq, j));
+					all = all & visited_contains_coherent(p, e.vis32, ch[j]);
 				redundant = sy.all(all) ? 1u : 0u;
 			}
 			if (redundant == 2) { if (tid == 0) e.st->pad_ = 1; redundant = 0; }
-			uint32_t cov = 0;
 			if (!redundant) {
-				// addKmersToBloom + getSeqAbsoluteKmerCoverage (bloom-dbg.h:79-109)
+				// addKmersToBloom (bloom-dbg.h:79-90)
 				for (uint32_t j = tid; j < cnk; j += T) {
-					uint64_t h = seq_kmer_hash<NW>(p, seq, j);
+					uint64_t h = ch[j];
 					for (unsigned i = 0; i < p.nh; i++) {
 						uint64_t q = pos_i(p, h, i);
 						atomic_or_u32(&e.vis32[q >> 5], 1u << (q & 31));
 					}
-					cov += solid_min_count(p, e.cnt, h);
 				}
 			}
-			cov = sy.sum(cov); // also the barrier that publishes the inserted bits
 			if (tid == 0) {
 				rec.redundant = (uint8_t)redundant;
 				if (!redundant) {
-					rec.coverage = cov;
 					rec.contig_id = e.st->counters.contig_id++;
 					e.st->counters.bases_assembled += len;
 				}
 				e.order[(*e.order_n)++] = ri;
 			}
+			sy.barrier(); // publishes the inserted bits to the next test
 		}
 	}
 	if (tid == 0) e.st->break_at = c;
@@ -388,7 +402,8 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 //   uint32_t max_slots();                       // upper bound on concurrent items of launch()
 //   template<class F> void launch(uint64_t n, F f, const char* name);               // f(i, slot)
 //   template<class F> void launch_slots(uint64_t n, F f, uint32_t slots, const char* name);
-//   template<class F> void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name); // one item per wave
+//   template<class F> void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name); // one item per wave, lane 0
+//   template<class F> void launch_wave(uint64_t n, F f, const char* name);   // f(item, lane, nlanes): one item per wave
 //   template<int NW> void launch_commit(CommitEnv<NW>, uint32_t c_begin, uint32_t c_end);
 template <class BE>
 class Engine {
@@ -496,7 +511,7 @@ class Engine {
 	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
 	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
 	uint32_t walk_tb_cap_ = 0, walk_buf_cap_ = 0, wslots_ = 0, cslots_ = 0;
-	std::vector<uint32_t> visited_now_;
+	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr;
 
 	void ensure_insert()
 	{
@@ -584,6 +599,7 @@ class Engine {
 		alloc_walk_scratch();
 		pool_cap_ = cfg_.pool_cap;
 		pool_ = (uint8_t*)be_.alloc(pool_cap_);
+		kh_ = (uint64_t*)be_.alloc(pool_cap_ * 8);
 		pool_used_ = (uint64_t*)be_.alloc(8);
 		rec_cap_ = cfg_.rec_cap;
 		recs_ = (ContigRec*)be_.alloc((uint64_t)rec_cap_ * sizeof(ContigRec));
@@ -616,7 +632,7 @@ class Engine {
 		free_tab(cend_); free_tab(wtab_);
 		be_.free(wclaims_); be_.free(la_pool_);
 		free_walk_scratch();
-		be_.free(pool_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
+		be_.free(pool_); be_.free(kh_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
 		be_.free(order_); be_.free(order_n_);
 		walk_ready_ = false;
 	}
@@ -637,9 +653,10 @@ class Engine {
 		free_tab(wtab_);
 		wtab_log2_++;
 		alloc_tab(wtab_, wtab_log2_);
-		be_.free(pool_);
+		be_.free(pool_); be_.free(kh_);
 		pool_cap_ *= 2;
 		pool_ = (uint8_t*)be_.alloc(pool_cap_);
+		kh_ = (uint64_t*)be_.alloc(pool_cap_ * 8);
 		if (cfg_.verbose)
 			fprintf(stderr, "abyss_amd: walker resources grown: %u frames, %u bases, 2^%u table, %llu pool\n",
 			    walk_tb_cap_, walk_buf_cap_, wtab_log2_, (unsigned long long)pool_cap_);
@@ -663,16 +680,18 @@ class Engine {
 
 	template <int NW>
 	uint32_t commit(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d,
-	    uint8_t* result_d, uint32_t c_begin, uint32_t c_end)
+	    uint8_t* result_d, const uint64_t* rkoff_d, uint32_t c_begin, uint32_t c_end)
 	{
 		CommitState cs;
 		cs.counters = counters_;
 		cs.break_at = c_begin; cs.pad_ = 0;
 		be_.h2d(cstate_, &cs, sizeof cs);
 		CommitEnv<NW> e;
-		e.p = p_; e.b = b; e.cnt = cnt_; e.vis32 = (uint32_t*)vis_;
+		e.p = p_; e.b = b; e.vis32 = (uint32_t*)vis_;
 		e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
-		e.recs = recs_; e.pool = pool_; e.result = result_d; e.cend = cend_; e.st = cstate_;
+		e.recs = recs_; e.pool = pool_; e.result = result_d;
+		e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
+		e.cend = cend_; e.st = cstate_;
 		e.order = order_; e.order_n = order_n_;
 		be_.template launch_commit<NW>(e, c_begin, c_end);
 		be_.d2h(&cs, cstate_, sizeof cs);
@@ -681,119 +700,138 @@ class Engine {
 		return cs.break_at;
 	}
 
-	// One batch of reads: rounds of {walk everything, re-walk what lower reads do not
-	// cover, commit in read order} until every candidate is accounted for.
+	// hashes + coverage of the contig records produced since the last call (parallel)
+	template <int NW>
+	void prep_new_records(uint32_t& prepped)
+	{
+		uint32_t nrec = 0;
+		be_.d2h(&nrec, rec_used_, 4);
+		nrec = std::min(nrec, rec_cap_);
+		if (nrec > prepped) {
+			FContigPrep<NW> f{ p_, cnt_, recs_, prepped, pool_, kh_ };
+			be_.launch_wave(nrec - prepped, f, "contig_prep");
+			prepped = nrec;
+		}
+	}
+	void clear_wtab()
+	{
+		be_.memset(wtab_.hmin, 0xFF, (wtab_.mask + 1) * 8);
+		be_.memset(wtab_.meta, 0xFF, (wtab_.mask + 1) * 8);
+	}
+
+	// One batch of reads.  Every candidate is walked once with deferral (a walker that
+	// meets the territory of a lower-numbered read stops: its read is almost always visited
+	// by its turn).  Then, until all candidates are accounted for: predict which deferred
+	// candidates will be needed after all, walk those privately in parallel, and run the
+	// ordered commit as far as the results allow.  Walk results are pure functions of the
+	// read and the solid filter, so they stay valid across iterations.
 	template <int NW>
 	void run_rounds(const Batch& b, std::vector<uint32_t>& cand_h, uint8_t* result_d,
 	    uint64_t read_base, const std::function<void(const ContigOut&)>& sink)
 	{
-		while (!cand_h.empty()) {
-			const uint32_t nc = (uint32_t)cand_h.size();
+		const uint32_t nc = (uint32_t)cand_h.size();
+		const uint32_t cmask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1);
+		uint32_t* cand_d = (uint32_t*)be_.alloc(nc * 4ull);
+		uint32_t* status_d = (uint32_t*)be_.alloc(nc * 4ull);
+		uint32_t* first_d = (uint32_t*)be_.alloc(nc * 4ull);
+		uint32_t* list_d = (uint32_t*)be_.alloc(nc * 4ull);
+		uint32_t* need_d = (uint32_t*)be_.alloc(nc * 4ull);
+		uint32_t* need_n = (uint32_t*)be_.alloc(8);
+		be_.h2d(cand_d, cand_h.data(), nc * 4ull);
+		// hashes of the candidates' read k-mers, used by the predictor and the commit
+		std::vector<uint32_t> len_h(b.n);
+		be_.d2h(len_h.data(), b.len, b.n * 4ull);
+		std::vector<uint64_t> rkoff(nc + 1, 0);
+		for (uint32_t i = 0; i < nc; i++) rkoff[i + 1] = rkoff[i] + (len_h[cand_h[i]] - p_.k + 1);
+		uint64_t* rkoff_d = (uint64_t*)be_.alloc((nc + 1) * 8ull);
+		be_.h2d(rkoff_d, rkoff.data(), (nc + 1) * 8ull);
+		rkh_ = (uint64_t*)be_.alloc(std::max<uint64_t>(rkoff[nc], 1) * 8);
+		{
+			FReadPrep<NW> f{ p_, b, cand_d, rkoff_d, rkh_, 0 };
+			be_.launch_wave(nc, f, "read_prep");
+		}
+		uint32_t base = 0; // candidates [0, base) are accounted for
+		while (base < nc) {
 			stats_.rounds++;
-			uint32_t* cand_d = (uint32_t*)be_.alloc(nc * 4ull);
-			uint32_t* status_d = (uint32_t*)be_.alloc(nc * 4ull);
-			uint32_t* first_d = (uint32_t*)be_.alloc(nc * 4ull);
-			uint32_t* list_d = (uint32_t*)be_.alloc(nc * 4ull);
-			uint32_t* need_d = (uint32_t*)be_.alloc(nc * 4ull);
-			uint32_t* need_n = (uint32_t*)be_.alloc(8);
-			be_.h2d(cand_d, cand_h.data(), nc * 4ull);
-			be_.memset(status_d, 0, nc * 4ull);
-			be_.memset(first_d, 0xFF, nc * 4ull);
-			{
-				std::vector<uint32_t> ident(nc);
-				for (uint32_t i = 0; i < nc; i++) ident[i] = i;
-				be_.h2d(list_d, ident.data(), nc * 4ull);
-			}
-			// fresh per-round walker state
-			be_.memset(wtab_.hmin, 0xFF, (wtab_.mask + 1) * 8);
-			be_.memset(wtab_.meta, 0xFF, (wtab_.mask + 1) * 8);
-			be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
+			// (re)start for the candidates [base, nc): nothing walked yet
+			be_.memset(status_d + base, 0, (nc - base) * 4ull);
+			be_.memset(first_d + base, 0xFF, (nc - base) * 4ull);
 			be_.memset(pool_used_, 0, 8);
 			be_.memset(rec_used_, 0, 4);
 			be_.memset(order_n_, 0, 4);
-
-			WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
-			// stage 1: every candidate walks; a walker that meets the territory of a
-			// lower-numbered read stops (its read is almost always visited by its turn)
-			env.claims = wclaims_;
-			env.owner_base = 0;
+			be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
+			uint32_t prepped = 0;
+			uint32_t owner_next = 0;
 			{
+				std::vector<uint32_t> ident(nc - base);
+				for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;
+				be_.h2d(list_d, ident.data(), (nc - base) * 4ull);
+			}
+			// stage 1: everybody walks, deferring to lower-numbered walkers
+			clear_wtab();
+			{
+				WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
+				env.claims = wclaims_;
+				env.owner_base = owner_next;
+				owner_next += nc;
 				FWalk<NW> fw{ env, list_d };
-				be_.launch_walkers(nc, fw, wslots_, "walk");
+				be_.launch_walkers(nc - base, fw, wslots_, "walk");
+				stats_.walked += nc - base;
 			}
-			stats_.walked += nc;
-			// stage 2: deferred candidates that lower reads do not cover are walked privately
-			be_.memset(need_n, 0, 4);
-			{
-				FPredict<NW> fp{ p_, b, cand_d, status_d, vis_, wclaims_,
-					(uint32_t)((1ull << cfg_.wclaim_log2) - 1), need_d, need_n, list_d };
-				be_.launch(nc, fp, "predict");
-			}
-			uint32_t nneed = 0;
-			be_.d2h(&nneed, need_n, 4);
-			uint32_t owner_next = nc;
-			if (nneed) {
-				env.claims = nullptr;
-				env.owner_base = owner_next; // owner ids distinct from stage 1
-				owner_next += nc;
-				FWalk<NW> fw{ env, need_d };
-				be_.launch_walkers(nneed, fw, wslots_, "rewalk");
-				stats_.rewalked += nneed;
-			}
-			// stage 3: ordered commit as far as the results allow.  A candidate that stops it
-			// (deferred but needed after all) is walked on the spot -- it is now the
-			// lowest-numbered read left -- and the commit resumes.
-			uint32_t committed = commit<NW>(b, cand_d, status_d, first_d, result_d, 0, nc);
-			bool overflowed = false;
-			uint32_t spot = 0;
+			prep_new_records<NW>(prepped);
+			uint32_t committed = base;
+			uint32_t force = 0xFFFFFFFFu;
+			bool overflow = false;
 			while (committed < nc) {
-				uint32_t st = 0;
-				be_.d2h(&st, status_d + committed, 4);
-				if (st == WS_OVERFLOW) { overflowed = true; break; }
-				if (spot >= 256 || owner_next > 0xF0000000u - nc) break; // re-plan the remainder
-				stats_.breaks++;
-				spot++;
-				WalkEnv<NW> env2 = make_env<NW>(b, cand_d, status_d, first_d);
-				env2.claims = nullptr;
-				env2.owner_base = owner_next;
-				owner_next += nc;
-				be_.h2d(need_d, &committed, 4);
-				FWalk<NW> fw{ env2, need_d };
-				be_.launch_walkers(1, fw, wslots_, "spotwalk");
-				stats_.rewalked++;
-				be_.d2h(&st, status_d + committed, 4);
-				if (st == WS_OVERFLOW) { overflowed = true; break; }
-				if (st != WS_COMPLETE) { fprintf(stderr, "abyss_amd: walker failed with status %u\n", st); abort(); }
-				uint32_t next = commit<NW>(b, cand_d, status_d, first_d, result_d, committed, nc);
-				if (next == committed) { fprintf(stderr, "abyss_amd: commit made no progress\n"); abort(); }
+				// stage 2: candidates without a result that lower reads will not cover
+				be_.memset(need_n, 0, 4);
+				{
+					FPredict<NW> fp{ p_, b, cand_d, status_d, vis_, rkoff_d, rkh_, wclaims_, cmask,
+						need_d, need_n, committed, force };
+					be_.launch(nc - committed, fp, "predict");
+				}
+				uint32_t nneed = 0;
+				be_.d2h(&nneed, need_n, 4);
+				if (nneed) {
+					if (owner_next > 0xF0000000u - nc) { overflow = true; break; } // owner ids exhausted: restart
+					clear_wtab();
+					WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
+					env.claims = nullptr;
+					env.owner_base = owner_next;
+					owner_next += nc;
+					FWalk<NW> fw{ env, need_d };
+					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
+					stats_.rewalked += nneed;
+					prep_new_records<NW>(prepped);
+				}
+				// stage 3: ordered commit as far as the results allow
+				uint32_t next = commit<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc);
+				if (next < nc) {
+					stats_.breaks++;
+					uint32_t st = 0;
+					be_.d2h(&st, status_d + next, 4);
+					if (st == WS_OVERFLOW) { committed = next; overflow = true; break; }
+					if (st == WS_COMPLETE || (next == committed && force == next)) {
+						fprintf(stderr, "abyss_amd: commit made no progress at candidate %u (status %u)\n", next, st);
+						abort();
+					}
+					force = next; // needed after all: walk it in the next iteration
+				}
 				committed = next;
 			}
 			deliver(cand_h, read_base, sink);
-			if (overflowed && committed == 0) grow_walk_resources();
-			// what is left goes to the next round, minus the reads that are entirely visited
-			// by now (the visited set only grows, so that verdict is final)
-			std::vector<uint32_t> rest(cand_h.begin() + committed, cand_h.end());
-			if (!rest.empty()) {
-				uint32_t nr = (uint32_t)rest.size();
-				uint8_t* nowv_d = (uint8_t*)be_.alloc(nr);
-				be_.h2d(cand_d, rest.data(), nr * 4ull);
-				FRefilter<NW> fr{ p_, b, cand_d, vis_, nowv_d };
-				be_.launch(nr, fr, "refilter");
-				std::vector<uint8_t> nowv(nr);
-				be_.d2h(nowv.data(), nowv_d, nr);
-				be_.free(nowv_d);
-				std::vector<uint32_t> keep;
-				for (uint32_t i = 0; i < nr; i++) {
-					// the first one stopped the commit, so it is known not to be visited
-					if (nowv[i] && i > 0) { visited_now_.push_back(rest[i]); counters_.visited_reads++; }
-					else keep.push_back(rest[i]);
-				}
-				rest.swap(keep);
+			if (overflow) {
+				// the candidate at `committed` ran out of some capacity.  Results not yet committed
+				// are dropped and the walk restarts from there; if nothing was committed in this
+				// attempt the capacities themselves are too small for that read.
+				if (committed == base) grow_walk_resources();
 			}
-			cand_h.swap(rest);
-			be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
-			be_.free(need_d); be_.free(need_n);
+			base = committed;
 		}
+		be_.free(rkh_); rkh_ = nullptr;
+		be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
+		be_.free(need_d); be_.free(need_n); be_.free(rkoff_d);
+		cand_h.clear();
 	}
 
 	void deliver(const std::vector<uint32_t>& cand_h, uint64_t read_base,
@@ -821,7 +859,7 @@ class Engine {
 			o.read_index = read_base + cand_h[r.cand];
 			o.seq.resize(r.len);
 			for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGT"[pool[r.seq_off + j] & 3];
-			o.coverage = r.coverage;
+			o.coverage = r.redundant ? 0 : r.coverage;
 			o.redundant = r.redundant != 0;
 			o.left_ext = r.left_ext; o.right_ext = r.right_ext;
 			o.left_code = r.left_code; o.right_code = r.right_code;
@@ -847,11 +885,9 @@ class Engine {
 			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
 		}
 		stats_.candidates += cand.size();
-		visited_now_.clear();
 		if (!cand.empty()) run_rounds<NW>(v, cand, res_d, first, sink);
 		if (results_host) {
 			be_.d2h(results_host + first, res_d, n);
-			for (uint32_t r : visited_now_) results_host[first + r] = RR_ALL_KMERS_VISITED;
 			for (uint64_t i = 0; i < n; i++)
 				if (results_host[first + i] == RES_CANDIDATE) {
 					fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)(first + i));

@@ -46,6 +46,16 @@ __global__ void __launch_bounds__(64) k_foreach_lane0(F f, uint64_t n)
 	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x);
 }
 
+// one item per wavefront, all 64 lanes cooperate (f strides its inner loop by lane)
+template <class F>
+__global__ void __launch_bounds__(256) k_foreach_wave(F f, uint64_t n)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	for (; w < n; w += nw) f(w, lane, 64u);
+}
+
 constexpr int COMMIT_THREADS = 1024;
 struct DeviceSync {
 	uint32_t* sh; // [COMMIT_THREADS / 64 + 2] shared words
@@ -180,6 +190,17 @@ struct HipBackend {
 		if (blocks > cap) blocks = cap;
 		begin(name);
 		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
+		end(name);
+	}
+	template <class F>
+	void launch_wave(uint64_t n, F f, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = (n + 3) / 4;
+		uint64_t cap = (uint64_t)cus * 8;
+		if (blocks > cap) blocks = cap;
+		begin(name);
+		hipLaunchKernelGGL(k_foreach_wave<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
 		end(name);
 	}
 	template <class F>

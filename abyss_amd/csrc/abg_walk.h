@@ -269,15 +269,31 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	int result;
 	for (;;) {
 		Vtx<NW> t, v;
+		// both neighbourhoods of the head in one probe round (8 k-mers x H counters in flight)
+		uint64_t bfh[4], brh[4], ffh[4], frh[4];
+		neighbour_hashes(p, head, (other == FORWARD) ? SENSE : ANTISENSE, bfh, brh);
+		neighbour_hashes(p, head, (dir == FORWARD) ? SENSE : ANTISENSE, ffh, frh);
+		unsigned bmask, fmask;
+		{
+			uint64_t h8[8];
+#pragma unroll
+			for (unsigned q = 0; q < 4; q++) {
+				h8[q] = brh[q] < bfh[q] ? brh[q] : bfh[q];
+				h8[4 + q] = frh[q] < ffh[q] ? frh[q] : ffh[q];
+			}
+			unsigned m8 = solid_mask8(p, e.cnt, h8);
+			bmask = m8 & 0xFu;
+			fmask = m8 >> 4;
+		}
 		if (look_behind) {
-			result = successor(p, e.cnt, head, other, p.trim, t, sc);
+			result = successor_m(p, e.cnt, head, other, p.trim, bmask, bfh, brh, t, sc);
 			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
 			if (n > 1) {
 				if (result == ER_DEAD_END) { result = ER_AMBI_IN; break; }
 				if (!vtx_equal(p, prev, t)) { result = ER_AMBI_IN; break; }
 			}
 		}
-		result = successor(p, e.cnt, head, dir, p.trim, v, sc);
+		result = successor_m(p, e.cnt, head, dir, p.trim, fmask, ffh, frh, v, sc);
 		if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
 		if (result != ER_LENGTH_LIMIT) break;
 		// path.push_back(v) / push_front(v)

@@ -31,6 +31,7 @@ struct SerialBackend {
 	uint32_t max_slots() const { return 1; }
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
+	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
 	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
