@@ -490,10 +490,16 @@ struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
 	uint8_t mask, next;
 };
 constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
+// The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on
+// the device), deeper ones in the global pool.
 template <int NW>
 struct SearchScratch {
-	TBFrame<NW>* tb;       // [tb_cap]
+	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
+	VKey* tb_keys;         // [tb_cap] (fh, rh) of tb[i].v: what the on-stack test scans
 	uint32_t tb_cap;
+	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
+	VKey* tbf_keys;
+	uint32_t tbf_cap;
 	uint32_t overflow;     // set when a stack capacity was exceeded
 	LAFrame<NW> la[FP_TRIM + 1];
 	VKey* la_visited;      // [LA_MAX_VISITED]
@@ -548,26 +554,48 @@ ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 // recursion is a depth-first search over an explicit frame stack that stops at the first
 // call that would return true.
 template <int NW>
+ABG_HD TBFrame<NW>& tb_frame(SearchScratch<NW>& sc, int i)
+{
+	return (uint32_t)i < sc.tbf_cap ? sc.tbf[i] : sc.tb[(uint32_t)i - sc.tbf_cap];
+}
+template <int NW>
 ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
     const Vtx<NW>& v0, int dir0, unsigned trim, SearchScratch<NW>& sc)
 {
-	TBFrame<NW>* st = sc.tb;
 	int top = -1;
+	const int cap = (int)(sc.tbf_cap + sc.tb_cap);
 	// "call" trueBranch(u0 -> v0, depth 0, dir0)
 	Vtx<NW> cu = u0, cv = v0;
 	unsigned cdepth = 0;
 	int cdir = dir0;
 	for (;;) {
 		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
+		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
 		bool on_stack = false;
-		for (int i = 0; i <= top; i++)
-			if (vtx_equal(p, cv, st[i].v)) { on_stack = true; break; }
+		{
+			const bool tie = (p.k & 1) ? kmer_is_tie(cv.s, p.k) : false;
+			const int nf = top + 1 < (int)sc.tbf_cap ? top + 1 : (int)sc.tbf_cap;
+			for (int i = 0; i < nf; i++) {
+				VKey kk = sc.tbf_keys[i];
+				bool same = (kk.fh == cv.fh) & (kk.rh == cv.rh);
+				bool swapped = (kk.fh == cv.rh) & (kk.rh == cv.fh);
+				on_stack = on_stack | same | (swapped & !tie);
+			}
+			for (int i = nf; i <= top; i++) {
+				VKey kk = sc.tb_keys[i - nf];
+				bool same = (kk.fh == cv.fh) & (kk.rh == cv.rh);
+				bool swapped = (kk.fh == cv.rh) & (kk.rh == cv.fh);
+				on_stack = on_stack | same | (swapped & !tie);
+			}
+		}
 		if (on_stack) return true;
 		if (cdepth >= trim) return true;
-		if (top + 1 >= (int)sc.tb_cap) { sc.overflow = 1; return true; }
+		if (top + 1 >= cap) { sc.overflow = 1; return true; }
 		top++;
 		{
-			TBFrame<NW>& f = st[top];
+			VKey& kk = (uint32_t)top < sc.tbf_cap ? sc.tbf_keys[top] : sc.tb_keys[(uint32_t)top - sc.tbf_cap];
+			kk.fh = cv.fh; kk.rh = cv.rh;
+			TBFrame<NW>& f = tb_frame(sc, top);
 			f.v = cv; f.ufh = cu.fh; f.urh = cu.rh;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
@@ -577,7 +605,7 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		// ---- resume frames until one of them makes a new call
 		bool called = false;
 		while (top >= 0 && !called) {
-			TBFrame<NW>& f = st[top];
+			TBFrame<NW>& f = tb_frame(sc, top);
 			int fdir = f.dir;
 			int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
 			if (f.stage == 0) {

@@ -26,7 +26,7 @@ struct Config {
 	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
 	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
 	uint32_t walk_slots = 8192;       // concurrent walkers (one per wavefront)
-	uint32_t tb_cap = 192;            // trueBranch frames per walker
+	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
 	uint32_t buf_cap = 1u << 13;      // extension bases per side per walker
 	uint64_t pool_cap = 1ull << 28;   // contig pool bytes
 	uint32_t rec_cap = 1u << 22;      // contig records per round
@@ -168,7 +168,8 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		unsigned k = p.k;
 		uint32_t nk = L - k + 1;
 		SearchScratch<NW> sc;
-		sc.tb = nullptr; sc.tb_cap = 0; sc.overflow = 0;
+		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0;
+		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
 		// the read and from the first k-mer of its reverse complement
@@ -203,10 +204,12 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 
 template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
-	WalkEnv<NW> e; const uint32_t* list;
-	ABG_HDN void operator()(uint64_t i, uint32_t slot)
+	WalkEnv<NW> e; const uint32_t* list; bool use_fast;
+	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes)
 	{
 		WalkEnv<NW> env = e;
+		env.fast = use_fast ? fast : nullptr;
+		env.fast_bytes = fast_bytes;
 		walk_read<NW>(env, list[i], slot);
 	}
 };
@@ -506,7 +509,7 @@ class Engine {
 	WalkTab wtab_{}, cend_{};
 	uint32_t wtab_log2_ = 0;
 	uint32_t* wclaims_ = nullptr;
-	void* tb_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
+	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; bool slow_frames_ = false; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
 	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
 	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
 	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
@@ -611,10 +614,11 @@ class Engine {
 	void alloc_walk_scratch()
 	{
 		tb_pool_ = be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(TBFrame<MAX_NW>));
+		tbk_pool_ = (VKey*)be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(VKey));
 		lbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
 		rbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
 	}
-	void free_walk_scratch() { be_.free(tb_pool_); be_.free(lbuf_); be_.free(rbuf_); }
+	void free_walk_scratch() { be_.free(tb_pool_); be_.free(tbk_pool_); be_.free(lbuf_); be_.free(rbuf_); }
 	void alloc_tab(WalkTab& t, uint32_t log2)
 	{
 		uint64_t cap = 1ull << log2;
@@ -670,7 +674,9 @@ class Engine {
 		e.tab = wtab_; e.claims = nullptr; e.claim_mask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1); e.owner_base = 0;
 		// scratch strides are sized for TBFrame<MAX_NW>; a smaller NW fits more frames in them
 		e.tb_pool = (TBFrame<NW>*)tb_pool_;
-		e.tb_cap = (uint32_t)((uint64_t)walk_tb_cap_ * sizeof(TBFrame<MAX_NW>) / sizeof(TBFrame<NW>));
+		e.tbk_pool = tbk_pool_;
+		e.tb_cap = walk_tb_cap_;
+		e.fast = nullptr; e.fast_bytes = 0;
 		e.la_pool = la_pool_;
 		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
 		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
@@ -774,7 +780,7 @@ class Engine {
 				env.claims = wclaims_;
 				env.owner_base = owner_next;
 				owner_next += nc;
-				FWalk<NW> fw{ env, list_d };
+				FWalk<NW> fw{ env, list_d, !slow_frames_ };
 				be_.launch_walkers(nc - base, fw, wslots_, "walk");
 				stats_.walked += nc - base;
 			}
@@ -799,7 +805,7 @@ class Engine {
 					env.claims = nullptr;
 					env.owner_base = owner_next;
 					owner_next += nc;
-					FWalk<NW> fw{ env, need_d };
+					FWalk<NW> fw{ env, need_d, !slow_frames_ };
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;
 					prep_new_records<NW>(prepped);

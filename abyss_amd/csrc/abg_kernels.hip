@@ -39,11 +39,14 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 // One walker per wavefront: a unitig walk is a long, branchy, latency-bound pointer chase;
 // 64 of them in one wave would serialise on every divergent branch, so each wave runs a
 // single walker on lane 0 with wave-uniform control flow and the other lanes masked off.
+// The walker's trueBranch stack (frames + keys) lives in WALK_LDS bytes of LDS.
+constexpr uint32_t WALK_LDS = 24576;
 template <class F>
 __global__ void __launch_bounds__(64) k_foreach_lane0(F f, uint64_t n)
 {
+	__shared__ __attribute__((aligned(16))) unsigned char lds[WALK_LDS];
 	if (threadIdx.x != 0) return;
-	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x);
+	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS);
 }
 
 // one item per wavefront, all 64 lanes cooperate (f strides its inner loop by lane)

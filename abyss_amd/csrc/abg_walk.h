@@ -205,7 +205,9 @@ struct WalkEnv {
 	uint32_t claim_mask;
 	uint32_t owner_base;       // owner ids of this launch are owner_base + candidate index
 	// per-slot scratch
-	TBFrame<NW>* tb_pool; uint32_t tb_cap;
+	TBFrame<NW>* tb_pool; VKey* tbk_pool; uint32_t tb_cap;
+	// fast per-walker memory (LDS on the device) for the trueBranch stack; NULL: use tb_pool
+	void* fast; uint32_t fast_bytes;
 	VKey* la_pool;
 	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
 	// contig output
@@ -256,7 +258,7 @@ ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i)
 // Returns the ExtCode, or -1 when the walker must stop (status written to *abort).
 template <int NW>
 ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owner, uint32_t contig,
-    uint32_t claim_id, SearchScratch<NW>& sc, uint32_t* ext_out, uint32_t* abort, bool* end_earlier)
+    uint32_t claim_id, bool may_defer, SearchScratch<NW>& sc, uint32_t* ext_out, uint32_t* abort, bool* end_earlier)
 {
 	const Params& p = e.p;
 	int other = (dir == FORWARD) ? REVERSE : FORWARD;
@@ -318,7 +320,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		if (e.claims) {
 			uint64_t hm = v.fh < v.rh ? v.fh : v.rh;
 			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
-			if (old < claim_id) { *abort = WS_DEFERRED; return -1; }
+			if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
 		}
 		prev = head;
 		head = v;
@@ -366,7 +368,16 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	const unsigned k = p.k;
 	SearchScratch<NW> sc;
 	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
+	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_cap = e.tb_cap;
+	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
+	if (e.fast) {
+		// fast tier: frames and keys side by side in LDS
+		uint32_t cap = e.fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
+		sc.tbf_keys = (VKey*)e.fast;
+		sc.tbf = (TBFrame<NW>*)((char*)e.fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
+		sc.tbf_cap = cap - 1;
+	}
 	sc.overflow = 0;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 
@@ -400,12 +411,15 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (e.claims) {
 			uint64_t hm = ckey.fh;
 			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
-			if (old < claim_id) { abort_status = WS_DEFERRED; break; }
+			if (old < claim_id && first == REC_END) { abort_status = WS_DEFERRED; break; }
 		}
+		// A walker defers to a lower-numbered one only until it has produced a contig of its
+		// own: after that its read cannot be skipped as "visited", so its result is needed.
+		const bool may_defer = (first == REC_END);
 		uint32_t lext = 0, rext = 0;
-		int lcode = walk_extend(e, w, REVERSE, owner, contig, claim_id, sc, &lext, &abort_status, &left_earlier);
+		int lcode = walk_extend(e, w, REVERSE, owner, contig, claim_id, may_defer, sc, &lext, &abort_status, &left_earlier);
 		if (lcode < 0) break;
-		int rcode = walk_extend(e, w, FORWARD, owner, contig, claim_id, sc, &rext, &abort_status, &right_earlier);
+		int rcode = walk_extend(e, w, FORWARD, owner, contig, claim_id, may_defer, sc, &rext, &abort_status, &right_earlier);
 		if (rcode < 0) break;
 		uint32_t n = w.nl + 1 + w.nr;
 
