@@ -365,17 +365,49 @@ ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, u
 	return ok;
 }
 
-// 4-bit mask: which of four canonical hashes does the solid filter contain?  The probe
-// positions of all four k-mers (up to four hash functions at a time) are computed first
-// and their loads issued back to back, so one probe round costs one memory latency
-// instead of sixteen.
-ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[4])
+// ---- wave-cooperative helpers ------------------------------------------------------
+// A "cooperative" caller is a whole wavefront executing the same code with identical
+// state in every lane (one unitig walker per wave).  Probes then spread over the lanes:
+// lane l handles hash function (l & 7) of k-mer (l >> 3), and a ballot gathers the verdict.
+// Non-cooperative callers (one item per lane, or the serial host check) pass coop = false.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD unsigned lane_id() { return __lane_id(); }
+ABG_HD uint64_t wave_ballot(bool v) { return __ballot(v ? 1 : 0); }
+ABG_HD bool wave_any(bool v) { return __ballot(v ? 1 : 0) != 0; }
+#else
+ABG_HD unsigned lane_id() { return 0; }
+ABG_HD uint64_t wave_ballot(bool v) { return v ? 1 : 0; }
+ABG_HD bool wave_any(bool v) { return v; }
+#endif
+
+// 8-bit mask: which of eight canonical hashes does the solid filter contain
+// (CountingBloomFilter::contains, CountingBloomFilter.hpp:190-196: min over the H
+// counters >= threshold)?  Serial form: the probe positions of all k-mers (up to four
+// hash functions at a time) are computed first and their loads issued back to back, so a
+// probe round costs one memory latency.  Cooperative form: one (k-mer, hash) per lane.
+ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[8], bool coop)
 {
-	unsigned ok = 0xFu;
-	for (unsigned base = 0; base < p.nh; base += 4) {
-		uint8_t c[4][4];
+	unsigned ok = 0xFFu;
+	if (coop) {
+		const unsigned lane = lane_id();
+		const unsigned b = lane >> 3, i = lane & 7;
+		uint64_t hb = h[0];
 #pragma unroll
-		for (unsigned b = 0; b < 4; b++) {
+		for (unsigned q = 1; q < 8; q++) hb = (b == q) ? h[q] : hb;
+		for (unsigned base = 0; base < p.nh; base += 8) {
+			bool bad = false;
+			if (base + i < p.nh) bad = cnt[pos_i(p, hb, base + i)] < p.kc;
+			uint64_t m = wave_ballot(bad);
+#pragma unroll
+			for (unsigned q = 0; q < 8; q++)
+				if ((m >> (8 * q)) & 0xFFu) ok &= ~(1u << q);
+		}
+		return ok;
+	}
+	for (unsigned base = 0; base < p.nh; base += 4) {
+		uint8_t c[8][4];
+#pragma unroll
+		for (unsigned b = 0; b < 8; b++) {
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++) {
 				unsigned ii = base + i < p.nh ? base + i : 0; // surplus slots re-probe hash 0
@@ -383,7 +415,7 @@ ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, co
 			}
 		}
 #pragma unroll
-		for (unsigned b = 0; b < 4; b++) {
+		for (unsigned b = 0; b < 8; b++) {
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++)
 				if (c[b][i] < p.kc) ok &= ~(1u << b);
@@ -391,15 +423,20 @@ ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, co
 	}
 	return ok;
 }
-
-// the same for eight hashes (both neighbourhoods of a vertex in one probe round)
-ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[8])
+// the same for four hashes
+ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[4], bool coop)
 {
-	unsigned ok = 0xFFu;
-	for (unsigned base = 0; base < p.nh; base += 4) {
-		uint8_t c[8][4];
+	if (coop) {
+		uint64_t h8[8];
 #pragma unroll
-		for (unsigned b = 0; b < 8; b++) {
+		for (unsigned q = 0; q < 4; q++) { h8[q] = h[q]; h8[4 + q] = h[q]; }
+		return solid_mask8(p, cnt, h8, true) & 0xFu;
+	}
+	unsigned ok = 0xFu;
+	for (unsigned base = 0; base < p.nh; base += 4) {
+		uint8_t c[4][4];
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++) {
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++) {
 				unsigned ii = base + i < p.nh ? base + i : 0;
@@ -407,7 +444,7 @@ ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, co
 			}
 		}
 #pragma unroll
-		for (unsigned b = 0; b < 8; b++) {
+		for (unsigned b = 0; b < 4; b++) {
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++)
 				if (c[b][i] < p.kc) ok &= ~(1u << b);
@@ -447,13 +484,13 @@ ABG_HD void neighbour_hashes(const Params& p, const Vtx<NW>& u, int sense, uint6
 // Returns a 4-bit mask (bit b = neighbour with base b exists) and the hash pairs.
 template <int NW>
 ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
-    const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
+    const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4], bool coop)
 {
 	neighbour_hashes(p, u, sense, fh4, rh4);
 	uint64_t h[4];
 #pragma unroll
 	for (unsigned b = 0; b < 4; b++) h[b] = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
-	return solid_mask4(p, cnt, h);
+	return solid_mask4(p, cnt, h, coop);
 }
 template <int NW>
 ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsigned b,
@@ -497,6 +534,8 @@ struct SearchScratch {
 	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
 	VKey* tb_keys;         // [tb_cap] (fh, rh) of tb[i].v: what the on-stack test scans
 	uint32_t tb_cap;
+	uint32_t n_tb_nodes, n_la, n_succ, n_tb_calls; // work counters (profiling aid)
+	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
 	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
 	VKey* tbf_keys;
 	uint32_t tbf_cap;
@@ -514,13 +553,14 @@ ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
 	unsigned nv = 0;
+	sc.n_la++;
 	VKey* vis = sc.la_visited;
 	vis[nv].fh = start.fh; vis[nv].rh = start.rh; nv++;
 	if (limit == 0) return true;
 	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
 	int depth = 0;
 	sc.la[0].v = start;
-	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, sc.la[0].nfh, sc.la[0].nrh);
+	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, sc.la[0].nfh, sc.la[0].nrh, sc.coop);
 	sc.la[0].next = 0;
 	while (depth >= 0) {
 		LAFrame<NW>& f = sc.la[depth];
@@ -542,7 +582,7 @@ ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 		if ((unsigned)(depth + 1) >= limit) return true;
 		depth++;
 		sc.la[depth].v = w;
-		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, sc.la[depth].nfh, sc.la[depth].nrh);
+		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, sc.la[depth].nfh, sc.la[depth].nrh, sc.coop);
 		sc.la[depth].next = 0;
 	}
 	return false;
@@ -575,23 +615,21 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		{
 			const bool tie = (p.k & 1) ? kmer_is_tie(cv.s, p.k) : false;
 			const int nf = top + 1 < (int)sc.tbf_cap ? top + 1 : (int)sc.tbf_cap;
-			for (int i = 0; i < nf; i++) {
-				VKey kk = sc.tbf_keys[i];
+			// cooperative callers spread the scan over the lanes
+			const int first = sc.coop ? (int)lane_id() : 0, step = sc.coop ? 64 : 1;
+			for (int i = first; i <= top; i += step) {
+				VKey kk = i < nf ? sc.tbf_keys[i] : sc.tb_keys[i - nf];
 				bool same = (kk.fh == cv.fh) & (kk.rh == cv.rh);
 				bool swapped = (kk.fh == cv.rh) & (kk.rh == cv.fh);
 				on_stack = on_stack | same | (swapped & !tie);
 			}
-			for (int i = nf; i <= top; i++) {
-				VKey kk = sc.tb_keys[i - nf];
-				bool same = (kk.fh == cv.fh) & (kk.rh == cv.rh);
-				bool swapped = (kk.fh == cv.rh) & (kk.rh == cv.fh);
-				on_stack = on_stack | same | (swapped & !tie);
-			}
+			if (sc.coop) on_stack = wave_any(on_stack);
 		}
 		if (on_stack) return true;
 		if (cdepth >= trim) return true;
 		if (top + 1 >= cap) { sc.overflow = 1; return true; }
 		top++;
+		sc.n_tb_nodes++;
 		{
 			VKey& kk = (uint32_t)top < sc.tbf_cap ? sc.tbf_keys[top] : sc.tb_keys[(uint32_t)top - sc.tbf_cap];
 			kk.fh = cv.fh; kk.rh = cv.rh;
@@ -600,7 +638,7 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
 			f.mask_same = (uint8_t)neighbour_mask(p, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE,
-			    f.nfh, f.nrh);
+			    f.nfh, f.nrh, sc.coop);
 		}
 		// ---- resume frames until one of them makes a new call
 		bool called = false;
@@ -627,7 +665,7 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				f.stage = 1;
 				f.next = 0;
 				f.mask_other = (uint8_t)neighbour_mask(p, cnt, f.v,
-				    fdir == FORWARD ? ANTISENSE : SENSE, f.nfh, f.nrh);
+				    fdir == FORWARD ? ANTISENSE : SENSE, f.nfh, f.nrh, sc.coop);
 				f.have_other = 1;
 			}
 			// stage 1: other-direction children, skipping the vertex we came from
@@ -664,6 +702,7 @@ ABG_HDN int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
 	vout = u;
+	sc.n_succ++;
 	for (unsigned i = 0;; i = (i == 0) ? 1u : (trim < 2 * i ? trim : 2 * i)) {
 		unsigned tb = 0;
 		for (unsigned b = 0; b < 4; b++) {
@@ -671,6 +710,7 @@ ABG_HDN int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
 			// trueBranch(e, dir, g, i, fpTrim) with a fresh visited set; at i == 0 every
 			// existing edge is a true branch (depth 0 >= trim 0)
+			if (i) sc.n_tb_calls++;
 			bool t = (i == 0) ? true : true_branch(p, cnt, u, w, dir, i, sc);
 			if (t) {
 				vout = w;
@@ -687,7 +727,7 @@ ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vt
     unsigned trim, Vtx<NW>& vout, SearchScratch<NW>& sc)
 {
 	uint64_t nfh[4], nrh[4];
-	unsigned mask = neighbour_mask(p, cnt, u, (dir == FORWARD) ? SENSE : ANTISENSE, nfh, nrh);
+	unsigned mask = neighbour_mask(p, cnt, u, (dir == FORWARD) ? SENSE : ANTISENSE, nfh, nrh, sc.coop);
 	return successor_m(p, cnt, u, dir, trim, mask, nfh, nrh, vout, sc);
 }
 

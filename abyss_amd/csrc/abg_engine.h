@@ -169,7 +169,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		uint32_t nk = L - k + 1;
 		SearchScratch<NW> sc;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0;
-		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
+		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
 		// the read and from the first k-mer of its reverse complement
@@ -205,11 +205,13 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
 	WalkEnv<NW> e; const uint32_t* list; bool use_fast;
-	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes)
+	// coop: called by all 64 lanes of a wavefront in lock step (HIP backend) or by one thread (serial)
+	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes, bool coop)
 	{
 		WalkEnv<NW> env = e;
 		env.fast = use_fast ? fast : nullptr;
 		env.fast_bytes = fast_bytes;
+		env.coop = coop;
 		walk_read<NW>(env, list[i], slot);
 	}
 };
@@ -514,7 +516,7 @@ class Engine {
 	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
 	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
 	uint32_t walk_tb_cap_ = 0, walk_buf_cap_ = 0, wslots_ = 0, cslots_ = 0;
-	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr;
+	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr; uint64_t* dbg_ = nullptr;
 
 	void ensure_insert()
 	{
@@ -676,7 +678,7 @@ class Engine {
 		e.tb_pool = (TBFrame<NW>*)tb_pool_;
 		e.tbk_pool = tbk_pool_;
 		e.tb_cap = walk_tb_cap_;
-		e.fast = nullptr; e.fast_bytes = 0;
+		e.fast = nullptr; e.fast_bytes = 0; e.dbg = dbg_; e.coop = false;
 		e.la_pool = la_pool_;
 		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
 		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
@@ -756,6 +758,28 @@ class Engine {
 			FReadPrep<NW> f{ p_, b, cand_d, rkoff_d, rkh_, 0 };
 			be_.launch_wave(nc, f, "read_prep");
 		}
+		const bool debug = getenv("ABG_WALK_DEBUG") != nullptr;
+		if (debug) { dbg_ = (uint64_t*)be_.alloc(nc * 64ull); }
+		auto dump = [&](const char* what, uint32_t nwalk) {
+			if (!debug) return;
+			std::vector<uint64_t> d(nc * 8ull);
+			be_.d2h(d.data(), dbg_, nc * 64ull);
+			uint64_t best = 0, bi = 0, sum_t = 0, sum_steps = 0, sum_nodes = 0, sum_succ = 0, sum_la = 0, nn = 0;
+			for (uint32_t i = 0; i < nc; i++) {
+				const uint64_t* x = &d[i * 8ull];
+				if (!x[0]) continue;
+				nn++; sum_t += x[0]; sum_steps += x[1]; sum_nodes += x[2]; sum_la += x[3]; sum_succ += x[4];
+				if (x[0] > best) { best = x[0]; bi = i; }
+			}
+			const uint64_t* x = &d[bi * 8ull];
+			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu tbnodes=%llu la=%llu succ=%llu | slowest: t=%.2fms steps=%llu tbnodes=%llu la=%llu succ=%llu tbcalls=%llu contigs=%llu st=%llu\n",
+			    what, nwalk, (unsigned long long)nn, sum_t / 1e5, (unsigned long long)sum_steps, (unsigned long long)sum_nodes,
+			    (unsigned long long)sum_la, (unsigned long long)sum_succ, x[0] / 1e5, (unsigned long long)x[1],
+			    (unsigned long long)x[2], (unsigned long long)x[3], (unsigned long long)x[4], (unsigned long long)x[5],
+			    (unsigned long long)x[6], (unsigned long long)x[7]);
+			be_.memset(dbg_, 0, nc * 64ull);
+		};
+		if (debug) be_.memset(dbg_, 0, nc * 64ull);
 		uint32_t base = 0; // candidates [0, base) are accounted for
 		while (base < nc) {
 			stats_.rounds++;
@@ -783,6 +807,7 @@ class Engine {
 				FWalk<NW> fw{ env, list_d, !slow_frames_ };
 				be_.launch_walkers(nc - base, fw, wslots_, "walk");
 				stats_.walked += nc - base;
+				dump("walk", nc - base);
 			}
 			prep_new_records<NW>(prepped);
 			uint32_t committed = base;
@@ -808,6 +833,7 @@ class Engine {
 					FWalk<NW> fw{ env, need_d, !slow_frames_ };
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;
+					dump("rewalk", nneed);
 					prep_new_records<NW>(prepped);
 				}
 				// stage 3: ordered commit as far as the results allow
@@ -835,6 +861,7 @@ class Engine {
 			base = committed;
 		}
 		be_.free(rkh_); rkh_ = nullptr;
+		if (debug) { be_.free(dbg_); dbg_ = nullptr; }
 		be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
 		be_.free(need_d); be_.free(need_n); be_.free(rkoff_d);
 		cand_h.clear();

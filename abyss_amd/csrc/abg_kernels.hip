@@ -36,17 +36,19 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 	for (; i < n; i += stride) f(i, slot);
 }
 
-// One walker per wavefront: a unitig walk is a long, branchy, latency-bound pointer chase;
-// 64 of them in one wave would serialise on every divergent branch, so each wave runs a
-// single walker on lane 0 with wave-uniform control flow and the other lanes masked off.
+// One walker per wavefront.  A unitig walk is a long, branchy, dependent chain; 64 of them
+// in one wave would serialise on every divergent branch.  Instead all 64 lanes of a wave
+// run ONE walker in lock step with identical state (wave-uniform control flow), and the
+// parts with data parallelism use the lanes: each lane computes one Bloom probe position
+// (k-mer x hash function) and a ballot classifies the 8 neighbours of the head; the
+// trueBranch on-stack test scans 64 frames at a time; atomics go through lane 0.
 // The walker's trueBranch stack (frames + keys) lives in WALK_LDS bytes of LDS.
-constexpr uint32_t WALK_LDS = 24576;
+constexpr uint32_t WALK_LDS = 16384;
 template <class F>
-__global__ void __launch_bounds__(64) k_foreach_lane0(F f, uint64_t n)
+__global__ void __launch_bounds__(64, 2) k_walkers(F f, uint64_t n)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[WALK_LDS];
-	if (threadIdx.x != 0) return;
-	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS);
+	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS, true);
 }
 
 // one item per wavefront, all 64 lanes cooperate (f strides its inner loop by lane)
@@ -212,7 +214,7 @@ struct HipBackend {
 		if (!n) return;
 		uint64_t blocks = n < slots ? n : slots;
 		begin(name);
-		hipLaunchKernelGGL(k_foreach_lane0<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
+		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
 		end(name);
 	}
 	template <int NW>

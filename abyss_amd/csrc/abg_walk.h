@@ -61,6 +61,44 @@ ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = 
 ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 #endif
 
+// Atomics issued by a cooperative caller (a whole wavefront in lock step, see
+// abg_core.h): lane 0 performs the operation, every lane receives its result.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t expect, uint64_t val, bool coop)
+{
+	if (!coop) return cas_u64(p, expect, val);
+	uint64_t r = 0;
+	if (__lane_id() == 0) r = cas_u64(p, expect, val);
+	return ((uint64_t)(uint32_t)__shfl((int)(r >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)r, 0);
+}
+ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop) return atomic_min_u32(p, v);
+	uint32_t r = 0;
+	if (__lane_id() == 0) r = atomic_min_u32(p, v);
+	return (uint32_t)__shfl((int)r, 0);
+}
+ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop) return atomic_add_u32(p, v);
+	uint32_t r = 0;
+	if (__lane_id() == 0) r = atomic_add_u32(p, v);
+	return (uint32_t)__shfl((int)r, 0);
+}
+ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool coop)
+{
+	if (!coop) return atomic_add_u64(p, v);
+	uint64_t r = 0;
+	if (__lane_id() == 0) r = atomic_add_u64(p, v);
+	return ((uint64_t)(uint32_t)__shfl((int)(r >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)r, 0);
+}
+#else
+ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
+ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool) { return atomic_min_u32(p, v); }
+ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool) { return atomic_add_u32(p, v); }
+ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool) { return atomic_add_u64(p, v); }
+#endif
+
 // ---------------------------------------------------------- packed read batch
 // Sequences are pure ACGT, 2 bits per base, 16 bases per 32-bit word, each sequence
 // starting on a word boundary.
@@ -129,13 +167,13 @@ enum { WT_NEW = 0, WT_SAME_CONTIG = 1, WT_EARLIER = 2, WT_FULL = 3 };
 // insert (key, owner) with contig number; returns WT_NEW (also when reviving a
 // tombstone), WT_SAME_CONTIG (already inserted by this contig walk: a cycle),
 // WT_EARLIER (inserted by an earlier contig of the same read; now re-tagged) or WT_FULL.
-ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t contig)
+ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t contig, bool coop = false)
 {
 	uint64_t s = wt_slot(t, key, owner);
 	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
 		uint64_t cur = ld_coherent(&t.hmin[s]);
 		if (cur == WT_EMPTY) {
-			uint64_t old = cas_u64(&t.hmin[s], WT_EMPTY, key.fh);
+			uint64_t old = wu_cas_u64(&t.hmin[s], WT_EMPTY, key.fh, coop);
 			if (old == WT_EMPTY) {
 				st_coherent(&t.hmax[s], key.rh);
 				st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
@@ -210,6 +248,8 @@ struct WalkEnv {
 	void* fast; uint32_t fast_bytes;
 	VKey* la_pool;
 	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
+	uint64_t* dbg;             // optional [ncand][8] per-walker work counters (profiling aid)
+	bool coop;                 // the walker is a whole wavefront in lock step
 	// contig output
 	uint8_t* pool; uint64_t pool_cap; uint64_t* pool_used;
 	ContigRec* recs; uint32_t rec_cap; uint32_t* rec_used;
@@ -283,7 +323,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 				h8[q] = brh[q] < bfh[q] ? brh[q] : bfh[q];
 				h8[4 + q] = frh[q] < ffh[q] ? frh[q] : ffh[q];
 			}
-			unsigned m8 = solid_mask8(p, e.cnt, h8);
+			unsigned m8 = solid_mask8(p, e.cnt, h8, sc.coop);
 			bmask = m8 & 0xFu;
 			fmask = m8 >> 4;
 		}
@@ -308,7 +348,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		}
 		n++; ext++;
 		// visited.insert(head), ExtendPath.h:650-658
-		int ins = wt_insert(e.tab, vtx_key(p, v), owner, contig);
+		int ins = wt_insert(e.tab, vtx_key(p, v), owner, contig, sc.coop);
 		if (ins == WT_FULL) { *abort = WS_OVERFLOW; return -1; }
 		if (ins == WT_SAME_CONTIG) {
 			result = ER_CYCLE;
@@ -319,7 +359,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		*end_earlier = (ins == WT_EARLIER);
 		if (e.claims) {
 			uint64_t hm = v.fh < v.rh ? v.fh : v.rh;
-			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
+			uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
 			if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
 		}
 		prev = head;
@@ -379,7 +419,15 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
+	sc.n_tb_nodes = sc.n_la = sc.n_succ = sc.n_tb_calls = 0;
+	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint64_t t_start = wall_clock64();
+#else
+	const uint64_t t_start = 0;
+#endif
+	uint64_t total_steps = 0;
 
 	WalkState<NW> w;
 	w.lbuf = e.lbuf_pool + (uint64_t)slot * e.buf_cap;
@@ -404,13 +452,13 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (fs != WT_EMPTY && (uint32_t)ld_coherent(&e.tab.meta[fs]) != WT_TOMB) continue;
 
 		w.seed = cur; w.nl = 0; w.nr = 0;
-		int ins = wt_insert(e.tab, ckey, owner, contig);
+		int ins = wt_insert(e.tab, ckey, owner, contig, sc.coop);
 		if (ins == WT_FULL) { abort_status = WS_OVERFLOW; break; }
 		bool seed_earlier = (ins == WT_EARLIER);
 		bool left_earlier = seed_earlier, right_earlier = seed_earlier;
 		if (e.claims) {
 			uint64_t hm = ckey.fh;
-			uint32_t old = atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id);
+			uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
 			if (old < claim_id && first == REC_END) { abort_status = WS_DEFERRED; break; }
 		}
 		// A walker defers to a lower-numbered one only until it has produced a contig of its
@@ -422,11 +470,12 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		int rcode = walk_extend(e, w, FORWARD, owner, contig, claim_id, may_defer, sc, &rext, &abort_status, &right_earlier);
 		if (rcode < 0) break;
 		uint32_t n = w.nl + 1 + w.nr;
+		total_steps += n;
 
 		if (!is_tip(n, lcode, rcode, p.trim)) {
 			// materialise the path: S = reverse(lbuf) + seed + rbuf, one slack base each side
 			uint64_t need = (uint64_t)n + k - 1 + 2;
-			uint64_t off = atomic_add_u64(e.pool_used, need);
+			uint64_t off = wu_atomic_add_u64(e.pool_used, need, sc.coop);
 			if (off + need > e.pool_cap) { abort_status = WS_OVERFLOW; break; }
 			uint8_t* S = e.pool + off + 1;
 			uint64_t slen = (uint64_t)n + k - 1;
@@ -440,7 +489,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 				int type = CT_LINEAR;
 				{
 					uint64_t nfh[4], nrh[4];
-					unsigned mask = neighbour_mask(p, e.cnt, back, SENSE, nfh, nrh);
+					unsigned mask = neighbour_mask(p, e.cnt, back, SENSE, nfh, nrh, sc.coop);
 					bool edge = false;
 					for (unsigned b = 0; b < 4; b++) {
 						if (!((mask >> b) & 1u)) continue;
@@ -479,7 +528,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			}
 			if (sc.overflow) { abort_status = WS_OVERFLOW; break; }
 			// ---- record for outputContig
-			uint32_t ri = atomic_add_u32(e.rec_used, 1);
+			uint32_t ri = wu_atomic_add_u32(e.rec_used, 1, sc.coop);
 			if (ri >= e.rec_cap) { abort_status = WS_OVERFLOW; break; }
 			ContigRec& rec = e.recs[ri];
 			rec.seq_off = off + 1 + (uint64_t)lo;
@@ -507,6 +556,16 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	}
 	e.first_rec[c] = first;
 	e.status[c] = abort_status ? abort_status : (uint32_t)WS_COMPLETE;
+	if (e.dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		const uint64_t t_end = wall_clock64();
+#else
+		const uint64_t t_end = 0;
+#endif
+		uint64_t* d = e.dbg + (uint64_t)c * 8;
+		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.n_tb_nodes; d[3] = sc.n_la;
+		d[4] = sc.n_succ; d[5] = sc.n_tb_calls; d[6] = contig; d[7] = abort_status;
+	}
 }
 
 // ------------------------------------------------------------ commit helpers

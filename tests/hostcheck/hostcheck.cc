@@ -34,7 +34,7 @@ struct SerialBackend {
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests
 	alignas(16) unsigned char fastbuf[2048];
-	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, (uint32_t)sizeof fastbuf); }
+	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, (uint32_t)sizeof fastbuf, false); }
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
 		SerialSync sy;
