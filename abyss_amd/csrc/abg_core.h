@@ -423,6 +423,33 @@ ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, co
 	}
 	return ok;
 }
+// Split form of the cooperative probe for callers that want to overlap the probe latency
+// with other memory operations: probe8_issue starts this lane's load (valid for
+// num_hashes <= 8), probe8_collect turns the loaded counters into the 8-bit mask.
+struct Probe8 { uint8_t c; bool active; };
+ABG_HD Probe8 probe8_issue(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[8])
+{
+	const unsigned lane = lane_id();
+	const unsigned b = lane >> 3, i = lane & 7;
+	uint64_t hb = h[0];
+#pragma unroll
+	for (unsigned q = 1; q < 8; q++) hb = (b == q) ? h[q] : hb;
+	Probe8 r;
+	r.active = i < p.nh;
+	r.c = 255;
+	if (r.active) r.c = cnt[pos_i(p, hb, i)];
+	return r;
+}
+ABG_HD unsigned probe8_collect(const Params& p, const Probe8& r)
+{
+	uint64_t m = wave_ballot(r.active && r.c < p.kc);
+	unsigned ok = 0xFFu;
+#pragma unroll
+	for (unsigned q = 0; q < 8; q++)
+		if ((m >> (8 * q)) & 0xFFu) ok &= ~(1u << q);
+	return ok;
+}
+
 // the same for four hashes
 ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, const uint64_t h[4], bool coop)
 {

@@ -4,7 +4,7 @@
 //   k_foreach      one item per lane (hash, claim, insert rounds, classify, predict, ...)
 //   k_foreach_w    the same, launched one wave per workgroup so that the <=32768 walkers
 //                  spread over all 256 CUs (each walker is a latency-bound pointer chase)
-//   k_commit       one 1024-thread workgroup: the ordered commit, cooperative per contig
+//   k_commit       one 256-thread workgroup: the ordered commit, cooperative per contig
 // Launch geometry: wave = 64 lanes, workgroups of 256 (4 waves), grids capped at
 // 256 CUs x 8 workgroups and grid-strided beyond that.
 //
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_foreach_wave(F f, uint64_t n)
 	for (; w < n; w += nw) f(w, lane, 64u);
 }
 
-constexpr int COMMIT_THREADS = 1024;
+constexpr int COMMIT_THREADS = 256;
 struct DeviceSync {
 	uint32_t* sh; // [COMMIT_THREADS / 64 + 2] shared words
 	__device__ uint32_t tid() const { return threadIdx.x; }

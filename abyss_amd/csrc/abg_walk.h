@@ -171,15 +171,13 @@ ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t conti
 {
 	uint64_t s = wt_slot(t, key, owner);
 	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
-		uint64_t cur = ld_coherent(&t.hmin[s]);
+		// optimistic: most insertions find their home slot free, so try to take it first
+		// (one round trip) instead of reading it and then taking it (two)
+		uint64_t cur = wu_cas_u64(&t.hmin[s], WT_EMPTY, key.fh, coop);
 		if (cur == WT_EMPTY) {
-			uint64_t old = wu_cas_u64(&t.hmin[s], WT_EMPTY, key.fh, coop);
-			if (old == WT_EMPTY) {
-				st_coherent(&t.hmax[s], key.rh);
-				st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
-				return WT_NEW;
-			}
-			cur = old;
+			st_coherent(&t.hmax[s], key.rh);
+			st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
+			return WT_NEW;
 		}
 		if (cur != key.fh) continue;
 		uint64_t m = ld_coherent(&t.meta[s]);
@@ -308,6 +306,8 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	if (n > 1) prev = (dir == FORWARD) ? ws_vertex(p, w, n - 2) : ws_vertex(p, w, 1);
 	uint32_t ext = 0;
 	bool look_behind = false;
+	bool pending = false; // the head was pushed but not yet entered into `visited`
+	const bool split = sc.coop && p.nh <= 8;
 	int result;
 	for (;;) {
 		Vtx<NW> t, v;
@@ -315,18 +315,38 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		uint64_t bfh[4], brh[4], ffh[4], frh[4];
 		neighbour_hashes(p, head, (other == FORWARD) ? SENSE : ANTISENSE, bfh, brh);
 		neighbour_hashes(p, head, (dir == FORWARD) ? SENSE : ANTISENSE, ffh, frh);
-		unsigned bmask, fmask;
-		{
-			uint64_t h8[8];
+		uint64_t h8[8];
 #pragma unroll
-			for (unsigned q = 0; q < 4; q++) {
-				h8[q] = brh[q] < bfh[q] ? brh[q] : bfh[q];
-				h8[4 + q] = frh[q] < ffh[q] ? frh[q] : ffh[q];
-			}
-			unsigned m8 = solid_mask8(p, e.cnt, h8, sc.coop);
-			bmask = m8 & 0xFu;
-			fmask = m8 >> 4;
+		for (unsigned q = 0; q < 4; q++) {
+			h8[q] = brh[q] < bfh[q] ? brh[q] : bfh[q];
+			h8[4 + q] = frh[q] < ffh[q] ? frh[q] : ffh[q];
 		}
+		// start the probe loads, then enter the head into `visited` while they are in flight
+		Probe8 pr;
+		if (split) pr = probe8_issue(p, e.cnt, h8);
+		if (pending) {
+			// visited.insert(head), ExtendPath.h:650-658
+			int ins = wt_insert(e.tab, vtx_key(p, head), owner, contig, sc.coop);
+			if (ins == WT_FULL) { *abort = WS_OVERFLOW; return -1; }
+			if (ins == WT_SAME_CONTIG) {
+				// a cycle: path.pop_back() / pop_front()
+				result = ER_CYCLE;
+				if (dir == FORWARD) w.nr--; else w.nl--;
+				n--; ext--;
+				break;
+			}
+			*end_earlier = (ins == WT_EARLIER);
+			if (e.claims) {
+				uint64_t hm = head.fh < head.rh ? head.fh : head.rh;
+				uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
+				if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
+			}
+			look_behind = true; // params.lookBehind after the first extension
+			pending = false;
+		}
+		unsigned m8 = split ? probe8_collect(p, pr) : solid_mask8(p, e.cnt, h8, sc.coop);
+		unsigned bmask = m8 & 0xFu, fmask = m8 >> 4;
+		// extendPathBySingleVertex (ExtendPath.h:403-459)
 		if (look_behind) {
 			result = successor_m(p, e.cnt, head, other, p.trim, bmask, bfh, brh, t, sc);
 			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
@@ -347,24 +367,9 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 			w.lbuf[w.nl++] = (uint8_t)kmer_get(v.s, 0);
 		}
 		n++; ext++;
-		// visited.insert(head), ExtendPath.h:650-658
-		int ins = wt_insert(e.tab, vtx_key(p, v), owner, contig, sc.coop);
-		if (ins == WT_FULL) { *abort = WS_OVERFLOW; return -1; }
-		if (ins == WT_SAME_CONTIG) {
-			result = ER_CYCLE;
-			if (dir == FORWARD) w.nr--; else w.nl--;
-			n--; ext--;
-			break;
-		}
-		*end_earlier = (ins == WT_EARLIER);
-		if (e.claims) {
-			uint64_t hm = v.fh < v.rh ? v.fh : v.rh;
-			uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
-			if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
-		}
 		prev = head;
 		head = v;
-		look_behind = true;
+		pending = true;
 	}
 	if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
 	*ext_out = ext;
@@ -472,7 +477,17 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		uint32_t n = w.nl + 1 + w.nr;
 		total_steps += n;
 
-		if (!is_tip(n, lcode, rcode, p.trim)) {
+		const bool tip = is_tip(n, lcode, rcode, p.trim);
+		if (tip && e.claims) {
+			// a tip is not output, so its k-mers stay unvisited: withdraw the claims on them, or
+			// the predictor would count reads lying on the tip as covered by this walker
+			for (uint32_t i = 0; i < n; i++) {
+				Vtx<NW> x = ws_vertex(p, w, i);
+				uint64_t hm = vtx_hash(x);
+				e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask] = 0xFFFFFFFFu;
+			}
+		}
+		if (!tip) {
 			// materialise the path: S = reverse(lbuf) + seed + rbuf, one slack base each side
 			uint64_t need = (uint64_t)n + k - 1 + 2;
 			uint64_t off = wu_atomic_add_u64(e.pool_used, need, sc.coop);
@@ -549,6 +564,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 					if (hi > lo && (vtx_equal(p, popped[q], nf) || vtx_equal(p, popped[q], nb))) continue;
 					uint64_t s = wt_find(e.tab, vtx_key(p, popped[q]), owner);
 					if (s != WT_EMPTY) st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB);
+					if (e.claims) { // trimmed off: not covered by this walker's contig after all
+						uint64_t hm = vtx_hash(popped[q]);
+						e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask] = 0xFFFFFFFFu;
+					}
 				}
 			}
 		}
