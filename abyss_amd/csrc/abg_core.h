@@ -22,9 +22,13 @@
 #include <hip/hip_runtime.h>
 #define ABG_HD __host__ __device__ __forceinline__
 #define ABG_HDN __host__ __device__
+// kept out of line on purpose: the rarely taken graph searches must not inflate the
+// register pressure of the unbranched walking loop that calls them
+#define ABG_HDX __host__ __device__ __attribute__((noinline))
 #else
 #define ABG_HD inline
 #define ABG_HDN
+#define ABG_HDX
 #endif
 
 namespace abg {
@@ -519,6 +523,14 @@ ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
 	for (unsigned b = 0; b < 4; b++) h[b] = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
 	return solid_mask4(p, cnt, h, coop);
 }
+// the neighbour of u with last (first) base b, hashes included
+template <int NW>
+ABG_HD Vtx<NW> neighbour_vertex(const Params& p, const Vtx<NW>& u, int sense, unsigned b)
+{
+	Vtx<NW> v = u;
+	vtx_shift(p, v, sense, b);
+	return v;
+}
 template <int NW>
 ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsigned b,
     uint64_t fh, uint64_t rh)
@@ -545,12 +557,10 @@ struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
 	uint8_t next;       // next base to try in the current stage
 	uint8_t mask_same, mask_other;
 	uint8_t have_other; // mask_other computed
-	uint64_t nfh[4], nrh[4]; // neighbour hashes of the current stage
 };
 template <int NW>
 struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
 	Vtx<NW> v;
-	uint64_t nfh[4], nrh[4];
 	uint8_t mask, next;
 };
 constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
@@ -575,7 +585,7 @@ struct SearchScratch {
 // from `start` in direction `dir`?  Depth-first, `visited` shared by the whole search
 // and never erased, neighbours tried in A,C,G,T order.
 template <int NW>
-ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start,
+ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start,
     int dir, unsigned limit, SearchScratch<NW>& sc)
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
@@ -586,15 +596,16 @@ ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 	if (limit == 0) return true;
 	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
 	int depth = 0;
+	uint64_t nfh[4], nrh[4];
 	sc.la[0].v = start;
-	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, sc.la[0].nfh, sc.la[0].nrh, sc.coop);
+	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, nfh, nrh, sc.coop);
 	sc.la[0].next = 0;
 	while (depth >= 0) {
 		LAFrame<NW>& f = sc.la[depth];
 		if (f.next >= 4) { depth--; continue; }
 		unsigned b = f.next++;
 		if (!((f.mask >> b) & 1u)) continue;
-		Vtx<NW> w = make_neighbour(p, f.v, sense, b, f.nfh[b], f.nrh[b]);
+		Vtx<NW> w = neighbour_vertex(p, f.v, sense, b);
 		bool seen = false;
 		for (unsigned i = 0; i < nv; i++) {
 			Vtx<NW> t; t.s = w.s; t.fh = vis[i].fh; t.rh = vis[i].rh;
@@ -609,7 +620,7 @@ ABG_HDN bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 		if ((unsigned)(depth + 1) >= limit) return true;
 		depth++;
 		sc.la[depth].v = w;
-		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, sc.la[depth].nfh, sc.la[depth].nrh, sc.coop);
+		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, nfh, nrh, sc.coop);
 		sc.la[depth].next = 0;
 	}
 	return false;
@@ -626,7 +637,7 @@ ABG_HD TBFrame<NW>& tb_frame(SearchScratch<NW>& sc, int i)
 	return (uint32_t)i < sc.tbf_cap ? sc.tbf[i] : sc.tb[(uint32_t)i - sc.tbf_cap];
 }
 template <int NW>
-ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
+ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
     const Vtx<NW>& v0, int dir0, unsigned trim, SearchScratch<NW>& sc)
 {
 	int top = -1;
@@ -664,8 +675,9 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 			f.v = cv; f.ufh = cu.fh; f.urh = cu.rh;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
+			uint64_t nfh[4], nrh[4];
 			f.mask_same = (uint8_t)neighbour_mask(p, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE,
-			    f.nfh, f.nrh, sc.coop);
+			    nfh, nrh, sc.coop);
 		}
 		// ---- resume frames until one of them makes a new call
 		bool called = false;
@@ -678,7 +690,7 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				if (f.next < 4) {
 					unsigned b = f.next++;
 					cu = f.v;
-					cv = make_neighbour(p, f.v, sense, b, f.nfh[b], f.nrh[b]);
+					cv = neighbour_vertex(p, f.v, sense, b);
 					cdepth = f.depth + 1u;
 					cdir = fdir;
 					called = true;
@@ -691,8 +703,9 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
 				f.next = 0;
+				uint64_t nfh[4], nrh[4];
 				f.mask_other = (uint8_t)neighbour_mask(p, cnt, f.v,
-				    fdir == FORWARD ? ANTISENSE : SENSE, f.nfh, f.nrh, sc.coop);
+				    fdir == FORWARD ? ANTISENSE : SENSE, nfh, nrh, sc.coop);
 				f.have_other = 1;
 			}
 			// stage 1: other-direction children, skipping the vertex we came from
@@ -703,7 +716,7 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				while (f.next < 4) {
 					unsigned b = f.next++;
 					if (!((f.mask_other >> b) & 1u)) continue;
-					Vtx<NW> w = make_neighbour(p, f.v, osense, b, f.nfh[b], f.nrh[b]);
+					Vtx<NW> w = neighbour_vertex(p, f.v, osense, b);
 					Vtx<NW> uu; uu.s = w.s; uu.fh = f.ufh; uu.rh = f.urh;
 					if (vtx_equal(p, w, uu)) continue; // source(*iei) == u
 					cu = f.v; cv = w; cdepth = 0; cdir = odir;
@@ -722,14 +735,52 @@ ABG_HDN bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 // threshold i = 0,1,2,4,...,trim.  Returns the code and (for LENGTH_LIMIT) the unique
 // successor; for AMBI_OUT the last true branch found, for DEAD_END `u` itself.
 // `mask`, `nfh`, `nrh` are the neighbour mask / hashes of `u` in direction `dir`.
+// The level-0 decision of successor(): with at most one neighbour present the answer is
+// DEAD_END or that neighbour; returns -1 when deeper levels must be consulted.
 template <int NW>
-ABG_HDN int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
+ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned mask,
+    const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout)
+{
+	if (mask == 0) { vout = u; return ER_DEAD_END; }
+	if (mask & (mask - 1)) return -1;
+	unsigned b = (mask & 1u) ? 0u : (mask & 2u) ? 1u : (mask & 4u) ? 2u : 3u;
+	uint64_t fh = nfh[0], rh = nrh[0];
+#pragma unroll
+	for (unsigned q = 1; q < 4; q++) { fh = (b == q) ? nfh[q] : fh; rh = (b == q) ? nrh[q] : rh; }
+	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
+	return ER_LENGTH_LIMIT;
+}
+template <int NW>
+ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
     unsigned trim, unsigned mask, const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout,
     SearchScratch<NW>& sc)
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
 	vout = u;
 	sc.n_succ++;
+	// Shortcut, exact by monotonicity of trueBranch in its threshold: every condition that
+	// makes trueBranch(e, i) return true (vertex on the stack, depth >= i, a true child) also
+	// holds for any smaller threshold, while exploration order, direction changes and the
+	// visited set do not depend on the threshold.  Hence the edges that are true at `trim`
+	// are true at every level of the loop below: two of them => the loop runs to i == trim
+	// and answers AMBI_OUT; exactly one => it is the only survivor at the first level with a
+	// single true branch, i.e. the loop's LENGTH_LIMIT answer.  Only when no edge is true at
+	// `trim` do the lower levels decide, and the loop below is run as written.
+	if (trim > 1 && (mask & (mask - 1))) {
+		unsigned tb = 0;
+		Vtx<NW> last = u;
+		for (unsigned b = 0; b < 4; b++) {
+			if (!((mask >> b) & 1u)) continue;
+			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
+			sc.n_tb_calls++;
+			if (true_branch(p, cnt, u, w, dir, trim, sc)) {
+				last = w;
+				if (++tb >= 2) break;
+			}
+		}
+		if (tb >= 2) { vout = last; return ER_AMBI_OUT; }
+		if (tb == 1) { vout = last; return ER_LENGTH_LIMIT; }
+	}
 	for (unsigned i = 0;; i = (i == 0) ? 1u : (trim < 2 * i ? trim : 2 * i)) {
 		unsigned tb = 0;
 		for (unsigned b = 0; b < 4; b++) {

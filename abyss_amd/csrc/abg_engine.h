@@ -298,7 +298,19 @@ struct FPredict {
 struct CommitState {
 	Counters counters;
 	uint32_t break_at;   // first candidate that could not be committed
-	uint32_t pad_;
+	uint32_t pad_;       // set when the contigEndKmers table overflowed (must not happen: it is grown ahead)
+	uint64_t cend_count; // entries in the contigEndKmers table
+};
+struct FRehash { // move every entry of one vertex table into another (owner 0)
+	WalkTab from, to; uint32_t* failed;
+	ABG_HD void operator()(uint64_t s, uint32_t) const
+	{
+		uint64_t h = from.hmin[s];
+		if (h == WT_EMPTY) return;
+		VKey key; key.fh = h; key.rh = from.hmax[s];
+		WalkTab t = to;
+		if (wt_insert(t, key, 0, 0) == WT_FULL) *failed = 1;
+	}
 };
 template <int NW>
 struct CommitEnv {
@@ -365,6 +377,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 					} else {
 						int a = wt_insert(e.cend, k1, 0, 0), bb = wt_insert(e.cend, k2, 0, 0);
 						if (a == WT_FULL || bb == WT_FULL) redundant = 2; // table overflow: reported
+						e.st->cend_count += (a == WT_NEW) + (bb == WT_NEW);
 					}
 				}
 				redundant = sy.bcast(redundant);
@@ -517,6 +530,7 @@ class Engine {
 	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
 	uint32_t walk_tb_cap_ = 0, walk_buf_cap_ = 0, wslots_ = 0, cslots_ = 0;
 	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr; uint64_t* dbg_ = nullptr;
+	uint64_t cend_count_ = 0;
 
 	void ensure_insert()
 	{
@@ -690,9 +704,17 @@ class Engine {
 	uint32_t commit(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d,
 	    uint8_t* result_d, const uint64_t* rkoff_d, uint32_t c_begin, uint32_t c_end)
 	{
+		// contigEndKmers grows ahead of demand: every record not yet committed may add two keys
+		{
+			uint32_t nrec = 0, nord = 0;
+			be_.d2h(&nrec, rec_used_, 4);
+			be_.d2h(&nord, order_n_, 4);
+			uint64_t need = cend_count_ + 2ull * (std::min(nrec, rec_cap_) - std::min(nord, rec_cap_));
+			while (need * 2 > cend_.mask + 1) grow_cend();
+		}
 		CommitState cs;
 		cs.counters = counters_;
-		cs.break_at = c_begin; cs.pad_ = 0;
+		cs.break_at = c_begin; cs.pad_ = 0; cs.cend_count = cend_count_;
 		be_.h2d(cstate_, &cs, sizeof cs);
 		CommitEnv<NW> e;
 		e.p = p_; e.b = b; e.vis32 = (uint32_t*)vis_;
@@ -704,7 +726,8 @@ class Engine {
 		be_.template launch_commit<NW>(e, c_begin, c_end);
 		be_.d2h(&cs, cstate_, sizeof cs);
 		counters_ = cs.counters;
-		if (cs.pad_) { fprintf(stderr, "abyss_amd: contigEndKmers table is full (raise cend_log2)\n"); abort(); }
+		cend_count_ = cs.cend_count;
+		if (cs.pad_) { fprintf(stderr, "abyss_amd: contigEndKmers table overflowed\n"); abort(); }
 		return cs.break_at;
 	}
 
@@ -720,6 +743,23 @@ class Engine {
 			be_.launch_wave(nrec - prepped, f, "contig_prep");
 			prepped = nrec;
 		}
+	}
+	void grow_cend()
+	{
+		uint32_t log2 = 1;
+		while ((1ull << log2) < cend_.mask + 1) log2++;
+		WalkTab bigger{};
+		alloc_tab(bigger, log2 + 2);
+		uint32_t* failed = (uint32_t*)be_.alloc(8);
+		be_.memset(failed, 0, 4);
+		FRehash f{ cend_, bigger, failed };
+		be_.launch(cend_.mask + 1, f, "rehash");
+		uint32_t bad = 0;
+		be_.d2h(&bad, failed, 4);
+		be_.free(failed);
+		if (bad) { fprintf(stderr, "abyss_amd: contigEndKmers rehash failed\n"); abort(); }
+		free_tab(cend_);
+		cend_ = bigger;
 	}
 	void clear_wtab()
 	{

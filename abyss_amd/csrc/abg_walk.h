@@ -69,28 +69,30 @@ ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t expect, uint64_t val, bool coop
 	if (!coop) return cas_u64(p, expect, val);
 	uint64_t r = 0;
 	if (__lane_id() == 0) r = cas_u64(p, expect, val);
-	return ((uint64_t)(uint32_t)__shfl((int)(r >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)r, 0);
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
 }
 ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool coop)
 {
 	if (!coop) return atomic_min_u32(p, v);
 	uint32_t r = 0;
 	if (__lane_id() == 0) r = atomic_min_u32(p, v);
-	return (uint32_t)__shfl((int)r, 0);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
 ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool coop)
 {
 	if (!coop) return atomic_add_u32(p, v);
 	uint32_t r = 0;
 	if (__lane_id() == 0) r = atomic_add_u32(p, v);
-	return (uint32_t)__shfl((int)r, 0);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
 ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool coop)
 {
 	if (!coop) return atomic_add_u64(p, v);
 	uint64_t r = 0;
 	if (__lane_id() == 0) r = atomic_add_u64(p, v);
-	return ((uint64_t)(uint32_t)__shfl((int)(r >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)r, 0);
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
 }
 #else
 ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
@@ -348,14 +350,16 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		unsigned bmask = m8 & 0xFu, fmask = m8 >> 4;
 		// extendPathBySingleVertex (ExtendPath.h:403-459)
 		if (look_behind) {
-			result = successor_m(p, e.cnt, head, other, p.trim, bmask, bfh, brh, t, sc);
+			result = successor_fast(p, head, other, bmask, bfh, brh, t);
+			if (result < 0) result = successor_m(p, e.cnt, head, other, p.trim, bmask, bfh, brh, t, sc);
 			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
 			if (n > 1) {
 				if (result == ER_DEAD_END) { result = ER_AMBI_IN; break; }
 				if (!vtx_equal(p, prev, t)) { result = ER_AMBI_IN; break; }
 			}
 		}
-		result = successor_m(p, e.cnt, head, dir, p.trim, fmask, ffh, frh, v, sc);
+		result = successor_fast(p, head, dir, fmask, ffh, frh, v);
+		if (result < 0) result = successor_m(p, e.cnt, head, dir, p.trim, fmask, ffh, frh, v, sc);
 		if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
 		if (result != ER_LENGTH_LIMIT) break;
 		// path.push_back(v) / push_front(v)
