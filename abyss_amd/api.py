@@ -151,11 +151,11 @@ class BloomDBG:
                     "abg_assemble_seqs")
         return results, contigs
 
-    def assemble_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int,
-                        want_results: bool = True) -> Tuple[Optional[np.ndarray], List[ContigRecord]]:
+    def assemble_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int, want_results: bool = True,
+                        want_contigs: bool = True) -> Tuple[Optional[np.ndarray], List[ContigRecord]]:
         results = np.zeros(n, dtype=np.uint8) if want_results else None
         contigs: List[ContigRecord] = []
-        cb = self._collector(contigs)
+        cb = self._collector(contigs) if want_contigs else _lib.CONTIG_CB()  # NULL: counters only
         self._check(self._lib.abg_assemble_packed(self._ctx, words_ptr, woff_ptr, len_ptr, n,
                                                   results.ctypes.data if want_results else None, cb, None),
                     "abg_assemble_packed")

@@ -83,10 +83,16 @@ def build_oracle(force: bool = False) -> None:
     _run(["make", "-C", ORACLE_DIR, "-j8"] + targets)
 
 
+READER_CHECK = os.path.join(ROOT, "tests", "hostcheck", "reader_check")
+
+
 def build_hostcheck(force: bool = False) -> str:
     src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cc")
     if force or _newer(HOSTCHECK, [src] + csrc_files()):
         _run(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", HOSTCHECK, src])
+    rsrc = os.path.join(ROOT, "tests", "hostcheck", "reader_check.cc")
+    if force or _newer(READER_CHECK, [rsrc, os.path.join(CSRC, "host", "fasta_reader.h")]):
+        _run(["g++", "-std=c++17", "-O2", "-o", READER_CHECK, rsrc])
     return HOSTCHECK
 
 

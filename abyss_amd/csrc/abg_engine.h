@@ -910,6 +910,7 @@ class Engine {
 	void deliver(const std::vector<uint32_t>& cand_h, uint64_t read_base,
 	    const std::function<void(const ContigOut&)>& sink)
 	{
+		if (!sink) return; // nobody wants the records: counters already reflect them
 		uint32_t n = 0;
 		be_.d2h(&n, order_n_, 4);
 		if (!n) return;

@@ -149,8 +149,8 @@ class Session {
 		if (hb.n()) {
 			DevBatch d = upload(hb);
 			std::vector<uint8_t> pres(hb.n());
-			auto sink = [&](const ContigOut& o) {
-				if (!cb) return;
+			std::function<void(const ContigOut&)> sink;
+			if (cb) sink = [&](const ContigOut& o) {
 				abg_contig c;
 				c.contig_id = o.contig_id; c.read_index = orig[o.read_index];
 				c.seq = o.seq.c_str(); c.length = (uint32_t)o.seq.size(); c.coverage = o.coverage;
@@ -170,8 +170,8 @@ class Session {
 	{
 		if (!n) return ABG_OK;
 		Batch b{ d_words, d_woff, d_len, d_woff /* unused in pass 2 */, n };
-		auto sink = [&](const ContigOut& o) {
-			if (!cb) return;
+		std::function<void(const ContigOut&)> sink;
+		if (cb) sink = [&](const ContigOut& o) {
 			abg_contig c;
 			c.contig_id = o.contig_id; c.read_index = o.read_index;
 			c.seq = o.seq.c_str(); c.length = (uint32_t)o.seq.size(); c.coverage = o.coverage;

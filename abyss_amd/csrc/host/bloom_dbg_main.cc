@@ -1,0 +1,295 @@
+// bloom_dbg_main.cc -- `abyss-bloom-dbg`, the drop-in host binary for the abyss-pe
+// pipeline: the command line, messages, exit codes and FASTA output of the reference's
+// BloomDBG/bloom-dbg.cc (options table :128,142-175; main :389-558) on top of the C ABI of
+// libabyss_amd.so (include/abyss_amd.h).  All assembly work happens on the GPU; this file
+// only parses options, reads sequence files and prints records.
+//
+// Not supported yet (the binary says so and exits 1): spaced seeds (-K, --qr-seed, -s),
+// -g/-C/-R auxiliary outputs, checkpoints, SAM/qseq input.
+#include "../../../include/abyss_amd.h"
+#include "fasta_reader.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <getopt.h>
+#include <string>
+#include <vector>
+
+#define PROGRAM "abyss-bloom-dbg"
+
+static const char VERSION_MESSAGE[] =
+    PROGRAM " (ABySS) 2.3.10 [abyss_amd: MI355X-native unitig stage]\n"
+            "Interface of the ABySS program written by Ben Vandervalk, Shaun Jackman, Hamid Mohamadi,\n"
+            "Justin Chu, and Anthony Raymond.\n";
+
+static const char USAGE_MESSAGE[] =
+    "Usage: " PROGRAM " -b <bloom_size> -H <bloom_hashes> -k <kmer_size> \\\n"
+    "    [options] <FASTQ> [FASTQ]... > assembly.fasta\n"
+    "\n"
+    "Perform a de Bruijn graph assembly of the given FASTQ files on an AMD MI355X.\n"
+    "\n"
+    "  -b  --bloom-size=N           overall memory budget in bytes; suffixes k, M, G [required]\n"
+    "      --chastity / --no-chastity   discard unchaste reads [default] / keep them\n"
+    "      --help                   display this help and exit\n"
+    "  -H  --num-hashes=N           number of Bloom filter hash functions [4]\n"
+    "  -i  --input-bloom=FILE       load the counting Bloom filter from FILE\n"
+    "  -j, --threads=N              accepted for compatibility (the GPU does the work)\n"
+    "      --trim-masked / --no-trim-masked\n"
+    "  -k, --kmer=N                 the size of a k-mer [<=192]\n"
+    "      --kc=N                   ignore k-mers having a count < N [2]\n"
+    "  -o, --out=FILE               write the contigs to FILE [STDOUT]\n"
+    "  -q, --trim-quality=N         trim bases from the ends of reads whose quality is less than N\n"
+    "  -Q, --mask-quality=N         mask all low quality bases as `N'\n"
+    "      --standard-quality / --illumina-quality\n"
+    "  -t, --trim-length=N          max branch length to trim, in k-mers [k]\n"
+    "  -T, --trace-file=FILE        write debugging info about each contig to FILE\n"
+    "      --read-log=FILE          write outcome of processing each read to FILE\n"
+    "  -v, --verbose                display verbose output\n"
+    "      --version                output version information and exit\n";
+
+enum { OPT_HELP = 1, OPT_VERSION, QR_SEED, MIN_KMER_COV, CHECKPOINT, KEEP_CHECKPOINT, CHECKPOINT_PREFIX, READ_LOG };
+static abghost::ReaderOptions ropt;
+static const char shortopts[] = "b:C:g:H:i:j:k:K:o:q:Q:R:s:t:T:v";
+static const struct option longopts[] = {
+	{ "bloom-size", required_argument, NULL, 'b' }, { "min-coverage", required_argument, NULL, 'c' },
+	{ "cov-track", required_argument, NULL, 'C' }, { "chastity", no_argument, &ropt.chastityFilter, 1 },
+	{ "no-chastity", no_argument, &ropt.chastityFilter, 0 }, { "checkpoint", required_argument, NULL, CHECKPOINT },
+	{ "keep-checkpoint", no_argument, NULL, KEEP_CHECKPOINT }, { "checkpoint-prefix", required_argument, NULL, CHECKPOINT_PREFIX },
+	{ "graph", required_argument, NULL, 'g' }, { "num-hashes", required_argument, NULL, 'H' },
+	{ "input-bloom", required_argument, NULL, 'i' }, { "help", no_argument, NULL, OPT_HELP },
+	{ "threads", required_argument, NULL, 'j' }, { "trim-masked", no_argument, &ropt.trimMasked, 1 },
+	{ "no-trim-masked", no_argument, &ropt.trimMasked, 0 }, { "kmer", required_argument, NULL, 'k' },
+	{ "kc", required_argument, NULL, MIN_KMER_COV }, { "single-kmer", required_argument, NULL, 'K' },
+	{ "out", required_argument, NULL, 'o' }, { "trim-quality", required_argument, NULL, 'q' },
+	{ "mask-quality", required_argument, NULL, 'Q' }, { "standard-quality", no_argument, &ropt.qualityOffset, 33 },
+	{ "illumina-quality", no_argument, &ropt.qualityOffset, 64 }, { "qr-seed", required_argument, NULL, QR_SEED },
+	{ "read-log", required_argument, NULL, READ_LOG }, { "ref", required_argument, NULL, 'R' },
+	{ "spaced-seed", required_argument, NULL, 's' }, { "trim-length", required_argument, NULL, 't' },
+	{ "trace-file", required_argument, NULL, 'T' }, { "verbose", no_argument, NULL, 'v' },
+	{ "version", no_argument, NULL, OPT_VERSION }, { NULL, 0, NULL, 0 }
+};
+
+// SIToBytes, Common/StringUtil.h:181-219: k/M/G are powers of 1024
+static bool si_to_bytes(const char* s, uint64_t* out)
+{
+	char* end;
+	double x = strtod(s, &end);
+	if (end == s) return false;
+	switch (*end) {
+	case 'k': case 'K': x *= 1024.0; end++; break;
+	case 'M': x *= 1048576.0; end++; break;
+	case 'G': x *= 1073741824.0; end++; break;
+	case 'T': x *= 1099511627776.0; end++; break;
+	default: break;
+	}
+	if (*end == 'B') end++;
+	if (*end) return false;
+	*out = (uint64_t)x;
+	return true;
+}
+
+struct Chunk { // one batch of sequences for the C ABI
+	std::string seqs;
+	std::vector<uint64_t> off{ 0 };
+	std::vector<std::string> ids;
+	void add(const std::string& id, const std::string& s) { seqs += s; off.push_back(seqs.size()); ids.push_back(id); }
+	size_t n() const { return ids.size(); }
+	void clear() { seqs.clear(); off.assign(1, 0); ids.clear(); }
+};
+
+struct Output {
+	FILE* out; FILE* trace; const Chunk* chunk; unsigned k;
+};
+static const char* ext_str(int c)
+{
+	static const char* s[] = { "AMBI_IN", "AMBI_OUT", "DEAD_END", "CYCLE", "LENGTH_LIMIT" };
+	return s[c];
+}
+static void on_contig(void* user, const abg_contig* c)
+{
+	Output* o = (Output*)user;
+	const std::string& rid = o->chunk->ids[c->read_index];
+	if (!c->redundant) // printContig, bloom-dbg.h:455-487
+		fprintf(o->out, ">%llu %u %u read:%s\n%s\n", (unsigned long long)c->contig_id, c->length, c->coverage, rid.c_str(), c->seq);
+	if (o->trace) { // ContigRecord operator<<, bloom-dbg.h:229-254
+		if (c->redundant) fputs("NA\t", o->trace); else fprintf(o->trace, "%llu\t", (unsigned long long)c->contig_id);
+		fprintf(o->trace, "%u\t%d\t%s\t", c->length, c->redundant, rid.c_str());
+		if (c->left_ext > 0) fprintf(o->trace, "%s\t%u\t", ext_str(c->left_code), c->left_ext); else fputs("NA\tNA\t", o->trace);
+		if (c->right_ext > 0) fprintf(o->trace, "%s\t%u\t", ext_str(c->right_code), c->right_ext); else fputs("NA\tNA\t", o->trace);
+		uint64_t a = o->chunk->off[c->read_index];
+		fprintf(o->trace, "READ\t%u\t%.*s\n", o->k, (int)o->k, o->chunk->seqs.c_str() + a + c->seed_pos);
+	}
+}
+static void check(int rc, abg_ctx* ctx, const char* what)
+{
+	if (rc == ABG_OK) return;
+	fprintf(stderr, PROGRAM ": %s: %s\n", what, abg_last_error(ctx));
+	exit(EXIT_FAILURE);
+}
+
+int main(int argc, char** argv)
+{
+	abg_params p;
+	abg_params_init(&p);
+	std::string bloomPath, outputPath, tracePath, readLogPath;
+	int verbose = 0;
+	bool die = false;
+	unsigned K = 0, qr = 0;
+	std::string spaced;
+	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
+		bool bad = false;
+		char* end = NULL;
+		switch (c) {
+		case '?': die = true; break;
+		case 'b': bad = !si_to_bytes(optarg, &p.bloom_bytes); break;
+		case 'H': p.num_hashes = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'i': bloomPath = optarg; break;
+		case 'j': (void)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'k': p.k = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'K': K = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'o': outputPath = optarg; break;
+		case 'q': ropt.qualityThreshold = (int)strtol(optarg, &end, 10); bad = *end; break;
+		case 'Q': ropt.internalQThreshold = (int)strtol(optarg, &end, 10); bad = *end; break;
+		case 's': spaced = optarg; break;
+		case 't': p.trim = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'T': tracePath = optarg; break;
+		case 'v': ++verbose; break;
+		case OPT_HELP: fputs(USAGE_MESSAGE, stdout); exit(EXIT_SUCCESS);
+		case OPT_VERSION: fputs(VERSION_MESSAGE, stdout); exit(EXIT_SUCCESS);
+		case MIN_KMER_COV: p.min_cov = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
+		case QR_SEED: qr = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
+		case READ_LOG: readLogPath = optarg; break;
+		case 'C': case 'g': case 'R': case CHECKPOINT: case KEEP_CHECKPOINT: case CHECKPOINT_PREFIX:
+			fprintf(stderr, PROGRAM ": option `-%c' is not supported by this build\n", c < 128 ? c : '-');
+			exit(EXIT_FAILURE);
+		}
+		if (bad) { // bloom-dbg.cc:472-475
+			fprintf(stderr, PROGRAM ": invalid option: `-%c%s'\n", (char)c, optarg);
+			exit(EXIT_FAILURE);
+		}
+	}
+	if (bloomPath.empty() && p.bloom_bytes == 0) { fprintf(stderr, PROGRAM ": missing mandatory option `-b'\n"); die = true; }
+	if (bloomPath.empty() && p.k == 0) { fprintf(stderr, PROGRAM ": missing mandatory option `-k'\n"); die = true; }
+	if (p.k > 0 && K > 0 && K > p.k / 2) { fprintf(stderr, PROGRAM ": value of `-K' must be <= k/2\n"); die = true; }
+	if (p.num_hashes > ABG_MAX_HASHES) { fprintf(stderr, PROGRAM ": number of hash functions (`-H`) must be <= %d\n", ABG_MAX_HASHES); die = true; }
+	if (argc - optind < 1) { fprintf(stderr, PROGRAM ": missing input file arguments\n"); die = true; }
+	if (die) { fprintf(stderr, "Try `%s --help' for more information.\n", PROGRAM); exit(EXIT_FAILURE); }
+	if (K || qr || !spaced.empty()) { fprintf(stderr, PROGRAM ": spaced seeds (-K, --qr-seed, -s) are not supported by this build\n"); exit(EXIT_FAILURE); }
+
+	// -i: [BTLCountingBloomFilter_v1] header + raw counters (CountingBloomFilter.hpp:262-329,344-379)
+	std::vector<uint8_t> prebuilt;
+	if (!bloomPath.empty()) {
+		FILE* f = fopen(bloomPath.c_str(), "rb");
+		if (!f) { fprintf(stderr, "error: `%s': %s\n", bloomPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		char* line = NULL; size_t cap = 0; ssize_t n;
+		if ((n = getline(&line, &cap, f)) <= 0 || strncmp(line, "[BTLCountingBloomFilter_v1]", 27)) {
+			fprintf(stderr, "ERROR: magic string does not match (likely version mismatch)\n"); exit(EXIT_FAILURE);
+		}
+		uint64_t size = 0, bytes = 0; unsigned hn = 0, ks = 0; bool end = false;
+		while ((n = getline(&line, &cap, f)) > 0) {
+			if (!strncmp(line, "[HeaderEnd]", 11)) { end = true; break; }
+			char key[64]; unsigned long long v;
+			if (sscanf(line, " %63[A-Za-z] = %llu", key, &v) == 2) {
+				if (!strcmp(key, "BloomFilterSize")) size = v; else if (!strcmp(key, "HashNum")) hn = (unsigned)v;
+				else if (!strcmp(key, "KmerSize")) ks = (unsigned)v; else if (!strcmp(key, "BloomFilterSizeInBytes")) bytes = v;
+			}
+		}
+		if (!end || !size) { fprintf(stderr, "ERROR: pre-built bloom filter does not have the correct header end.\n"); exit(EXIT_FAILURE); }
+		prebuilt.resize(bytes ? bytes : size);
+		if (fread(prebuilt.data(), 1, prebuilt.size(), f) != prebuilt.size()) { fprintf(stderr, "error: `%s': short read\n", bloomPath.c_str()); exit(EXIT_FAILURE); }
+		fclose(f); free(line);
+		p.k = ks; p.num_hashes = hn; p.counters = size; // bloom-dbg.cc:320-322
+	}
+	p.verbose = verbose;
+	abg_ctx* ctx = NULL;
+	if (abg_create(&p, &ctx) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
+	const uint32_t trim = p.trim == 0xFFFFFFFFu ? p.k : p.trim;
+	if (verbose) {
+		fprintf(stderr, "Assembling with k-mer size %u\n", p.k);
+		fprintf(stderr, "Assembly parameters:\n\tK-mer size (-k): %u\n\tK-mer coverage threshold (--kc): %u\n"
+		    "\tMax branch trim length (-t): %u\n\tBloom size in bytes (-b): %llu\n\tBloom hash functions (-H): %u\n",
+		    p.k, p.min_cov, trim, (unsigned long long)p.bloom_bytes, p.num_hashes);
+	}
+	FILE* out = stdout;
+	if (!outputPath.empty() && !(out = fopen(outputPath.c_str(), "w"))) { fprintf(stderr, "error: `%s': %s\n", outputPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	const size_t CHUNK_BASES = 256u << 20;
+	int first_asm = optind;
+	std::string id, comment, seq;
+	Chunk chunk;
+	uint64_t counters = 0;
+	abg_filter_size(ctx, &counters);
+	if (prebuilt.empty()) {
+		// PASS 1: loadBloomFilter, BloomIO.h:97-118 (a ":" argument separates load and assembly files)
+		for (int i = optind; i < argc; ++i) {
+			if (!strcmp(argv[i], ":")) { first_asm = i + 1; break; }
+			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
+			abghost::FastaReader in(argv[i], ropt);
+			uint64_t n = 0;
+			while (in.read(id, comment, seq)) {
+				chunk.add(id, seq); n++;
+				if (chunk.seqs.size() >= CHUNK_BASES) { check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load"); chunk.clear(); }
+			}
+			if (chunk.n()) { check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load"); chunk.clear(); }
+			if (verbose) fprintf(stderr, "Loaded %llu reads from `%s` into Bloom filter\n", (unsigned long long)n, argv[i]);
+		}
+	} else {
+		if (prebuilt.size() != counters) { fprintf(stderr, PROGRAM ": Bloom file size does not match its header\n"); exit(EXIT_FAILURE); }
+		check(abg_counters_import(ctx, prebuilt.data()), ctx, "import");
+	}
+	if (verbose) {
+		uint64_t pop = 0, filt = 0;
+		abg_counting_stats(ctx, &pop, &filt);
+		fprintf(stderr, "Bloom filter FPR: %.3g%%\n", 100.0 * pow((double)pop / (double)counters, p.num_hashes));
+		fprintf(stderr, "Counting Bloom filter stats:\n\t#counters               = %llu\n\t#size (B)               = %llu\n"
+		    "\tthreshold               = %u\n\tpopcount                = %llu\n\tFPR                     = %.3g%%\n",
+		    (unsigned long long)counters, (unsigned long long)counters, p.min_cov, (unsigned long long)filt,
+		    100.0 * pow((double)filt / (double)counters, p.num_hashes));
+		fprintf(stderr, "Trimming branches %u k-mers or shorter\n", trim);
+	}
+	// PASS 2: assemble, bloom-dbg.h:900-951,972-1089
+	FILE* trace = NULL; FILE* readlog = NULL;
+	if (!tracePath.empty()) {
+		if (!(trace = fopen(tracePath.c_str(), "w"))) { fprintf(stderr, "error: `%s': %s\n", tracePath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		fputs("contig_id\tlength\tredundant\tread_id\tleft_result\tleft_extension\tright_result\tright_extension\tseed_type\tseed_length\tseed\n", trace);
+	}
+	if (!readLogPath.empty()) {
+		if (!(readlog = fopen(readLogPath.c_str(), "w"))) { fprintf(stderr, "error: `%s': %s\n", readLogPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		fputs("read_id\tresult\n", readlog);
+	}
+	static const char* rr[] = { "NA", "SHORTER_THAN_K", "NON_ACGT", "BLUNT_END", "NOT_SOLID", "ALL_KMERS_VISITED", "ALL_BRANCH_KMERS_VISITED", "GENERATED_CONTIGS" };
+	Output o{ out, trace, &chunk, p.k };
+	std::vector<uint8_t> results;
+	auto flush = [&]() {
+		if (!chunk.n()) return;
+		results.assign(chunk.n(), 0);
+		check(abg_assemble_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n(), results.data(), on_contig, &o), ctx, "assemble");
+		if (readlog) for (size_t i = 0; i < chunk.n(); i++) fprintf(readlog, "%s\t%s\n", chunk.ids[i].c_str(), rr[results[i]]);
+		chunk.clear();
+	};
+	for (int i = first_asm; i < argc; ++i) {
+		if (!strcmp(argv[i], ":")) continue;
+		abghost::FastaReader in(argv[i], ropt);
+		while (in.read(id, comment, seq)) {
+			chunk.add(id, seq);
+			if (chunk.seqs.size() >= CHUNK_BASES) flush();
+		}
+	}
+	flush();
+	if (verbose) {
+		abg_counters c;
+		abg_get_counters(ctx, &c);
+		fprintf(stderr, "Processed %llu reads, solid reads: %llu (%.3g%%), visited reads: %llu (%.3g%%)\n",
+		    (unsigned long long)c.reads_processed, (unsigned long long)c.solid_reads, 100.0f * c.solid_reads / c.reads_processed,
+		    (unsigned long long)c.visited_reads, 100.0f * c.visited_reads / c.reads_processed);
+		fprintf(stderr, "Assembled %llu bp in %llu contigs\nAssembly complete\n", (unsigned long long)c.bases_assembled,
+		    (unsigned long long)c.next_contig_id);
+	}
+	if (trace) fclose(trace);
+	if (readlog) fclose(readlog);
+	if (out != stdout) fclose(out); else fflush(stdout);
+	abg_destroy(ctx);
+	return EXIT_SUCCESS;
+}

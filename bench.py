@@ -157,9 +157,12 @@ def main() -> int:
         g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local)
         g.profile_enable(True)
         g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
-        _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False)
-        unitigs = sum(not c.redundant for c in contigs)
-        bases = sum(len(c.seq) for c in contigs if not c.redundant)
+        # contigs stay on the device (no per-contig callback into Python): the unitig count and
+        # their total length come from the assembly counters (AssemblyCounters.h:15-31)
+        g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False,
+                          want_contigs=False)
+        c = g.assembly_counters()
+        unitigs, bases = c["next_contig_id"], c["bases_assembled"]
 
     for _ in range(a.warmup):
         step()

@@ -1,0 +1,77 @@
+"""The drop-in `abyss-bloom-dbg` binary on a real MI355X: same command line as abyss-pe issues
+(bin/abyss-pe:191-235,553-555: `abyss-bloom-dbg -k$k -q3 -b$B -j$j reads... > name-1.fa`),
+byte-identical unitig FASTA / read log / trace against the reference's golden outputs and,
+when the unmodified reference binary travelled with the snapshot (oracle/_ref), against a
+live run of it on a bigger FASTQ read set (BASELINE.json configs[0] sized: 200 kbp, k=32)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from abyss_amd import build, synth
+from util import GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+
+def cli():
+    path = build.build_cli()
+    assert path and os.path.exists(path)
+    return path
+
+
+def strip_length_column(trace: bytes) -> bytes:
+    return b"".join(b"\t".join(r.split(b"\t")[:1] + r.split(b"\t")[2:]) + b"\n" for r in trace.splitlines())
+
+
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed"])
+def test_cli_reproduces_golden(name, tmp_path):
+    g = GoldenCase(name)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as f:
+        for i, s in enumerate(g.reads):
+            f.write(b">r%d\n%s\n" % (i, s))
+    r = subprocess.run([cli()] + g.meta["options"] + ["-j1", "-v", "--read-log=rl.tsv", "-T", "tr.tsv", "reads.fa"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == g.fasta
+    assert open(tmp_path / "rl.tsv", "rb").read() == g.readlog
+    assert strip_length_column(open(tmp_path / "tr.tsv", "rb").read()) == g.trace
+    assert ("popcount                = %d" % g.meta["filtered_popcount"]).encode() in r.stderr
+    assert b"Assembly complete" in r.stderr
+
+
+def test_cli_option_errors(tmp_path):
+    (tmp_path / "r.fa").write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    for args, msg in ((["-k32", "r.fa"], b"missing mandatory option `-b'"), (["-b1M", "r.fa"], b"missing mandatory option `-k'"),
+                      (["-k32", "-b1M"], b"missing input file arguments"), (["-k32", "-b1M", "-K8", "r.fa"], b"not supported"),
+                      (["-k32", "-bXYZ", "r.fa"], b"invalid option")):
+        r = subprocess.run([cli()] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
+    r = subprocess.run([cli(), "-k32", "-b1M", "nonexistent.fq"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"nonexistent.fq" in r.stderr
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref/abyss-bloom-dbg did not travel with the snapshot")
+def test_cli_matches_reference_binary_on_fastq(tmp_path):
+    # BASELINE.json configs[0]: 200 kbp, 40x, 2x150 bp, k=32, B=100M, -q3, as abyss-pe runs it
+    m1, m2 = synth.make_read_set(200000, 40.0)
+    synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)
+    synth.write_fastq(str(tmp_path / "r2.fq"), m2, "r", 2)
+    args = ["-k32", "-q3", "-b100M", "--read-log=rl_%s.tsv", "-T", "tr_%s.tsv", "r1.fq", "r2.fq"]
+    ref_out, _ = ob.run_ref([a % "ref" if "%s" in a else a for a in args], cwd=str(tmp_path), threads=1)
+    r = subprocess.run([cli(), "-j1"] + [a % "amd" if "%s" in a else a for a in args], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == ref_out
+    assert len(ref_out) > 100000
+    assert open(tmp_path / "rl_amd.tsv", "rb").read() == open(tmp_path / "rl_ref.tsv", "rb").read()
+    assert strip_length_column(open(tmp_path / "tr_amd.tsv", "rb").read()) == \
+        strip_length_column(open(tmp_path / "tr_ref.tsv", "rb").read())
+    # gzip input goes through the same reader (Common/Uncompress.cpp in the reference)
+    subprocess.run(["gzip", "-k", "r1.fq", "r2.fq"], cwd=tmp_path, check=True)
+    rz = subprocess.run([cli(), "-k32", "-q3", "-b100M", "r1.fq.gz", "r2.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE)
+    assert rz.returncode == 0 and rz.stdout == ref_out
