@@ -375,10 +375,13 @@ ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, u
 // lane l handles hash function (l & 7) of k-mer (l >> 3), and a ballot gathers the verdict.
 // Non-cooperative callers (one item per lane, or the serial host check) pass coop = false.
 #if defined(__HIP_DEVICE_COMPILE__)
+// AND over the lanes of a wave-per-item kernel (nlanes == 64) / identity for serial callers
+ABG_HD bool wave_all_lanes(bool v, uint32_t nlanes) { return nlanes > 1 ? __ballot(v ? 0 : 1) == 0 : v; }
 ABG_HD unsigned lane_id() { return __lane_id(); }
 ABG_HD uint64_t wave_ballot(bool v) { return __ballot(v ? 1 : 0); }
 ABG_HD bool wave_any(bool v) { return __ballot(v ? 1 : 0) != 0; }
 #else
+ABG_HD bool wave_all_lanes(bool v, uint32_t) { return v; }
 ABG_HD unsigned lane_id() { return 0; }
 ABG_HD uint64_t wave_ballot(bool v) { return v ? 1 : 0; }
 ABG_HD bool wave_any(bool v) { return v; }

@@ -266,6 +266,39 @@ struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum m
 		if (cov) atomic_add_u32(&rec.coverage, cov);
 	}
 };
+// Settles, in parallel and against the current visited snapshot, what the ordered commit
+// would otherwise test one by one: a candidate read / a contig whose k-mers are ALL visited
+// already stays so (the visited set only grows), so "read is visited" and "contig is
+// redundant" are final for them.  flags: bit 0 of read_flag[c] = read entirely visited;
+// rec.pre_redundant = contig entirely visited (long contigs only: short ones use the exact
+// contigEndKmers rule, bloom-dbg.h:576-584).
+template <int NW>
+struct FPreCommit {
+	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
+	ContigRec* recs; const uint8_t* vis; const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff;
+	uint8_t* read_flag; uint32_t first;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		uint32_t c = first + (uint32_t)i;
+		uint64_t r = cand_read[c];
+		uint32_t nk = b.len[r] - p.k + 1;
+		bool all = true;
+		for (uint32_t j = lane; j < nk; j += nlanes) all = all & visited_contains(p, vis, rkh[rkoff[c] + j]);
+		all = wave_all_lanes(all, nlanes);
+		if (lane == 0) read_flag[c] = all ? 1 : 0;
+		if (all || status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
+			ContigRec& rec = recs[ri];
+			uint32_t cnk = rec.len - p.k + 1;
+			if (rec.len < p.k + FP_TRIM - 1 || rec.pre_redundant) continue;
+			bool red = true;
+			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains(p, vis, kh[rec.seq_off + j]);
+			red = wave_all_lanes(red, nlanes);
+			if (lane == 0 && red) rec.pre_redundant = 1;
+		}
+	}
+};
+
 // Which candidates without a result will still be unvisited at their turn?  A read is
 // predicted "covered" when each of its k-mers is already visited or lies in the territory
 // of a lower-numbered walker that completed.  Mispredictions only cost time: the ordered
@@ -320,6 +353,7 @@ struct CommitEnv {
 	const uint64_t* kh;      // hash of the k-mer starting at each pool offset (FContigPrep)
 	const uint64_t* rkh;     // hashes of the candidates' read k-mers (FReadPrep)
 	const uint64_t* rkoff;
+	const uint8_t* read_flag; // FPreCommit: 1 = the read is entirely visited already
 	WalkTab cend;            // contigEndKmers (bloom-dbg.h:992), owner 0
 	CommitState* st;
 	uint32_t* order;         // [rec_cap] records in commit order
@@ -350,11 +384,17 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 		uint64_t r = e.cand_read[c];
 		uint32_t nk = e.b.len[r] - k + 1;
 		// allKmersInBloom(seq, assembledKmerSet) at this read's turn (bloom-dbg.h:823)
-		bool mine = true;
-		const uint64_t* rh = e.rkh + e.rkoff[c];
-		for (uint32_t j = tid; j < nk; j += T)
-			mine = mine & visited_contains_coherent(p, e.vis32, rh[j]);
-		if (sy.all(mine)) {
+		bool visited;
+		if (e.read_flag[c]) {
+			visited = true; // settled ahead: every k-mer was visited before this commit started
+		} else {
+			bool mine = true;
+			const uint64_t* rh = e.rkh + e.rkoff[c];
+			for (uint32_t j = tid; j < nk; j += T)
+				mine = mine & visited_contains_coherent(p, e.vis32, rh[j]);
+			visited = sy.all(mine);
+		}
+		if (visited) {
 			if (tid == 0) { e.result[r] = RR_ALL_KMERS_VISITED; e.st->counters.visited_reads++; }
 			continue;
 		}
@@ -381,6 +421,8 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 					}
 				}
 				redundant = sy.bcast(redundant);
+			} else if (rec.pre_redundant) {
+				redundant = 1; // settled ahead of the commit
 			} else {
 				bool all = true;
 				for (uint32_t j = tid; j < cnk; j += T)
@@ -406,7 +448,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 				}
 				e.order[(*e.order_n)++] = ri;
 			}
-			sy.barrier(); // publishes the inserted bits to the next test
+			if (!redundant) sy.barrier(); // publishes the inserted bits to the next test
 		}
 	}
 	if (tid == 0) e.st->break_at = c;
@@ -531,6 +573,8 @@ class Engine {
 	uint32_t walk_tb_cap_ = 0, walk_buf_cap_ = 0, wslots_ = 0, cslots_ = 0;
 	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr; uint64_t* dbg_ = nullptr;
 	uint64_t cend_count_ = 0;
+	uint8_t* read_flag_ = nullptr;
+	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	void ensure_insert()
 	{
@@ -716,7 +760,12 @@ class Engine {
 		cs.counters = counters_;
 		cs.break_at = c_begin; cs.pad_ = 0; cs.cend_count = cend_count_;
 		be_.h2d(cstate_, &cs, sizeof cs);
+		{
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
+			be_.launch_wave(c_end - c_begin, f, "precommit");
+		}
 		CommitEnv<NW> e;
+		e.read_flag = read_flag_;
 		e.p = p_; e.b = b; e.vis32 = (uint32_t*)vis_;
 		e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d;
@@ -794,6 +843,7 @@ class Engine {
 		uint64_t* rkoff_d = (uint64_t*)be_.alloc((nc + 1) * 8ull);
 		be_.h2d(rkoff_d, rkoff.data(), (nc + 1) * 8ull);
 		rkh_ = (uint64_t*)be_.alloc(std::max<uint64_t>(rkoff[nc], 1) * 8);
+		read_flag_ = (uint8_t*)be_.alloc(nc);
 		{
 			FReadPrep<NW> f{ p_, b, cand_d, rkoff_d, rkh_, 0 };
 			be_.launch_wave(nc, f, "read_prep");
@@ -837,9 +887,13 @@ class Engine {
 				for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;
 				be_.h2d(list_d, ident.data(), (nc - base) * 4ull);
 			}
-			// stage 1: everybody walks, deferring to lower-numbered walkers
-			clear_wtab();
-			{
+			// stage 1: everybody walks, deferring to lower-numbered walkers.  It pays when many
+			// candidates share unitigs; when most of them turned out to be needed in the previous
+			// batch they would only be walked twice, so it is skipped and everybody is walked in
+			// full by the first stage-2 launch instead.
+			const bool defer_stage = needed_frac_ < 0.5;
+			if (defer_stage) {
+				clear_wtab();
 				WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
 				env.claims = wclaims_;
 				env.owner_base = owner_next;
@@ -853,6 +907,7 @@ class Engine {
 			uint32_t committed = base;
 			uint32_t force = 0xFFFFFFFFu;
 			bool overflow = false;
+			uint64_t batch_rewalked = 0;
 			while (committed < nc) {
 				// stage 2: candidates without a result that lower reads will not cover
 				be_.memset(need_n, 0, 4);
@@ -873,6 +928,7 @@ class Engine {
 					FWalk<NW> fw{ env, need_d, !slow_frames_ };
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;
+					batch_rewalked += nneed;
 					dump("rewalk", nneed);
 					prep_new_records<NW>(prepped);
 				}
@@ -892,6 +948,7 @@ class Engine {
 				committed = next;
 			}
 			deliver(cand_h, read_base, sink);
+			if (nc - base >= 64) needed_frac_ = std::min(1.0, (double)batch_rewalked / (double)(nc - base));
 			if (overflow) {
 				// the candidate at `committed` ran out of some capacity.  Results not yet committed
 				// are dropped and the walk restarts from there; if nothing was committed in this
@@ -901,6 +958,7 @@ class Engine {
 			base = committed;
 		}
 		be_.free(rkh_); rkh_ = nullptr;
+		be_.free(read_flag_); read_flag_ = nullptr;
 		if (debug) { be_.free(dbg_); dbg_ = nullptr; }
 		be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
 		be_.free(need_d); be_.free(need_n); be_.free(rkoff_d);

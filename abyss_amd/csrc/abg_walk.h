@@ -224,7 +224,7 @@ struct ContigRec {
 	uint32_t left_ext, right_ext;
 	uint8_t left_code, right_code;
 	uint8_t redundant;    // filled by the commit
-	uint8_t pad_;
+	uint8_t pre_redundant; // settled ahead of the commit: every k-mer already visited
 	uint32_t coverage;    // filled by the commit
 	uint64_t contig_id;   // filled by the commit
 };
@@ -555,7 +555,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			rec.cand = c; rec.next = REC_END; rec.seed_pos = it;
 			rec.left_ext = lext; rec.right_ext = rext;
 			rec.left_code = (uint8_t)lcode; rec.right_code = (uint8_t)rcode;
-			rec.redundant = 0; rec.pad_ = 0; rec.coverage = 0; rec.contig_id = ~0ULL;
+			rec.redundant = 0; rec.pre_redundant = 0; rec.coverage = 0; rec.contig_id = ~0ULL;
 			if (last == REC_END) first = ri; else e.recs[last].next = ri;
 			last = ri;
 			// ---- assembledKmers.insert(contigPath): vertices trimmed off the ends are not
