@@ -25,9 +25,10 @@ struct Config {
 	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
 	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
 	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
-	uint32_t walk_slots = 8192;       // concurrent walkers (one per wavefront)
+	uint32_t drain_threshold = 4096;  // pending ops at or below which the retry tail runs in one workgroup
+	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
-	uint32_t buf_cap = 1u << 13;      // extension bases per side per walker
+	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
 	uint64_t pool_cap = 1ull << 28;   // contig pool bytes
 	uint32_t rec_cap = 1u << 22;      // contig records per round
 	uint32_t wtab_log2 = 26;          // walker vertex table entries
@@ -97,6 +98,47 @@ struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
 		h0[t] = rh < fh ? rh : fh;
 	}
 };
+// Fused PASS 1 front end: each lane owns HC_RUN consecutive k-mer ops, hashes the first from
+// scratch (NTF64/NTR64 base forms) and rolls along the read for the rest (NTC64,
+// nthash.hpp:242-257,275-279), stores the canonical hashes (64 contiguous bytes per lane) and
+// issues the H claims of every op right away, so the hashing ALU work hides under the
+// latency of the claim atomics.
+constexpr uint32_t HC_RUN = 8;
+struct FHashClaim {
+	Params p; Batch b; uint64_t* h0; uint64_t T; uint64_t* claim; uint64_t cmask; uint32_t epoch;
+	ABG_HD void operator()(uint64_t g, uint32_t) const
+	{
+		uint64_t t0 = g * HC_RUN;
+		if (t0 >= T) return;
+		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
+		uint64_t r = find_seq(b.koff, b.n, t0);
+		uint64_t rend = b.koff[r + 1];
+		unsigned k = p.k;
+		uint64_t fh = 0, rh = 0;
+		bool fresh = true;
+		for (uint64_t t = t0; t < t1; t++) {
+			while (t >= rend) { r++; rend = b.koff[r + 1]; fresh = true; }
+			uint32_t j = (uint32_t)(t - b.koff[r]);
+			if (fresh) {
+				fh = 0; rh = 0;
+				for (unsigned i = 0; i < k; i++) {
+					fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
+					rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
+				}
+				fresh = false;
+			} else {
+				unsigned out = batch_base(b, r, j - 1), in = batch_base(b, r, j + k - 1);
+				fh = srol1(fh) ^ seed_of(in) ^ p.seed_k[out];
+				rh = sror1(rh ^ p.seedrc_k[in] ^ seed_of(3u - out));
+			}
+			uint64_t h = rh < fh ? rh : fh;
+			h0[t] = h;
+			uint64_t v = claim_val(epoch, (uint32_t)t);
+			for (unsigned i = 0; i < p.nh; i++)
+				atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
+		}
+	}
+};
 struct FClaim { // first round: every op claims its H counters
 	Params p; const uint64_t* h0; uint64_t* claim; uint64_t cmask; uint32_t epoch;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
@@ -141,6 +183,67 @@ struct FInsertRound {
 		}
 	}
 };
+// Tail of the reservation rounds inside ONE workgroup: when few ops are still pending, a
+// launch per round is all latency, so the remaining rounds run in a loop here with
+// workgroup barriers between the claim and the apply phase.  Claims and counters are read
+// through L2 (other lanes of the workgroup wrote them moments ago).
+// Sync policy: tid(), nthreads(), barrier(), bcast(uint32_t).
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint8_t ld_coherent_u8(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+ABG_HD uint8_t ld_coherent_u8(const uint8_t* p) { return *p; }
+#endif
+struct InsertDrainEnv {
+	Params p; const uint64_t* h0; uint8_t* cnt;
+	uint32_t* list_a; uint32_t* list_b; uint32_t n; // pending ops in list_a
+	uint64_t* claim_a; uint64_t* claim_b; uint64_t cmask; uint32_t epoch; // claims of list_a are in claim_a under `epoch`
+	uint32_t* counter;   // scratch word; [1] receives the number of rounds run
+};
+template <class Sync>
+ABG_HDN void insert_drain(InsertDrainEnv e, Sync& sy)
+{
+	const Params& p = e.p;
+	const uint32_t tid = sy.tid(), T = sy.nthreads();
+	uint32_t n = e.n, rounds = 0;
+	uint32_t* cur = e.list_a; uint32_t* nxt = e.list_b;
+	uint64_t* ccur = e.claim_a; uint64_t* cnext = e.claim_b;
+	uint32_t epoch = e.epoch;
+	while (n) {
+		if (tid == 0) e.counter[0] = 0;
+		sy.barrier();
+		for (uint32_t i = tid; i < n; i += T) {
+			uint32_t t = ld_coherent(&cur[i]); // written by another lane in the previous round
+			uint64_t h = e.h0[t];
+			uint64_t v = claim_val(epoch, t);
+			bool win = true;
+			for (unsigned j = 0; j < p.nh; j++)
+				win = win & (ld_coherent(&ccur[pos_i(p, h, j) & e.cmask]) == v);
+			if (win) {
+				unsigned mn = 255;
+				for (unsigned j = 0; j < p.nh; j++) { unsigned c = ld_coherent_u8(&e.cnt[pos_i(p, h, j)]); mn = c < mn ? c : mn; }
+				if (mn < 255)
+					for (unsigned j = 0; j < p.nh; j++) {
+						uint64_t q = pos_i(p, h, j);
+						if (ld_coherent_u8(&e.cnt[q]) == mn) e.cnt[q] = (uint8_t)(mn + 1);
+					}
+			} else {
+				uint32_t slot = atomic_add_u32(&e.counter[0], 1);
+				nxt[slot] = t;
+				uint64_t v2 = claim_val(epoch + 1, t);
+				for (unsigned j = 0; j < p.nh; j++)
+					atomic_min_u64(&cnext[pos_i(p, h, j) & e.cmask], v2);
+			}
+		}
+		sy.barrier();
+		n = sy.bcast(ld_coherent(&e.counter[0]));
+		uint32_t* tl = cur; cur = nxt; nxt = tl;
+		uint64_t* tc = ccur; ccur = cnext; cnext = tc;
+		epoch++;
+		rounds++;
+	}
+	if (tid == 0) e.counter[1] = rounds;
+	sy.barrier();
+}
 struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219-242), 8 counters per item
 	const uint64_t* cnt8; uint32_t kc; uint64_t* out; // out[0] non-zero, out[1] >= kc
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -465,6 +568,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 //   template<class F> void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name); // one item per wave, lane 0
 //   template<class F> void launch_wave(uint64_t n, F f, const char* name);   // f(item, lane, nlanes): one item per wave
 //   template<int NW> void launch_commit(CommitEnv<NW>, uint32_t c_begin, uint32_t c_end);
+//   void launch_drain(InsertDrainEnv);          // one workgroup running insert_drain
 template <class BE>
 class Engine {
   public:
@@ -613,8 +717,6 @@ class Engine {
 		uint64_t* kv_d = (uint64_t*)be_.alloc(kv.size() * 8);
 		be_.h2d(kv_d, kv.data(), kv.size() * 8);
 		v.koff = kv_d;
-		FHash fh{ p_, v, h0_ };
-		be_.launch(T, fh, "hash");
 		uint64_t cmask = (1ull << cfg_.claim_log2) - 1;
 		if (epoch_ > 0xFFFFFF00u) { // claim epochs exhausted: start over
 			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
@@ -622,12 +724,27 @@ class Engine {
 		}
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
-		FClaim fc{ p_, h0_, ccur, cmask, epoch_ };
-		be_.launch(T, fc, "claim");
+		{
+			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_ };
+			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
+		}
 		uint64_t npend = T;
 		const uint32_t* pin = nullptr; // NULL: all ops 0..T-1
 		uint32_t* pout = pend_[0];
 		while (npend) {
+			if (pin && npend <= cfg_.drain_threshold) {
+				// few ops left: finish all remaining rounds inside one workgroup
+				uint32_t* other = (pin == pend_[0]) ? pend_[1] : pend_[0];
+				InsertDrainEnv de{ p_, h0_, cnt_, const_cast<uint32_t*>(pin), other, (uint32_t)npend,
+					ccur, cnext, cmask, epoch_, pend_n_ };
+				be_.launch_drain(de);
+				uint32_t r[2] = { 0, 0 };
+				be_.d2h(r, pend_n_, 8);
+				epoch_ += r[1];
+				last_rounds_ += r[1];
+				stats_.insert_rounds += r[1];
+				break;
+			}
 			be_.memset(pend_n_, 0, 4);
 			FInsertRound fr{ p_, h0_, cnt_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_ };
 			be_.launch(npend, fr, pin ? "insert_retry" : "insert_round");

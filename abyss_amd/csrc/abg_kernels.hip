@@ -62,8 +62,9 @@ __global__ void __launch_bounds__(256) k_foreach_wave(F f, uint64_t n)
 }
 
 constexpr int COMMIT_THREADS = 256;
+constexpr int SYNC_WORDS = 34; // up to 16 waves (1024 threads) + broadcast slot at [32]
 struct DeviceSync {
-	uint32_t* sh; // [COMMIT_THREADS / 64 + 2] shared words
+	uint32_t* sh; // [SYNC_WORDS] shared words: one per wave + a broadcast slot
 	__device__ uint32_t tid() const { return threadIdx.x; }
 	__device__ uint32_t nthreads() const { return blockDim.x; }
 	__device__ void barrier() { __syncthreads(); }
@@ -82,9 +83,9 @@ struct DeviceSync {
 	__device__ uint32_t bcast(uint32_t v)
 	{
 		__syncthreads();
-		if (threadIdx.x == 0) sh[COMMIT_THREADS / 64] = v;
+		if (threadIdx.x == 0) sh[32] = v;
 		__syncthreads();
-		uint32_t r = sh[COMMIT_THREADS / 64];
+		uint32_t r = sh[32];
 		__syncthreads();
 		return r;
 	}
@@ -92,9 +93,16 @@ struct DeviceSync {
 template <int NW>
 __global__ void __launch_bounds__(COMMIT_THREADS) k_commit(abg::CommitEnv<NW> e, uint32_t c_begin, uint32_t c_end)
 {
-	__shared__ uint32_t sh[COMMIT_THREADS / 64 + 2];
+	__shared__ uint32_t sh[SYNC_WORDS];
 	DeviceSync sy{ sh };
 	abg::commit_candidates<NW>(e, c_begin, c_end, sy);
+}
+
+__global__ void __launch_bounds__(1024) k_insert_drain(abg::InsertDrainEnv e)
+{
+	__shared__ uint32_t sh[SYNC_WORDS];
+	DeviceSync sy{ sh };
+	abg::insert_drain(e, sy);
 }
 
 struct ProfEntry { double ms = 0; uint64_t launches = 0; };
@@ -216,6 +224,12 @@ struct HipBackend {
 		begin(name);
 		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
 		end(name);
+	}
+	void launch_drain(abg::InsertDrainEnv e)
+	{
+		begin("insert_drain");
+		hipLaunchKernelGGL(k_insert_drain, dim3(1), dim3(1024), 0, stream, e);
+		end("insert_drain");
 	}
 	template <int NW>
 	void launch_commit(abg::CommitEnv<NW> e, uint32_t c_begin, uint32_t c_end)

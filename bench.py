@@ -178,16 +178,15 @@ def main() -> int:
         elapsed = float(t.item())
 
     # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
-    names = ["hash", "claim", "insert_round", "insert_retry", "classify", "walk", "rewalk", "spotwalk", "predict",
-             "refilter", "commit", "popcount"]
+    names = ["hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep", "walk", "rewalk",
+             "contig_prep", "predict", "precommit", "commit", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names}
     stats = g.stats()
     H = 4
     per_kmer_bases = (read_len / 4.0) / (read_len - a.k + 1)
     # algorithmic bytes per read k-mer of each streaming kernel (DESIGN.md "Roofline")
     alg_bytes = {
-        "hash": per_kmer_bases + 8,                 # 2-bit bases in, canonical hash out
-        "claim": 8 + H * 8,                         # hash in, H claim slots
+        "hash_claim": per_kmer_bases + 8 + H * 8,   # 2-bit bases in, canonical hash out, H claim slots
         "insert_round": 8 + H * 8 + 2 * H,          # hash + H claim slots + H counter reads + H counter writes
         "classify": per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1),  # solid + visited probes + look-ahead
     }

@@ -35,6 +35,7 @@ struct SerialBackend {
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests
 	alignas(16) unsigned char fastbuf[2048];
 	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, (uint32_t)sizeof fastbuf, false); }
+	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
 		SerialSync sy;
@@ -59,7 +60,7 @@ void* hc_create(unsigned k, unsigned nh, unsigned kc, unsigned trim, uint64_t co
 	s->cfg.insert_batch_kmers = insert_batch ? insert_batch : (1u << 16);
 	s->cfg.walk_slots = 1; s->cfg.tb_cap = 4096; s->cfg.buf_cap = 1u << 20;
 	s->cfg.pool_cap = 1ull << 26; s->cfg.rec_cap = 1u << 18; s->cfg.wtab_log2 = 22;
-	s->cfg.wclaim_log2 = 18; s->cfg.cend_log2 = 16;
+	s->cfg.wclaim_log2 = 18; s->cfg.cend_log2 = 16; s->cfg.drain_threshold = 64; s->cfg.buf_cap = 1u << 20;
 	if (p2_first_batch) s->cfg.p2_first_batch = p2_first_batch;
 	p.insert_batch_kmers = 0; p.claim_log2 = 0; p.walk_slots = 0; p.wtab_log2 = 0;
 	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }
