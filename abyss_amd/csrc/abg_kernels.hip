@@ -45,10 +45,20 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 // The walker's trueBranch stack (frames + keys) lives in WALK_LDS bytes of LDS.
 constexpr uint32_t WALK_LDS = 16384;
 template <class F>
-__global__ void __launch_bounds__(64, 2) k_walkers(F f, uint64_t n)
+__global__ void __launch_bounds__(64, 2) k_walkers(F f, uint64_t n, unsigned long long* ticket)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[WALK_LDS];
-	for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS, true);
+	// walks differ in length by orders of magnitude: waves draw candidates from a ticket
+	// counter (in candidate order) instead of striding, so no wave is left with a queue of
+	// long walks while others idle
+	for (;;) {
+		unsigned long long i = 0;
+		if (threadIdx.x == 0) i = atomicAdd(ticket, 1ull);
+		i = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32) |
+		    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)i);
+		if (i >= n) break;
+		f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS, true);
+	}
 }
 
 // one item per wavefront, all 64 lanes cooperate (f strides its inner loop by lane)
@@ -116,6 +126,7 @@ struct HipBackend {
 	std::map<std::string, ProfEntry> prof;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	uint32_t cus = 256;
+	unsigned long long* ticket = nullptr;
 
 	explicit HipBackend(int dev = 0) : device(dev)
 	{
@@ -133,6 +144,7 @@ struct HipBackend {
 	}
 	~HipBackend()
 	{
+		if (ticket) hipFree(ticket);
 		if (ev0) hipEventDestroy(ev0);
 		if (ev1) hipEventDestroy(ev1);
 		if (stream) hipStreamDestroy(stream);
@@ -221,8 +233,10 @@ struct HipBackend {
 	{
 		if (!n) return;
 		uint64_t blocks = n < slots ? n : slots;
+		if (!ticket) ticket = (unsigned long long*)alloc(8);
+		check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
 		begin(name);
-		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
+		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
 		end(name);
 	}
 	void launch_drain(abg::InsertDrainEnv e)
