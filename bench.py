@@ -112,6 +112,19 @@ def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
     return {"value": kmers / wall / 1e6, "unit": "Mk-mers/s", "cores": 1, "kind": "port", "sample": sample}
 
 
+def aggregate(elapsed: float, kmers_local: int, steps: int, world: int, device=None):
+    """Whole-job numbers from per-rank ones: time = MAX over ranks of the timed region, units =
+    SUM over ranks (every rank processes its own read set).  Returns (seconds, total k-mers)."""
+    if world == 1:
+        return elapsed, kmers_local * steps
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = torch.tensor([kmers_local * steps], dtype=torch.int64, device=device)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +141,10 @@ def main() -> int:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
+        # "nccl" is RCCL on ROCm; ABG_BENCH_BACKEND=gloo lets the launch path be exercised on a
+        # box with fewer GPUs than ranks (ranks then share devices)
+        dist.init_process_group(backend=os.environ.get("ABG_BENCH_BACKEND", "nccl"))
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -172,10 +188,8 @@ def main() -> int:
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    red_dev = device if (world > 1 and dist.get_backend() == "nccl") else None
+    elapsed, total_kmers = aggregate(elapsed, kmers, a.steps, world, red_dev)
 
     # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
     names = ["hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep", "walk", "rewalk",
@@ -201,7 +215,7 @@ def main() -> int:
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": world * kmers * a.steps / elapsed / 1e6, "unit": "Mk-mers/s",
+            "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d, B=%s, H=4, 1xMI355X per rank"

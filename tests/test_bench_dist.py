@@ -1,0 +1,42 @@
+"""The N>1 path of bench.py (one process per GPU, replicas: no collective on the data path):
+the whole-job aggregation (MAX of the timed region, SUM of units) under torch.distributed with
+world_size 2 on the gloo backend, and the JSON contract of the bench line."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_aggregate_world2_gloo(tmp_path):
+    script = tmp_path / "agg.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        import bench
+        dist.init_process_group(backend="gloo")
+        rank = dist.get_rank()
+        # rank 0 took 2.0 s for 100 units/step, rank 1 took 3.5 s for 150 units/step, 2 steps each
+        t, n = bench.aggregate(2.0 if rank == 0 else 3.5, 100 if rank == 0 else 150, 2, dist.get_world_size())
+        if rank == 0:
+            print(json.dumps({"t": t, "n": n}))
+        dist.barrier()
+        dist.destroy_process_group()
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"t": 3.5, "n": 500}
+
+
+def test_aggregate_single_rank():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.aggregate(1.25, 87, 3, 1) == (1.25, 261)
