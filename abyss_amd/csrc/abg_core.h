@@ -88,6 +88,24 @@ ABG_HD uint64_t seed_of(unsigned b)
 	return b == 0 ? SEED_A : b == 1 ? SEED_C : b == 2 ? SEED_G : SEED_T;
 }
 
+// In a cooperative caller every lane holds the same value, but the compiler cannot know
+// that for anything loaded through a pointer; uni() re-materialises a value from lane 0
+// (v_readfirstlane), which makes it provably wave-uniform: the arithmetic that follows is
+// then selected onto the scalar unit (native 64-bit ops, SGPRs) instead of 64 redundant
+// vector lanes whose register spills would all go to memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint32_t uni(uint32_t x, bool coop) { return coop ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
+ABG_HD uint64_t uni(uint64_t x, bool coop)
+{
+	if (!coop) return x;
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+#else
+ABG_HD uint32_t uni(uint32_t x, bool) { return x; }
+ABG_HD uint64_t uni(uint64_t x, bool) { return x; }
+#endif
+
 // Exact h % m for a 64-bit h and runtime divisor m (CountingBloomFilter.hpp:56-58,
 // BloomFilter.hpp:187,252).  Round-up magic-number division (65-bit magic, the
 // "branch-free" scheme of Granlund-Montgomery / libdivide): q = floor(h / m) for
@@ -336,6 +354,17 @@ ABG_HD bool vtx_equal(const Params& p, const Vtx<NW>& a, const Vtx<NW>& b)
 	if (a.fh == b.fh && a.rh == b.rh) return true;
 	if (a.fh == b.rh && a.rh == b.fh) return !kmer_is_tie(a.s, p.k);
 	return false;
+}
+
+template <int NW>
+ABG_HD Vtx<NW> uni(const Vtx<NW>& v, bool coop)
+{
+	Vtx<NW> r;
+#pragma unroll
+	for (int j = 0; j < NW; j++) r.s.w[j] = uni(v.s.w[j], coop);
+	r.fh = uni(v.fh, coop);
+	r.rh = uni(v.rh, coop);
+	return r;
 }
 
 // --------------------------------------------------------- Bloom filter probes
@@ -608,7 +637,7 @@ ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 		if (f.next >= 4) { depth--; continue; }
 		unsigned b = f.next++;
 		if (!((f.mask >> b) & 1u)) continue;
-		Vtx<NW> w = neighbour_vertex(p, f.v, sense, b);
+		Vtx<NW> w = neighbour_vertex(p, uni(f.v, sc.coop), sense, b);
 		bool seen = false;
 		for (unsigned i = 0; i < nv; i++) {
 			Vtx<NW> t; t.s = w.s; t.fh = vis[i].fh; t.rh = vis[i].rh;
@@ -650,6 +679,9 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 	unsigned cdepth = 0;
 	int cdir = dir0;
 	for (;;) {
+		cu = uni(cu, sc.coop); cv = uni(cv, sc.coop);
+		cdepth = uni((uint32_t)cdepth, sc.coop); cdir = (int)uni((uint32_t)cdir, sc.coop);
+		top = (int)uni((uint32_t)top, sc.coop);
 		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
 		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
 		bool on_stack = false;
@@ -686,28 +718,34 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		bool called = false;
 		while (top >= 0 && !called) {
 			TBFrame<NW>& f = tb_frame(sc, top);
-			int fdir = f.dir;
+			const Vtx<NW> fv = uni(f.v, sc.coop);
+			const unsigned fdepth = uni((uint32_t)f.depth, sc.coop);
+			int fdir = (int)uni((uint32_t)f.dir, sc.coop);
 			int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
-			if (f.stage == 0) {
-				while (f.next < 4 && !((f.mask_same >> f.next) & 1u)) f.next++;
-				if (f.next < 4) {
-					unsigned b = f.next++;
-					cu = f.v;
-					cv = neighbour_vertex(p, f.v, sense, b);
-					cdepth = f.depth + 1u;
+			if (uni((uint32_t)f.stage, sc.coop) == 0) {
+				unsigned nx = uni((uint32_t)f.next, sc.coop);
+				const unsigned ms = uni((uint32_t)f.mask_same, sc.coop);
+				while (nx < 4 && !((ms >> nx) & 1u)) nx++;
+				if (nx < 4) {
+					unsigned b = nx++;
+					f.next = (uint8_t)nx;
+					cu = fv;
+					cv = neighbour_vertex(p, fv, sense, b);
+					cdepth = fdepth + 1u;
 					cdir = fdir;
 					called = true;
 					break;
 				}
+				f.next = (uint8_t)nx;
 				// same-direction children exhausted: may we change direction?
 				// (depth >= fpTrim || lookAhead(v, dir, fpTrim), ExtendPath.h:208,230)
-				bool flip = f.depth >= FP_TRIM;
-				if (!flip) flip = look_ahead(p, cnt, f.v, fdir, FP_TRIM, sc);
+				bool flip = fdepth >= FP_TRIM;
+				if (!flip) flip = look_ahead(p, cnt, fv, fdir, FP_TRIM, sc);
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
 				f.next = 0;
 				uint64_t nfh[4], nrh[4];
-				f.mask_other = (uint8_t)neighbour_mask(p, cnt, f.v,
+				f.mask_other = (uint8_t)neighbour_mask(p, cnt, fv,
 				    fdir == FORWARD ? ANTISENSE : SENSE, nfh, nrh, sc.coop);
 				f.have_other = 1;
 			}
@@ -716,16 +754,20 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
 				int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
 				bool made = false;
-				while (f.next < 4) {
-					unsigned b = f.next++;
-					if (!((f.mask_other >> b) & 1u)) continue;
-					Vtx<NW> w = neighbour_vertex(p, f.v, osense, b);
-					Vtx<NW> uu; uu.s = w.s; uu.fh = f.ufh; uu.rh = f.urh;
+				unsigned nx = uni((uint32_t)f.next, sc.coop);
+				const unsigned mo = uni((uint32_t)f.mask_other, sc.coop);
+				const uint64_t ufh = uni(f.ufh, sc.coop), urh = uni(f.urh, sc.coop);
+				while (nx < 4) {
+					unsigned b = nx++;
+					if (!((mo >> b) & 1u)) continue;
+					Vtx<NW> w = neighbour_vertex(p, fv, osense, b);
+					Vtx<NW> uu; uu.s = w.s; uu.fh = ufh; uu.rh = urh;
 					if (vtx_equal(p, w, uu)) continue; // source(*iei) == u
-					cu = f.v; cv = w; cdepth = 0; cdir = odir;
+					cu = fv; cv = w; cdepth = 0; cdir = odir;
 					made = true;
 					break;
 				}
+				f.next = (uint8_t)nx;
 				if (made) { called = true; break; }
 				top--; // visited.erase(v); return false
 			}
