@@ -94,7 +94,18 @@ ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool coop)
 	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
 	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
 }
+// write-through stores do not coalesce across lanes: one lane stores for the wave
+ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) st_coherent(p, v);
+}
+ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) *p = v;
+}
 #else
+ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool) { st_coherent(p, v); }
+ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool) { *p = v; }
 ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
 ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool) { return atomic_min_u32(p, v); }
 ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool) { return atomic_add_u32(p, v); }
@@ -177,8 +188,8 @@ ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t conti
 		// (one round trip) instead of reading it and then taking it (two)
 		uint64_t cur = wu_cas_u64(&t.hmin[s], WT_EMPTY, key.fh, coop);
 		if (cur == WT_EMPTY) {
-			st_coherent(&t.hmax[s], key.rh);
-			st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
+			wu_st_coherent(&t.hmax[s], key.rh, coop);
+			wu_st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig, coop);
 			return WT_NEW;
 		}
 		if (cur != key.fh) continue;
@@ -187,7 +198,7 @@ ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t conti
 		if (ld_coherent(&t.hmax[s]) != key.rh) continue;
 		uint32_t c = (uint32_t)m;
 		if (c == contig) return WT_SAME_CONTIG;
-		st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig);
+		wu_st_coherent(&t.meta[s], ((uint64_t)owner << 32) | contig, coop);
 		return c == WT_TOMB ? WT_NEW : WT_EARLIER;
 	}
 	return WT_FULL;
@@ -491,7 +502,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			for (uint32_t i = 0; i < n; i++) {
 				Vtx<NW> x = ws_vertex(p, w, i);
 				uint64_t hm = vtx_hash(x);
-				e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask] = 0xFFFFFFFFu;
+				wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
 			}
 		}
 		if (!tip) {
@@ -570,10 +581,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 					if (popped_earlier[q]) continue;
 					if (hi > lo && (vtx_equal(p, popped[q], nf) || vtx_equal(p, popped[q], nb))) continue;
 					uint64_t s = wt_find(e.tab, vtx_key(p, popped[q]), owner);
-					if (s != WT_EMPTY) st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB);
+					if (s != WT_EMPTY) wu_st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB, sc.coop);
 					if (e.claims) { // trimmed off: not covered by this walker's contig after all
 						uint64_t hm = vtx_hash(popped[q]);
-						e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask] = 0xFFFFFFFFu;
+						wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
 					}
 				}
 			}
