@@ -166,6 +166,8 @@ struct FInsertRound {
 		bool win = true;
 		for (unsigned j = 0; j < p.nh; j++)
 			win = win & (claim_cur[pos_i(p, h, j) & cmask] == v);
+		// losers queue for the next round: one counter bump per wavefront
+		const uint32_t slot = wave_append_slot(next_n, !win);
 		if (win) {
 			unsigned mn = 255;
 			for (unsigned j = 0; j < p.nh; j++) { unsigned c = cnt[pos_i(p, h, j)]; mn = c < mn ? c : mn; }
@@ -175,7 +177,6 @@ struct FInsertRound {
 					if (cnt[q] == mn) cnt[q] = (uint8_t)(mn + 1);
 				}
 		} else {
-			uint32_t slot = atomic_add_u32(next_n, 1);
 			next[slot] = t;
 			uint64_t v2 = claim_val(epoch + 1, t);
 			for (unsigned j = 0; j < p.nh; j++)
@@ -471,88 +472,142 @@ ABG_HD bool visited_contains_coherent(const Params& p, const uint32_t* vis32, ui
 	}
 	return ok;
 }
+// Per-candidate descriptor staged in fast memory by commit_candidates (one per thread,
+// COMMIT_CHUNK at a time) so that the sequential loop does not pay a chain of dependent
+// global loads per candidate.
+struct CommitDesc {
+	uint64_t r;          // read index
+	uint64_t rkoff;      // offset of the read's k-mer hashes in rkh
+	uint64_t seq_off;    // first contig record: pool offset
+	uint32_t nk;         // read k-mers
+	uint32_t status;     // WalkStatus
+	uint32_t first;      // first contig record (REC_END: none)
+	uint32_t len, next;  // first contig record: length, next record
+	uint8_t visited;     // FPreCommit: the read is entirely visited already
+	uint8_t pre_redundant; // first contig record
+	uint8_t pad_[2];
+};
+constexpr uint32_t COMMIT_CHUNK = 256;
+
 // The only inherently sequential part of PASS 2: in read order, decide "all k-mers
 // visited?" for the read, then for each of its contigs the redundancy test and the
 // insertion into the visited filter (outputContig, bloom-dbg.h:538-620).  All hashing and
 // the coverage sums were done in parallel beforehand; this loop only tests and sets bits.
-// Sync policy: tid(), nthreads(), barrier(), all(bool), bcast(uint32_t from tid 0)
+// Sync policy: tid(), nthreads(), barrier(), all(bool), bcast(uint32_t from tid 0),
+// descs() -> CommitDesc[COMMIT_CHUNK] in memory shared by the threads.
 template <int NW, class Sync>
 ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_end, Sync& sy)
 {
 	const Params& p = e.p;
 	const unsigned k = p.k;
 	const uint32_t tid = sy.tid(), T = sy.nthreads();
+	CommitDesc* descs = sy.descs();
 	uint32_t c = c_begin;
-	for (; c < c_end; c++) {
-		uint64_t r = e.cand_read[c];
-		uint32_t nk = e.b.len[r] - k + 1;
-		// allKmersInBloom(seq, assembledKmerSet) at this read's turn (bloom-dbg.h:823)
-		bool visited;
-		if (e.read_flag[c]) {
-			visited = true; // settled ahead: every k-mer was visited before this commit started
-		} else {
-			bool mine = true;
-			const uint64_t* rh = e.rkh + e.rkoff[c];
-			for (uint32_t j = tid; j < nk; j += T)
-				mine = mine & visited_contains_coherent(p, e.vis32, rh[j]);
-			visited = sy.all(mine);
+	bool stop = false;
+	for (uint32_t c0 = c_begin; c0 < c_end && !stop; c0 += COMMIT_CHUNK) {
+		const uint32_t nchunk = c_end - c0 < COMMIT_CHUNK ? c_end - c0 : COMMIT_CHUNK;
+		sy.barrier();
+		for (uint32_t i = tid; i < nchunk; i += T) {
+			CommitDesc d;
+			uint32_t cc = c0 + i;
+			d.r = e.cand_read[cc];
+			d.nk = e.b.len[d.r] - k + 1;
+			d.rkoff = e.rkoff[cc];
+			d.status = e.status[cc];
+			d.first = e.first_rec[cc];
+			d.visited = e.read_flag[cc];
+			d.seq_off = 0; d.len = 0; d.next = REC_END; d.pre_redundant = 0; d.pad_[0] = d.pad_[1] = 0;
+			if (d.status == WS_COMPLETE && d.first != REC_END) {
+				const ContigRec& rec = e.recs[d.first];
+				d.seq_off = rec.seq_off; d.len = rec.len; d.next = rec.next; d.pre_redundant = rec.pre_redundant;
+			}
+			descs[i] = d;
 		}
-		if (visited) {
-			if (tid == 0) { e.result[r] = RR_ALL_KMERS_VISITED; e.st->counters.visited_reads++; }
-			continue;
-		}
-		if (e.status[c] != WS_COMPLETE) break;
-		if (tid == 0) e.result[r] = RR_GENERATED_CONTIGS;
-		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
-			ContigRec& rec = e.recs[ri];
-			const uint8_t* seq = e.pool + rec.seq_off;
-			const uint64_t* ch = e.kh + rec.seq_off;
-			uint32_t len = rec.len, cnk = len - k + 1;
-			uint32_t redundant = 0;
-			if (len < k + FP_TRIM - 1) {
-				// short contigs: exact set of canonical end k-mers (bloom-dbg.h:576-584)
-				if (tid == 0) {
-					Vtx<NW> v1 = canonical_end_vertex<NW>(p, seq);
-					Vtx<NW> v2 = canonical_end_vertex<NW>(p, seq + len - k);
-					VKey k1 = vtx_key(p, v1), k2 = vtx_key(p, v2);
-					if (wt_find(e.cend, k1, 0) != WT_EMPTY && wt_find(e.cend, k2, 0) != WT_EMPTY) {
-						redundant = 1;
-					} else {
-						int a = wt_insert(e.cend, k1, 0, 0), bb = wt_insert(e.cend, k2, 0, 0);
-						if (a == WT_FULL || bb == WT_FULL) redundant = 2; // table overflow: reported
-						e.st->cend_count += (a == WT_NEW) + (bb == WT_NEW);
-					}
-				}
-				redundant = sy.bcast(redundant);
-			} else if (rec.pre_redundant) {
-				redundant = 1; // settled ahead of the commit
+		sy.barrier();
+		for (uint32_t i = 0; i < nchunk; i++) {
+			c = c0 + i;
+			const CommitDesc d = descs[i];
+			const uint64_t r = d.r;
+			const uint32_t nk = d.nk;
+			// allKmersInBloom(seq, assembledKmerSet) at this read's turn (bloom-dbg.h:823)
+			bool visited;
+			if (d.visited) {
+				visited = true; // settled ahead: every k-mer was visited before this commit started
 			} else {
-				bool all = true;
-				for (uint32_t j = tid; j < cnk; j += T)
-					all = all & visited_contains_coherent(p, e.vis32, ch[j]);
-				redundant = sy.all(all) ? 1u : 0u;
+				bool mine = true;
+				const uint64_t* rh = e.rkh + d.rkoff;
+				for (uint32_t j = tid; j < nk; j += T)
+					mine = mine & visited_contains_coherent(p, e.vis32, rh[j]);
+				visited = sy.all(mine);
 			}
-			if (redundant == 2) { if (tid == 0) e.st->pad_ = 1; redundant = 0; }
-			if (!redundant) {
-				// addKmersToBloom (bloom-dbg.h:79-90)
-				for (uint32_t j = tid; j < cnk; j += T) {
-					uint64_t h = ch[j];
-					for (unsigned i = 0; i < p.nh; i++) {
-						uint64_t q = pos_i(p, h, i);
-						atomic_or_u32(&e.vis32[q >> 5], 1u << (q & 31));
+			if (visited) {
+				if (tid == 0) { e.result[r] = RR_ALL_KMERS_VISITED; e.st->counters.visited_reads++; }
+				continue;
+			}
+			if (d.status != WS_COMPLETE) { stop = true; break; }
+			if (tid == 0) e.result[r] = RR_GENERATED_CONTIGS;
+			uint32_t ri = d.first;
+			uint64_t seq_off = d.seq_off;
+			uint32_t len = d.len, next = d.next;
+			uint32_t pre = d.pre_redundant;
+			while (ri != REC_END) {
+				ContigRec& rec = e.recs[ri];
+				const uint8_t* seq = e.pool + seq_off;
+				const uint64_t* ch = e.kh + seq_off;
+				const uint32_t cnk = len - k + 1;
+				uint32_t redundant = 0;
+				if (len < k + FP_TRIM - 1) {
+					// short contigs: exact set of canonical end k-mers (bloom-dbg.h:576-584)
+					if (tid == 0) {
+						Vtx<NW> v1 = canonical_end_vertex<NW>(p, seq);
+						Vtx<NW> v2 = canonical_end_vertex<NW>(p, seq + len - k);
+						VKey k1 = vtx_key(p, v1), k2 = vtx_key(p, v2);
+						if (wt_find(e.cend, k1, 0) != WT_EMPTY && wt_find(e.cend, k2, 0) != WT_EMPTY) {
+							redundant = 1;
+						} else {
+							int a = wt_insert(e.cend, k1, 0, 0), bb = wt_insert(e.cend, k2, 0, 0);
+							if (a == WT_FULL || bb == WT_FULL) redundant = 2; // table overflow: reported
+							e.st->cend_count += (a == WT_NEW) + (bb == WT_NEW);
+						}
+					}
+					redundant = sy.bcast(redundant);
+				} else if (pre) {
+					redundant = 1; // settled ahead of the commit
+				} else {
+					bool all = true;
+					for (uint32_t j = tid; j < cnk; j += T)
+						all = all & visited_contains_coherent(p, e.vis32, ch[j]);
+					redundant = sy.all(all) ? 1u : 0u;
+				}
+				if (redundant == 2) { if (tid == 0) e.st->pad_ = 1; redundant = 0; }
+				if (!redundant) {
+					// addKmersToBloom (bloom-dbg.h:79-90)
+					for (uint32_t j = tid; j < cnk; j += T) {
+						uint64_t h = ch[j];
+						for (unsigned q = 0; q < p.nh; q++) {
+							uint64_t pos = pos_i(p, h, q);
+							atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
+						}
 					}
 				}
-			}
-			if (tid == 0) {
-				rec.redundant = (uint8_t)redundant;
-				if (!redundant) {
-					rec.contig_id = e.st->counters.contig_id++;
-					e.st->counters.bases_assembled += len;
+				if (tid == 0) {
+					rec.redundant = (uint8_t)redundant;
+					if (!redundant) {
+						rec.contig_id = e.st->counters.contig_id++;
+						e.st->counters.bases_assembled += len;
+					}
+					e.order[(*e.order_n)++] = ri;
 				}
-				e.order[(*e.order_n)++] = ri;
+				if (!redundant) sy.barrier(); // publishes the inserted bits to the next test
+				// next record of this read (fields from global memory: reads rarely have more than 2-3)
+				ri = next;
+				if (ri != REC_END) {
+					const ContigRec& nr = e.recs[ri];
+					seq_off = nr.seq_off; len = nr.len; next = nr.next; pre = nr.pre_redundant;
+				}
 			}
-			if (!redundant) sy.barrier(); // publishes the inserted bits to the next test
 		}
+		if (!stop) c = c0 + nchunk;
 	}
 	if (tid == 0) e.st->break_at = c;
 	sy.barrier();

@@ -75,6 +75,8 @@ constexpr int COMMIT_THREADS = 256;
 constexpr int SYNC_WORDS = 34; // up to 16 waves (1024 threads) + broadcast slot at [32]
 struct DeviceSync {
 	uint32_t* sh; // [SYNC_WORDS] shared words: one per wave + a broadcast slot
+	abg::CommitDesc* dsc = nullptr; // [COMMIT_CHUNK] in LDS (commit kernel only)
+	__device__ abg::CommitDesc* descs() { return dsc; }
 	__device__ uint32_t tid() const { return threadIdx.x; }
 	__device__ uint32_t nthreads() const { return blockDim.x; }
 	__device__ void barrier() { __syncthreads(); }
@@ -104,7 +106,8 @@ template <int NW>
 __global__ void __launch_bounds__(COMMIT_THREADS) k_commit(abg::CommitEnv<NW> e, uint32_t c_begin, uint32_t c_end)
 {
 	__shared__ uint32_t sh[SYNC_WORDS];
-	DeviceSync sy{ sh };
+	__shared__ abg::CommitDesc dsc[abg::COMMIT_CHUNK];
+	DeviceSync sy{ sh, dsc };
 	abg::commit_candidates<NW>(e, c_begin, c_end, sy);
 }
 

@@ -61,6 +61,29 @@ ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = 
 ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 #endif
 
+// Append slots for a one-item-per-lane kernel: every lane of the wave that `want`s a slot
+// gets a distinct index from *counter with ONE atomic per wavefront (ballot + prefix popcount)
+// instead of one same-address atomic per lane.  Must be reached by all active lanes together.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
+{
+	const uint64_t m = __ballot(want ? 1 : 0);
+	if (m == 0) return 0;
+	const unsigned lane = __lane_id();
+	const int leader = __ffsll((unsigned long long)m) - 1;
+	uint32_t base = 0;
+	if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+	base = (uint32_t)__shfl((int)base, leader);
+	return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+#else
+ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
+{
+	if (!want) return 0;
+	uint32_t o = *counter; *counter = o + 1; return o;
+}
+#endif
+
 // Atomics issued by a cooperative caller (a whole wavefront in lock step, see
 // abg_core.h): lane 0 performs the operation, every lane receives its result.
 #if defined(__HIP_DEVICE_COMPILE__)

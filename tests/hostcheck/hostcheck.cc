@@ -18,6 +18,8 @@ struct SerialSync {
 	bool all(bool v) { return v; }
 	uint32_t sum(uint32_t v) { return v; }
 	uint32_t bcast(uint32_t v) { return v; }
+	abg::CommitDesc buf[abg::COMMIT_CHUNK];
+	abg::CommitDesc* descs() { return buf; }
 };
 
 struct SerialBackend {
