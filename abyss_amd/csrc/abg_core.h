@@ -88,24 +88,6 @@ ABG_HD uint64_t seed_of(unsigned b)
 	return b == 0 ? SEED_A : b == 1 ? SEED_C : b == 2 ? SEED_G : SEED_T;
 }
 
-// In a cooperative caller every lane holds the same value, but the compiler cannot know
-// that for anything loaded through a pointer; uni() re-materialises a value from lane 0
-// (v_readfirstlane), which makes it provably wave-uniform: the arithmetic that follows is
-// then selected onto the scalar unit (native 64-bit ops, SGPRs) instead of 64 redundant
-// vector lanes whose register spills would all go to memory.
-#if defined(__HIP_DEVICE_COMPILE__)
-ABG_HD uint32_t uni(uint32_t x, bool coop) { return coop ? (uint32_t)__builtin_amdgcn_readfirstlane((int)x) : x; }
-ABG_HD uint64_t uni(uint64_t x, bool coop)
-{
-	if (!coop) return x;
-	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
-	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
-}
-#else
-ABG_HD uint32_t uni(uint32_t x, bool) { return x; }
-ABG_HD uint64_t uni(uint64_t x, bool) { return x; }
-#endif
-
 // Exact h % m for a 64-bit h and runtime divisor m (CountingBloomFilter.hpp:56-58,
 // BloomFilter.hpp:187,252).  Round-up magic-number division (65-bit magic, the
 // "branch-free" scheme of Granlund-Montgomery / libdivide): q = floor(h / m) for
@@ -354,17 +336,6 @@ ABG_HD bool vtx_equal(const Params& p, const Vtx<NW>& a, const Vtx<NW>& b)
 	if (a.fh == b.fh && a.rh == b.rh) return true;
 	if (a.fh == b.rh && a.rh == b.fh) return !kmer_is_tie(a.s, p.k);
 	return false;
-}
-
-template <int NW>
-ABG_HD Vtx<NW> uni(const Vtx<NW>& v, bool coop)
-{
-	Vtx<NW> r;
-#pragma unroll
-	for (int j = 0; j < NW; j++) r.s.w[j] = uni(v.s.w[j], coop);
-	r.fh = uni(v.fh, coop);
-	r.rh = uni(v.rh, coop);
-	return r;
 }
 
 // --------------------------------------------------------- Bloom filter probes
@@ -637,7 +608,7 @@ ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 		if (f.next >= 4) { depth--; continue; }
 		unsigned b = f.next++;
 		if (!((f.mask >> b) & 1u)) continue;
-		Vtx<NW> w = neighbour_vertex(p, uni(f.v, sc.coop), sense, b);
+		Vtx<NW> w = neighbour_vertex(p, f.v, sense, b);
 		bool seen = false;
 		for (unsigned i = 0; i < nv; i++) {
 			Vtx<NW> t; t.s = w.s; t.fh = vis[i].fh; t.rh = vis[i].rh;
@@ -679,9 +650,6 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 	unsigned cdepth = 0;
 	int cdir = dir0;
 	for (;;) {
-		cu = uni(cu, sc.coop); cv = uni(cv, sc.coop);
-		cdepth = uni((uint32_t)cdepth, sc.coop); cdir = (int)uni((uint32_t)cdir, sc.coop);
-		top = (int)uni((uint32_t)top, sc.coop);
 		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
 		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
 		bool on_stack = false;
@@ -718,13 +686,13 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		bool called = false;
 		while (top >= 0 && !called) {
 			TBFrame<NW>& f = tb_frame(sc, top);
-			const Vtx<NW> fv = uni(f.v, sc.coop);
-			const unsigned fdepth = uni((uint32_t)f.depth, sc.coop);
-			int fdir = (int)uni((uint32_t)f.dir, sc.coop);
+			const Vtx<NW> fv = f.v;
+			const unsigned fdepth = (uint32_t)f.depth;
+			int fdir = (int)(uint32_t)f.dir;
 			int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
-			if (uni((uint32_t)f.stage, sc.coop) == 0) {
-				unsigned nx = uni((uint32_t)f.next, sc.coop);
-				const unsigned ms = uni((uint32_t)f.mask_same, sc.coop);
+			if ((uint32_t)f.stage == 0) {
+				unsigned nx = (uint32_t)f.next;
+				const unsigned ms = (uint32_t)f.mask_same;
 				while (nx < 4 && !((ms >> nx) & 1u)) nx++;
 				if (nx < 4) {
 					unsigned b = nx++;
@@ -754,9 +722,9 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 				int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
 				int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
 				bool made = false;
-				unsigned nx = uni((uint32_t)f.next, sc.coop);
-				const unsigned mo = uni((uint32_t)f.mask_other, sc.coop);
-				const uint64_t ufh = uni(f.ufh, sc.coop), urh = uni(f.urh, sc.coop);
+				unsigned nx = (uint32_t)f.next;
+				const unsigned mo = (uint32_t)f.mask_other;
+				const uint64_t ufh = f.ufh, urh = f.urh;
 				while (nx < 4) {
 					unsigned b = nx++;
 					if (!((mo >> b) & 1u)) continue;

@@ -347,8 +347,6 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	int result;
 	for (;;) {
 		Vtx<NW> t, v;
-		head = uni(head, sc.coop); prev = uni(prev, sc.coop);
-		n = uni(n, sc.coop); ext = uni(ext, sc.coop);
 		// both neighbourhoods of the head in one probe round (8 k-mers x H counters in flight)
 		uint64_t bfh[4], brh[4], ffh[4], frh[4];
 		neighbour_hashes(p, head, (other == FORWARD) ? SENSE : ANTISENSE, bfh, brh);
@@ -490,8 +488,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	cur.s = batch_kmer<NW>(e.batch, r, 0, k);
 	vtx_rehash(p, cur);
 	for (uint32_t it = 0; it < nk; it++) {
-		cur = uni(cur, sc.coop);
-		if (it > 0) vtx_shift(p, cur, SENSE, uni((uint32_t)batch_base(e.batch, r, it + k - 1), sc.coop));
+		if (it > 0) vtx_shift(p, cur, SENSE, (uint32_t)batch_base(e.batch, r, it + k - 1));
 		VKey ckey = vtx_key(p, cur);
 		// assembledKmers.find(*it), bloom-dbg.h:842
 		uint64_t fs = wt_find(e.tab, ckey, owner);

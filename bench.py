@@ -83,11 +83,11 @@ def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
     when it is not built -- timed on the host cores on a bounded sample of the same workload
     (same read length, coverage, error rate, k, H; genome and B scaled down together)."""
     import oracle_binding as ob
-    genome, cov, L = 600_000, 50.0, 150
+    genome, cov, L = 2_400_000, 50.0, 150  # ~70 M read k-mers: 15-20 s on the 256-thread host
     m1, m2 = synth.make_read_set(genome, cov, read_len=L)
     n_reads = 2 * m1.shape[0]
     kmers = n_reads * (L - k + 1)
-    sample = "%d x 2x%d bp reads of a %d bp genome (50x, 0.5%% err), k=%d, B=40M, H=4" % (m1.shape[0], L, genome, k)
+    sample = "%d x 2x%d bp reads of a %d bp genome (50x, 0.5%% err), k=%d, B=160M, H=4" % (m1.shape[0], L, genome, k)
     if ob.have_ref():
         with tempfile.TemporaryDirectory() as td:
             synth.write_fastq(os.path.join(td, "r1.fq"), m1, "r", 1)
@@ -98,13 +98,13 @@ def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
             ob.run_ref(["-k%d" % k, "-b1M", "one.fq"], cwd=td, threads=1)
             startup = time.time() - t0
             t0 = time.time()
-            out, _ = ob.run_ref(["-k%d" % k, "-b40M", "-H4", "r1.fq", "r2.fq"], cwd=td, threads=cores)
+            out, _ = ob.run_ref(["-k%d" % k, "-b160M", "-H4", "r1.fq", "r2.fq"], cwd=td, threads=cores)
             wall = time.time() - t0
         return {"value": kmers / wall / 1e6, "unit": "Mk-mers/s", "cores": cores, "kind": "reference",
                 "sample": sample + "; whole-binary wall %.1f s incl. FASTQ parse and %.1f s fixed start-up" % (wall, startup),
                 "value_excl_startup": kmers / max(wall - startup, 1e-9) / 1e6}
     buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
-    o = ob.Oracle(k, bloom_bytes=40 << 20)
+    o = ob.Oracle(k, bloom_bytes=160 << 20)
     t0 = time.time()
     o.load(buf, off)
     o.assemble(buf, off)
@@ -198,20 +198,40 @@ def main() -> int:
     stats = g.stats()
     H = 4
     per_kmer_bases = (read_len / 4.0) / (read_len - a.k + 1)
-    # algorithmic bytes per read k-mer of each streaming kernel (DESIGN.md "Roofline")
-    alg_bytes = {
-        "hash_claim": per_kmer_bases + 8 + H * 8,   # 2-bit bases in, canonical hash out, H claim slots
-        "insert_round": 8 + H * 8 + 2 * H,          # hash + H claim slots + H counter reads + H counter writes
-        "classify": per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1),  # solid + visited probes + look-ahead
+    unitig_kmers = max(bases - unitigs * (a.k - 1), 0)
+    # Algorithmic bytes of one step per kernel family (SURVEY.md 8d terms):
+    # per read k-mer for the streaming kernels, per unitig k-mer for the walk and the commit.
+    alg_total = {
+        "hash_claim": (per_kmer_bases + 8 + H * 8) * kmers,      # 2-bit bases, hash out, H claim slots
+        "insert_round": (8 + H * 8 + 2 * H) * kmers,             # hash, H claims, H counter reads + writes
+        "classify": (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers,
+        "rewalk": 8 * H * unitig_kmers,                          # 8 neighbour queries x H per unitig k-mer
+        "walk": 8 * H * unitig_kmers,
+        "commit": 3 * H * unitig_kmers,                          # redundancy test + insertion + coverage
     }
-    dom = max(alg_bytes, key=lambda nm: prof[nm][0])
-    dms, dn = prof[dom]
-    # bytes per launch = alg_bytes x (k-mers / launches); duration per launch = dms / launches
-    achieved = (alg_bytes[dom] * kmers / 1e9) / (dms / 1e3) if dms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": dms / max(dn, 1), "launches": dn,
-                "alg_bytes_per_kmer": alg_bytes[dom]}
+    per_kernel = {}
+    for nm, total in alg_total.items():
+        ms, n = prof[nm]
+        if n:
+            # bytes per launch / average launch duration == total bytes / total duration
+            gbs = total / 1e9 / (ms / 1e3)
+            per_kernel[nm] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / n, "launches": n}
+    dom = max(per_kernel, key=lambda nm: prof[nm][0])
+    traffic = None
+    tsrc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tsrc) and a.pairs == 5_000_000:
+        # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) of
+        # this same command, committed with the profile; KB units, per launch like `achieved`
+        t = json.load(open(tsrc)).get({"rewalk": "k_walkers", "walk": "k_walkers", "commit": "k_commit",
+                                       "insert_round": "FInsertRound", "hash_claim": "FHashClaim",
+                                       "classify": "FClassify"}[dom])
+        if t:
+            traffic = (t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024 / max(t["FETCH_SIZE"]["dispatches"], 1)
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
+                "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "launches": per_kernel[dom]["launches"],
+                "note": "dominant kernel by time; it is a latency-bound graph walk, not a stream (DESIGN.md 5)",
+                "kernels": per_kernel}
 
     if rank == 0:
         out = {
