@@ -580,7 +580,9 @@ struct SearchScratch {
 	VKey* tbf_keys;
 	uint32_t tbf_cap;
 	uint32_t overflow;     // set when a stack capacity was exceeded
-	LAFrame<NW> la[FP_TRIM + 1];
+	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
+	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
+	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
 	VKey* la_visited;      // [LA_MAX_VISITED]
 };
 
@@ -763,12 +765,16 @@ ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned m
 	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
 	return ER_LENGTH_LIMIT;
 }
+// (The neighbour hashes are recomputed here rather than passed in: an array handed to this
+// out-of-line function would have to live in memory at every call site, i.e. in the per-lane
+// scratch of the unbranched walking loop.)
 template <int NW>
 ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
-    unsigned trim, unsigned mask, const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout,
-    SearchScratch<NW>& sc)
+    unsigned trim, unsigned mask, Vtx<NW>& vout, SearchScratch<NW>& sc)
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
+	uint64_t nfh[4], nrh[4];
+	neighbour_hashes(p, u, sense, nfh, nrh);
 	vout = u;
 	sc.n_succ++;
 	// Shortcut, exact by monotonicity of trueBranch in its threshold: every condition that
@@ -819,7 +825,7 @@ ABG_HDN int successor(const Params& p, const uint8_t* __restrict__ cnt, const Vt
 {
 	uint64_t nfh[4], nrh[4];
 	unsigned mask = neighbour_mask(p, cnt, u, (dir == FORWARD) ? SENSE : ANTISENSE, nfh, nrh, sc.coop);
-	return successor_m(p, cnt, u, dir, trim, mask, nfh, nrh, vout, sc);
+	return successor_m(p, cnt, u, dir, trim, mask, vout, sc);
 }
 
 } // namespace abg

@@ -385,7 +385,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		// extendPathBySingleVertex (ExtendPath.h:403-459)
 		if (look_behind) {
 			result = successor_fast(p, head, other, bmask, bfh, brh, t);
-			if (result < 0) result = successor_m(p, e.cnt, head, other, p.trim, bmask, bfh, brh, t, sc);
+			if (result < 0) result = successor_m(p, e.cnt, head, other, p.trim, bmask, t, sc);
 			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
 			if (n > 1) {
 				if (result == ER_DEAD_END) { result = ER_AMBI_IN; break; }
@@ -393,7 +393,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 			}
 		}
 		result = successor_fast(p, head, dir, fmask, ffh, frh, v);
-		if (result < 0) result = successor_m(p, e.cnt, head, dir, p.trim, fmask, ffh, frh, v, sc);
+		if (result < 0) result = successor_m(p, e.cnt, head, dir, p.trim, fmask, v, sc);
 		if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
 		if (result != ER_LENGTH_LIMIT) break;
 		// path.push_back(v) / push_front(v)
@@ -454,11 +454,15 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_cap = e.tb_cap;
 	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
+	sc.la = sc.la_local;
 	if (e.fast) {
-		// fast tier: frames and keys side by side in LDS
-		uint32_t cap = e.fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
-		sc.tbf_keys = (VKey*)e.fast;
-		sc.tbf = (TBFrame<NW>*)((char*)e.fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
+		// fast tier (LDS): lookAhead frames, then trueBranch keys and frames side by side
+		const uint32_t la_bytes = (uint32_t)((sizeof(LAFrame<NW>) * (FP_TRIM + 1) + 15) & ~15ull);
+		sc.la = (LAFrame<NW>*)e.fast;
+		char* rest = (char*)e.fast + la_bytes;
+		uint32_t cap = (e.fast_bytes - la_bytes) / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
+		sc.tbf_keys = (VKey*)rest;
+		sc.tbf = (TBFrame<NW>*)(rest + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
