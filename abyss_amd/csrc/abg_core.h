@@ -574,7 +574,6 @@ struct SearchScratch {
 	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
 	VKey* tb_keys;         // [tb_cap] (fh, rh) of tb[i].v: what the on-stack test scans
 	uint32_t tb_cap;
-	uint32_t n_tb_nodes, n_la, n_succ, n_tb_calls; // work counters (profiling aid)
 	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
 	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
 	VKey* tbf_keys;
@@ -595,7 +594,6 @@ ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 {
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
 	unsigned nv = 0;
-	sc.n_la++;
 	VKey* vis = sc.la_visited;
 	vis[nv].fh = start.fh; vis[nv].rh = start.rh; nv++;
 	if (limit == 0) return true;
@@ -672,7 +670,6 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		if (cdepth >= trim) return true;
 		if (top + 1 >= cap) { sc.overflow = 1; return true; }
 		top++;
-		sc.n_tb_nodes++;
 		{
 			VKey& kk = (uint32_t)top < sc.tbf_cap ? sc.tbf_keys[top] : sc.tb_keys[(uint32_t)top - sc.tbf_cap];
 			kk.fh = cv.fh; kk.rh = cv.rh;
@@ -776,7 +773,6 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	uint64_t nfh[4], nrh[4];
 	neighbour_hashes(p, u, sense, nfh, nrh);
 	vout = u;
-	sc.n_succ++;
 	// Shortcut, exact by monotonicity of trueBranch in its threshold: every condition that
 	// makes trueBranch(e, i) return true (vertex on the stack, depth >= i, a true child) also
 	// holds for any smaller threshold, while exploration order, direction changes and the
@@ -791,7 +787,6 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
-			sc.n_tb_calls++;
 			if (true_branch(p, cnt, u, w, dir, trim, sc)) {
 				last = w;
 				if (++tb >= 2) break;
@@ -807,7 +802,6 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
 			// trueBranch(e, dir, g, i, fpTrim) with a fresh visited set; at i == 0 every
 			// existing edge is a true branch (depth 0 >= trim 0)
-			if (i) sc.n_tb_calls++;
 			bool t = (i == 0) ? true : true_branch(p, cnt, u, w, dir, i, sc);
 			if (t) {
 				vout = w;

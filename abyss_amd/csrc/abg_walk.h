@@ -466,7 +466,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
-	sc.n_tb_nodes = sc.n_la = sc.n_succ = sc.n_tb_calls = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -624,8 +623,8 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		const uint64_t t_end = 0;
 #endif
 		uint64_t* d = e.dbg + (uint64_t)c * 8;
-		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.n_tb_nodes; d[3] = sc.n_la;
-		d[4] = sc.n_succ; d[5] = sc.n_tb_calls; d[6] = contig; d[7] = abort_status;
+		d[0] = t_end - t_start; d[1] = total_steps; d[2] = 0; d[3] = 0;
+		d[4] = 0; d[5] = 0; d[6] = contig; d[7] = abort_status;
 	}
 }
 
