@@ -15,7 +15,7 @@ class Params(C.Structure):
         ("bloom_bytes", C.c_uint64), ("counters", C.c_uint64), ("spaced_seed", C.c_char_p),
         ("device", C.c_int32), ("verbose", C.c_int32), ("insert_batch_kmers", C.c_uint64),
         ("claim_log2", C.c_uint32), ("walk_slots", C.c_uint32), ("wtab_log2", C.c_uint32),
-        ("reserved_", C.c_uint32 * 7),
+        ("cascade_levels", C.c_uint32), ("reserved_", C.c_uint32 * 6),
     ]
 
 
@@ -49,7 +49,7 @@ def symbols():
         "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_filter_size",
         "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
         "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
-        "abg_assemble_packed", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
+        "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
     ]
 
@@ -82,6 +82,7 @@ def load(path: str | None = None):
     lib.abg_visited_import.argtypes = [vp, u8p]
     lib.abg_assemble_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64, vp, CONTIG_CB, vp]
     lib.abg_assemble_packed.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, CONTIG_CB, vp]
+    lib.abg_cascade_export.argtypes = [vp, C.c_uint32, u8p]
     lib.abg_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.abg_set_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.abg_hash_seq.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint64, u64p]

@@ -122,6 +122,11 @@ class BloomDBG:
         assert arr.size == self.size
         self._check(self._lib.abg_counters_import(self._ctx, arr.ctypes.data), "abg_counters_import")
 
+    def cascade_level(self, level: int) -> np.ndarray:
+        out = np.empty(self.size // 8, dtype=np.uint8)
+        self._check(self._lib.abg_cascade_export(self._ctx, level, out.ctypes.data), "abg_cascade_export")
+        return out
+
     def visited(self) -> np.ndarray:
         out = np.empty(self.size // 8, dtype=np.uint8)
         self._check(self._lib.abg_visited_export(self._ctx, out.ctypes.data), "abg_visited_export")
@@ -191,6 +196,24 @@ class BloomDBG:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self._lib.abg_profile_get(self._ctx, name.encode(), C.byref(ms), C.byref(n)), "abg_profile_get")
         return ms.value, n.value
+
+
+def counting_bloom_file(counters: np.ndarray, k: int, num_hashes: int) -> bytes:
+    """`operator<<` of CountingBloomFilter<uint8_t> (CountingBloomFilter.hpp:344-379): the TOML-ish
+    header in the key order cpptoml emits, then the raw counters."""
+    n = int(counters.size)
+    head = ("[BTLCountingBloomFilter_v1]\n\tBloomFilterSize = %d\n\tHashNum = %d\n\tKmerSize = %d\n"
+            "\tBloomFilterSizeInBytes = %d\n\tBitsPerCounter = 8\n[HeaderEnd]\n" % (n, num_hashes, k, n))
+    return head.encode() + np.ascontiguousarray(counters, dtype=np.uint8).tobytes()
+
+
+def bit_bloom_file(bits: np.ndarray, k: int, num_hashes: int) -> bytes:
+    """`operator<<` of BloomFilter (BloomFilter.hpp:261-294) for a filter of bits.size * 8 bits."""
+    nbytes = int(bits.size)
+    head = ("[BTLBloomFilter_v1]\n\tnEntry = 0\n\tdFPR = 0.0000000000000000\n\tEntry = 0\n"
+            "\tBloomFilterSizeInBytes = %d\n\tBloomFilterSize = %d\n\tHashNum = %d\n\tKmerSize = %d\n[HeaderEnd]\n"
+            % (nbytes, nbytes * 8, num_hashes, k))
+    return head.encode() + np.ascontiguousarray(bits, dtype=np.uint8).tobytes()
 
 
 def format_fasta(contigs: Iterable[ContigRecord], read_ids: Sequence[bytes]) -> bytes:

@@ -70,6 +70,9 @@ def build_cli(force: bool = False) -> str:
         build_lib()
         _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
               "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
+        _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o",
+              os.path.join(BIN_DIR, "abyss-bloom"), os.path.join(CSRC, "host", "bloom_main.cc"),
+              "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
     return out
 
 

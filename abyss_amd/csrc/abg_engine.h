@@ -21,7 +21,8 @@ namespace abg {
 
 struct Config {
 	uint32_t k = 0, nh = 4, kc = 2, trim = 0;
-	uint64_t counters = 0;            // number of uint8 counters == visited bits
+	uint64_t counters = 0;            // number of uint8 counters == visited bits (cascade mode: bits per level)
+	uint32_t cascade_levels = 0;      // > 0: HashAgnosticCascadingBloom of that many levels instead of counters
 	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
 	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
 	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
@@ -149,13 +150,42 @@ struct FClaim { // first round: every op claims its H counters
 			atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
 	}
 };
+// HashAgnosticCascadingBloom::insert (Bloom/HashAgnosticCascadingBloom.h:124-133): set the
+// k-mer's bits in the first level that does not contain it yet.  Called by the one op that
+// holds the claims on all of its positions, so no other op of the round reads or writes
+// those bits (other bits of the same words are set with atomicOr by their owners).
+struct Cascade {
+	uint32_t* bits;       // levels x level_words uint32 words; NULL: counting mode
+	uint64_t level_words;
+	uint32_t levels;
+};
+ABG_HD void cascade_insert(const Params& p, const Cascade& c, uint64_t h, bool coherent)
+{
+	for (uint32_t l = 0; l < c.levels; l++) {
+		uint32_t* lv = c.bits + (uint64_t)l * c.level_words;
+		bool contains = true; // BloomFilter::contains, BloomFilter.hpp:249-259
+		for (unsigned j = 0; j < p.nh; j++) {
+			uint64_t q = pos_i(p, h, j);
+			uint32_t w = coherent ? ld_coherent(&lv[q >> 5]) : lv[q >> 5];
+			contains = contains & (((w >> (q & 31)) & 1u) != 0);
+		}
+		if (!contains) {
+			for (unsigned j = 0; j < p.nh; j++) { // BloomFilter::insert, BloomFilter.hpp:182-191
+				uint64_t q = pos_i(p, h, j);
+				atomic_or_u32(&lv[q >> 5], 1u << (q & 31));
+			}
+			return;
+		}
+	}
+}
+
 // One round of the deterministic-reservation insert: an op that holds the claim on all
 // of its counters is the earliest pending op touching them, so applying it now is what
 // the sequential loop of the reference would do (CountingBloomFilter::incrementMin,
 // CountingBloomFilter.hpp:135-162); the others re-claim in the other table for the next
 // round.  pend == NULL means "all ops 0..n-1".
 struct FInsertRound {
-	Params p; const uint64_t* h0; uint8_t* cnt;
+	Params p; const uint64_t* h0; uint8_t* cnt; Cascade casc;
 	const uint32_t* pend; uint32_t* next; uint32_t* next_n;
 	const uint64_t* claim_cur; uint64_t* claim_next; uint64_t cmask; uint32_t epoch;
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -168,7 +198,9 @@ struct FInsertRound {
 			win = win & (claim_cur[pos_i(p, h, j) & cmask] == v);
 		// losers queue for the next round: one counter bump per wavefront
 		const uint32_t slot = wave_append_slot(next_n, !win);
-		if (win) {
+		if (win && casc.bits) {
+			cascade_insert(p, casc, h, false);
+		} else if (win) {
 			unsigned mn = 255;
 			for (unsigned j = 0; j < p.nh; j++) { unsigned c = cnt[pos_i(p, h, j)]; mn = c < mn ? c : mn; }
 			if (mn < 255)
@@ -195,7 +227,7 @@ ABG_HD uint8_t ld_coherent_u8(const uint8_t* p) { return __hip_atomic_load(p, __
 ABG_HD uint8_t ld_coherent_u8(const uint8_t* p) { return *p; }
 #endif
 struct InsertDrainEnv {
-	Params p; const uint64_t* h0; uint8_t* cnt;
+	Params p; const uint64_t* h0; uint8_t* cnt; Cascade casc;
 	uint32_t* list_a; uint32_t* list_b; uint32_t n; // pending ops in list_a
 	uint64_t* claim_a; uint64_t* claim_b; uint64_t cmask; uint32_t epoch; // claims of list_a are in claim_a under `epoch`
 	uint32_t* counter;   // scratch word; [1] receives the number of rounds run
@@ -219,7 +251,9 @@ ABG_HDN void insert_drain(InsertDrainEnv e, Sync& sy)
 			bool win = true;
 			for (unsigned j = 0; j < p.nh; j++)
 				win = win & (ld_coherent(&ccur[pos_i(p, h, j) & e.cmask]) == v);
-			if (win) {
+			if (win && e.casc.bits) {
+				cascade_insert(p, e.casc, h, true);
+			} else if (win) {
 				unsigned mn = 255;
 				for (unsigned j = 0; j < p.nh; j++) { unsigned c = ld_coherent_u8(&e.cnt[pos_i(p, h, j)]); mn = c < mn ? c : mn; }
 				if (mn < 255)
@@ -633,9 +667,19 @@ class Engine {
 		uint64_t rem = cfg_.counters % 8; // CountingBloomFilter ctor, hpp:40-50
 		m_ = rem ? cfg_.counters + 8 - rem : cfg_.counters;
 		p_ = make_params(cfg_.k, cfg_.nh, cfg_.kc, cfg_.trim, m_);
-		cnt_ = (uint8_t*)be_.alloc(m_);
-		be_.memset(cnt_, 0, m_);
-		vis_bytes_ = (m_ / 8 + 4 + 3) & ~3ull;
+		if (cfg_.cascade_levels) {
+			// `abyss-bloom build -t rolling-hash -l N`: N bit filters of m_ bits (Bloom/bloom.cc:585-602)
+			casc_.levels = cfg_.cascade_levels;
+			casc_.level_words = (m_ + 31) / 32;
+			casc_.bits = (uint32_t*)be_.alloc(casc_.levels * casc_.level_words * 4);
+			be_.memset(casc_.bits, 0, casc_.levels * casc_.level_words * 4);
+			cnt_ = (uint8_t*)be_.alloc(8);
+			vis_bytes_ = 8;
+		} else {
+			cnt_ = (uint8_t*)be_.alloc(m_);
+			be_.memset(cnt_, 0, m_);
+			vis_bytes_ = (m_ / 8 + 4 + 3) & ~3ull;
+		}
 		vis_ = (uint8_t*)be_.alloc(vis_bytes_);
 		be_.memset(vis_, 0, vis_bytes_);
 		cstate_ = (CommitState*)be_.alloc(sizeof(CommitState));
@@ -645,12 +689,16 @@ class Engine {
 	~Engine()
 	{
 		be_.free(cnt_); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
+		if (casc_.bits) be_.free(casc_.bits);
 		free_insert();
 		free_walk();
 	}
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	uint8_t* counters_dev() { return cnt_; }
+	bool cascade_mode() const { return casc_.bits != nullptr; }
+	uint32_t cascade_levels() const { return casc_.levels; }
+	uint8_t* cascade_level_dev(uint32_t l) { return (uint8_t*)(casc_.bits + (uint64_t)l * casc_.level_words); }
 	uint8_t* visited_dev() { return vis_; }
 	uint64_t visited_bytes() const { return m_ / 8; }
 	Counters counters() const { return counters_; }
@@ -714,6 +762,7 @@ class Engine {
 	uint8_t* vis_ = nullptr;
 	CommitState* cstate_ = nullptr;
 	uint64_t* scal_ = nullptr;
+	Cascade casc_{ nullptr, 0, 0 };
 	Counters counters_;
 	Stats stats_;
 	uint64_t last_rounds_ = 0;
@@ -791,7 +840,7 @@ class Engine {
 			if (pin && npend <= cfg_.drain_threshold) {
 				// few ops left: finish all remaining rounds inside one workgroup
 				uint32_t* other = (pin == pend_[0]) ? pend_[1] : pend_[0];
-				InsertDrainEnv de{ p_, h0_, cnt_, const_cast<uint32_t*>(pin), other, (uint32_t)npend,
+				InsertDrainEnv de{ p_, h0_, cnt_, casc_, const_cast<uint32_t*>(pin), other, (uint32_t)npend,
 					ccur, cnext, cmask, epoch_, pend_n_ };
 				be_.launch_drain(de);
 				uint32_t r[2] = { 0, 0 };
@@ -802,7 +851,7 @@ class Engine {
 				break;
 			}
 			be_.memset(pend_n_, 0, 4);
-			FInsertRound fr{ p_, h0_, cnt_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_ };
+			FInsertRound fr{ p_, h0_, cnt_, casc_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_ };
 			be_.launch(npend, fr, pin ? "insert_retry" : "insert_round");
 			uint32_t nn = 0;
 			be_.d2h(&nn, pend_n_, 4);

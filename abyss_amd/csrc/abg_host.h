@@ -51,6 +51,8 @@ class Session {
 		cfg.k = p.k; cfg.nh = p.num_hashes; cfg.kc = p.min_cov;
 		cfg.trim = (p.trim == 0xFFFFFFFFu) ? p.k : p.trim;
 		cfg.counters = p.counters ? p.counters : counters_for_budget(p.bloom_bytes);
+		cfg.cascade_levels = p.cascade_levels;
+		if (p.cascade_levels && (!p.counters || p.counters % 64)) return fail(ABG_EINVAL, "cascade mode needs `counters` = bits per level, a multiple of 64");
 		if (!cfg.counters) return fail(ABG_EINVAL, "bloom_bytes / counters must be > 0");
 		cfg.verbose = p.verbose;
 		if (p.insert_batch_kmers) cfg.insert_batch_kmers = p.insert_batch_kmers;
@@ -125,6 +127,7 @@ class Session {
 	int assemble_seqs(const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
 	    abg_contig_cb cb, void* user)
 	{
+		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
 		const uint32_t k = cfg.k;
 		HostBatch hb;
 		std::vector<uint64_t> orig; // packed index -> caller index
@@ -168,6 +171,7 @@ class Session {
 	int assemble_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len,
 	    uint64_t n, uint8_t* results, abg_contig_cb cb, void* user)
 	{
+		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
 		if (!n) return ABG_OK;
 		Batch b{ d_words, d_woff, d_len, d_woff /* unused in pass 2 */, n };
 		std::function<void(const ContigOut&)> sink;

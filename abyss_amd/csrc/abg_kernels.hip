@@ -327,7 +327,7 @@ int abg_counting_stats(abg_ctx* ctx, uint64_t* popcount, uint64_t* filtered_popc
 }
 int abg_counters_export(abg_ctx* ctx, uint8_t* host_out)
 {
-	if (!ctx || !host_out) return ABG_EINVAL;
+	if (!ctx || !host_out || ctx->s.eng->cascade_mode()) return ABG_EINVAL;
 	ctx->s.be.d2h(host_out, ctx->s.eng->counters_dev(), ctx->s.eng->size());
 	return ABG_OK;
 }
@@ -360,6 +360,12 @@ int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d
 {
 	if (!ctx || (n && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
 	return ctx->s.assemble_packed(d_words, d_woff, d_len, n, results, cb, user);
+}
+int abg_cascade_export(abg_ctx* ctx, uint32_t level, uint8_t* host_out)
+{
+	if (!ctx || !host_out || !ctx->s.eng->cascade_mode() || level >= ctx->s.eng->cascade_levels()) return ABG_EINVAL;
+	ctx->s.be.d2h(host_out, ctx->s.eng->cascade_level_dev(level), ctx->s.eng->size() / 8);
+	return ABG_OK;
 }
 int abg_get_counters(const abg_ctx* ctx, abg_counters* out)
 {

@@ -74,7 +74,11 @@ typedef struct abg_params {
 	uint32_t claim_log2;
 	uint32_t walk_slots;
 	uint32_t wtab_log2;
-	uint32_t reserved_[7];
+	/* > 0: build a HashAgnosticCascadingBloom of this many levels instead of the counting filter
+	 * (`abyss-bloom build -t rolling-hash -l N`, Bloom/bloom.cc:585-602); `counters` is then the
+	 * number of BITS per level.  PASS 2 is not available in this mode. */
+	uint32_t cascade_levels;
+	uint32_t reserved_[6];
 } abg_params;
 
 /* AssemblyCounters, BloomDBG/AssemblyCounters.h:15-31 */
@@ -144,6 +148,10 @@ int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, u
 /* the same on device-resident packed reads (pure ACGT, len >= k) */
 int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
     const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user);
+
+/* one level of the cascading filter (abg_filter_size()/8 bytes); the reference serialises the
+ * last one (HashAgnosticCascadingBloom.h:143-150) */
+int abg_cascade_export(abg_ctx* ctx, uint32_t level, uint8_t* host_out);
 
 int abg_get_counters(const abg_ctx* ctx, abg_counters* out);
 int abg_set_counters(abg_ctx* ctx, const abg_counters* in); /* resume, Checkpoint.h:159-228 */

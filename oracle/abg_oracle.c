@@ -1449,6 +1449,73 @@ orc_in_mask(const orc_ctx* c, const char* kmer)
 	return m;
 }
 
+/* ---------------------------------------------------- HashAgnosticCascadingBloom */
+struct orc_cascade {
+	orc_ctx* hasher;   /* k, H and the k-mer iterator (its own filters are unused) */
+	unsigned levels;
+	uint64_t bits;
+	uint8_t** data;
+};
+orc_cascade*
+orc_cascade_create(unsigned k, unsigned num_hashes, unsigned levels, uint64_t level_bits)
+{
+	if (!levels || !level_bits || level_bits % 64) return NULL;
+	orc_cascade* c = (orc_cascade*)calloc(1, sizeof *c);
+	c->hasher = orc_create(k, num_hashes, 0, k, 64, NULL);
+	if (!c->hasher) { free(c); return NULL; }
+	c->hasher->m = level_bits; /* hash positions are taken modulo the level size */
+	c->levels = levels;
+	c->bits = level_bits;
+	c->data = (uint8_t**)calloc(levels, sizeof(uint8_t*));
+	for (unsigned i = 0; i < levels; i++) c->data[i] = (uint8_t*)calloc(level_bits / 8, 1);
+	return c;
+}
+void
+orc_cascade_destroy(orc_cascade* c)
+{
+	if (!c) return;
+	for (unsigned i = 0; i < c->levels; i++) free(c->data[i]);
+	free(c->data);
+	c->hasher->m = 64;
+	orc_destroy(c->hasher);
+	free(c);
+}
+static int
+cb_cascade_insert(void* u, size_t pos, const vtx* v)
+{
+	(void)pos;
+	orc_cascade* c = (orc_cascade*)u;
+	uint64_t hashes[ORC_MAX_HASHES];
+	get_hashes(c->hasher, v->h, hashes);
+	/* HashAgnosticCascadingBloom::insert, HashAgnosticCascadingBloom.h:124-133 */
+	for (unsigned l = 0; l < c->levels; l++) {
+		int contains = 1; /* BloomFilter::contains, BloomFilter.hpp:249-259 */
+		for (unsigned i = 0; i < c->hasher->nh; i++) {
+			uint64_t p = hashes[i] % c->bits;
+			if (!(c->data[l][p / 8] & (1u << (p % 8)))) { contains = 0; break; }
+		}
+		if (!contains) {
+			for (unsigned i = 0; i < c->hasher->nh; i++) { /* BloomFilter::insert, :182-191 */
+				uint64_t p = hashes[i] % c->bits;
+				c->data[l][p / 8] |= (uint8_t)(1u << (p % 8));
+			}
+			break;
+		}
+	}
+	return 0;
+}
+void
+orc_cascade_load_seqs(orc_cascade* c, const char* seqs, const uint64_t* offsets, uint64_t n)
+{
+	for (uint64_t i = 0; i < n; i++)
+		foreach_kmer(c->hasher, seqs + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), cb_cascade_insert, c);
+}
+uint8_t*
+orc_cascade_level(orc_cascade* c, unsigned level)
+{
+	return level < c->levels ? c->data[level] : NULL;
+}
+
 /* SpacedSeed::kmerPair, SpacedSeed.h:18-25 */
 void
 orc_seed_kmer_pair(unsigned k, unsigned K, char* out)

@@ -119,6 +119,16 @@ int orc_successor(const orc_ctx*, const char* kmer, int dir, unsigned trim, unsi
 unsigned orc_out_mask(const orc_ctx*, const char* kmer);
 unsigned orc_in_mask(const orc_ctx*, const char* kmer);
 
+/* HashAgnosticCascadingBloom (Bloom/HashAgnosticCascadingBloom.h:26-182) as built by
+ * `abyss-bloom build -t rolling-hash -l LEVELS` (Bloom/bloom.cc:585-602): `levels` bit filters
+ * of `level_bits` bits (multiple of 64); insert = first level that does not contain the
+ * k-mer (:124-133); the last level is what is serialised (:143-150). */
+typedef struct orc_cascade orc_cascade;
+orc_cascade* orc_cascade_create(unsigned k, unsigned num_hashes, unsigned levels, uint64_t level_bits);
+void orc_cascade_destroy(orc_cascade*);
+void orc_cascade_load_seqs(orc_cascade*, const char* seqs, const uint64_t* offsets, uint64_t n);
+uint8_t* orc_cascade_level(orc_cascade*, unsigned level); /* level_bits / 8 bytes */
+
 /* spaced seeds, BloomDBG/SpacedSeed.h:18-75 (out must hold k+1 bytes) */
 void orc_seed_kmer_pair(unsigned k, unsigned K, char* out);
 void orc_seed_qr(unsigned len, char* out);

@@ -9,11 +9,14 @@
 #include "vendor/nthash/nthash.hpp"
 #include "vendor/btl_bloomfilter/CountingBloomFilter.hpp"
 #include "vendor/btl_bloomfilter/BloomFilter.hpp"
+#include "Bloom/HashAgnosticCascadingBloom.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <sstream>
+#include <fstream>
 
 static bool acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
@@ -68,6 +71,24 @@ int main(int argc, char** argv)
 		if (argc >= 7) bloom.storeFilter(argv[6]);
 		fprintf(stderr, "size=%zu popcount=%zu filtered=%zu\n", bloom.size(), bloom.popCount(), bloom.filtered_popcount());
 		for (size_t i = 0; i < bloom.size(); i++) putchar(bloom[i]);
+		return 0;
+	}
+	if (argc >= 6 && !strcmp(argv[1], "cascade")) {
+		// tier1 cascade LEVEL_BITS K H LEVELS [file] < seqs : HashAgnosticCascadingBloom as built by
+		// `abyss-bloom build -t rolling-hash -l LEVELS` (Bloom/bloom.cc:585-602); dumps the last level
+		size_t bits = strtoull(argv[2], 0, 10);
+		unsigned k = atoi(argv[3]), H = atoi(argv[4]), L = atoi(argv[5]);
+		HashAgnosticCascadingBloom bloom(bits, H, L, k);
+		std::string line;
+		while (std::getline(std::cin, line))
+			each_kmer(line, k, H, [&](size_t, const uint64_t* h) { bloom.insert(h); });
+		fprintf(stderr, "size=%zu popcount=%zu\n", bloom.size(), bloom.popcount());
+		if (argc >= 7) { std::ofstream f(argv[6], std::ios::binary); f << bloom; }
+		std::ostringstream os;
+		os << bloom;
+		std::string all = os.str();
+		size_t pos = all.find("[HeaderEnd]\n");
+		fwrite(all.data() + pos + 12, 1, all.size() - pos - 12, stdout);
 		return 0;
 	}
 	fprintf(stderr, "usage: tier1 tables | hash K H SEQ | counters M K H KC [file] < seqs\n");

@@ -113,6 +113,20 @@ def main():
     np.savez_compressed(os.path.join(HERE, "tier1_counters.npz"), counters=np.frombuffer(r.stdout, dtype=np.uint8),
                         lines=np.frombuffer(lines.encode(), dtype=np.uint8), m=m, k=k, H=H)
     print("tier1:", r.stderr.decode().strip())
+    # Bloom file formats + cascading filter (abyss-bloom build -t counting / -t rolling-hash -l 2)
+    m1, m2 = synth.make_read_set(20000, 30.0)
+    reads = "\n".join(bytes(r).decode() for r in synth.codes_to_ascii(np.concatenate([m1, m2])))
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([TIER1, "counters", "262144", "32", "3", "0", os.path.join(td, "c.bloom")], input=reads.encode(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        open(os.path.join(HERE, "file_counting_k32_h3.bloom"), "wb").write(open(os.path.join(td, "c.bloom"), "rb").read())
+        r = subprocess.run([TIER1, "cascade", str(1 << 20), "32", "2", "2", os.path.join(td, "b.bloom")], input=reads.encode(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        open(os.path.join(HERE, "file_cascade_k32_h2_l2.bloom"), "wb").write(open(os.path.join(td, "b.bloom"), "rb").read())
+        r = subprocess.run([TIER1, "cascade", str(1 << 16), "24", "3", "3", os.path.join(td, "b3.bloom")], input=reads.encode(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        open(os.path.join(HERE, "file_cascade_k24_h3_l3.bloom"), "wb").write(open(os.path.join(td, "b3.bloom"), "rb").read())
+    print("bloom files written")
 
 
 if __name__ == "__main__":

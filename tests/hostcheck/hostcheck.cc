@@ -68,6 +68,19 @@ void* hc_create(unsigned k, unsigned nh, unsigned kc, unsigned trim, uint64_t co
 	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }
 	return s;
 }
+void* hc_create_cascade(unsigned k, unsigned nh, unsigned levels, uint64_t level_bits, uint64_t insert_batch, unsigned claim_log2)
+{
+	Sess* s = new Sess();
+	abg_params p;
+	memset(&p, 0, sizeof p);
+	p.k = k; p.num_hashes = nh; p.min_cov = 0; p.trim = k; p.counters = level_bits; p.cascade_levels = levels;
+	s->cfg.claim_log2 = claim_log2 ? claim_log2 : 14;
+	s->cfg.insert_batch_kmers = insert_batch ? insert_batch : (1u << 16);
+	s->cfg.drain_threshold = 64;
+	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }
+	return s;
+}
+uint8_t* hc_cascade_level(void* h, unsigned l) { return ((Sess*)h)->eng->cascade_level_dev(l); }
 void hc_destroy(void* h) { delete (Sess*)h; }
 uint64_t hc_size(void* h) { return ((Sess*)h)->eng->size(); }
 uint8_t* hc_counters(void* h) { return ((Sess*)h)->eng->counters_dev(); }
