@@ -54,17 +54,39 @@ def matrix_to_seqs(ascii_matrix: np.ndarray) -> Tuple[bytes, np.ndarray]:
     return np.ascontiguousarray(ascii_matrix).tobytes(), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
 
 
+def spaced_seed_kmer_pair(k: int, K: int) -> str:
+    """SpacedSeed::kmerPair (BloomDBG/SpacedSeed.h:18-26): `-K`."""
+    assert K <= k // 2
+    return "1" * K + "0" * (k - 2 * K) + "1" * K
+
+
+def spaced_seed_qr(length: int) -> str:
+    """SpacedSeed::qrSeed (SpacedSeed.h:40-52): '0' at the quadratic residues mod `length`."""
+    residues = {j * j % length for j in range(1, length)}
+    return "".join("0" if i in residues else "1" for i in range(length))
+
+
+def spaced_seed_qr_pair(k: int, length: int) -> str:
+    """SpacedSeed::qrSeedPair (SpacedSeed.h:64-73): `--qr-seed`."""
+    assert length <= k // 2
+    q = spaced_seed_qr(length)
+    return q + "0" * (k - 2 * length) + q[::-1]
+
+
 class BloomDBG:
     """One assembly: solid counting filter + visited filter + counters on one GPU."""
 
     def __init__(self, k: int, bloom_bytes: int = 0, counters: int = 0, num_hashes: int = 4, min_cov: int = 2,
-                 trim: Optional[int] = None, device: int = 0, verbose: int = 0, **tuning):
+                 trim: Optional[int] = None, device: int = 0, verbose: int = 0, spaced_seed: Optional[str] = None,
+                 **tuning):
         self._lib = _lib.load()
         p = _lib.Params()
         self._lib.abg_params_init(C.byref(p))
         p.k, p.num_hashes, p.min_cov = k, num_hashes, min_cov
         p.trim = 0xFFFFFFFF if trim is None else trim
         p.bloom_bytes, p.counters, p.device, p.verbose = bloom_bytes, counters, device, verbose
+        self._seed = spaced_seed.encode() if spaced_seed else None  # must outlive abg_create
+        p.spaced_seed = self._seed
         for key, val in tuning.items():
             setattr(p, key, val)
         self._ctx = C.c_void_p()

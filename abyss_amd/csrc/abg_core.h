@@ -139,6 +139,19 @@ inline Mod64 make_mod64(uint64_t m)
 }
 
 // -------------------------------------------------------------- parameters
+// Spaced seed (MaskedKmer::mask(), BloomDBG/MaskedKmer.h:25-48; SpacedSeed.h): '1' positions
+// take part in hashing and comparison, '0' positions do not.  maskHash (nthash.hpp:537-547)
+// XORs the contribution of every '0' position out of the two strand hashes; the table holds
+// those contributions per masked position and base.
+constexpr int MAX_K = MAX_NW * 32;
+struct MaskTab {
+	uint32_t k, nmasked;
+	uint8_t ones[MAX_K];              // ones[i] = 1 when mask[i] == '1'
+	uint16_t ones_prefix[MAX_K + 1];  // number of '1's in mask[0, i)
+	uint8_t pos[MAX_K];               // the masked ('0') positions
+	uint64_t F[MAX_K][4];             // srol^(k-1-pos)(seed[b])    : term of base b in the forward hash
+	uint64_t R[MAX_K][4];             // srol^(pos)(seed[3-b])      : term of base b in the reverse hash
+};
 struct Params {
 	uint32_t k;        // k-mer size
 	uint32_t nh;       // number of hash functions (H)
@@ -152,6 +165,9 @@ struct Params {
 	uint64_t seedrc_k[4];   // srol^k(seed[3-b])
 	uint64_t seedrc_km1[4]; // srol^(k-1)(seed[3-b])
 	uint64_t seed_km1[4];   // srol^(k-1)(seed[b])
+	uint64_t care[MAX_NW];  // 2 bits per base, 11 where the position is compared/hashed ('1' or no mask)
+	const MaskTab* mask;    // device copy of the spaced-seed table; NULL without a spaced seed
+	uint32_t ident_fast;    // even k, no mask: see vtx_ident
 };
 inline Params make_params(uint32_t k, uint32_t nh, uint32_t kc, uint32_t trim, uint64_t m)
 {
@@ -165,8 +181,33 @@ inline Params make_params(uint32_t k, uint32_t nh, uint32_t kc, uint32_t trim, u
 		p.seedrc_km1[b] = srol_n(seed_of(3 - b), k - 1);
 		p.seed_km1[b] = srol_n(seed_of(b), k - 1);
 	}
+	for (int j = 0; j < MAX_NW; j++) p.care[j] = 0;
+	for (unsigned i = 0; i < k; i++) p.care[i >> 5] |= 3ULL << (2 * (i & 31));
+	p.mask = nullptr;
+	p.ident_fast = (k & 1) ? 0u : 1u;
 	return p;
 }
+// host-side construction of the spaced-seed table; `mask` is k characters of '0'/'1'
+inline void make_mask(const char* mask, uint32_t k, MaskTab& t, Params& p)
+{
+	t.k = k; t.nmasked = 0;
+	t.ones_prefix[0] = 0;
+	p.ident_fast = 0;
+	for (int j = 0; j < MAX_NW; j++) p.care[j] = 0;
+	for (unsigned i = 0; i < k; i++) {
+		bool one = mask[i] == '1';
+		t.ones[i] = one ? 1 : 0;
+		t.ones_prefix[i + 1] = (uint16_t)(t.ones_prefix[i] + (one ? 1 : 0));
+		if (one) { p.care[i >> 5] |= 3ULL << (2 * (i & 31)); continue; }
+		unsigned j = t.nmasked++;
+		t.pos[j] = (uint8_t)i;
+		for (unsigned b = 0; b < 4; b++) {
+			t.F[j][b] = srol_n(seed_of(b), k - 1 - i);
+			t.R[j][b] = srol_n(seed_of(3 - b), i);
+		}
+	}
+}
+ABG_HD bool pos_cared(const Params& p, unsigned i) { return ((p.care[i >> 5] >> (2 * (i & 31))) & 1ULL) != 0; }
 
 // NTE64 (nthash.hpp:337-342; note precedence i ^ (k * multiSeed)); hash 0 is the
 // canonical hash itself (RollingHash::getHashes, RollingHash.h:141-146).
@@ -257,24 +298,14 @@ ABG_HD bool kmer_is_canonical(const Kmer<NW>& s, unsigned k)
 	}
 	return true;
 }
-// true when isCanonical() holds for both the k-mer and its reverse complement,
-// which happens only for odd k with a reverse-palindromic flank; such a k-mer
-// and its reverse complement are DIFFERENT vertices for the reference
-// (RollingBloomDBGVertex::compare, RollingBloomDBG.h:114-159).
+// LightweightKmer::operator== (LightweightKmer.h:131-146): positional equality over the
+// compared ('1') positions
 template <int NW>
-ABG_HD bool kmer_is_tie(const Kmer<NW>& s, unsigned k)
-{
-	if ((k & 1) == 0) return false;
-	for (unsigned i = 0; i < k / 2; i++)
-		if (kmer_get(s, i) != 3u - kmer_get(s, k - 1 - i)) return false;
-	return true;
-}
-template <int NW>
-ABG_HD bool kmer_equal(const Kmer<NW>& a, const Kmer<NW>& b)
+ABG_HD bool kmer_equal(const Params& p, const Kmer<NW>& a, const Kmer<NW>& b)
 {
 	bool e = true;
 #pragma unroll
-	for (int j = 0; j < NW; j++) e = e && (a.w[j] == b.w[j]);
+	for (int j = 0; j < NW; j++) e = e && (((a.w[j] ^ b.w[j]) & p.care[j]) == 0);
 	return e;
 }
 
@@ -286,10 +317,91 @@ struct Vtx {
 	Kmer<NW> s;
 	uint64_t fh, rh;
 };
+// (fh, rh) of the identity below
+struct VKey { uint64_t fh, rh; };
+// The two strand hashes that make the canonical hash: the rolling (fh, rh) themselves, or,
+// under a spaced seed, maskHash's fsVal / rsVal (nthash.hpp:537-547): every masked
+// position's term XORed out.
 template <int NW>
-ABG_HD uint64_t vtx_hash(const Vtx<NW>& v) { return v.rh < v.fh ? v.rh : v.fh; } // RollingHash.h:28-31
+ABG_HD void strand_hashes(const Params& p, const Kmer<NW>& s, uint64_t fh, uint64_t rh, uint64_t& fs, uint64_t& rs)
+{
+	fs = fh; rs = rh;
+	if (p.mask) {
+		const MaskTab& m = *p.mask;
+		for (unsigned j = 0; j < m.nmasked; j++) {
+			unsigned b = kmer_get(s, m.pos[j]);
+			fs ^= m.F[j][b];
+			rs ^= m.R[j][b];
+		}
+	}
+}
+// canonical hash (RollingHash.h:28-31,74-79)
+template <int NW>
+ABG_HD uint64_t vtx_hash(const Params& p, const Vtx<NW>& v)
+{
+	uint64_t fs, rs;
+	strand_hashes(p, v.s, v.fh, v.rh, fs, rs);
+	return rs < fs ? rs : fs;
+}
+// Identity of a vertex under RollingBloomDBGVertex::operator== (RollingBloomDBG.h:92-159):
+// equal canonical hash AND equal k-mers when each is read in the orientation its own
+// isCanonical() selects, over the compared positions.  The compared string of a vertex is
+// its k-mer if isCanonical() holds, else the reverse complement; the strand hash of that
+// orientation stands for the string, so identity = (hash of the canonical orientation, hash
+// of the other one) -- their minimum is the canonical hash.  This reproduces the reference's
+// quirk for odd k (both orientations of a k-mer with a reverse-palindromic flank claim to be
+// canonical: (fs, rs) != (rs, fs), two different vertices) and, under a spaced seed, its
+// use of the UNMASKED k-mer to pick the orientation.  For even k without a mask isCanonical()
+// can only tie on a true palindrome, so the ordered pair (min, max) is the same relation
+// and needs no look at the k-mer (p.ident_fast).
+template <int NW>
+ABG_HD VKey vtx_ident(const Params& p, const Vtx<NW>& v)
+{
+	VKey key;
+	if (p.ident_fast) {
+		key.fh = v.rh < v.fh ? v.rh : v.fh;
+		key.rh = v.rh < v.fh ? v.fh : v.rh;
+		return key;
+	}
+	uint64_t fs, rs;
+	strand_hashes(p, v.s, v.fh, v.rh, fs, rs);
+	bool canon = kmer_is_canonical(v.s, p.k);
+	key.fh = canon ? fs : rs;
+	key.rh = canon ? rs : fs;
+	return key;
+}
+ABG_HD bool key_equal(const VKey& a, const VKey& b) { return a.fh == b.fh && a.rh == b.rh; }
 
-// RollingHash::reset (RollingHash.h:69-80): NTF64 / NTR64 base forms, nthash.hpp:220-239
+// Canonical hash of one k-mer computed from scratch: RollingHash::reset (RollingHash.h:69-80),
+// i.e. NTF64 / NTR64 base forms (nthash.hpp:220-239), and under a spaced seed what NTMC64 +
+// maskHash (nthash.hpp:537-547,560-575) leave: only the '1' positions contribute (so a
+// non-ACGT character under a '0' is never looked at).  get(i) returns the code 0..3 of base i.
+template <class Get>
+ABG_HD void scratch_hashes(const Params& p, Get get, uint64_t& fh, uint64_t& rh)
+{
+	fh = 0; rh = 0;
+	const unsigned k = p.k;
+	if (!p.mask) {
+		for (unsigned i = 0; i < k; i++) {
+			fh = srol1(fh) ^ seed_of(get(i));
+			rh = srol1(rh) ^ seed_of(3u - get(k - 1 - i));
+		}
+	} else {
+		for (unsigned i = 0; i < k; i++) {
+			fh = srol1(fh); rh = srol1(rh);
+			if (pos_cared(p, i)) fh ^= seed_of(get(i));
+			if (pos_cared(p, k - 1 - i)) rh ^= seed_of(3u - get(k - 1 - i));
+		}
+	}
+}
+template <class Get>
+ABG_HD uint64_t scratch_hash(const Params& p, Get get)
+{
+	uint64_t fh, rh;
+	scratch_hashes(p, get, fh, rh);
+	return rh < fh ? rh : fh;
+}
+// RollingHash::reset: the rolling (unmasked) state of a vertex
 template <int NW>
 ABG_HD void vtx_rehash(const Params& p, Vtx<NW>& v)
 {
@@ -326,16 +438,10 @@ ABG_HD void vtx_revcomp(const Params& p, Vtx<NW>& v)
 	v.s = kmer_revcomp(v.s, p.k);
 	uint64_t t = v.fh; v.fh = v.rh; v.rh = t;
 }
-// RollingBloomDBGVertex::operator== (RollingBloomDBG.h:92-99): equal canonical hash and
-// RC-invariant k-mer comparison.  Two k-mers with equal (fh, rh) are the same string;
-// with swapped (fh, rh) they are reverse complements, which the reference treats as
-// the same vertex unless the k-mer is in the odd-k tie class (kmer_is_tie).
 template <int NW>
 ABG_HD bool vtx_equal(const Params& p, const Vtx<NW>& a, const Vtx<NW>& b)
 {
-	if (a.fh == b.fh && a.rh == b.rh) return true;
-	if (a.fh == b.rh && a.rh == b.fh) return !kmer_is_tie(a.s, p.k);
-	return false;
+	return key_equal(vtx_ident(p, a), vtx_ident(p, b));
 }
 
 // --------------------------------------------------------- Bloom filter probes
@@ -515,15 +621,33 @@ ABG_HD void neighbour_hashes(const Params& p, const Vtx<NW>& u, int sense, uint6
 		}
 	}
 }
-// Returns a 4-bit mask (bit b = neighbour with base b exists) and the hash pairs.
+// Under a spaced seed the four neighbours in one direction share their masked-out terms: the
+// mask starts and ends with '1' (MaskedKmer.h:43), so no masked position holds the base that
+// differs between them.  (df, dr) turn their rolling hashes into maskHash's strand hashes.
+template <int NW>
+ABG_HD void neighbour_mask_delta(const Params& p, const Vtx<NW>& u, int sense, uint64_t& df, uint64_t& dr)
+{
+	df = 0; dr = 0;
+	if (p.mask) {
+		Kmer<NW> sh = u.s;
+		kmer_shift(sh, p.k, sense, 0);
+		strand_hashes(p, sh, 0, 0, df, dr);
+	}
+}
+// Returns a 4-bit mask (bit b = neighbour with base b exists) and the (rolling) hash pairs.
 template <int NW>
 ABG_HD unsigned neighbour_mask(const Params& p, const uint8_t* __restrict__ cnt,
     const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4], bool coop)
 {
 	neighbour_hashes(p, u, sense, fh4, rh4);
+	uint64_t df, dr;
+	neighbour_mask_delta(p, u, sense, df, dr);
 	uint64_t h[4];
 #pragma unroll
-	for (unsigned b = 0; b < 4; b++) h[b] = rh4[b] < fh4[b] ? rh4[b] : fh4[b];
+	for (unsigned b = 0; b < 4; b++) {
+		uint64_t fs = fh4[b] ^ df, rs = rh4[b] ^ dr;
+		h[b] = rs < fs ? rs : fs;
+	}
 	return solid_mask4(p, cnt, h, coop);
 }
 // the neighbour of u with last (first) base b, hashes included
@@ -549,11 +673,10 @@ ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsi
 // Explicit stacks for the reference's recursive searches.  One SearchScratch per
 // concurrently running searcher (GPU thread); capacities are fixed at launch and
 // overflow is reported (never silently truncated).
-struct VKey { uint64_t fh, rh; };
 template <int NW>
 struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
 	Vtx<NW> v;          // the vertex this call inserted into `visited`
-	uint64_t ufh, urh;  // the vertex we came from (skipped when changing direction)
+	uint64_t ufh, urh;  // identity of the vertex we came from (skipped when changing direction)
 	uint16_t depth;
 	uint8_t dir;        // direction of this call
 	uint8_t stage;      // 0: same-direction children, 1: other-direction children
@@ -572,7 +695,7 @@ constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
 template <int NW>
 struct SearchScratch {
 	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
-	VKey* tb_keys;         // [tb_cap] (fh, rh) of tb[i].v: what the on-stack test scans
+	VKey* tb_keys;         // [tb_cap] vtx_ident of tb[i].v: what the on-stack test scans
 	uint32_t tb_cap;
 	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
 	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
@@ -595,7 +718,7 @@ ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
 	unsigned nv = 0;
 	VKey* vis = sc.la_visited;
-	vis[nv].fh = start.fh; vis[nv].rh = start.rh; nv++;
+	vis[nv++] = vtx_ident(p, start);
 	if (limit == 0) return true;
 	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
 	int depth = 0;
@@ -609,16 +732,13 @@ ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const 
 		unsigned b = f.next++;
 		if (!((f.mask >> b) & 1u)) continue;
 		Vtx<NW> w = neighbour_vertex(p, f.v, sense, b);
+		const VKey wk = vtx_ident(p, w);
 		bool seen = false;
-		for (unsigned i = 0; i < nv; i++) {
-			Vtx<NW> t; t.s = w.s; t.fh = vis[i].fh; t.rh = vis[i].rh;
-			// vtx_equal needs the k-mer only for the tie test, which is a property of
-			// either orientation of the same k-mer
-			if (vtx_equal(p, w, t)) { seen = true; break; }
-		}
+		for (unsigned i = 0; i < nv; i++)
+			if (key_equal(vis[i], wk)) { seen = true; break; }
 		if (seen) continue;
 		// recursive call lookAhead(w, depth + 1)
-		if (nv < (unsigned)LA_MAX_VISITED) { vis[nv].fh = w.fh; vis[nv].rh = w.rh; nv++; }
+		if (nv < (unsigned)LA_MAX_VISITED) vis[nv++] = wk;
 		else sc.overflow = 1;
 		if ((unsigned)(depth + 1) >= limit) return true;
 		depth++;
@@ -653,16 +773,14 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
 		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
 		bool on_stack = false;
+		const VKey ck = vtx_ident(p, cv);
 		{
-			const bool tie = (p.k & 1) ? kmer_is_tie(cv.s, p.k) : false;
 			const int nf = top + 1 < (int)sc.tbf_cap ? top + 1 : (int)sc.tbf_cap;
 			// cooperative callers spread the scan over the lanes
 			const int first = sc.coop ? (int)lane_id() : 0, step = sc.coop ? 64 : 1;
 			for (int i = first; i <= top; i += step) {
 				VKey kk = i < nf ? sc.tbf_keys[i] : sc.tb_keys[i - nf];
-				bool same = (kk.fh == cv.fh) & (kk.rh == cv.rh);
-				bool swapped = (kk.fh == cv.rh) & (kk.rh == cv.fh);
-				on_stack = on_stack | same | (swapped & !tie);
+				on_stack = on_stack | ((kk.fh == ck.fh) & (kk.rh == ck.rh));
 			}
 			if (sc.coop) on_stack = wave_any(on_stack);
 		}
@@ -672,9 +790,13 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 		top++;
 		{
 			VKey& kk = (uint32_t)top < sc.tbf_cap ? sc.tbf_keys[top] : sc.tb_keys[(uint32_t)top - sc.tbf_cap];
-			kk.fh = cv.fh; kk.rh = cv.rh;
+			kk = ck;
 			TBFrame<NW>& f = tb_frame(sc, top);
-			f.v = cv; f.ufh = cu.fh; f.urh = cu.rh;
+			// the caller is the frame below (or the root edge's source)
+			const VKey uk = top > 0 ? ((uint32_t)(top - 1) < sc.tbf_cap ? sc.tbf_keys[top - 1]
+			                                                          : sc.tb_keys[(uint32_t)(top - 1) - sc.tbf_cap])
+			                        : vtx_ident(p, cu);
+			f.v = cv; f.ufh = uk.fh; f.urh = uk.rh;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
 			uint64_t nfh[4], nrh[4];
@@ -728,8 +850,8 @@ ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const
 					unsigned b = nx++;
 					if (!((mo >> b) & 1u)) continue;
 					Vtx<NW> w = neighbour_vertex(p, fv, osense, b);
-					Vtx<NW> uu; uu.s = w.s; uu.fh = ufh; uu.rh = urh;
-					if (vtx_equal(p, w, uu)) continue; // source(*iei) == u
+					const VKey wk = vtx_ident(p, w);
+					if ((wk.fh == ufh) & (wk.rh == urh)) continue; // source(*iei) == u
 					cu = fv; cv = w; cdepth = 0; cdir = odir;
 					made = true;
 					break;

@@ -23,6 +23,7 @@ struct Config {
 	uint32_t k = 0, nh = 4, kc = 2, trim = 0;
 	uint64_t counters = 0;            // number of uint8 counters == visited bits (cascade mode: bits per level)
 	uint32_t cascade_levels = 0;      // > 0: HashAgnosticCascadingBloom of that many levels instead of counters
+	std::string spaced_seed;          // k characters of '0'/'1', or empty (MaskedKmer::mask())
 	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
 	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
 	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
@@ -90,13 +91,7 @@ struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
 	{
 		uint64_t r = find_seq(b.koff, b.n, t);
 		uint32_t j = (uint32_t)(t - b.koff[r]);
-		uint64_t fh = 0, rh = 0;
-		unsigned k = p.k;
-		for (unsigned i = 0; i < k; i++) {
-			fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
-			rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
-		}
-		h0[t] = rh < fh ? rh : fh;
+		h0[t] = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
 	}
 };
 // Fused PASS 1 front end: each lane owns HC_RUN consecutive k-mer ops, hashes the first from
@@ -120,6 +115,15 @@ struct FHashClaim {
 		for (uint64_t t = t0; t < t1; t++) {
 			while (t >= rend) { r++; rend = b.koff[r + 1]; fresh = true; }
 			uint32_t j = (uint32_t)(t - b.koff[r]);
+			if (p.mask) {
+				// spaced seed: from scratch over the '1' positions (not the headline configuration)
+				uint64_t h = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
+				h0[t] = h;
+				uint64_t v = claim_val(epoch, (uint32_t)t);
+				for (unsigned i = 0; i < p.nh; i++)
+					atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
+				continue;
+			}
 			if (fresh) {
 				fh = 0; rh = 0;
 				for (unsigned i = 0; i < k; i++) {
@@ -327,7 +331,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		bool solid = true;
 		for (uint32_t j = 0; j < nk; j++) {
 			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!solid_contains(p, cnt, vtx_hash(v))) { solid = false; break; }
+			if (!solid_contains(p, cnt, vtx_hash(p, v))) { solid = false; break; }
 		}
 		if (!solid) { result[r] = RR_NOT_SOLID; return; }
 		// allKmersInBloom(seq, assembledKmerSet) against the snapshot
@@ -335,7 +339,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		bool visited = true;
 		for (uint32_t j = 0; j < nk; j++) {
 			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(v))) { visited = false; break; }
+			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
 		}
 		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
 	}
@@ -355,27 +359,16 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 	}
 };
 
+// (contig sequences hold code 4 = 'N' in columns no '1' of the spaced seed covers: never read)
 template <int NW>
 ABG_HDN uint64_t seq_kmer_hash(const Params& p, const uint8_t* seq, uint64_t j)
 {
-	uint64_t fh = 0, rh = 0;
-	unsigned k = p.k;
-	for (unsigned i = 0; i < k; i++) {
-		fh = srol1(fh) ^ seed_of(seq[j + i]);
-		rh = srol1(rh) ^ seed_of(3u - seq[j + k - 1 - i]);
-	}
-	return rh < fh ? rh : fh;
+	return scratch_hash(p, [&](unsigned i) { return (unsigned)seq[j + i]; });
 }
 template <int NW>
 ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uint32_t j)
 {
-	uint64_t fh = 0, rh = 0;
-	unsigned k = p.k;
-	for (unsigned i = 0; i < k; i++) {
-		fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
-		rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
-	}
-	return rh < fh ? rh : fh;
+	return scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
 }
 template <int NW>
 struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave per candidate)
@@ -594,9 +587,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 				if (len < k + FP_TRIM - 1) {
 					// short contigs: exact set of canonical end k-mers (bloom-dbg.h:576-584)
 					if (tid == 0) {
-						Vtx<NW> v1 = canonical_end_vertex<NW>(p, seq);
-						Vtx<NW> v2 = canonical_end_vertex<NW>(p, seq + len - k);
-						VKey k1 = vtx_key(p, v1), k2 = vtx_key(p, v2);
+						VKey k1 = canonical_end_key(p, seq), k2 = canonical_end_key(p, seq + len - k);
 						if (wt_find(e.cend, k1, 0) != WT_EMPTY && wt_find(e.cend, k2, 0) != WT_EMPTY) {
 							redundant = 1;
 						} else {
@@ -667,6 +658,14 @@ class Engine {
 		uint64_t rem = cfg_.counters % 8; // CountingBloomFilter ctor, hpp:40-50
 		m_ = rem ? cfg_.counters + 8 - rem : cfg_.counters;
 		p_ = make_params(cfg_.k, cfg_.nh, cfg_.kc, cfg_.trim, m_);
+		if (!cfg_.spaced_seed.empty()) {
+			MaskTab* mt = new MaskTab;
+			make_mask(cfg_.spaced_seed.c_str(), cfg_.k, *mt, p_);
+			mask_d_ = (MaskTab*)be_.alloc(sizeof(MaskTab));
+			be_.h2d(mask_d_, mt, sizeof(MaskTab));
+			delete mt;
+			p_.mask = mask_d_;
+		}
 		if (cfg_.cascade_levels) {
 			// `abyss-bloom build -t rolling-hash -l N`: N bit filters of m_ bits (Bloom/bloom.cc:585-602)
 			casc_.levels = cfg_.cascade_levels;
@@ -690,6 +689,7 @@ class Engine {
 	{
 		be_.free(cnt_); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
 		if (casc_.bits) be_.free(casc_.bits);
+		if (mask_d_) be_.free(mask_d_);
 		free_insert();
 		free_walk();
 	}
@@ -763,6 +763,7 @@ class Engine {
 	CommitState* cstate_ = nullptr;
 	uint64_t* scal_ = nullptr;
 	Cascade casc_{ nullptr, 0, 0 };
+	MaskTab* mask_d_ = nullptr;
 	Counters counters_;
 	Stats stats_;
 	uint64_t last_rounds_ = 0;
@@ -1212,7 +1213,7 @@ class Engine {
 			o.contig_id = r.redundant ? ~0ULL : r.contig_id;
 			o.read_index = read_base + cand_h[r.cand];
 			o.seq.resize(r.len);
-			for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGT"[pool[r.seq_off + j] & 3];
+			for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGTN"[pool[r.seq_off + j] <= 4 ? pool[r.seq_off + j] : 4];
 			o.coverage = r.redundant ? 0 : r.coverage;
 			o.redundant = r.redundant != 0;
 			o.left_ext = r.left_ext; o.right_ext = r.right_ext;

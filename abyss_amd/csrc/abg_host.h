@@ -47,7 +47,16 @@ class Session {
 	{
 		if (p.k < 2 || p.k > ABG_MAX_KMER) return fail(ABG_EINVAL, "k must be in 2.." + std::to_string(ABG_MAX_KMER));
 		if (p.num_hashes < 1 || p.num_hashes > ABG_MAX_HASHES) return fail(ABG_EINVAL, "num_hashes must be in 1..32");
-		if (p.spaced_seed && p.spaced_seed[0]) return fail(ABG_EINVAL, "spaced seeds (-s/-K/--qr-seed) are not supported yet");
+		if (p.spaced_seed && p.spaced_seed[0]) {
+			// MaskedKmer::setMask (BloomDBG/MaskedKmer.h:25-48); RollingBloomDBGVertex::compare
+			// additionally asserts a symmetric pattern (RollingBloomDBG.h:141-145)
+			std::string m(p.spaced_seed);
+			if (m.size() != p.k) return fail(ABG_EINVAL, "spaced seed must be exactly k bits long");
+			if (m.find_first_not_of("01") != std::string::npos) return fail(ABG_EINVAL, "spaced seed must contain only '0's or '1's");
+			if (m.front() != '1' || m.back() != '1') return fail(ABG_EINVAL, "spaced seed must begin and end with '1's");
+			if (!std::equal(m.begin(), m.end(), m.rbegin())) return fail(ABG_EINVAL, "spaced seed must be symmetric");
+			if (m.find('0') != std::string::npos) cfg.spaced_seed = m; // all '1's == no mask
+		}
 		cfg.k = p.k; cfg.nh = p.num_hashes; cfg.kc = p.min_cov;
 		cfg.trim = (p.trim == 0xFFFFFFFFu) ? p.k : p.trim;
 		cfg.counters = p.counters ? p.counters : counters_for_budget(p.bloom_bytes);
@@ -85,20 +94,16 @@ class Session {
 			if (L < k) continue; // RollingHashIterator.h:37-40
 			up.assign(s, L);
 			for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
-			uint64_t a = 0;
-			while (a < L) {
-				while (a < L && !is_acgt(up[a])) a++;
-				uint64_t b = a;
-				while (b < L && is_acgt(up[b])) b++;
-				if (b - a >= k) {
-					for (uint64_t q = a; q + k <= b;) {
-						uint64_t e = std::min<uint64_t>(b, q + max_piece);
-						hb.add_ascii(up.data() + q, (uint32_t)(e - q), k);
-						if (e == b) break;
-						q = e - (k - 1);
-					}
+			valid_runs(up, runs_);
+			for (auto& run : runs_) {
+				// k-mers run.first .. run.second - 1 start in this piece
+				uint64_t pa = run.first, pb = run.second - 1 + k;
+				for (uint64_t q = pa; q + k <= pb;) {
+					uint64_t e = std::min<uint64_t>(pb, q + max_piece);
+					hb.add_ascii(up.data() + q, (uint32_t)(e - q), k);
+					if (e == pb) break;
+					q = e - (k - 1);
 				}
-				a = b;
 			}
 			if (hb.koff.back() >= cfg.insert_batch_kmers) { flush_load(hb); hb.clear(); }
 		}
@@ -196,13 +201,10 @@ class Session {
 		std::vector<uint32_t> start; // start position of each packed piece
 		std::string up(seq, len);
 		for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
-		uint64_t a = 0;
-		while (a < len) {
-			while (a < len && !is_acgt(up[a])) a++;
-			uint64_t b = a;
-			while (b < len && is_acgt(up[b])) b++;
-			if (b - a >= k) { hb.add_ascii(up.data() + a, (uint32_t)(b - a), k); start.push_back((uint32_t)a); }
-			a = b;
+		valid_runs(up, runs_);
+		for (auto& run : runs_) {
+			hb.add_ascii(up.data() + run.first, (uint32_t)(run.second - run.first + k - 1), k);
+			start.push_back((uint32_t)run.first);
 		}
 		uint64_t T = hb.koff.back();
 		*n_out = T;
@@ -232,6 +234,45 @@ class Session {
 
   private:
 	static bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+	std::vector<std::pair<uint64_t, uint64_t>> runs_;
+	std::vector<uint8_t> bad_;
+	// Maximal runs [first, second) of consecutive start positions of the k-mers
+	// RollingHashIterator yields for an upper-cased sequence (RollingHashIterator.h:35-97):
+	// those with an ACGT character at every position the spaced seed looks at (all of them
+	// without one).  A run of k-mers a..b-1 is the text [a, b - 1 + k); characters under a
+	// '0' may be anything (they are packed as some base and never contribute to a hash).
+	void valid_runs(const std::string& up, std::vector<std::pair<uint64_t, uint64_t>>& runs)
+	{
+		runs.clear();
+		const uint64_t L = up.size(), k = cfg.k;
+		if (L < k) return;
+		const uint64_t nk = L - k + 1;
+		if (cfg.spaced_seed.empty()) {
+			uint64_t a = 0;
+			while (a < L) {
+				while (a < L && !is_acgt(up[a])) a++;
+				uint64_t b = a;
+				while (b < L && is_acgt(up[b])) b++;
+				if (b - a >= k) runs.emplace_back(a, b - k + 1);
+				a = b;
+			}
+			return;
+		}
+		bad_.assign(nk, 0);
+		const std::string& m = cfg.spaced_seed;
+		for (uint64_t x = 0; x < L; x++) {
+			if (is_acgt(up[x])) continue;
+			for (uint64_t i = 0; i < k; i++)
+				if (m[i] == '1' && x >= i && x - i < nk) bad_[x - i] = 1;
+		}
+		for (uint64_t j = 0; j < nk;) {
+			if (bad_[j]) { j++; continue; }
+			uint64_t e = j;
+			while (e < nk && !bad_[e]) e++;
+			runs.emplace_back(j, e);
+			j = e;
+		}
+	}
 	struct DevBatch { Batch b; void* words; void* woff; void* len; void* koff; };
 	DevBatch upload(const HostBatch& hb)
 	{

@@ -174,25 +174,20 @@ ABG_HD uint64_t find_seq(const uint64_t* koff, uint64_t n, uint64_t t)
 // ---------------------------------------------------------------- vertex table
 constexpr uint64_t WT_EMPTY = ~0ULL;
 constexpr uint32_t WT_TOMB = 0xFFFFFFFEu;      // contig field of a tombstoned entry
-constexpr uint64_t WT_TIE_SALT = 0x9E3779B97F4A7C15ULL;
 struct WalkTab {
 	uint64_t* hmin;   // [cap]  WT_EMPTY when free
 	uint64_t* hmax;   // [cap]
 	uint64_t* meta;   // [cap]  owner << 32 | contig
 	uint64_t mask;    // cap - 1 (cap is a power of two)
 };
-// identity of a vertex under RollingBloomDBGVertex::operator== (see vtx_equal)
-template <int NW>
-ABG_HD VKey vtx_key(const Params& p, const Vtx<NW>& v)
+// table key of a vertex: its identity (vtx_ident), kept clear of the "free slot" value
+ABG_HD VKey wt_key(VKey key)
 {
-	VKey key;
-	bool f_lt = v.fh < v.rh;
-	key.fh = f_lt ? v.fh : v.rh; // min
-	key.rh = f_lt ? v.rh : v.fh; // max
-	if ((p.k & 1) && kmer_is_tie(v.s, p.k) && f_lt) key.rh ^= WT_TIE_SALT;
 	if (key.fh == WT_EMPTY) key.fh = WT_EMPTY - 1;
 	return key;
 }
+template <int NW>
+ABG_HD VKey vtx_key(const Params& p, const Vtx<NW>& v) { return wt_key(vtx_ident(p, v)); }
 ABG_HD uint64_t wt_slot(const WalkTab& t, const VKey& key, uint32_t owner)
 {
 	uint64_t x = key.fh ^ ((uint64_t)(owner + 1) * 0xD6E8FEB86659FD93ULL);
@@ -352,10 +347,16 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		neighbour_hashes(p, head, (other == FORWARD) ? SENSE : ANTISENSE, bfh, brh);
 		neighbour_hashes(p, head, (dir == FORWARD) ? SENSE : ANTISENSE, ffh, frh);
 		uint64_t h8[8];
+		{
+			uint64_t bdf, bdr, fdf, fdr; // spaced seed: masked-out terms (zero without one)
+			neighbour_mask_delta(p, head, (other == FORWARD) ? SENSE : ANTISENSE, bdf, bdr);
+			neighbour_mask_delta(p, head, (dir == FORWARD) ? SENSE : ANTISENSE, fdf, fdr);
 #pragma unroll
-		for (unsigned q = 0; q < 4; q++) {
-			h8[q] = brh[q] < bfh[q] ? brh[q] : bfh[q];
-			h8[4 + q] = frh[q] < ffh[q] ? frh[q] : ffh[q];
+			for (unsigned q = 0; q < 4; q++) {
+				uint64_t bf = bfh[q] ^ bdf, br = brh[q] ^ bdr, ff = ffh[q] ^ fdf, fr = frh[q] ^ fdr;
+				h8[q] = br < bf ? br : bf;
+				h8[4 + q] = fr < ff ? fr : ff;
+			}
 		}
 		// start the probe loads, then enter the head into `visited` while they are in flight
 		Probe8 pr;
@@ -373,7 +374,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 			}
 			*end_earlier = (ins == WT_EARLIER);
 			if (e.claims) {
-				uint64_t hm = head.fh < head.rh ? head.fh : head.rh;
+				uint64_t hm = vtx_hash(p, head);
 				uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
 				if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
 			}
@@ -524,7 +525,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			// the predictor would count reads lying on the tip as covered by this walker
 			for (uint32_t i = 0; i < n; i++) {
 				Vtx<NW> x = ws_vertex(p, w, i);
-				uint64_t hm = vtx_hash(x);
+				uint64_t hm = vtx_hash(p, x);
 				wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
 			}
 		}
@@ -539,6 +540,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			int64_t lo = 0, hi = (int64_t)n; // path = vertices [lo, hi) over S
 			// ---- trimBranchKmers (bloom-dbg.h:723-757)
 			Vtx<NW> popped[2]; bool popped_earlier[2]; int npopped = 0;
+			Vtx<NW> pushed; int pushed_side = 0; // see preprocessCircularContig below
 			if (n > 1) {
 				Vtx<NW> front = pool_vertex<NW>(p, S, 0), back = pool_vertex<NW>(p, S, n - 1);
 				// getContigType (bloom-dbg.h:629-645): edge(back, front) via adjacency (RollingBloomDBG.h:558-574)
@@ -555,10 +557,13 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 					if (edge) {
 						Vtx<NW> x = front;
 						vtx_shift(p, x, ANTISENSE, kmer_get(back.s, 0));
-						type = kmer_equal(x.s, back.s) ? CT_CIRCULAR : CT_HAIRPIN;
+						type = kmer_equal(p, x.s, back.s) ? CT_CIRCULAR : CT_HAIRPIN;
 					}
 				}
-				// preprocessCircularContig (bloom-dbg.h:648-702)
+				// preprocessCircularContig (bloom-dbg.h:648-702).  The vertex it appends is a copy of
+				// the other end (or its reverse complement), which under a spaced seed may differ from
+				// the window of S at the masked positions, so it is kept as a vertex of its own.
+				// (pushed_side 1: appended at the back, -1: at the front)
 				if (type != CT_LINEAR && n > 2) {
 					bool bstart = ambiguous1(p, e.cnt, front, FORWARD, sc) || ambiguous1(p, e.cnt, front, REVERSE, sc);
 					bool bend = ambiguous1(p, e.cnt, back, FORWARD, sc) || ambiguous1(p, e.cnt, back, REVERSE, sc);
@@ -567,20 +572,27 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 						unsigned nb = (type == CT_CIRCULAR) ? kmer_get(front.s, k - 1) : 3u - kmer_get(front.s, 0);
 						S[hi + k - 1] = (uint8_t)nb;
 						hi++;
+						pushed = front; pushed_side = 1;
+						if (type != CT_CIRCULAR) vtx_revcomp(p, pushed);
 					} else if (!bstart && bend) {
 						unsigned nb = (type == CT_CIRCULAR) ? kmer_get(back.s, 0) : 3u - kmer_get(back.s, k - 1);
 						S[lo - 1] = (uint8_t)nb;
 						lo--;
+						pushed = back; pushed_side = -1;
+						if (type != CT_CIRCULAR) vtx_revcomp(p, pushed);
 					}
 				}
 				int64_t l = hi - lo;
 				Vtx<NW> p0 = pool_vertex<NW>(p, S, lo), p1 = pool_vertex<NW>(p, S, lo + 1);
 				Vtx<NW> q1 = pool_vertex<NW>(p, S, hi - 1), q2 = pool_vertex<NW>(p, S, hi - 2);
+				if (pushed_side > 0) q1 = pushed;
+				if (pushed_side < 0) p0 = pushed;
 				(void)l;
 				bool amb1 = ambiguous2(p, e.cnt, p0, p1, FORWARD, sc);
 				bool amb2 = ambiguous2(p, e.cnt, q1, q2, REVERSE, sc);
 				if (amb1) { popped[npopped] = p0; popped_earlier[npopped] = (lo == 0) ? (w.nl ? left_earlier : seed_earlier) : true; npopped++; lo++; }
 				if (amb2) { popped[npopped] = q1; popped_earlier[npopped] = (hi == (int64_t)n) ? (w.nr ? right_earlier : seed_earlier) : true; npopped++; hi--; }
+				if ((pushed_side < 0 && amb1) || (pushed_side > 0 && amb2)) pushed_side = 0; // trimmed off again
 			}
 			if (sc.overflow) { abort_status = WS_OVERFLOW; break; }
 			// ---- record for outputContig
@@ -600,15 +612,30 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			// or the same vertex is still an end of the path (circular / hairpin duplicates)
 			if (npopped) {
 				Vtx<NW> nf = pool_vertex<NW>(p, S, lo), nb = pool_vertex<NW>(p, S, hi - 1);
+				if (pushed_side < 0) nf = pushed;
+				if (pushed_side > 0) nb = pushed;
 				for (int q = 0; q < npopped; q++) {
 					if (popped_earlier[q]) continue;
 					if (hi > lo && (vtx_equal(p, popped[q], nf) || vtx_equal(p, popped[q], nb))) continue;
 					uint64_t s = wt_find(e.tab, vtx_key(p, popped[q]), owner);
 					if (s != WT_EMPTY) wu_st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB, sc.coop);
 					if (e.claims) { // trimmed off: not covered by this walker's contig after all
-						uint64_t hm = vtx_hash(popped[q]);
+						uint64_t hm = vtx_hash(p, popped[q]);
 						wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
 					}
+				}
+			}
+			// ---- pathToSeq (bloom-dbg.h:130-158) under a spaced seed: a column keeps its 'N' unless
+			// a '1' of some path k-mer lies over it.  Vertex i covers column c with mask[c - i];
+			// mask[0] == mask[k-1] == '1', so only paths shorter than k can leave columns open.
+			if (p.mask && hi > lo && (uint64_t)(hi - lo) < k) {
+				const MaskTab& m = *p.mask;
+				const uint32_t np = (uint32_t)(hi - lo);
+				uint8_t* C = S + lo;
+				for (uint32_t col = np; col + 1 < k; col++) {
+					// offsets j = col - i for i in [0, np): [col - np + 1, col]
+					uint32_t j0 = col - np + 1, j1 = col + 1;
+					if (m.ones_prefix[j1] == m.ones_prefix[j0]) C[col] = 4;
 				}
 			}
 		}
@@ -629,21 +656,41 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 }
 
 // ------------------------------------------------------------ commit helpers
-// canonicalize(Sequence&) (Common/Sequence.h:39-44) applied to the k-mer at seq[0..k):
-// returns the vertex of whichever of the k-mer / its reverse complement is
-// lexicographically smaller as a string.
-template <int NW>
-ABG_HDN Vtx<NW> canonical_end_vertex(const Params& p, const uint8_t* seq)
+// Contig sequences hold codes 0..3 = ACGT and 4 = 'N' (only in columns no '1' of a spaced seed
+// covers).  Order and complement as the reference's characters have them: A < C < G < N < T,
+// complementBaseChar('N') == 'N'.
+ABG_HD unsigned code_rank(unsigned c) { return c == 4 ? 3u : (c == 3 ? 4u : c); }
+ABG_HD unsigned code_comp(unsigned c) { return c == 4 ? 4u : 3u - c; }
+// Key of an end k-mer of a contig in contigEndKmers (bloom-dbg.h:556-564,578-583):
+// canonicalize(Sequence&) (Common/Sequence.h:39-44) turns the k-mer at seq[0..k) into whichever
+// of it / its reverse complement is the smaller string; the Vertex built from that text is
+// then identified as every vertex is (vtx_ident): its strand hashes ordered by ITS isCanonical().
+ABG_HDN VKey canonical_end_key(const Params& p, const uint8_t* seq)
 {
-	Vtx<NW> v = pool_vertex<NW>(p, seq, 0);
-	// rc < seq ?
+	const unsigned k = p.k;
 	bool rc_less = false;
-	for (unsigned i = 0; i < p.k; i++) {
-		unsigned a = 3u - kmer_get(v.s, p.k - 1 - i), b = kmer_get(v.s, i);
+	for (unsigned i = 0; i < k; i++) {
+		unsigned a = code_rank(code_comp(seq[k - 1 - i])), b = code_rank(seq[i]);
 		if (a != b) { rc_less = a < b; break; }
 	}
-	if (rc_less) vtx_revcomp(p, v);
-	return v;
+	auto text = [&](unsigned i) -> unsigned { return rc_less ? code_comp(seq[k - 1 - i]) : (unsigned)seq[i]; };
+	uint64_t fs, rs;
+	scratch_hashes(p, text, fs, rs);
+	VKey key;
+	if (p.ident_fast) {
+		key.fh = rs < fs ? rs : fs;
+		key.rh = rs < fs ? fs : rs;
+		return wt_key(key);
+	}
+	bool canon = true; // LightweightKmer::isCanonical (LightweightKmer.h:88-101) of the text
+	for (unsigned i = 0; i < k / 2; i++) {
+		unsigned c1 = code_rank(text(i)), c2 = code_rank(code_comp(text(k - 1 - i)));
+		if (c1 > c2) { canon = false; break; }
+		if (c1 < c2) break;
+	}
+	key.fh = canon ? fs : rs;
+	key.rh = canon ? rs : fs;
+	return wt_key(key);
 }
 
 } // namespace abg

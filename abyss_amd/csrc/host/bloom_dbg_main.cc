@@ -130,6 +130,30 @@ static void check(int rc, abg_ctx* ctx, const char* what)
 	exit(EXIT_FAILURE);
 }
 
+// SpacedSeed::kmerPair (BloomDBG/SpacedSeed.h:18-26): K ones, a gap, K ones
+static std::string spaced_seed_kmer_pair(unsigned k, unsigned K)
+{
+	std::string seed(k, '0');
+	for (unsigned i = 0; i < K && i < k; i++) seed[i] = seed[k - 1 - i] = '1';
+	return seed;
+}
+// SpacedSeed::qrSeed (SpacedSeed.h:40-52): position i is '0' when i is a quadratic residue mod len
+static std::string spaced_seed_qr(unsigned len)
+{
+	std::string seed(len, '1');
+	for (unsigned long i = 0; i < len; i++)
+		for (unsigned long j = 1; j < len; j++)
+			if (j * j % len == i) { seed[i] = '0'; break; }
+	return seed;
+}
+// SpacedSeed::qrSeedPair (SpacedSeed.h:64-73): a QR seed, a gap, the mirrored QR seed
+static std::string spaced_seed_qr_pair(unsigned k, unsigned len)
+{
+	std::string seed(k, '0'), q = spaced_seed_qr(len);
+	for (unsigned i = 0; i < len && i < k; i++) seed[i] = seed[k - 1 - i] = q[i];
+	return seed;
+}
+
 int main(int argc, char** argv)
 {
 	abg_params p;
@@ -149,18 +173,18 @@ int main(int argc, char** argv)
 		case 'i': bloomPath = optarg; break;
 		case 'j': (void)strtoul(optarg, &end, 10); bad = *end; break;
 		case 'k': p.k = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
-		case 'K': K = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'K': qr = 0; spaced.clear(); K = (unsigned)strtoul(optarg, &end, 10); bad = *end; break; // resetSpacedSeedParams, AssemblyParams.h:96-100
 		case 'o': outputPath = optarg; break;
 		case 'q': ropt.qualityThreshold = (int)strtol(optarg, &end, 10); bad = *end; break;
 		case 'Q': ropt.internalQThreshold = (int)strtol(optarg, &end, 10); bad = *end; break;
-		case 's': spaced = optarg; break;
+		case 's': K = 0; qr = 0; spaced = optarg; break;
 		case 't': p.trim = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
 		case 'T': tracePath = optarg; break;
 		case 'v': ++verbose; break;
 		case OPT_HELP: fputs(USAGE_MESSAGE, stdout); exit(EXIT_SUCCESS);
 		case OPT_VERSION: fputs(VERSION_MESSAGE, stdout); exit(EXIT_SUCCESS);
 		case MIN_KMER_COV: p.min_cov = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
-		case QR_SEED: qr = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
+		case QR_SEED: K = 0; spaced.clear(); qr = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
 		case READ_LOG: readLogPath = optarg; break;
 		case 'C': case 'g': case 'R': case CHECKPOINT: case KEEP_CHECKPOINT: case CHECKPOINT_PREFIX:
 			fprintf(stderr, PROGRAM ": option `-%c' is not supported by this build\n", c < 128 ? c : '-');
@@ -174,10 +198,23 @@ int main(int argc, char** argv)
 	if (bloomPath.empty() && p.bloom_bytes == 0) { fprintf(stderr, PROGRAM ": missing mandatory option `-b'\n"); die = true; }
 	if (bloomPath.empty() && p.k == 0) { fprintf(stderr, PROGRAM ": missing mandatory option `-k'\n"); die = true; }
 	if (p.k > 0 && K > 0 && K > p.k / 2) { fprintf(stderr, PROGRAM ": value of `-K' must be <= k/2\n"); die = true; }
+	if (p.k > 0 && qr > 0 && (qr < 11 || qr > p.k / 2)) { fprintf(stderr, PROGRAM ": value of `--qr-seed' must be >= 11 and <= k/2\n"); die = true; }
 	if (p.num_hashes > ABG_MAX_HASHES) { fprintf(stderr, PROGRAM ": number of hash functions (`-H`) must be <= %d\n", ABG_MAX_HASHES); die = true; }
 	if (argc - optind < 1) { fprintf(stderr, PROGRAM ": missing input file arguments\n"); die = true; }
 	if (die) { fprintf(stderr, "Try `%s --help' for more information.\n", PROGRAM); exit(EXIT_FAILURE); }
-	if (K || qr || !spaced.empty()) { fprintf(stderr, PROGRAM ": spaced seeds (-K, --qr-seed, -s) are not supported by this build\n"); exit(EXIT_FAILURE); }
+
+	// initGlobals (bloom-dbg.cc:214-233) + SpacedSeed.h:18-75
+	std::string mask;
+	if (K > 0) mask = spaced_seed_kmer_pair(p.k, K);
+	else if (qr > 0) mask = spaced_seed_qr_pair(p.k, qr);
+	else mask = spaced;
+	if (!mask.empty()) {
+		// MaskedKmer::setMask, MaskedKmer.h:25-48
+		if (mask.size() != p.k) { fprintf(stderr, "error: spaced seed must be exactly k bits long\n"); exit(EXIT_FAILURE); }
+		if (mask.find_first_not_of("01") != std::string::npos) { fprintf(stderr, "error: spaced seed must contain only '0's or '1's\n"); exit(EXIT_FAILURE); }
+		if (mask.front() != '1' || mask.back() != '1') { fprintf(stderr, "error: spaced seed must begin and end with '1's\n"); exit(EXIT_FAILURE); }
+		p.spaced_seed = mask.c_str();
+	}
 
 	// -i: [BTLCountingBloomFilter_v1] header + raw counters (CountingBloomFilter.hpp:262-329,344-379)
 	std::vector<uint8_t> prebuilt;
@@ -209,6 +246,7 @@ int main(int argc, char** argv)
 	const uint32_t trim = p.trim == 0xFFFFFFFFu ? p.k : p.trim;
 	if (verbose) {
 		fprintf(stderr, "Assembling with k-mer size %u\n", p.k);
+		if (!mask.empty()) fprintf(stderr, "Using spaced seed %s\n", mask.c_str());
 		fprintf(stderr, "Assembly parameters:\n\tK-mer size (-k): %u\n\tK-mer coverage threshold (--kc): %u\n"
 		    "\tMax branch trim length (-t): %u\n\tBloom size in bytes (-b): %llu\n\tBloom hash functions (-H): %u\n",
 		    p.k, p.min_cov, trim, (unsigned long long)p.bloom_bytes, p.num_hashes);

@@ -66,7 +66,9 @@ typedef struct abg_params {
 	uint32_t trim;       /* -t  max branch length to trim; UINT32_MAX = k (bloom-dbg.cc:507-509) */
 	uint64_t bloom_bytes;/* -b  memory budget; counters = roundUp64(round(B/1.125)) (bloom-dbg.cc:365-367) */
 	uint64_t counters;   /* if non-zero, use exactly this many counters instead of bloom_bytes (-i, tests) */
-	const char* spaced_seed; /* -s / -K / --qr-seed mask; NULL or "" = none.  Not supported yet: ABG_EINVAL */
+	const char* spaced_seed; /* -s / -K / --qr-seed pattern (MaskedKmer::mask(), BloomDBG/MaskedKmer.h:25-48): k
+	                          * characters '0'/'1', beginning and ending with '1', symmetric; NULL or "" = none.
+	                          * Only read during abg_create. */
 	int32_t device;      /* HIP device ordinal */
 	int32_t verbose;
 	/* tuning; 0 = default */

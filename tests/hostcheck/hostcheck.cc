@@ -52,11 +52,12 @@ typedef abg::Session<SerialBackend> Sess;
 extern "C" {
 
 void* hc_create(unsigned k, unsigned nh, unsigned kc, unsigned trim, uint64_t counters,
-    uint64_t insert_batch, unsigned claim_log2, uint64_t p2_first_batch)
+    uint64_t insert_batch, unsigned claim_log2, uint64_t p2_first_batch, const char* spaced_seed)
 {
 	Sess* s = new Sess();
 	abg_params p;
 	memset(&p, 0, sizeof p);
+	p.spaced_seed = spaced_seed;
 	p.k = k; p.num_hashes = nh; p.min_cov = kc; p.trim = trim; p.counters = counters;
 	s->cfg.claim_log2 = claim_log2 ? claim_log2 : 16;
 	s->cfg.insert_batch_kmers = insert_batch ? insert_batch : (1u << 16);

@@ -26,7 +26,7 @@ def strip_length_column(trace: bytes) -> bytes:
     return b"".join(b"\t".join(r.split(b"\t")[:1] + r.split(b"\t")[2:]) + b"\n" for r in trace.splitlines())
 
 
-@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed"])
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k48_K16", "k50_qr11"])
 def test_cli_reproduces_golden(name, tmp_path):
     g = GoldenCase(name)
     fa = tmp_path / "reads.fa"
@@ -46,7 +46,9 @@ def test_cli_reproduces_golden(name, tmp_path):
 def test_cli_option_errors(tmp_path):
     (tmp_path / "r.fa").write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
     for args, msg in ((["-k32", "r.fa"], b"missing mandatory option `-b'"), (["-b1M", "r.fa"], b"missing mandatory option `-k'"),
-                      (["-k32", "-b1M"], b"missing input file arguments"), (["-k32", "-b1M", "-K8", "r.fa"], b"not supported"),
+                      (["-k32", "-b1M"], b"missing input file arguments"), (["-k32", "-b1M", "-K17", "r.fa"], b"must be <= k/2"),
+                      (["-k32", "-b1M", "--qr-seed=7", "r.fa"], b"must be >= 11 and <= k/2"),
+                      (["-k32", "-b1M", "-s101", "r.fa"], b"spaced seed must be exactly k bits long"),
                       (["-k32", "-bXYZ", "r.fa"], b"invalid option")):
         r = subprocess.run([cli()] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)

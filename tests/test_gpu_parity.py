@@ -9,7 +9,7 @@ import pytest
 
 import oracle_binding as ob
 from abyss_amd import api, synth
-from util import GOLDEN, GoldenCase, contig_tuple
+from util import GOLDEN, GoldenCase, contig_tuple, mask_of
 
 pytestmark = pytest.mark.gpu
 
@@ -36,10 +36,10 @@ def test_counter_array_matches_reference_filter():
     assert np.array_equal(g.counters(), z["counters"])
 
 
-@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96"])
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96", "k48_K16", "k50_qr11"])
 def test_reproduces_reference_run(name):
     gc = GoldenCase(name)
-    g = api.BloomDBG(**gc.kwargs())
+    g = api.BloomDBG(spaced_seed=mask_of(gc), **gc.kwargs())
     assert g.size == gc.meta["counters"]
     g.load(gc.buf, gc.off)
     assert g.counting_stats()[1] == gc.meta["filtered_popcount"]
@@ -67,6 +67,43 @@ def test_matches_oracle(k, G, cov):
     ro, co = o.assemble(buf, off)
     rg, cg = g.assemble(buf, off)
     assert np.array_equal(ro, rg)
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in cg]
+    assert np.array_equal(o.visited(), g.visited())
+    assert o.assembly_counters() == g.assembly_counters()
+
+
+def _with_ns(ascii_matrix, rate, seed):
+    rng = np.random.default_rng(seed)
+    a = ascii_matrix.copy()
+    hit = rng.random(a.shape) < rate
+    hit[::2] = False
+    a[hit] = ord("N")
+    return a
+
+
+@pytest.mark.parametrize("k,mask,G", [
+    (40, api.spaced_seed_kmer_pair(40, 12), 60000),
+    (33, api.spaced_seed_kmer_pair(33, 11), 40000),
+    (64, api.spaced_seed_qr_pair(64, 23), 100000),       # BASELINE.json configs[3] in the small: --qr-seed
+    (100, api.spaced_seed_kmer_pair(100, 32), 40000),
+])
+def test_spaced_seed_matches_oracle(k, mask, G):
+    m1, m2 = synth.make_read_set(G, 35.0, err=0.01, genome_seed=k, read_seed=k + 1)
+    asc = _with_ns(synth.codes_to_ascii(np.concatenate([m1, m2])), 0.004, k)
+    buf, off = api.matrix_to_seqs(asc)
+    counters = 1 << 22
+    o = ob.Oracle(k, counters=counters, mask=mask.encode())
+    g = api.BloomDBG(k, counters=counters, spaced_seed=mask)
+    o.load(buf, off)
+    g.load(buf, off)
+    assert np.array_equal(o.counters(), g.counters())
+    po, ho = o.hash_seq(bytes(asc[1]))
+    pg, hg = g.hash_seq(bytes(asc[1]))
+    assert np.array_equal(po, pg) and np.array_equal(ho, hg)
+    ro, co = o.assemble(buf, off)
+    rg, cg = g.assemble(buf, off)
+    assert np.array_equal(ro, rg)
+    assert any(b"N" in c.seq for c in co)
     assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in cg]
     assert np.array_equal(o.visited(), g.visited())
     assert o.assembly_counters() == g.assembly_counters()

@@ -10,14 +10,14 @@ import pytest
 
 import oracle_binding as ob
 from abyss_amd import _lib, api, build, synth
-from util import GOLDEN, GoldenCase, contig_tuple, random_reads
+from util import GOLDEN, GoldenCase, contig_tuple, mask_of, random_reads
 
 
 class HostCheck:
-    def __init__(self, k, counters, num_hashes=4, min_cov=2, trim=None, insert_batch=0, claim_log2=0, p2_first=0):
+    def __init__(self, k, counters, num_hashes=4, min_cov=2, trim=None, insert_batch=0, claim_log2=0, p2_first=0, mask=None):
         l = C.CDLL(build.build_hostcheck())
         l.hc_create.restype = C.c_void_p
-        l.hc_create.argtypes = [C.c_uint] * 4 + [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64]
+        l.hc_create.argtypes = [C.c_uint] * 4 + [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.c_char_p]
         l.hc_destroy.argtypes = [C.c_void_p]
         l.hc_size.restype = C.c_uint64
         l.hc_size.argtypes = [C.c_void_p]
@@ -35,7 +35,8 @@ class HostCheck:
         l.hc_mod_check.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64]
         self.l = l
         self.k, self.num_hashes = k, num_hashes
-        self.h = l.hc_create(k, num_hashes, min_cov, k if trim is None else trim, counters, insert_batch, claim_log2, p2_first)
+        self.h = l.hc_create(k, num_hashes, min_cov, k if trim is None else trim, counters, insert_batch, claim_log2, p2_first,
+                               mask.encode() if mask else None)
         assert self.h
 
     def __del__(self):
@@ -114,12 +115,12 @@ def test_hash_stream_matches_reference_vectors():
         assert [[str(int(x)) for x in row] for row in h] == v["hashes"]
 
 
-@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96"])
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96", "k48_K16", "k50_qr11"])
 def test_device_logic_reproduces_reference_run(name):
     g = GoldenCase(name)
     kw = g.kwargs()
     hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
-                   claim_log2=16, p2_first=128)
+                   claim_log2=16, p2_first=128, mask=mask_of(g))
     hc.load(g.buf, g.off)
     assert hc.counting_stats()[1] == g.meta["filtered_popcount"]
     results, contigs = hc.assemble(g.buf, g.off)
@@ -142,6 +143,49 @@ def test_device_logic_matches_oracle(k, G):
     hc.load(buf, off)
     assert np.array_equal(o.counters(), hc.counters())
     assert o.counting_stats() == hc.counting_stats()
+    ro, co = o.assemble(buf, off)
+    rh, ch = hc.assemble(buf, off)
+    assert np.array_equal(ro, rh)
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
+    assert np.array_equal(o.visited(), hc.visited())
+    assert o.assembly_counters() == hc.assembly_counters()
+
+
+def _with_ns(ascii_matrix, rate, seed):
+    """Replace a fraction `rate` of the characters by 'N' (in half of the reads only, so that PASS 2
+    still sees plenty of pure-ACGT reads)."""
+    rng = np.random.default_rng(seed)
+    a = ascii_matrix.copy()
+    hit = rng.random(a.shape) < rate
+    hit[::2] = False
+    a[hit] = ord("N")
+    return a
+
+
+@pytest.mark.parametrize("k,mask,G", [
+    (40, api.spaced_seed_kmer_pair(40, 12), 15000),
+    (33, api.spaced_seed_kmer_pair(33, 11), 12000),          # odd k: the isCanonical tie quirk under a mask
+    (64, api.spaced_seed_qr_pair(64, 23), 15000),
+    (31, "1101101011110101010111101011011", 12000),          # -s with a dense pattern (symmetric)
+    (100, api.spaced_seed_kmer_pair(100, 32), 15000),
+])
+def test_spaced_seed_device_logic_matches_oracle(k, mask, G):
+    """Spaced seeds (-K / --qr-seed / -s): reads with 'N' under a '0' still yield k-mers in PASS 1
+    (RollingHashIterator.h:35-97), contigs shorter than 2k-1 can carry 'N' columns (pathToSeq)."""
+    assert mask == mask[::-1] and len(mask) == k
+    m1, m2 = synth.make_read_set(G, 35.0, err=0.01, genome_seed=k, read_seed=k + 1)
+    asc = _with_ns(synth.codes_to_ascii(np.concatenate([m1, m2])), 0.004, k)
+    buf, off = api.matrix_to_seqs(asc)
+    counters = 1 << 21
+    o = ob.Oracle(k, counters=counters, mask=mask.encode())
+    hc = HostCheck(k, counters, insert_batch=20000, claim_log2=14, p2_first=64, mask=mask)
+    o.load(buf, off)
+    hc.load(buf, off)
+    assert np.array_equal(o.counters(), hc.counters())
+    seq = bytes(asc[1])
+    po, ho = o.hash_seq(seq)
+    ph, hh = hc.hash_seq(seq)
+    assert np.array_equal(po, ph) and np.array_equal(ho, hh)
     ro, co = o.assemble(buf, off)
     rh, ch = hc.assemble(buf, off)
     assert np.array_equal(ro, rh)

@@ -44,6 +44,16 @@ class GoldenCase:
                     trim=o["trim"])
 
 
+def mask_of(g):
+    """Spaced seed of a golden case (SpacedSeed.h:18-75), or None."""
+    from abyss_amd import api
+    if "K" in g.opts:
+        return api.spaced_seed_kmer_pair(g.opts["k"], g.opts["K"])
+    if "qr" in g.opts:
+        return api.spaced_seed_qr_pair(g.opts["k"], g.opts["qr"])
+    return None
+
+
 def contig_tuple(c):
     return (c.contig_id, c.read_index, bytes(c.seq), c.coverage, c.redundant, c.left_ext, c.right_ext,
             c.left_code, c.right_code, c.seed_pos)
