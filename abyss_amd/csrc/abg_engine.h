@@ -351,9 +351,21 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 	// coop: called by all 64 lanes of a wavefront in lock step (HIP backend) or by one thread (serial)
 	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes, bool coop)
 	{
+		if (use_fast && fast) {
+			// the environment goes to fast memory as well (see walk_read): every lane of a
+			// cooperative caller stores the same values
+			WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
+			const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
+			*env = e;
+			env->fast = (char*)fast + a;
+			env->fast_bytes = fast_bytes - a;
+			env->coop = coop;
+			walk_read<NW>(*env, list[i], slot);
+			return;
+		}
 		WalkEnv<NW> env = e;
-		env.fast = use_fast ? fast : nullptr;
-		env.fast_bytes = fast_bytes;
+		env.fast = nullptr;
+		env.fast_bytes = 0;
 		env.coop = coop;
 		walk_read<NW>(env, list[i], slot);
 	}

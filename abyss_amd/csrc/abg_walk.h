@@ -450,20 +450,34 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 {
 	const Params& p = e.p;
 	const unsigned k = p.k;
-	SearchScratch<NW> sc;
+	// The search scratch and the path state are handed by reference to out-of-line functions, so
+	// they live in memory.  As locals that is per-lane scratch: 64 copies per cooperative wave
+	// and a 256-byte transaction per dword touched.  With fast memory (LDS) available they are
+	// carved out of it instead: one copy per wave, read by broadcast.
+	SearchScratch<NW> sc_local;
+	WalkState<NW> w_local;
+	SearchScratch<NW>* scp = &sc_local;
+	WalkState<NW>* wp = &w_local;
+	char* fast = (char*)e.fast;
+	uint32_t fast_bytes = e.fast_bytes;
+	if (fast) {
+		const uint32_t a = (uint32_t)((sizeof(SearchScratch<NW>) + 15) & ~15ull), b = (uint32_t)((sizeof(WalkState<NW>) + 15) & ~15ull);
+		scp = (SearchScratch<NW>*)fast;
+		wp = (WalkState<NW>*)(fast + a);
+		fast += a + b; fast_bytes -= a + b;
+	}
+	SearchScratch<NW>& sc = *scp;
+	WalkState<NW>& w = *wp;
 	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_cap = e.tb_cap;
 	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
 	sc.la = sc.la_local;
-	if (e.fast) {
-		// fast tier (LDS): lookAhead frames, then trueBranch keys and frames side by side
-		const uint32_t la_bytes = (uint32_t)((sizeof(LAFrame<NW>) * (FP_TRIM + 1) + 15) & ~15ull);
-		sc.la = (LAFrame<NW>*)e.fast;
-		char* rest = (char*)e.fast + la_bytes;
-		uint32_t cap = (e.fast_bytes - la_bytes) / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
-		sc.tbf_keys = (VKey*)rest;
-		sc.tbf = (TBFrame<NW>*)(rest + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
+	if (fast) {
+		// the rest of the fast tier: trueBranch keys and frames side by side
+		uint32_t cap = fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
+		sc.tbf_keys = (VKey*)fast;
+		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
@@ -476,7 +490,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 #endif
 	uint64_t total_steps = 0;
 
-	WalkState<NW> w;
 	w.lbuf = e.lbuf_pool + (uint64_t)slot * e.buf_cap;
 	w.rbuf = e.rbuf_pool + (uint64_t)slot * e.buf_cap;
 
