@@ -60,7 +60,7 @@ def load(path: str | None = None):
     if _lib is not None:
         return _lib
     if path is None:
-        path = build.LIB
+        path = os.environ.get("ABG_LIB") or build.LIB  # ABG_LIB: a differently tuned build (experiments)
         if not os.path.exists(path):
             build.build_lib()
     lib = C.CDLL(path)

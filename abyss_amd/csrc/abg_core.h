@@ -493,6 +493,41 @@ ABG_HD uint64_t wave_ballot(bool v) { return v ? 1 : 0; }
 ABG_HD bool wave_any(bool v) { return v; }
 #endif
 
+// A value that is the same in every lane of a cooperative wave, read back through lane 0 so that
+// the compiler knows it (scalar registers, scalar ALU); the identity for other callers.
+template <bool COOP> ABG_HD uint32_t uni32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (COOP) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+	return v;
+}
+template <bool COOP> ABG_HD uint64_t uni64(uint64_t v)
+{
+	return ((uint64_t)uni32<COOP>((uint32_t)(v >> 32)) << 32) | uni32<COOP>((uint32_t)v);
+}
+template <bool COOP, class T> ABG_HD T* uniptr(T* p) { return (T*)uni64<COOP>((uint64_t)p); }
+// a copy of the parameters whose fields the compiler knows to be wave-uniform
+template <bool COOP> ABG_HD Params uniform_params(const Params& p)
+{
+	Params u;
+	u.k = uni32<COOP>(p.k); u.nh = uni32<COOP>(p.nh); u.kc = uni32<COOP>(p.kc);
+	u.trim = uni32<COOP>(p.trim); u.nw = uni32<COOP>(p.nw);
+	u.mod.m = uni64<COOP>(p.mod.m); u.mod.magic = uni64<COOP>(p.mod.magic);
+	u.mod.shift = uni32<COOP>(p.mod.shift); u.mod.pow2 = uni32<COOP>(p.mod.pow2);
+	u.kmul = uni64<COOP>(p.kmul);
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		u.seed_k[b] = uni64<COOP>(p.seed_k[b]); u.seedrc_k[b] = uni64<COOP>(p.seedrc_k[b]);
+		u.seedrc_km1[b] = uni64<COOP>(p.seedrc_km1[b]); u.seed_km1[b] = uni64<COOP>(p.seed_km1[b]);
+	}
+#pragma unroll
+	for (int j = 0; j < MAX_NW; j++) u.care[j] = 0; // callers only use it without a spaced seed
+	u.mask = nullptr;
+	u.ident_fast = uni32<COOP>(p.ident_fast);
+	return u;
+}
+
 // 8-bit mask: which of eight canonical hashes does the solid filter contain
 // (CountingBloomFilter::contains, CountingBloomFilter.hpp:190-196: min over the H
 // counters >= threshold)?  Serial form: the probe positions of all k-mers (up to four
@@ -597,13 +632,22 @@ ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, co
 // (RollingBloomDBG.h:302-427): the k-mer shifted by one base with last (first) base
 // A,C,G,T in that order, present iff the solid filter contains it (vertex_exists,
 // :436-446).  The four neighbours' hashes are XOR deltas off one shifted state.
+// a[i] for a run-time i without indexing memory: keeps a table held in registers in registers
+ABG_HD uint64_t sel4(const uint64_t a[4], unsigned i)
+{
+	uint64_t r = a[0];
+	r = (i == 1) ? a[1] : r;
+	r = (i == 2) ? a[2] : r;
+	r = (i == 3) ? a[3] : r;
+	return r;
+}
 template <int NW>
 ABG_HD void neighbour_hashes(const Params& p, const Vtx<NW>& u, int sense, uint64_t fh4[4], uint64_t rh4[4])
 {
 	unsigned k = p.k;
 	if (sense == SENSE) {
 		unsigned out = kmer_get(u.s, 0);
-		uint64_t fb = srol1(u.fh) ^ p.seed_k[out];
+		uint64_t fb = srol1(u.fh) ^ sel4(p.seed_k, out);
 		uint64_t rb = sror1(u.rh ^ seed_of(3u - out));
 #pragma unroll
 		for (unsigned b = 0; b < 4; b++) {
@@ -613,7 +657,7 @@ ABG_HD void neighbour_hashes(const Params& p, const Vtx<NW>& u, int sense, uint6
 	} else {
 		unsigned out = kmer_get(u.s, k - 1);
 		uint64_t fb = sror1(u.fh ^ seed_of(out));
-		uint64_t rb = srol1(u.rh) ^ p.seedrc_k[out];
+		uint64_t rb = srol1(u.rh) ^ sel4(p.seedrc_k, out);
 #pragma unroll
 		for (unsigned b = 0; b < 4; b++) {
 			fh4[b] = fb ^ p.seed_km1[b];
@@ -702,6 +746,8 @@ struct SearchScratch {
 	VKey* tbf_keys;
 	uint32_t tbf_cap;
 	uint32_t overflow;     // set when a stack capacity was exceeded
+	uint32_t dbg_calls;    // profiling aid: out-of-line successor() calls and the clock ticks spent in them
+	uint64_t dbg_search;
 	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
 	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
 	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)

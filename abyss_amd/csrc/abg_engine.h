@@ -1097,7 +1097,7 @@ class Engine {
 				if (x[0] > best) { best = x[0]; bi = i; }
 			}
 			const uint64_t* x = &d[bi * 8ull];
-			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu tbnodes=%llu la=%llu succ=%llu | slowest: t=%.2fms steps=%llu tbnodes=%llu la=%llu succ=%llu tbcalls=%llu contigs=%llu st=%llu\n",
+			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu search_ticks=%llu search_calls=%llu succ=%llu | slowest: t=%.2fms steps=%llu tbnodes=%llu la=%llu succ=%llu tbcalls=%llu contigs=%llu st=%llu\n",
 			    what, nwalk, (unsigned long long)nn, sum_t / 1e5, (unsigned long long)sum_steps, (unsigned long long)sum_nodes,
 			    (unsigned long long)sum_la, (unsigned long long)sum_succ, x[0] / 1e5, (unsigned long long)x[1],
 			    (unsigned long long)x[2], (unsigned long long)x[3], (unsigned long long)x[4], (unsigned long long)x[5],

@@ -43,9 +43,15 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 // (k-mer x hash function) and a ballot classifies the 8 neighbours of the head; the
 // trueBranch on-stack test scans 64 frames at a time; atomics go through lane 0.
 // The walker's trueBranch stack (frames + keys) lives in WALK_LDS bytes of LDS.
-constexpr uint32_t WALK_LDS = 16384;
+#ifndef ABG_WALK_LDS
+#define ABG_WALK_LDS 16384
+#endif
+#ifndef ABG_WALK_WAVES
+#define ABG_WALK_WAVES 2 // wavefronts per SIMD the walker kernel is compiled for (register budget 512 / waves)
+#endif
+constexpr uint32_t WALK_LDS = ABG_WALK_LDS;
 template <class F>
-__global__ void __launch_bounds__(64, 2) k_walkers(F f, uint64_t n, unsigned long long* ticket)
+__global__ void __launch_bounds__(64, ABG_WALK_WAVES) k_walkers(F f, uint64_t n, unsigned long long* ticket)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[WALK_LDS];
 	// walks differ in length by orders of magnitude: waves draw candidates from a ticket

@@ -126,9 +126,14 @@ ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool coop)
 {
 	if (!coop || __lane_id() == 0) *p = v;
 }
+ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) *p = v;
+}
 #else
 ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool) { st_coherent(p, v); }
 ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool) { *p = v; }
+ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool) { *p = v; }
 ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
 ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool) { return atomic_min_u32(p, v); }
 ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool) { return atomic_add_u32(p, v); }
@@ -291,6 +296,11 @@ struct WalkState {
 	Vtx<NW> seed;
 	uint8_t* lbuf; uint8_t* rbuf;
 	uint32_t nl, nr;
+	// hand-over between walk_extend and walk_linear
+	Vtx<NW> head;     // last vertex of the path in the walking direction
+	VKey prev_key;    // identity of the vertex before it
+	uint32_t ext;     // vertices appended by this extendPath call so far
+	int32_t ins;      // LIN_INS: what the insertion of `head` into the visited set returned
 };
 template <int NW>
 ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
@@ -321,6 +331,133 @@ ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i)
 	return v;
 }
 
+// profiling aid (ABG_WALK_DEBUG): the 100 MHz wall clock, only read when a debug buffer is attached
+ABG_HD uint64_t dbg_clock(const uint64_t* dbg)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return dbg ? wall_clock64() : 0;
+#else
+	(void)dbg; return 0;
+#endif
+}
+// The unbranched stretch of extendPath as a loop of its own.  A step is "simple" when the head,
+// newly entered into the visited set, has exactly one neighbour on either side and the one
+// behind it is the vertex the path came from: then successor() answers at its level 0 in both
+// directions (ExtendPath.h:314-362) and the path grows by the one neighbour ahead.  The loop
+// keeps that state -- and wave-uniform copies of every parameter it reads -- in registers and
+// takes as many simple steps as it can; anything else (a branch, a dead end, a cycle, an entry of
+// an earlier contig, a claim of a lower-numbered walker, a full buffer) is handed back to
+// walk_extend, which runs the step as written in the reference.  Being out of line, the loop
+// has a register allocation of its own: the searches the general code calls do not spill into it.
+// Entered with w.head pushed but not yet entered into the visited set.
+enum { LIN_GENERAL = 0, // w.head is in the visited set; its step is not simple
+       LIN_INS = 1,     // inserting w.head returned w.ins (not WT_NEW); nothing else was done for it
+       LIN_DEFER = 2 }; // w.head collides with the claim of a lower-numbered walker
+template <int NW, bool COOP>
+ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir_in, const uint32_t owner_in,
+    const uint32_t contig_in, const uint32_t claim_id_in, const bool may_defer_in)
+{
+	const Params p = uniform_params<COOP>(e.p);
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(e.cnt);
+	WalkTab tab;
+	tab.hmin = uniptr<COOP>(e.tab.hmin); tab.hmax = uniptr<COOP>(e.tab.hmax); tab.meta = uniptr<COOP>(e.tab.meta);
+	tab.mask = uni64<COOP>(e.tab.mask);
+	uint32_t* claims = uniptr<COOP>(e.claims);
+	const uint32_t claim_mask = uni32<COOP>(e.claim_mask), buf_cap = uni32<COOP>(e.buf_cap);
+	const int dir = (int)uni32<COOP>((uint32_t)dir_in);
+	const uint32_t owner = uni32<COOP>(owner_in), contig = uni32<COOP>(contig_in), claim_id = uni32<COOP>(claim_id_in);
+	const bool may_defer = uni32<COOP>(may_defer_in ? 1u : 0u) != 0;
+	const int fsense = (dir == FORWARD) ? SENSE : ANTISENSE, bsense = (dir == FORWARD) ? ANTISENSE : SENSE;
+	uint8_t* buf = uniptr<COOP>(dir == FORWARD ? w.rbuf : w.lbuf);
+	uint32_t nbuf = uni32<COOP>(dir == FORWARD ? w.nr : w.nl);
+	uint32_t ext = uni32<COOP>(w.ext);
+	Vtx<NW> head;
+#pragma unroll
+	for (int j = 0; j < NW; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
+	head.fh = uni64<COOP>(w.head.fh); head.rh = uni64<COOP>(w.head.rh);
+	VKey prev_key;
+	prev_key.fh = uni64<COOP>(w.prev_key.fh); prev_key.rh = uni64<COOP>(w.prev_key.rh);
+	// The rolling-hash tables as named scalars: an array in registers that is indexed at run time
+	// (even through a chain of selects, which the optimiser folds back into an indexed load)
+	// would be demoted to per-lane scratch.
+	const uint64_t sk0 = p.seed_k[0], sk1 = p.seed_k[1], sk2 = p.seed_k[2], sk3 = p.seed_k[3];
+	const uint64_t rk0 = p.seedrc_k[0], rk1 = p.seedrc_k[1], rk2 = p.seedrc_k[2], rk3 = p.seedrc_k[3];
+	const uint64_t sm0 = p.seed_km1[0], sm1 = p.seed_km1[1], sm2 = p.seed_km1[2], sm3 = p.seed_km1[3];
+	const uint64_t rm0 = p.seedrc_km1[0], rm1 = p.seedrc_km1[1], rm2 = p.seedrc_km1[2], rm3 = p.seedrc_km1[3];
+	auto pick = [](unsigned i, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3) -> uint64_t {
+		return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+	};
+	const unsigned k = p.k;
+	uint32_t why;
+	int32_t ins = WT_NEW;
+	for (;;) {
+		// rolling states of the head shifted one base either way, before the incoming base is
+		// added (neighbour_hashes; NTC64 / NTC64L, nthash.hpp:242-304)
+		const unsigned out_s = kmer_get(head.s, 0), out_a = kmer_get(head.s, k - 1);
+		const uint64_t fb_s = srol1(head.fh) ^ pick(out_s, sk0, sk1, sk2, sk3);
+		const uint64_t rb_s = sror1(head.rh ^ seed_of(3u - out_s));
+		const uint64_t fb_a = sror1(head.fh ^ seed_of(out_a));
+		const uint64_t rb_a = srol1(head.rh) ^ pick(out_a, rk0, rk1, rk2, rk3);
+		// hashes of neighbour `b` in direction `sense`
+		auto nbr = [&](int sense, unsigned b, uint64_t& fh, uint64_t& rh) {
+			if (sense == SENSE) { fh = fb_s ^ seed_of(b); rh = rb_s ^ pick(b, rm0, rm1, rm2, rm3); }
+			else { fh = fb_a ^ pick(b, sm0, sm1, sm2, sm3); rh = rb_a ^ seed_of(3u - b); }
+		};
+		// probe round over the 8 neighbours (q < 4: behind, q >= 4: ahead), in flight while the
+		// head enters the visited set (ExtendPath.h:650-658)
+		uint8_t my_c = 255; bool my_active = false;
+		if (COOP) {
+			const unsigned lane = lane_id(), q = lane >> 3, i = lane & 7;
+			uint64_t fh, rh;
+			nbr(q < 4 ? bsense : fsense, q & 3u, fh, rh);
+			my_active = i < p.nh;
+			if (my_active) my_c = cnt[pos_i(p, rh < fh ? rh : fh, i)];
+		}
+		const VKey hkey = vtx_ident(p, head);
+		ins = (int32_t)uni32<COOP>((uint32_t)wt_insert(tab, wt_key(hkey), owner, contig, COOP));
+		if (ins != WT_NEW) { why = LIN_INS; break; }
+		if (claims) {
+			const uint64_t hm = hkey.fh < hkey.rh ? hkey.fh : hkey.rh; // the canonical hash (no spaced seed here)
+			uint32_t old = wu_atomic_min_u32(&claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask], claim_id, COOP);
+			if (uni32<COOP>(old) < claim_id && may_defer) { why = LIN_DEFER; break; }
+		}
+		unsigned m8 = 0xFFu;
+		if (COOP) {
+			const uint64_t bad = wave_ballot(my_active && my_c < p.kc);
+#pragma unroll
+			for (unsigned q = 0; q < 8; q++)
+				if ((bad >> (8 * q)) & 0xFFu) m8 &= ~(1u << q);
+		} else {
+			for (unsigned q = 0; q < 8; q++) {
+				uint64_t fh, rh;
+				nbr(q < 4 ? bsense : fsense, q & 3u, fh, rh);
+				if (!solid_contains(p, cnt, rh < fh ? rh : fh)) m8 &= ~(1u << q);
+			}
+		}
+		const unsigned bmask = m8 & 0xFu, fmask = m8 >> 4;
+		why = LIN_GENERAL;
+		if (bmask == 0 || (bmask & (bmask - 1)) || fmask == 0 || (fmask & (fmask - 1)) || nbuf >= buf_cap) break;
+		const unsigned bb = (bmask & 1u) ? 0u : (bmask & 2u) ? 1u : (bmask & 4u) ? 2u : 3u;
+		const unsigned fb = (fmask & 1u) ? 0u : (fmask & 2u) ? 1u : (fmask & 4u) ? 2u : 3u;
+		// look behind (extendPathBySingleVertex, ExtendPath.h:417-437): the one vertex behind must be the previous one
+		Vtx<NW> t = head;
+		kmer_shift(t.s, k, bsense, bb);
+		nbr(bsense, bb, t.fh, t.rh);
+		if (!key_equal(vtx_ident(p, t), prev_key)) break;
+		// path.push_back(v) / push_front(v)
+		wu_st_u8(&buf[nbuf], (uint8_t)fb, COOP);
+		nbuf++; ext++;
+		prev_key = hkey;
+		uint64_t nfh, nrh;
+		nbr(fsense, fb, nfh, nrh);
+		kmer_shift(head.s, k, fsense, fb);
+		head.fh = nfh; head.rh = nrh;
+	}
+	w.head = head; w.prev_key = prev_key; w.ext = ext; w.ins = ins;
+	if (dir == FORWARD) w.nr = nbuf; else w.nl = nbuf;
+	return why;
+}
+
 // extendPath (ExtendPath.h:620-706) with the ExtendPathParams of processRead
 // (bloom-dbg.h:845-850): trimLen = trim, fpTrim = 5, no length limit, lookBehind = true,
 // lookBehindStartVertex = false; extendPathBySingleVertex (:403-459) inlined.
@@ -333,14 +470,32 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	int other = (dir == FORWARD) ? REVERSE : FORWARD;
 	uint32_t n = w.nl + 1 + w.nr;
 	Vtx<NW> head = (dir == FORWARD) ? ws_vertex(p, w, n - 1) : ws_vertex(p, w, 0);
-	Vtx<NW> prev = head;
-	if (n > 1) prev = (dir == FORWARD) ? ws_vertex(p, w, n - 2) : ws_vertex(p, w, 1);
+	VKey prev_key = vtx_ident(p, head); // identity of the vertex before the head (the head itself when n == 1)
+	if (n > 1) prev_key = vtx_ident(p, (dir == FORWARD) ? ws_vertex(p, w, n - 2) : ws_vertex(p, w, 1));
 	uint32_t ext = 0;
 	bool look_behind = false;
 	bool pending = false; // the head was pushed but not yet entered into `visited`
 	const bool split = sc.coop && p.nh <= 8;
+	// runs of simple steps go to walk_linear (no spaced seed; cooperative probes hold up to 8 hash functions)
+	const bool lean = !p.mask && (p.nh <= 8 || !sc.coop);
+	int ins_given = -1; // walk_linear already inserted the head: what the insertion returned
 	int result;
 	for (;;) {
+		if (pending && lean) {
+			w.head = head; w.prev_key = prev_key; w.ext = ext;
+			const uint32_t why = sc.coop ? walk_linear<NW, true>(e, w, dir, owner, contig, claim_id, may_defer)
+			                             : walk_linear<NW, false>(e, w, dir, owner, contig, claim_id, may_defer);
+			head = w.head; prev_key = w.prev_key; ext = w.ext;
+			n = w.nl + 1 + w.nr;
+			if (why == LIN_DEFER) { *abort = WS_DEFERRED; return -1; }
+			if (why == LIN_INS) {
+				ins_given = w.ins;
+			} else {
+				*end_earlier = false; // the head was new to the table
+				look_behind = true;
+				pending = false;
+			}
+		}
 		Vtx<NW> t, v;
 		// both neighbourhoods of the head in one probe round (8 k-mers x H counters in flight)
 		uint64_t bfh[4], brh[4], ffh[4], frh[4];
@@ -363,7 +518,8 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		if (split) pr = probe8_issue(p, e.cnt, h8);
 		if (pending) {
 			// visited.insert(head), ExtendPath.h:650-658
-			int ins = wt_insert(e.tab, vtx_key(p, head), owner, contig, sc.coop);
+			int ins = ins_given >= 0 ? ins_given : wt_insert(e.tab, vtx_key(p, head), owner, contig, sc.coop);
+			ins_given = -1;
 			if (ins == WT_FULL) { *abort = WS_OVERFLOW; return -1; }
 			if (ins == WT_SAME_CONTIG) {
 				// a cycle: path.pop_back() / pop_front()
@@ -386,15 +542,23 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		// extendPathBySingleVertex (ExtendPath.h:403-459)
 		if (look_behind) {
 			result = successor_fast(p, head, other, bmask, bfh, brh, t);
-			if (result < 0) result = successor_m(p, e.cnt, head, other, p.trim, bmask, t, sc);
+			if (result < 0) {
+				const uint64_t t0 = dbg_clock(e.dbg);
+				result = successor_m(p, e.cnt, head, other, p.trim, bmask, t, sc);
+				if (e.dbg) { sc.dbg_search += dbg_clock(e.dbg) - t0; sc.dbg_calls++; }
+			}
 			if (result == ER_AMBI_OUT) { result = ER_AMBI_IN; break; }
 			if (n > 1) {
 				if (result == ER_DEAD_END) { result = ER_AMBI_IN; break; }
-				if (!vtx_equal(p, prev, t)) { result = ER_AMBI_IN; break; }
+				if (!key_equal(prev_key, vtx_ident(p, t))) { result = ER_AMBI_IN; break; }
 			}
 		}
 		result = successor_fast(p, head, dir, fmask, ffh, frh, v);
-		if (result < 0) result = successor_m(p, e.cnt, head, dir, p.trim, fmask, v, sc);
+		if (result < 0) {
+			const uint64_t t0 = dbg_clock(e.dbg);
+			result = successor_m(p, e.cnt, head, dir, p.trim, fmask, v, sc);
+			if (e.dbg) { sc.dbg_search += dbg_clock(e.dbg) - t0; sc.dbg_calls++; }
+		}
 		if (sc.overflow) { *abort = WS_OVERFLOW; return -1; }
 		if (result != ER_LENGTH_LIMIT) break;
 		// path.push_back(v) / push_front(v)
@@ -406,7 +570,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 			w.lbuf[w.nl++] = (uint8_t)kmer_get(v.s, 0);
 		}
 		n++; ext++;
-		prev = head;
+		prev_key = vtx_ident(p, head);
 		head = v;
 		pending = true;
 	}
@@ -481,6 +645,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
+	sc.dbg_search = 0; sc.dbg_calls = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -663,7 +828,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		const uint64_t t_end = 0;
 #endif
 		uint64_t* d = e.dbg + (uint64_t)c * 8;
-		d[0] = t_end - t_start; d[1] = total_steps; d[2] = 0; d[3] = 0;
+		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
 		d[4] = 0; d[5] = 0; d[6] = contig; d[7] = abort_status;
 	}
 }
