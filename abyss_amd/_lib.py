@@ -35,7 +35,8 @@ class Contig(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("insert_rounds", "walk_rounds", "candidates", "walked", "rewalked", "commit_breaks")]
+                ("insert_rounds", "walk_rounds", "candidates", "walked", "rewalked", "commit_breaks",
+                 "commit_rounds")]
 
 
 CONTIG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Contig))

@@ -38,6 +38,8 @@ struct Config {
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
 	uint64_t p2_first_batch = 4096;   // PASS 2 read batches grow geometrically from here
 	uint64_t p2_max_batch = 1ull << 21;
+	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
+	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
 };
 
@@ -651,6 +653,262 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 	sy.barrier();
 }
 
+// ---- parallel form of the ordered commit ---------------------------------------------
+// The sequential loop above decides, in read order: read c is skipped when all its k-mers are
+// visited; else each of its contigs is dropped when all its k-mers are visited (short ones: when
+// both end k-mers are in contigEndKmers) and otherwise inserted.  Every decision depends only
+// on the insertions made EARLIER in that order, so the decisions are the unique fixed point of
+//     T[bit]   = earliest commit position of an inserted contig holding the bit
+//     visited  = every bit of the read/contig was set before the range, or T[bit] < own position
+//     inserted = read not visited, contig not dropped
+// and can be found by iterating from "every contig is inserted": compute T with one atomicMin
+// per (k-mer, hash), re-decide everything in parallel, repeat while a decision changed.  A
+// contig that turns out to be dropped was, by definition, not the earliest setter of any of
+// its bits, so removing it leaves T as it was: only a skipped read whose contigs would have
+// been inserted (or a dropped short contig) moves T, and the iteration typically settles in
+// one or two passes.  By induction on the commit position the fixed point is what the
+// sequential loop computes.  Costs 4 bytes per filter bit for T; without that memory the
+// engine uses the sequential kernel.
+constexpr uint32_t T_NEVER = 0xFFFFFFFFu;
+struct ParCommit {
+	Params p; Batch b;
+	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
+	ContigRec* recs; const uint8_t* pool; uint8_t* result;
+	const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff; const uint8_t* read_flag;
+	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
+	uint32_t* T;           // [filter bits] time stamps
+	WalkTab cend;          // contigEndKmers (bloom-dbg.h:992), owner 0
+	WalkTab tcend;         // end k-mers of this range's inserted short contigs; meta = earliest position
+	uint32_t* off;         // [n + 1] commit position of each candidate's first contig
+	uint32_t* cnt;         // [n] scratch: records per candidate / ... (see the functors)
+	uint32_t* cnt2;        // [n]
+	uint64_t* cnt3;        // [n]
+	uint8_t* active;       // [n] the read is not visited at its turn
+	uint32_t* short_list;  // records of short contigs (unordered)
+	uint32_t* scal;        // [0] changed  [1] break candidate  [2] short_list length  [3] new contigEndKmers entries
+	uint32_t c_begin, c_end, brk;
+};
+ABG_HD bool pc_bit_before(const ParCommit& e, uint64_t h, uint32_t time)
+{
+	bool ok = true;
+	for (unsigned q = 0; q < e.p.nh; q++) {
+		uint64_t pos = pos_i(e.p, h, q);
+		bool set = ((e.vis32[pos >> 5] >> (pos & 31)) & 1u) != 0;
+		ok = ok & (set | (e.T[pos] < time));
+	}
+	return ok;
+}
+struct FPcCount { // records of each candidate whose walk completed
+	ParCommit e;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t c = e.c_begin + (uint32_t)i, n = 0;
+		if (e.status[c] == WS_COMPLETE)
+			for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) n++;
+		e.cnt[i] = n;
+	}
+};
+struct FPcStamp { // commit positions, the optimistic first assumption, the list of short contigs
+	ParCommit e;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t c = e.c_begin + (uint32_t)i;
+		if (e.status[c] != WS_COMPLETE) return;
+		uint32_t t = e.off[i];
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next, t++) {
+			ContigRec& rec = e.recs[ri];
+			rec.time = t;
+			const bool is_short = rec.len < e.p.k + FP_TRIM - 1;
+			rec.ins = (!e.read_flag[c] && (is_short || !rec.pre_redundant)) ? 1u : 0u;
+			if (is_short) e.short_list[atomic_add_u32(&e.scal[2], 1)] = ri;
+		}
+	}
+};
+struct FPcTimeMin { // T: one wave per candidate
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		uint32_t c = e.c_begin + (uint32_t)i;
+		if (e.status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+			const ContigRec& rec = e.recs[ri];
+			if (!rec.ins) continue;
+			const uint64_t* ch = e.kh + rec.seq_off;
+			const uint32_t cnk = rec.len - e.p.k + 1;
+			for (uint32_t j = lane; j < cnk; j += nlanes) {
+				uint64_t h = ch[j];
+				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(&e.T[pos_i(e.p, h, q)], rec.time);
+			}
+		}
+	}
+};
+// find-or-create an entry and lower its position (single caller: see FPcShort)
+ABG_HD void wt_upsert_min(const WalkTab& t, const VKey& key, uint64_t time)
+{
+	uint64_t s = wt_slot(t, key, 0);
+	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
+		uint64_t cur = t.hmin[s];
+		if (cur == WT_EMPTY) { t.hmin[s] = key.fh; t.hmax[s] = key.rh; t.meta[s] = time; return; }
+		if (cur == key.fh && t.hmax[s] == key.rh) { if (time < t.meta[s]) t.meta[s] = time; return; }
+	}
+}
+// The end k-mers of the short contigs, by ONE thread (there are few; concurrent insertion of the
+// same key would need a two-word atomic).  mode 0: positions of the ones assumed inserted go
+// into tcend; mode 1 (after the decisions): the inserted ones before the break enter
+// contigEndKmers for good.
+struct FPcShort {
+	ParCommit e; uint32_t mode;
+	ABG_HDN void operator()(uint64_t, uint32_t) const
+	{
+		const uint32_t n = e.scal[2];
+		uint32_t added = 0;
+		for (uint32_t i = 0; i < n; i++) {
+			const ContigRec& rec = e.recs[e.short_list[i]];
+			if (!rec.ins) continue;
+			if (mode == 1 && rec.cand >= e.brk) continue;
+			const uint8_t* seq = e.pool + rec.seq_off;
+			VKey k1 = canonical_end_key(e.p, seq), k2 = canonical_end_key(e.p, seq + rec.len - e.p.k);
+			if (mode == 0) {
+				wt_upsert_min(e.tcend, k1, rec.time);
+				wt_upsert_min(e.tcend, k2, rec.time);
+			} else {
+				int a = wt_insert(e.cend, k1, 0, 0), b = wt_insert(e.cend, k2, 0, 0);
+				added += (a == WT_NEW) + (b == WT_NEW);
+				if (a == WT_FULL || b == WT_FULL) e.scal[4] = 1;
+			}
+		}
+		if (mode == 1) e.scal[3] = added;
+	}
+};
+ABG_HD bool pc_end_before(const ParCommit& e, const VKey& key, uint32_t time)
+{
+	if (wt_find(e.cend, key, 0) != WT_EMPTY) return true;
+	uint64_t s = wt_find(e.tcend, key, 0);
+	return s != WT_EMPTY && e.tcend.meta[s] < (uint64_t)time;
+}
+struct FPcDecide { // one wave per candidate: re-decide the read and its contigs against T
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		const unsigned k = e.p.k;
+		bool visited = e.read_flag[c] != 0;
+		if (!visited) {
+			const uint32_t nk = e.b.len[e.cand_read[c]] - k + 1;
+			const uint64_t* rh = e.rkh + e.rkoff[c];
+			const uint32_t t0 = e.off[i];
+			bool mine = true;
+			for (uint32_t j = lane; j < nk; j += nlanes) mine = mine & pc_bit_before(e, rh[j], t0);
+			visited = wave_all_lanes(mine, nlanes);
+		}
+		if (lane == 0) e.active[i] = visited ? 0 : 1;
+		if (e.status[c] != WS_COMPLETE) return;
+		bool changed = false;
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+			ContigRec& rec = e.recs[ri];
+			uint32_t ins = 0;
+			if (!visited) {
+				bool red;
+				if (rec.len < k + FP_TRIM - 1) {
+					// short contigs: exact set of canonical end k-mers (bloom-dbg.h:576-584)
+					const uint8_t* seq = e.pool + rec.seq_off;
+					red = pc_end_before(e, canonical_end_key(e.p, seq), rec.time) &&
+					      pc_end_before(e, canonical_end_key(e.p, seq + rec.len - k), rec.time);
+				} else if (rec.pre_redundant) {
+					red = true;
+				} else {
+					const uint64_t* ch = e.kh + rec.seq_off;
+					const uint32_t cnk = rec.len - k + 1;
+					bool mine = true;
+					for (uint32_t j = lane; j < cnk; j += nlanes) mine = mine & pc_bit_before(e, ch[j], rec.time);
+					red = wave_all_lanes(mine, nlanes);
+				}
+				ins = red ? 0u : 1u;
+			}
+			// Does the change move T?  A long contig dropped because all its bits were set earlier
+			// was not the earliest setter of any bit that matters, and neither is a contig of a
+			// skipped read unless some unset bit carries its own position: then T, and with it every
+			// other decision, stays as it is.  Anything else calls for another pass.
+			if (ins != rec.ins) {
+				bool moves = true;
+				if (rec.ins && rec.len >= k + FP_TRIM - 1) {
+					moves = false;
+					if (visited) {
+						const uint64_t* ch = e.kh + rec.seq_off;
+						const uint32_t cnk = rec.len - k + 1;
+						bool mine = false;
+						for (uint32_t j = lane; j < cnk; j += nlanes)
+							for (unsigned q = 0; q < e.p.nh; q++) {
+								uint64_t pos = pos_i(e.p, ch[j], q);
+								mine = mine | (e.T[pos] == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
+							}
+						moves = !wave_all_lanes(!mine, nlanes);
+					}
+				}
+				changed = changed | moves;
+			}
+			if (lane == 0) rec.ins = ins;
+		}
+		if (changed && lane == 0) e.scal[0] = 1;
+	}
+};
+struct FPcBreak { // first candidate that is needed but has no result
+	ParCommit e;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t c = e.c_begin + (uint32_t)i;
+		if (e.active[i] && e.status[c] != WS_COMPLETE) atomic_min_u32(&e.scal[1], c);
+	}
+};
+struct FPcApply { // one wave per candidate before the break: results, visited bits, per-candidate totals
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		if (c >= e.brk) { if (lane == 0) { e.cnt[i] = 0; e.cnt2[i] = 0; e.cnt3[i] = 0; } return; }
+		const uint64_t r = e.cand_read[c];
+		uint32_t nrec = 0, nins = 0; uint64_t bases = 0;
+		if (!e.active[i]) {
+			if (lane == 0) e.result[r] = RR_ALL_KMERS_VISITED;
+		} else {
+			if (lane == 0) e.result[r] = RR_GENERATED_CONTIGS;
+			for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+				ContigRec& rec = e.recs[ri];
+				nrec++;
+				if (lane == 0) rec.redundant = rec.ins ? 0 : 1;
+				if (!rec.ins) continue;
+				nins++; bases += rec.len;
+				// addKmersToBloom (bloom-dbg.h:79-90)
+				const uint64_t* ch = e.kh + rec.seq_off;
+				const uint32_t cnk = rec.len - e.p.k + 1;
+				for (uint32_t j = lane; j < cnk; j += nlanes) {
+					uint64_t h = ch[j];
+					for (unsigned q = 0; q < e.p.nh; q++) {
+						uint64_t pos = pos_i(e.p, h, q);
+						atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
+					}
+				}
+			}
+		}
+		if (lane == 0) { e.cnt[i] = nrec; e.cnt2[i] = nins; e.cnt3[i] = bases; }
+	}
+};
+struct FPcWrite { // commit order of the records and the contig ids (off = record offsets, cnt2 = id offsets)
+	ParCommit e; uint32_t* order; uint32_t order_base; uint64_t id_base;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		if (c >= e.brk || !e.active[i]) return;
+		uint32_t o = order_base + e.cnt[i];
+		uint64_t id = id_base + e.cnt2[i];
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+			ContigRec& rec = e.recs[ri];
+			order[o++] = ri;
+			if (rec.ins) rec.contig_id = id++;
+		}
+	}
+};
+
 // ================================================================== Engine
 // Backend concept:
 //   void* alloc(size_t); void free(void*); void memset(void*, int, size_t);
@@ -702,6 +960,7 @@ class Engine {
 		be_.free(cnt_); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
+		if (T_) be_.free(T_);
 		free_insert();
 		free_walk();
 	}
@@ -762,7 +1021,7 @@ class Engine {
 		be_.free(result_d);
 	}
 
-	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0; };
+	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0; };
 	Stats stats() const { return stats_; }
 
   private:
@@ -776,6 +1035,8 @@ class Engine {
 	uint64_t* scal_ = nullptr;
 	Cascade casc_{ nullptr, 0, 0 };
 	MaskTab* mask_d_ = nullptr;
+	uint32_t* T_ = nullptr; // parallel commit: time stamp per filter bit
+	bool use_par_commit() const { return cfg_.par_commit && m_ * 4ull <= cfg_.par_commit_max_bytes; }
 	Counters counters_;
 	Stats stats_;
 	uint64_t last_rounds_ = 0;
@@ -1015,6 +1276,104 @@ class Engine {
 		return cs.break_at;
 	}
 
+	// The same commit as a parallel fixed-point computation (see ParCommit).
+	template <int NW>
+	uint32_t commit_par(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d,
+	    uint8_t* result_d, uint64_t* rkoff_d, uint32_t c_begin, uint32_t c_end)
+	{
+		const uint32_t n = c_end - c_begin;
+		uint32_t nrec = 0, nord = 0;
+		be_.d2h(&nrec, rec_used_, 4);
+		be_.d2h(&nord, order_n_, 4);
+		nrec = std::min(nrec, rec_cap_);
+		{
+			uint64_t need = cend_count_ + 2ull * (nrec - std::min(nord, rec_cap_));
+			while (need * 2 > cend_.mask + 1) grow_cend();
+		}
+		if (!T_) T_ = (uint32_t*)be_.alloc(m_ * 4ull);
+		{
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
+			be_.launch_wave(n, f, "precommit");
+		}
+		ParCommit e;
+		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
+		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
+		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_;
+		e.c_begin = c_begin; e.c_end = c_end; e.brk = c_end;
+		e.off = (uint32_t*)be_.alloc((n + 1ull) * 4); e.cnt = (uint32_t*)be_.alloc(n * 4ull + 4);
+		e.cnt2 = (uint32_t*)be_.alloc(n * 4ull + 4); e.cnt3 = (uint64_t*)be_.alloc(n * 8ull + 8);
+		e.active = (uint8_t*)be_.alloc(n + 8ull); e.short_list = (uint32_t*)be_.alloc(nrec * 4ull + 4);
+		e.scal = (uint32_t*)be_.alloc(64);
+		uint32_t scal_h[8] = { 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0 };
+		be_.h2d(e.scal, scal_h, sizeof scal_h);
+		e.tcend = WalkTab{ nullptr, nullptr, nullptr, 0 };
+		// commit positions
+		std::vector<uint32_t> c1(n), c2(n), off(n + 1ull);
+		{ FPcCount f{ e }; be_.launch(n, f, "pc_count"); }
+		be_.d2h(c1.data(), e.cnt, n * 4ull);
+		off[0] = 0;
+		for (uint32_t i = 0; i < n; i++) off[i + 1] = off[i] + c1[i];
+		be_.h2d(e.off, off.data(), (n + 1ull) * 4);
+		{ FPcStamp f{ e }; be_.launch(n, f, "pc_stamp"); }
+		be_.d2h(scal_h, e.scal, sizeof scal_h);
+		const uint32_t nshort = scal_h[2];
+		if (nshort) {
+			uint32_t log2 = 4;
+			while ((1ull << log2) < 4ull * nshort) log2++;
+			alloc_tab(e.tcend, log2);
+		}
+		// the fixed point
+		for (uint32_t round = 0;; round++) {
+			be_.memset(e.T, 0xFF, m_ * 4ull);
+			if (nshort) {
+				be_.memset(e.tcend.hmin, 0xFF, (e.tcend.mask + 1) * 8);
+				FPcShort f{ e, 0 };
+				be_.launch(1, f, "pc_short");
+			}
+			be_.memset(e.scal, 0, 4);
+			{ FPcTimeMin f{ e }; be_.launch_wave(n, f, "pc_timemin"); }
+			{ FPcDecide f{ e }; be_.launch_wave(n, f, "pc_decide"); }
+			be_.d2h(scal_h, e.scal, 4);
+			stats_.commit_rounds++;
+			if (!scal_h[0]) break;
+		}
+		{ FPcBreak f{ e }; be_.launch(n, f, "pc_break"); }
+		be_.d2h(scal_h, e.scal, sizeof scal_h);
+		const uint32_t brk = std::min(scal_h[1], c_end);
+		e.brk = brk;
+		{ FPcApply f{ e }; be_.launch_wave(n, f, "pc_apply"); }
+		if (nshort) { FPcShort f{ e, 1 }; be_.launch(1, f, "pc_short"); }
+		// commit order, contig ids, counters
+		std::vector<uint64_t> c3(n);
+		std::vector<uint8_t> act(n);
+		be_.d2h(c1.data(), e.cnt, n * 4ull);
+		be_.d2h(c2.data(), e.cnt2, n * 4ull);
+		be_.d2h(c3.data(), e.cnt3, n * 8ull);
+		be_.d2h(act.data(), e.active, n);
+		be_.d2h(scal_h, e.scal, sizeof scal_h);
+		if (scal_h[4]) { fprintf(stderr, "abyss_amd: contigEndKmers table overflowed\n"); abort(); }
+		uint32_t orec = 0; uint64_t oid = 0, bases = 0, visited = 0;
+		for (uint32_t i = 0; i < n && c_begin + i < brk; i++) {
+			uint32_t r = c1[i], q = c2[i];
+			c1[i] = orec; c2[i] = (uint32_t)oid;
+			orec += r; oid += q; bases += c3[i];
+			if (!act[i]) visited++;
+		}
+		be_.h2d(e.cnt, c1.data(), n * 4ull);
+		be_.h2d(e.cnt2, c2.data(), n * 4ull);
+		{ FPcWrite f{ e, order_, nord, counters_.contig_id }; be_.launch(n, f, "pc_write"); }
+		nord += orec;
+		be_.h2d(order_n_, &nord, 4);
+		counters_.contig_id += oid;
+		counters_.bases_assembled += bases;
+		counters_.visited_reads += visited;
+		cend_count_ += scal_h[3];
+		if (nshort) free_tab(e.tcend);
+		be_.free(e.off); be_.free(e.cnt); be_.free(e.cnt2); be_.free(e.cnt3); be_.free(e.active);
+		be_.free(e.short_list); be_.free(e.scal);
+		return brk;
+	}
+
 	// hashes + coverage of the contig records produced since the last call (parallel)
 	template <int NW>
 	void prep_new_records(uint32_t& prepped)
@@ -1168,7 +1527,8 @@ class Engine {
 					prep_new_records<NW>(prepped);
 				}
 				// stage 3: ordered commit as far as the results allow
-				uint32_t next = commit<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc);
+				uint32_t next = use_par_commit() ? commit_par<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc)
+				                                 : commit<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc);
 				if (next < nc) {
 					stats_.breaks++;
 					uint32_t st = 0;

@@ -434,7 +434,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 	out->candidates = s.candidates;
 	out->walked = s.walked;
 	out->rewalked = s.rewalked;
-	out->commit_breaks = s.breaks;
+	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds;
 	return ABG_OK;
 }
 

@@ -203,7 +203,7 @@ enum { WT_NEW = 0, WT_SAME_CONTIG = 1, WT_EARLIER = 2, WT_FULL = 3 };
 // insert (key, owner) with contig number; returns WT_NEW (also when reviving a
 // tombstone), WT_SAME_CONTIG (already inserted by this contig walk: a cycle),
 // WT_EARLIER (inserted by an earlier contig of the same read; now re-tagged) or WT_FULL.
-ABG_HD int wt_insert(WalkTab& t, const VKey& key, uint32_t owner, uint32_t contig, bool coop = false)
+ABG_HD int wt_insert(const WalkTab& t, const VKey& key, uint32_t owner, uint32_t contig, bool coop = false)
 {
 	uint64_t s = wt_slot(t, key, owner);
 	for (uint64_t probes = 0; probes <= t.mask; probes++, s = (s + 1) & t.mask) {
@@ -261,6 +261,8 @@ struct ContigRec {
 	uint8_t pre_redundant; // settled ahead of the commit: every k-mer already visited
 	uint32_t coverage;    // filled by the commit
 	uint64_t contig_id;   // filled by the commit
+	uint32_t time;        // parallel commit: position of this contig in the commit order of its range
+	uint32_t ins;         // parallel commit: the contig is (assumed to be) inserted into the visited set
 };
 constexpr uint32_t REC_END = 0xFFFFFFFFu;
 

@@ -194,6 +194,42 @@ def test_spaced_seed_device_logic_matches_oracle(k, mask, G):
     assert o.assembly_counters() == hc.assembly_counters()
 
 
+def test_parallel_commit_needs_several_passes_and_stays_exact():
+    """A filter so small that false positives chain reads and contigs together: the fixed-point
+    commit needs more than one pass per batch here, and must still equal the sequential order."""
+    k, counters = 25, 1 << 19
+    m1, m2 = synth.make_read_set(30000, 40.0, err=0.02, genome_seed=30, read_seed=34)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    o = ob.Oracle(k, counters=counters)
+    hc = HostCheck(k, counters, insert_batch=20000, claim_log2=14, p2_first=64)
+    o.load(buf, off)
+    hc.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    rh, ch = hc.assemble(buf, off)
+    st = hc.stats()
+    assert st["commit_rounds"] > st["walk_rounds"]
+    assert np.array_equal(ro, rh)
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
+    assert np.array_equal(o.visited(), hc.visited())
+    assert o.assembly_counters() == hc.assembly_counters()
+
+
+def test_ordered_commit_kernel_still_exact(monkeypatch):
+    """ABG_PAR_COMMIT=0 selects the single-workgroup ordered commit (the fallback when the time
+    stamps of the parallel form do not fit in memory)."""
+    monkeypatch.setenv("ABG_PAR_COMMIT", "0")
+    g = GoldenCase("k40_mixed")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, p2_first=128)
+    hc.load(g.buf, g.off)
+    results, contigs = hc.assemble(g.buf, g.off)
+    assert hc.stats()["commit_rounds"] == 0
+    assert api.format_fasta(contigs, g.ids) == g.fasta
+    assert api.format_read_log(results, g.ids) == g.readlog
+    assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
 def test_saturating_counters_and_duplicate_kmers():
     # heavy duplication: 300 copies of the same read saturate counters at 255
     # (CountingBloomFilter.hpp:146-149); homopolymers give runs of identical k-mers
