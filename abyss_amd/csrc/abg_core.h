@@ -930,6 +930,151 @@ ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned m
 	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
 	return ER_LENGTH_LIMIT;
 }
+// The rolling-hash tables as named scalars, for loops that must stay in registers: an array
+// held in registers that is indexed at run time -- even through a chain of selects, which the
+// optimiser folds back into an indexed load -- is demoted to per-lane scratch memory.
+struct SeedTabs { uint64_t sk0, sk1, sk2, sk3, rk0, rk1, rk2, rk3, sm0, sm1, sm2, sm3, rm0, rm1, rm2, rm3; };
+ABG_HD SeedTabs seed_tabs(const Params& p)
+{
+	SeedTabs t;
+	t.sk0 = p.seed_k[0]; t.sk1 = p.seed_k[1]; t.sk2 = p.seed_k[2]; t.sk3 = p.seed_k[3];
+	t.rk0 = p.seedrc_k[0]; t.rk1 = p.seedrc_k[1]; t.rk2 = p.seedrc_k[2]; t.rk3 = p.seedrc_k[3];
+	t.sm0 = p.seed_km1[0]; t.sm1 = p.seed_km1[1]; t.sm2 = p.seed_km1[2]; t.sm3 = p.seed_km1[3];
+	t.rm0 = p.seedrc_km1[0]; t.rm1 = p.seedrc_km1[1]; t.rm2 = p.seedrc_km1[2]; t.rm3 = p.seedrc_km1[3];
+	return t;
+}
+ABG_HD uint64_t pick4(unsigned i, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+// rolling state of `v` shifted one base in direction `sense`, before the incoming base is added
+// (the part of neighbour_hashes the four neighbours share)
+template <int NW>
+ABG_HD void nbr_base(const SeedTabs& t, const Vtx<NW>& v, unsigned k, int sense, uint64_t& fb, uint64_t& rb)
+{
+	if (sense == SENSE) {
+		const unsigned out = kmer_get(v.s, 0);
+		fb = srol1(v.fh) ^ pick4(out, t.sk0, t.sk1, t.sk2, t.sk3);
+		rb = sror1(v.rh ^ seed_of(3u - out));
+	} else {
+		const unsigned out = kmer_get(v.s, k - 1);
+		fb = sror1(v.fh ^ seed_of(out));
+		rb = srol1(v.rh) ^ pick4(out, t.rk0, t.rk1, t.rk2, t.rk3);
+	}
+}
+// hashes of the neighbour with base b
+ABG_HD void nbr_hash(const SeedTabs& t, int sense, uint64_t fb, uint64_t rb, unsigned b, uint64_t& fh, uint64_t& rh)
+{
+	if (sense == SENSE) { fh = fb ^ seed_of(b); rh = rb ^ pick4(b, t.rm0, t.rm1, t.rm2, t.rm3); }
+	else { fh = fb ^ pick4(b, t.sm0, t.sm1, t.sm2, t.sm3); rh = rb ^ seed_of(3u - b); }
+}
+
+// trueBranch for the common shape of a real branch: a chain.  While every vertex reached has
+// exactly one neighbour ahead, trueBranch's recursion (ExtendPath.h:174-244) is a straight
+// descent that answers true as soon as it meets a vertex of the chain again (visited.find) or
+// gets `trim` edges deep -- no backtracking, no direction change, no lookAhead.  This follows
+// up to four such chains (the branches of `u` in direction `dir` named by `mask`) at once, 16
+// lanes each, so that one probe round trip advances all of them; a cooperative caller's
+// successor() thereby pays the depth of one branch instead of the sum over the branches, and
+// pays it without frame traffic.  Branches proven true are returned in true_mask; any other
+// outcome (a vertex with no or several neighbours ahead, more than four hash functions, a
+// spaced seed, chains longer than the key space) is left to the general search.
+template <int NW, bool COOP>
+ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restrict__ cnt_in, const Vtx<NW>& u,
+    const int dir_in, const unsigned trim_in, const unsigned mask_in, SearchScratch<NW>& sc)
+{
+	if (p_in.mask || p_in.nh > 4) return 0;
+	const Params p = uniform_params<COOP>(p_in);
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
+	const int dir = (int)uni32<COOP>((uint32_t)dir_in);
+	const unsigned trim = uni32<COOP>(trim_in), mask = uni32<COOP>(mask_in);
+	const int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
+	const SeedTabs tabs = seed_tabs(p);
+	// the fast tier of the trueBranch stack is idle here: it holds the chains' vertex identities
+	VKey* const keys = uniptr<COOP>(sc.tbf_keys);
+	const uint32_t key_space = (uint32_t)(((char*)uniptr<COOP>(sc.tbf + sc.tbf_cap) - (char*)keys) / sizeof(VKey));
+	const uint32_t per_chain = key_space / 4;
+	if (!keys || trim > per_chain) return 0;
+	const unsigned lane = COOP ? lane_id() : 0u;
+	const unsigned ngroups = COOP ? 4u : 1u;
+	unsigned true_mask = 0;
+	// serial callers take the branches one after the other (group 0); cooperative ones all at once
+	for (unsigned first = 0; first < 4; first += ngroups) {
+		const unsigned grp = COOP ? lane >> 4 : 0u, sub = COOP ? lane & 15u : 0u;
+		// the branch of this group: the (first + grp)-th set bit of mask
+		unsigned my_b = 4, seen = 0;
+#pragma unroll
+		for (unsigned b = 0; b < 4; b++)
+			if ((mask >> b) & 1u) { if (seen == first + grp) my_b = b; seen++; }
+		if (COOP ? first >= seen : my_b >= 4) break;
+		bool active = my_b < 4;
+		bool is_true = false;
+		Vtx<NW> v = u;
+		if (active) {
+			uint64_t fb, rb, fh, rh;
+			nbr_base(tabs, u, p.k, sense, fb, rb);
+			nbr_hash(tabs, sense, fb, rb, my_b, fh, rh);
+			v = make_neighbour(p, u, sense, my_b, fh, rh);
+		}
+		VKey* const mykeys = keys + (uint64_t)grp * per_chain;
+		unsigned depth = 0;
+		while (COOP ? wave_any(active) : active) {
+			if (active) {
+				const VKey key = vtx_ident(p, v);
+				// visited.find(v): the vertices of this chain so far
+				bool hit = false;
+				for (unsigned i = sub; i < depth; i += (COOP ? 16u : 1u)) hit = hit | key_equal(mykeys[i], key);
+				if (COOP) hit = ((wave_ballot(hit) >> (16 * grp)) & 0xFFFFull) != 0;
+				if (hit || depth >= trim) { is_true = true; active = false; }
+				else {
+					if (sub == 0) mykeys[depth] = key;
+					// the neighbours ahead: lane (b, i) of the group probes hash i of neighbour b
+					uint64_t fb, rb;
+					nbr_base(tabs, v, p.k, sense, fb, rb);
+					unsigned cm = 0;
+					if (COOP) {
+						const unsigned b = sub >> 2, i = sub & 3u;
+						uint64_t fh, rh;
+						nbr_hash(tabs, sense, fb, rb, b, fh, rh);
+						bool bad = false;
+						if (i < p.nh) bad = cnt[pos_i(p, rh < fh ? rh : fh, i)] < p.kc;
+						const unsigned gb = (unsigned)((wave_ballot(bad) >> (16 * grp)) & 0xFFFFull);
+#pragma unroll
+						for (unsigned q = 0; q < 4; q++) if (((gb >> (4 * q)) & 0xFu) == 0) cm |= 1u << q;
+					} else {
+						for (unsigned q = 0; q < 4; q++) {
+							uint64_t fh, rh;
+							nbr_hash(tabs, sense, fb, rb, q, fh, rh);
+							if (solid_contains(p, cnt, rh < fh ? rh : fh)) cm |= 1u << q;
+						}
+					}
+					if (cm == 0 || (cm & (cm - 1))) active = false; // not a chain: the general search decides
+					else {
+						const unsigned c = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u;
+						uint64_t fh, rh;
+						nbr_hash(tabs, sense, fb, rb, c, fh, rh);
+						v = make_neighbour(p, v, sense, c, fh, rh);
+						depth++;
+					}
+				}
+			}
+		}
+		if (COOP) {
+			const uint64_t tb = wave_ballot(is_true && sub == 0);
+#pragma unroll
+			for (unsigned g = 0; g < 4; g++) {
+				if (!((tb >> (16 * g)) & 1ull)) continue;
+				// which branch was group g's?
+				unsigned seen2 = 0;
+#pragma unroll
+				for (unsigned b = 0; b < 4; b++)
+					if ((mask >> b) & 1u) { if (seen2 == first + g) true_mask |= 1u << b; seen2++; }
+			}
+		} else if (is_true) true_mask |= 1u << my_b;
+	}
+	return true_mask;
+}
+
 // (The neighbour hashes are recomputed here rather than passed in: an array handed to this
 // out-of-line function would have to live in memory at every call site, i.e. in the per-lane
 // scratch of the unbranched walking loop.)
@@ -950,12 +1095,15 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	// single true branch, i.e. the loop's LENGTH_LIMIT answer.  Only when no edge is true at
 	// `trim` do the lower levels decide, and the loop below is run as written.
 	if (trim > 1 && (mask & (mask - 1))) {
+		// branches that are plain chains are settled together (see chain_true_branches)
+		const unsigned chain_true = sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
+		                                    : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc);
 		unsigned tb = 0;
 		Vtx<NW> last = u;
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
-			if (true_branch(p, cnt, u, w, dir, trim, sc)) {
+			if (((chain_true >> b) & 1u) || true_branch(p, cnt, u, w, dir, trim, sc)) {
 				last = w;
 				if (++tb >= 2) break;
 			}

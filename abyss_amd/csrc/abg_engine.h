@@ -25,9 +25,9 @@ struct Config {
 	uint32_t cascade_levels = 0;      // > 0: HashAgnosticCascadingBloom of that many levels instead of counters
 	std::string spaced_seed;          // k characters of '0'/'1', or empty (MaskedKmer::mask())
 	// tuning (defaults sized for one MI355X; overridable through abg_params / env)
-	uint64_t insert_batch_kmers = 1ull << 25; // k-mer ops per ordered-insert batch
-	uint32_t claim_log2 = 28;         // PASS 1 claim slots per table (x2 tables, 8 B each)
-	uint32_t drain_threshold = 1u << 17; // pending ops at or below which the retry tail runs in one workgroup
+	uint64_t insert_batch_kmers = 1ull << 24; // k-mer ops per ordered-insert batch (a genome k-mer then recurs ~once per batch at 50x)
+	uint32_t claim_log2 = 30;         // PASS 1 claim slots per table (x2 tables, 8 B each: 16 GiB; false conflicts fall with the load)
+	uint32_t drain_threshold = 1u << 12; // pending ops at or below which the retry tail runs in one workgroup
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
 	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
