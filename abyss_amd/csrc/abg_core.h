@@ -522,11 +522,23 @@ template <bool COOP> ABG_HD Params uniform_params(const Params& p)
 		u.seedrc_km1[b] = uni64<COOP>(p.seedrc_km1[b]); u.seed_km1[b] = uni64<COOP>(p.seed_km1[b]);
 	}
 #pragma unroll
-	for (int j = 0; j < MAX_NW; j++) u.care[j] = 0; // callers only use it without a spaced seed
-	u.mask = nullptr;
+	for (int j = 0; j < MAX_NW; j++) u.care[j] = uni64<COOP>(p.care[j]);
+	u.mask = uniptr<COOP>(p.mask);
 	u.ident_fast = uni32<COOP>(p.ident_fast);
 	return u;
 }
+
+// cooperative callers work on the uniform copy, the others on the original
+template <bool COOP> struct ParamsView {
+	Params v;
+	ABG_HD explicit ParamsView(const Params& p) : v(uniform_params<true>(p)) {}
+	ABG_HD const Params& get() const { return v; }
+};
+template <> struct ParamsView<false> {
+	const Params& r;
+	ABG_HD explicit ParamsView(const Params& p) : r(p) {}
+	ABG_HD const Params& get() const { return r; }
+};
 
 // 8-bit mask: which of eight canonical hashes does the solid filter contain
 // (CountingBloomFilter::contains, CountingBloomFilter.hpp:190-196: min over the H
@@ -713,223 +725,6 @@ ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsi
 	return v;
 }
 
-// ------------------------------------------------------------ search scratch
-// Explicit stacks for the reference's recursive searches.  One SearchScratch per
-// concurrently running searcher (GPU thread); capacities are fixed at launch and
-// overflow is reported (never silently truncated).
-template <int NW>
-struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
-	Vtx<NW> v;          // the vertex this call inserted into `visited`
-	uint64_t ufh, urh;  // identity of the vertex we came from (skipped when changing direction)
-	uint16_t depth;
-	uint8_t dir;        // direction of this call
-	uint8_t stage;      // 0: same-direction children, 1: other-direction children
-	uint8_t next;       // next base to try in the current stage
-	uint8_t mask_same, mask_other;
-	uint8_t have_other; // mask_other computed
-};
-template <int NW>
-struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
-	Vtx<NW> v;
-	uint8_t mask, next;
-};
-constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
-// The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on
-// the device), deeper ones in the global pool.
-template <int NW>
-struct SearchScratch {
-	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
-	VKey* tb_keys;         // [tb_cap] vtx_ident of tb[i].v: what the on-stack test scans
-	uint32_t tb_cap;
-	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
-	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
-	VKey* tbf_keys;
-	uint32_t tbf_cap;
-	uint32_t overflow;     // set when a stack capacity was exceeded
-	uint32_t dbg_calls;    // profiling aid: out-of-line successor() calls and the clock ticks spent in them
-	uint64_t dbg_search;
-	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
-	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
-	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
-	VKey* la_visited;      // [LA_MAX_VISITED]
-};
-
-// lookAhead (ExtendPath.h:100-161): is there a path of >= `limit` further vertices
-// from `start` in direction `dir`?  Depth-first, `visited` shared by the whole search
-// and never erased, neighbours tried in A,C,G,T order.
-template <int NW>
-ABG_HDX bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start,
-    int dir, unsigned limit, SearchScratch<NW>& sc)
-{
-	int sense = (dir == FORWARD) ? SENSE : ANTISENSE;
-	unsigned nv = 0;
-	VKey* vis = sc.la_visited;
-	vis[nv++] = vtx_ident(p, start);
-	if (limit == 0) return true;
-	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
-	int depth = 0;
-	uint64_t nfh[4], nrh[4];
-	sc.la[0].v = start;
-	sc.la[0].mask = (uint8_t)neighbour_mask(p, cnt, start, sense, nfh, nrh, sc.coop);
-	sc.la[0].next = 0;
-	while (depth >= 0) {
-		LAFrame<NW>& f = sc.la[depth];
-		if (f.next >= 4) { depth--; continue; }
-		unsigned b = f.next++;
-		if (!((f.mask >> b) & 1u)) continue;
-		Vtx<NW> w = neighbour_vertex(p, f.v, sense, b);
-		const VKey wk = vtx_ident(p, w);
-		bool seen = false;
-		for (unsigned i = 0; i < nv; i++)
-			if (key_equal(vis[i], wk)) { seen = true; break; }
-		if (seen) continue;
-		// recursive call lookAhead(w, depth + 1)
-		if (nv < (unsigned)LA_MAX_VISITED) vis[nv++] = wk;
-		else sc.overflow = 1;
-		if ((unsigned)(depth + 1) >= limit) return true;
-		depth++;
-		sc.la[depth].v = w;
-		sc.la[depth].mask = (uint8_t)neighbour_mask(p, cnt, w, sense, nfh, nrh, sc.coop);
-		sc.la[depth].next = 0;
-	}
-	return false;
-}
-
-// trueBranch (ExtendPath.h:174-261).  Edge (u -> v) walked in direction `dir`.  Every
-// `return true` of the recursion propagates to the root, and `visited` holds exactly the
-// vertices of the active calls (inserted on entry, erased on a false return), so the
-// recursion is a depth-first search over an explicit frame stack that stops at the first
-// call that would return true.
-template <int NW>
-ABG_HD TBFrame<NW>& tb_frame(SearchScratch<NW>& sc, int i)
-{
-	return (uint32_t)i < sc.tbf_cap ? sc.tbf[i] : sc.tb[(uint32_t)i - sc.tbf_cap];
-}
-template <int NW>
-ABG_HDX bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
-    const Vtx<NW>& v0, int dir0, unsigned trim, SearchScratch<NW>& sc)
-{
-	int top = -1;
-	const int cap = (int)(sc.tbf_cap + sc.tb_cap);
-	// "call" trueBranch(u0 -> v0, depth 0, dir0)
-	Vtx<NW> cu = u0, cv = v0;
-	unsigned cdepth = 0;
-	int cdir = dir0;
-	for (;;) {
-		// ---- entry of a call (u=cu, v=cv, depth=cdepth, dir=cdir)
-		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
-		bool on_stack = false;
-		const VKey ck = vtx_ident(p, cv);
-		{
-			const int nf = top + 1 < (int)sc.tbf_cap ? top + 1 : (int)sc.tbf_cap;
-			// cooperative callers spread the scan over the lanes
-			const int first = sc.coop ? (int)lane_id() : 0, step = sc.coop ? 64 : 1;
-			for (int i = first; i <= top; i += step) {
-				VKey kk = i < nf ? sc.tbf_keys[i] : sc.tb_keys[i - nf];
-				on_stack = on_stack | ((kk.fh == ck.fh) & (kk.rh == ck.rh));
-			}
-			if (sc.coop) on_stack = wave_any(on_stack);
-		}
-		if (on_stack) return true;
-		if (cdepth >= trim) return true;
-		if (top + 1 >= cap) { sc.overflow = 1; return true; }
-		top++;
-		{
-			VKey& kk = (uint32_t)top < sc.tbf_cap ? sc.tbf_keys[top] : sc.tb_keys[(uint32_t)top - sc.tbf_cap];
-			kk = ck;
-			TBFrame<NW>& f = tb_frame(sc, top);
-			// the caller is the frame below (or the root edge's source)
-			const VKey uk = top > 0 ? ((uint32_t)(top - 1) < sc.tbf_cap ? sc.tbf_keys[top - 1]
-			                                                          : sc.tb_keys[(uint32_t)(top - 1) - sc.tbf_cap])
-			                        : vtx_ident(p, cu);
-			f.v = cv; f.ufh = uk.fh; f.urh = uk.rh;
-			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
-			f.have_other = 0; f.mask_other = 0;
-			uint64_t nfh[4], nrh[4];
-			f.mask_same = (uint8_t)neighbour_mask(p, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE,
-			    nfh, nrh, sc.coop);
-		}
-		// ---- resume frames until one of them makes a new call
-		bool called = false;
-		while (top >= 0 && !called) {
-			TBFrame<NW>& f = tb_frame(sc, top);
-			const Vtx<NW> fv = f.v;
-			const unsigned fdepth = (uint32_t)f.depth;
-			int fdir = (int)(uint32_t)f.dir;
-			int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
-			if ((uint32_t)f.stage == 0) {
-				unsigned nx = (uint32_t)f.next;
-				const unsigned ms = (uint32_t)f.mask_same;
-				while (nx < 4 && !((ms >> nx) & 1u)) nx++;
-				if (nx < 4) {
-					unsigned b = nx++;
-					f.next = (uint8_t)nx;
-					cu = fv;
-					cv = neighbour_vertex(p, fv, sense, b);
-					cdepth = fdepth + 1u;
-					cdir = fdir;
-					called = true;
-					break;
-				}
-				f.next = (uint8_t)nx;
-				// same-direction children exhausted: may we change direction?
-				// (depth >= fpTrim || lookAhead(v, dir, fpTrim), ExtendPath.h:208,230)
-				bool flip = fdepth >= FP_TRIM;
-				if (!flip) flip = look_ahead(p, cnt, fv, fdir, FP_TRIM, sc);
-				if (!flip) { top--; continue; } // visited.erase(v); return false
-				f.stage = 1;
-				f.next = 0;
-				uint64_t nfh[4], nrh[4];
-				f.mask_other = (uint8_t)neighbour_mask(p, cnt, fv,
-				    fdir == FORWARD ? ANTISENSE : SENSE, nfh, nrh, sc.coop);
-				f.have_other = 1;
-			}
-			// stage 1: other-direction children, skipping the vertex we came from
-			{
-				int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
-				int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
-				bool made = false;
-				unsigned nx = (uint32_t)f.next;
-				const unsigned mo = (uint32_t)f.mask_other;
-				const uint64_t ufh = f.ufh, urh = f.urh;
-				while (nx < 4) {
-					unsigned b = nx++;
-					if (!((mo >> b) & 1u)) continue;
-					Vtx<NW> w = neighbour_vertex(p, fv, osense, b);
-					const VKey wk = vtx_ident(p, w);
-					if ((wk.fh == ufh) & (wk.rh == urh)) continue; // source(*iei) == u
-					cu = fv; cv = w; cdepth = 0; cdir = odir;
-					made = true;
-					break;
-				}
-				f.next = (uint8_t)nx;
-				if (made) { called = true; break; }
-				top--; // visited.erase(v); return false
-			}
-		}
-		if (!called) return false; // root call returned false
-	}
-}
-
-// successor (ExtendPath.h:314-362): iterative deepening over the branch-length
-// threshold i = 0,1,2,4,...,trim.  Returns the code and (for LENGTH_LIMIT) the unique
-// successor; for AMBI_OUT the last true branch found, for DEAD_END `u` itself.
-// `mask`, `nfh`, `nrh` are the neighbour mask / hashes of `u` in direction `dir`.
-// The level-0 decision of successor(): with at most one neighbour present the answer is
-// DEAD_END or that neighbour; returns -1 when deeper levels must be consulted.
-template <int NW>
-ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned mask,
-    const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout)
-{
-	if (mask == 0) { vout = u; return ER_DEAD_END; }
-	if (mask & (mask - 1)) return -1;
-	unsigned b = (mask & 1u) ? 0u : (mask & 2u) ? 1u : (mask & 4u) ? 2u : 3u;
-	uint64_t fh = nfh[0], rh = nrh[0];
-#pragma unroll
-	for (unsigned q = 1; q < 4; q++) { fh = (b == q) ? nfh[q] : fh; rh = (b == q) ? nrh[q] : rh; }
-	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
-	return ER_LENGTH_LIMIT;
-}
 // The rolling-hash tables as named scalars, for loops that must stay in registers: an array
 // held in registers that is indexed at run time -- even through a chain of selects, which the
 // optimiser folds back into an indexed load -- is demoted to per-lane scratch memory.
@@ -969,6 +764,303 @@ ABG_HD void nbr_hash(const SeedTabs& t, int sense, uint64_t fb, uint64_t rb, uns
 	else { fh = fb ^ pick4(b, t.sm0, t.sm1, t.sm2, t.sm3); rh = rb ^ seed_of(3u - b); }
 }
 
+// 4-bit mask of the neighbours of `v` in direction `sense` that the solid filter contains
+// (neighbour_mask without arrays; cooperative callers probe one (neighbour, hash) per lane)
+template <int NW, bool COOP>
+ABG_HD unsigned nbr_mask_lean(const Params& p, const SeedTabs& t, const uint8_t* __restrict__ cnt, const Vtx<NW>& v, int sense)
+{
+	uint64_t fb, rb, df, dr;
+	nbr_base(t, v, p.k, sense, fb, rb);
+	neighbour_mask_delta(p, v, sense, df, dr);
+	unsigned ok = 0xFu;
+	if (COOP) {
+		const unsigned lane = lane_id(), b = (lane >> 3) & 3u, i = lane & 7u;
+		uint64_t fh, rh;
+		nbr_hash(t, sense, fb, rb, b, fh, rh);
+		fh ^= df; rh ^= dr;
+		const uint64_t h = rh < fh ? rh : fh;
+		for (unsigned base = 0; base < p.nh; base += 8) {
+			bool bad = false;
+			if (lane < 32 && base + i < p.nh) bad = cnt[pos_i(p, h, base + i)] < p.kc;
+			const uint64_t m = wave_ballot(bad);
+#pragma unroll
+			for (unsigned q = 0; q < 4; q++)
+				if ((m >> (8 * q)) & 0xFFu) ok &= ~(1u << q);
+		}
+	} else {
+		for (unsigned q = 0; q < 4; q++) {
+			uint64_t fh, rh;
+			nbr_hash(t, sense, fb, rb, q, fh, rh);
+			fh ^= df; rh ^= dr;
+			if (!solid_contains(p, cnt, rh < fh ? rh : fh)) ok &= ~(1u << q);
+		}
+	}
+	return ok;
+}
+template <int NW>
+ABG_HD Vtx<NW> nbr_vertex_lean(const Params& p, const SeedTabs& t, const Vtx<NW>& v, int sense, unsigned b)
+{
+	uint64_t fb, rb, fh, rh;
+	nbr_base(t, v, p.k, sense, fb, rb);
+	nbr_hash(t, sense, fb, rb, b, fh, rh);
+	return make_neighbour(p, v, sense, b, fh, rh);
+}
+
+// ------------------------------------------------------------ search scratch
+// Explicit stacks for the reference's recursive searches.  One SearchScratch per
+// concurrently running searcher (GPU thread); capacities are fixed at launch and
+// overflow is reported (never silently truncated).
+template <int NW>
+struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
+	Vtx<NW> v;          // the vertex this call inserted into `visited`
+	uint64_t ufh, urh;  // identity of the vertex we came from (skipped when changing direction)
+	uint16_t depth;
+	uint8_t dir;        // direction of this call
+	uint8_t stage;      // 0: same-direction children, 1: other-direction children
+	uint8_t next;       // next base to try in the current stage
+	uint8_t mask_same, mask_other;
+	uint8_t have_other; // mask_other computed
+};
+template <int NW>
+struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
+	Vtx<NW> v;
+	uint8_t mask, next;
+};
+constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
+// The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on
+// the device), deeper ones in the global pool.
+template <int NW>
+struct SearchScratch {
+	TBFrame<NW>* tb;       // [tb_cap] frames beyond the fast tier
+	VKey* tb_keys;         // [tb_cap] vtx_ident of tb[i].v: what the on-stack test scans
+	uint32_t tb_cap;
+	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
+	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
+	VKey* tbf_keys;
+	uint32_t tbf_cap;
+	uint32_t overflow;     // set when a stack capacity was exceeded
+	uint32_t dbg_calls;    // profiling aid: out-of-line successor() calls and the clock ticks spent in them
+	uint64_t dbg_search;
+	uint64_t dbg_nodes;    // trueBranch calls entered (frames pushed)
+	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
+	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
+	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
+	VKey* la_visited;      // [LA_MAX_VISITED]
+};
+
+// lookAhead (ExtendPath.h:100-161): is there a path of >= `limit` further vertices
+// from `start` in direction `dir`?  Depth-first, `visited` shared by the whole search
+// and never erased, neighbours tried in A,C,G,T order.
+template <int NW, bool COOP>
+ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in, const Vtx<NW>& start,
+    int dir, unsigned limit, SearchScratch<NW>& sc)
+{
+	const ParamsView<COOP> pview(p_in);
+	const Params& p = pview.get();
+	const SeedTabs tabs = seed_tabs(p);
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
+	const int sense = ((int)uni32<COOP>((uint32_t)dir) == FORWARD) ? SENSE : ANTISENSE;
+	limit = uni32<COOP>(limit);
+	unsigned nv = 0;
+	VKey* const vis = uniptr<COOP>(sc.la_visited);
+	LAFrame<NW>* const la = uniptr<COOP>(sc.la);
+	vis[nv++] = vtx_ident(p, start);
+	if (limit == 0) return true;
+	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
+	int depth = 0;
+	la[0].v = start;
+	la[0].mask = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, start, sense);
+	la[0].next = 0;
+	while (depth >= 0) {
+		LAFrame<NW>& f = la[depth];
+		unsigned nx = uni32<COOP>((uint32_t)f.next);
+		const unsigned fm = uni32<COOP>((uint32_t)f.mask);
+		while (nx < 4 && !((fm >> nx) & 1u)) nx++;
+		if (nx >= 4) { depth--; continue; }
+		const unsigned b = nx;
+		f.next = (uint8_t)(nx + 1);
+		Vtx<NW> fv;
+#pragma unroll
+		for (int j = 0; j < NW; j++) fv.s.w[j] = uni64<COOP>(f.v.s.w[j]);
+		fv.fh = uni64<COOP>(f.v.fh); fv.rh = uni64<COOP>(f.v.rh);
+		const Vtx<NW> w = nbr_vertex_lean(p, tabs, fv, sense, b);
+		const VKey wk = vtx_ident(p, w);
+		// visited.find(w): cooperative callers spread the scan over the lanes
+		bool seen = false;
+		for (unsigned i = COOP ? lane_id() : 0u; i < nv; i += (COOP ? 64u : 1u)) seen = seen | key_equal(vis[i], wk);
+		if (COOP) seen = wave_any(seen);
+		if (seen) continue;
+		// recursive call lookAhead(w, depth + 1)
+		if (nv < (unsigned)LA_MAX_VISITED) vis[nv++] = wk;
+		else sc.overflow = 1;
+		if ((unsigned)(depth + 1) >= limit) return true;
+		depth++;
+		la[depth].v = w;
+		la[depth].mask = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, w, sense);
+		la[depth].next = 0;
+	}
+	return false;
+}
+template <int NW>
+ABG_HD bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start,
+    int dir, unsigned limit, SearchScratch<NW>& sc)
+{
+	return sc.coop ? look_ahead_t<NW, true>(p, cnt, start, dir, limit, sc)
+	               : look_ahead_t<NW, false>(p, cnt, start, dir, limit, sc);
+}
+
+// trueBranch (ExtendPath.h:174-261).  Edge (u -> v) walked in direction `dir`.  Every
+// `return true` of the recursion propagates to the root, and `visited` holds exactly the
+// vertices of the active calls (inserted on entry, erased on a false return), so the
+// recursion is a depth-first search over an explicit frame stack that stops at the first
+// call that would return true.
+template <int NW, bool COOP>
+ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_in, const Vtx<NW>& u0,
+    const Vtx<NW>& v0, int dir0, unsigned trim_in, SearchScratch<NW>& sc, unsigned* max_depth)
+{
+	unsigned maxd = 0; // deepest call entered (reported when the answer is false, see successor_m)
+	// wave-uniform copies of everything the loop reads (scalar registers for cooperative callers)
+	const ParamsView<COOP> pview(p_in);
+	const Params& p = pview.get();
+	const SeedTabs tabs = seed_tabs(p);
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
+	const unsigned trim = uni32<COOP>(trim_in);
+	TBFrame<NW>* const tbf = uniptr<COOP>(sc.tbf);
+	TBFrame<NW>* const tbs = uniptr<COOP>(sc.tb);
+	VKey* const tbf_keys = uniptr<COOP>(sc.tbf_keys);
+	VKey* const tbs_keys = uniptr<COOP>(sc.tb_keys);
+	const uint32_t tbf_cap = uni32<COOP>(sc.tbf_cap);
+	const int cap = (int)(tbf_cap + uni32<COOP>(sc.tb_cap));
+	auto frame = [&](int i) -> TBFrame<NW>& { return (uint32_t)i < tbf_cap ? tbf[i] : tbs[(uint32_t)i - tbf_cap]; };
+	auto keyat = [&](int i) -> VKey& { return (uint32_t)i < tbf_cap ? tbf_keys[i] : tbs_keys[(uint32_t)i - tbf_cap]; };
+	auto uniform_vtx = [&](const Vtx<NW>& x) {
+		Vtx<NW> r;
+#pragma unroll
+		for (int j = 0; j < NW; j++) r.s.w[j] = uni64<COOP>(x.s.w[j]);
+		r.fh = uni64<COOP>(x.fh); r.rh = uni64<COOP>(x.rh);
+		return r;
+	};
+	int top = -1;
+	// "call" trueBranch(u0 -> v0, depth 0, dir0)
+	Vtx<NW> cv = uniform_vtx(v0);
+	VKey cuk = vtx_ident(p, uniform_vtx(u0)); // identity of the vertex the call comes from
+	unsigned cdepth = 0;
+	int cdir = (int)uni32<COOP>((uint32_t)dir0);
+	for (;;) {
+		// ---- entry of a call (u, v=cv, depth=cdepth, dir=cdir)
+		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
+		bool on_stack = false;
+		const VKey ck = vtx_ident(p, cv);
+		{
+			// cooperative callers spread the scan over the lanes
+			const int first = COOP ? (int)lane_id() : 0, step = COOP ? 64 : 1;
+			for (int i = first; i <= top; i += step) {
+				const VKey kk = keyat(i);
+				on_stack = on_stack | ((kk.fh == ck.fh) & (kk.rh == ck.rh));
+			}
+			if (COOP) on_stack = wave_any(on_stack);
+		}
+		if (on_stack) return true;
+		if (cdepth >= trim) return true;
+		if (top + 1 >= cap) { sc.overflow = 1; return true; }
+		maxd = cdepth > maxd ? cdepth : maxd;
+		top++;
+		sc.dbg_nodes++;
+		{
+			keyat(top) = ck;
+			TBFrame<NW>& f = frame(top);
+			f.v = cv; f.ufh = cuk.fh; f.urh = cuk.rh;
+			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
+			f.have_other = 0; f.mask_other = 0;
+			f.mask_same = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE);
+		}
+		// ---- resume frames until one of them makes a new call
+		bool called = false;
+		while (top >= 0 && !called) {
+			TBFrame<NW>& f = frame(top);
+			const Vtx<NW> fv = uniform_vtx(f.v);
+			const unsigned fdepth = uni32<COOP>((uint32_t)f.depth);
+			const int fdir = (int)uni32<COOP>((uint32_t)f.dir);
+			const int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
+			if (uni32<COOP>((uint32_t)f.stage) == 0) {
+				unsigned nx = uni32<COOP>((uint32_t)f.next);
+				const unsigned ms = uni32<COOP>((uint32_t)f.mask_same);
+				while (nx < 4 && !((ms >> nx) & 1u)) nx++;
+				if (nx < 4) {
+					unsigned b = nx++;
+					f.next = (uint8_t)nx;
+					cuk = keyat(top); cuk.fh = uni64<COOP>(cuk.fh); cuk.rh = uni64<COOP>(cuk.rh);
+					cv = nbr_vertex_lean(p, tabs, fv, sense, b);
+					cdepth = fdepth + 1u;
+					cdir = fdir;
+					called = true;
+					break;
+				}
+				f.next = (uint8_t)nx;
+				// same-direction children exhausted: may we change direction?
+				// (depth >= fpTrim || lookAhead(v, dir, fpTrim), ExtendPath.h:208,230)
+				bool flip = fdepth >= FP_TRIM;
+				if (!flip) flip = look_ahead_t<NW, COOP>(p, cnt, fv, fdir, FP_TRIM, sc);
+				if (!flip) { top--; continue; } // visited.erase(v); return false
+				f.stage = 1;
+				f.next = 0;
+				f.mask_other = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE);
+				f.have_other = 1;
+			}
+			// stage 1: other-direction children, skipping the vertex we came from
+			{
+				const int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
+				const int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
+				bool made = false;
+				unsigned nx = uni32<COOP>((uint32_t)f.next);
+				const unsigned mo = uni32<COOP>((uint32_t)f.mask_other);
+				const uint64_t ufh = uni64<COOP>(f.ufh), urh = uni64<COOP>(f.urh);
+				while (nx < 4) {
+					unsigned b = nx++;
+					if (!((mo >> b) & 1u)) continue;
+					const Vtx<NW> w = nbr_vertex_lean(p, tabs, fv, osense, b);
+					const VKey wk = vtx_ident(p, w);
+					if ((wk.fh == ufh) & (wk.rh == urh)) continue; // source(*iei) == u
+					cuk = keyat(top); cuk.fh = uni64<COOP>(cuk.fh); cuk.rh = uni64<COOP>(cuk.rh);
+					cv = w; cdepth = 0; cdir = odir;
+					made = true;
+					break;
+				}
+				f.next = (uint8_t)nx;
+				if (made) { called = true; break; }
+				top--; // visited.erase(v); return false
+			}
+		}
+		if (!called) { *max_depth = maxd; return false; } // root call returned false
+	}
+}
+template <int NW>
+ABG_HD bool true_branch(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u0,
+    const Vtx<NW>& v0, int dir0, unsigned trim, SearchScratch<NW>& sc, unsigned* max_depth)
+{
+	return sc.coop ? true_branch_t<NW, true>(p, cnt, u0, v0, dir0, trim, sc, max_depth)
+	               : true_branch_t<NW, false>(p, cnt, u0, v0, dir0, trim, sc, max_depth);
+}
+
+// successor (ExtendPath.h:314-362): iterative deepening over the branch-length
+// threshold i = 0,1,2,4,...,trim.  Returns the code and (for LENGTH_LIMIT) the unique
+// successor; for AMBI_OUT the last true branch found, for DEAD_END `u` itself.
+// `mask`, `nfh`, `nrh` are the neighbour mask / hashes of `u` in direction `dir`.
+// The level-0 decision of successor(): with at most one neighbour present the answer is
+// DEAD_END or that neighbour; returns -1 when deeper levels must be consulted.
+template <int NW>
+ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned mask,
+    const uint64_t nfh[4], const uint64_t nrh[4], Vtx<NW>& vout)
+{
+	if (mask == 0) { vout = u; return ER_DEAD_END; }
+	if (mask & (mask - 1)) return -1;
+	unsigned b = (mask & 1u) ? 0u : (mask & 2u) ? 1u : (mask & 4u) ? 2u : 3u;
+	uint64_t fh = nfh[0], rh = nrh[0];
+#pragma unroll
+	for (unsigned q = 1; q < 4; q++) { fh = (b == q) ? nfh[q] : fh; rh = (b == q) ? nrh[q] : rh; }
+	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
+	return ER_LENGTH_LIMIT;
+}
 // trueBranch for the common shape of a real branch: a chain.  While every vertex reached has
 // exactly one neighbour ahead, trueBranch's recursion (ExtendPath.h:174-244) is a straight
 // descent that answers true as soon as it meets a vertex of the chain again (visited.find) or
@@ -1086,41 +1178,44 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	uint64_t nfh[4], nrh[4];
 	neighbour_hashes(p, u, sense, nfh, nrh);
 	vout = u;
-	// Shortcut, exact by monotonicity of trueBranch in its threshold: every condition that
-	// makes trueBranch(e, i) return true (vertex on the stack, depth >= i, a true child) also
-	// holds for any smaller threshold, while exploration order, direction changes and the
-	// visited set do not depend on the threshold.  Hence the edges that are true at `trim`
-	// are true at every level of the loop below: two of them => the loop runs to i == trim
-	// and answers AMBI_OUT; exactly one => it is the only survivor at the first level with a
-	// single true branch, i.e. the loop's LENGTH_LIMIT answer.  Only when no edge is true at
-	// `trim` do the lower levels decide, and the loop below is run as written.
-	if (trim > 1 && (mask & (mask - 1))) {
+	// Exact by monotonicity of trueBranch in its threshold: every condition that makes
+	// trueBranch(e, i) return true (vertex on the stack, depth >= i, a true child) also holds
+	// for any smaller threshold, while exploration order, direction changes and the visited set
+	// do not depend on the threshold.  So each edge is searched ONCE, at `trim`:
+	//  - an edge that is true at `trim` is true at every level of the loop of successor();
+	//  - an edge that is false at `trim` was explored exhaustively without meeting the stack, and
+	//    its search at a threshold i stops with true exactly when some call is i deep: it is
+	//    true at level i iff i <= D, the deepest call of that exhaustive search.
+	// Two edges true at `trim` => the loop runs to i == trim and answers AMBI_OUT; otherwise the
+	// levels i = 0, 1, 2, 4, ..., trim are replayed on the recorded depths.
+	unsigned depth_of[4] = { 0, 0, 0, 0 }; // per edge: trim if true at trim, else D
+	if (trim > 0 && (mask & (mask - 1))) {
 		// branches that are plain chains are settled together (see chain_true_branches)
-		const unsigned chain_true = sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
-		                                    : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc);
+		const unsigned chain_true = (trim > 1) ? (sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
+		                                                  : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc))
+		                                       : 0u;
 		unsigned tb = 0;
-		Vtx<NW> last = u;
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
-			if (((chain_true >> b) & 1u) || true_branch(p, cnt, u, w, dir, trim, sc)) {
-				last = w;
-				if (++tb >= 2) break;
+			unsigned d = 0;
+			if (((chain_true >> b) & 1u) || true_branch(p, cnt, u, w, dir, trim, sc, &d)) {
+				vout = w;
+				depth_of[b] = trim;
+				if (++tb >= 2) return ER_AMBI_OUT;
+			} else {
+				depth_of[b] = d;
 			}
 		}
-		if (tb >= 2) { vout = last; return ER_AMBI_OUT; }
-		if (tb == 1) { vout = last; return ER_LENGTH_LIMIT; }
 	}
 	for (unsigned i = 0;; i = (i == 0) ? 1u : (trim < 2 * i ? trim : 2 * i)) {
 		unsigned tb = 0;
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;
-			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
-			// trueBranch(e, dir, g, i, fpTrim) with a fresh visited set; at i == 0 every
-			// existing edge is a true branch (depth 0 >= trim 0)
-			bool t = (i == 0) ? true : true_branch(p, cnt, u, w, dir, i, sc);
-			if (t) {
-				vout = w;
+			// trueBranch(e, dir, g, i, fpTrim) with a fresh visited set; at i == 0 every existing
+			// edge is a true branch (depth 0 >= trim 0)
+			if (i == 0 || depth_of[b] >= i) {
+				vout = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
 				if (++tb >= 2) break;
 			}
 		}

@@ -10,6 +10,7 @@
 #include "abg_walk.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +39,7 @@ struct Config {
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
 	uint64_t p2_first_batch = 4096;   // PASS 2 read batches grow geometrically from here
 	uint64_t p2_max_batch = 1ull << 21;
+	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
@@ -312,7 +314,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		unsigned k = p.k;
 		uint32_t nk = L - k + 1;
 		SearchScratch<NW> sc;
-		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0;
+		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
@@ -1016,7 +1018,7 @@ class Engine {
 			assemble_range(b, done, bs, result_d, results_host, sink);
 			done += bs;
 			counters_.reads_processed += bs;
-			p2_batch_ = std::min<uint64_t>(p2_batch_ * 2, cfg_.p2_max_batch);
+			p2_batch_ = std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 		}
 		be_.free(result_d);
 	}
@@ -1035,6 +1037,7 @@ class Engine {
 	uint64_t* scal_ = nullptr;
 	Cascade casc_{ nullptr, 0, 0 };
 	MaskTab* mask_d_ = nullptr;
+	std::chrono::steady_clock::time_point dbg_t0_;
 	uint32_t* T_ = nullptr; // parallel commit: time stamp per filter bit
 	bool use_par_commit() const { return cfg_.par_commit && m_ * 4ull <= cfg_.par_commit_max_bytes; }
 	Counters counters_;
@@ -1448,6 +1451,8 @@ class Engine {
 			if (!debug) return;
 			std::vector<uint64_t> d(nc * 8ull);
 			be_.d2h(d.data(), dbg_, nc * 64ull);
+			const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0_).count();
+			fprintf(stderr, "[walkdbg] launch+copy wall %.1f ms; ", wall_ms);
 			uint64_t best = 0, bi = 0, sum_t = 0, sum_steps = 0, sum_nodes = 0, sum_succ = 0, sum_la = 0, nn = 0;
 			for (uint32_t i = 0; i < nc; i++) {
 				const uint64_t* x = &d[i * 8ull];
@@ -1456,7 +1461,7 @@ class Engine {
 				if (x[0] > best) { best = x[0]; bi = i; }
 			}
 			const uint64_t* x = &d[bi * 8ull];
-			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu search_ticks=%llu search_calls=%llu succ=%llu | slowest: t=%.2fms steps=%llu tbnodes=%llu la=%llu succ=%llu tbcalls=%llu contigs=%llu st=%llu\n",
+			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu search_ticks=%llu search_calls=%llu tbnodes=%llu | slowest: t=%.2fms steps=%llu search_ticks=%llu search_calls=%llu tbnodes=%llu x=%llu contigs=%llu st=%llu\n",
 			    what, nwalk, (unsigned long long)nn, sum_t / 1e5, (unsigned long long)sum_steps, (unsigned long long)sum_nodes,
 			    (unsigned long long)sum_la, (unsigned long long)sum_succ, x[0] / 1e5, (unsigned long long)x[1],
 			    (unsigned long long)x[2], (unsigned long long)x[3], (unsigned long long)x[4], (unsigned long long)x[5],
@@ -1520,6 +1525,7 @@ class Engine {
 					env.owner_base = owner_next;
 					owner_next += nc;
 					FWalk<NW> fw{ env, need_d, !slow_frames_ };
+					if (debug) { uint32_t tmp; be_.d2h(&tmp, rec_used_, 4); dbg_t0_ = std::chrono::steady_clock::now(); }
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;
 					batch_rewalked += nneed;

@@ -647,7 +647,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf_cap = cap - 1;
 	}
 	sc.overflow = 0;
-	sc.dbg_search = 0; sc.dbg_calls = 0;
+	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -831,7 +831,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 #endif
 		uint64_t* d = e.dbg + (uint64_t)c * 8;
 		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
-		d[4] = 0; d[5] = 0; d[6] = contig; d[7] = abort_status;
+		d[4] = sc.dbg_nodes; d[5] = 0; d[6] = contig; d[7] = abort_status;
 	}
 }
 
