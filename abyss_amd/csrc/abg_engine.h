@@ -687,6 +687,7 @@ struct ParCommit {
 	uint64_t* cnt3;        // [n]
 	uint8_t* active;       // [n] the read is not visited at its turn
 	uint32_t* short_list;  // records of short contigs (unordered)
+	VKey* short_keys;      // [2 per entry of short_list] their canonical end k-mers (FPcShortKeys)
 	uint32_t* scal;        // [0] changed  [1] break candidate  [2] short_list length  [3] new contigEndKmers entries
 	uint32_t c_begin, c_end, brk;
 };
@@ -754,6 +755,16 @@ ABG_HD void wt_upsert_min(const WalkTab& t, const VKey& key, uint64_t time)
 		if (cur == key.fh && t.hmax[s] == key.rh) { if (time < t.meta[s]) t.meta[s] = time; return; }
 	}
 }
+struct FPcShortKeys { // end k-mers of the short contigs, in parallel
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t) const
+	{
+		const ContigRec& rec = e.recs[e.short_list[i]];
+		const uint8_t* seq = e.pool + rec.seq_off;
+		e.short_keys[2 * i] = canonical_end_key(e.p, seq);
+		e.short_keys[2 * i + 1] = canonical_end_key(e.p, seq + rec.len - e.p.k);
+	}
+};
 // The end k-mers of the short contigs, by ONE thread (there are few; concurrent insertion of the
 // same key would need a two-word atomic).  mode 0: positions of the ones assumed inserted go
 // into tcend; mode 1 (after the decisions): the inserted ones before the break enter
@@ -768,8 +779,7 @@ struct FPcShort {
 			const ContigRec& rec = e.recs[e.short_list[i]];
 			if (!rec.ins) continue;
 			if (mode == 1 && rec.cand >= e.brk) continue;
-			const uint8_t* seq = e.pool + rec.seq_off;
-			VKey k1 = canonical_end_key(e.p, seq), k2 = canonical_end_key(e.p, seq + rec.len - e.p.k);
+			const VKey k1 = e.short_keys[2 * i], k2 = e.short_keys[2 * i + 1];
 			if (mode == 0) {
 				wt_upsert_min(e.tcend, k1, rec.time);
 				wt_upsert_min(e.tcend, k2, rec.time);
@@ -1320,10 +1330,14 @@ class Engine {
 		{ FPcStamp f{ e }; be_.launch(n, f, "pc_stamp"); }
 		be_.d2h(scal_h, e.scal, sizeof scal_h);
 		const uint32_t nshort = scal_h[2];
+		e.short_keys = nullptr;
 		if (nshort) {
 			uint32_t log2 = 4;
 			while ((1ull << log2) < 4ull * nshort) log2++;
 			alloc_tab(e.tcend, log2);
+			e.short_keys = (VKey*)be_.alloc(2ull * nshort * sizeof(VKey));
+			FPcShortKeys f{ e };
+			be_.launch(nshort, f, "pc_short_keys");
 		}
 		// the fixed point
 		for (uint32_t round = 0;; round++) {
@@ -1371,7 +1385,7 @@ class Engine {
 		counters_.bases_assembled += bases;
 		counters_.visited_reads += visited;
 		cend_count_ += scal_h[3];
-		if (nshort) free_tab(e.tcend);
+		if (nshort) { free_tab(e.tcend); be_.free(e.short_keys); }
 		be_.free(e.off); be_.free(e.cnt); be_.free(e.cnt2); be_.free(e.cnt3); be_.free(e.active);
 		be_.free(e.short_list); be_.free(e.scal);
 		return brk;

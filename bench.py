@@ -193,7 +193,8 @@ def main() -> int:
 
     # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
     names = ["hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep", "walk", "rewalk",
-             "contig_prep", "predict", "precommit", "commit", "popcount"]
+             "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
+             "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names}
     stats = g.stats()
     H = 4
@@ -208,6 +209,9 @@ def main() -> int:
         "rewalk": 8 * H * unitig_kmers,                          # 8 neighbour queries x H per unitig k-mer
         "walk": 8 * H * unitig_kmers,
         "commit": 3 * H * unitig_kmers,                          # redundancy test + insertion + coverage
+        "pc_timemin": 4 * H * unitig_kmers,                      # one 4-byte time stamp per (k-mer, hash)
+        "pc_decide": 8 * H * unitig_kmers,                       # time stamp + filter word per (k-mer, hash)
+        "pc_apply": 4 * H * unitig_kmers,                        # filter word per (k-mer, hash)
     }
     per_kernel = {}
     for nm, total in alg_total.items():
@@ -224,7 +228,8 @@ def main() -> int:
         # this same command, committed with the profile; KB units, per launch like `achieved`
         t = json.load(open(tsrc)).get({"rewalk": "k_walkers", "walk": "k_walkers", "commit": "k_commit",
                                        "insert_round": "FInsertRound", "hash_claim": "FHashClaim",
-                                       "classify": "FClassify"}[dom])
+                                       "classify": "FClassify", "pc_timemin": "FPcTimeMin", "pc_decide": "FPcDecide",
+                                       "pc_apply": "FPcApply"}[dom])
         if t:
             traffic = (t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024 / max(t["FETCH_SIZE"]["dispatches"], 1)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,

@@ -168,7 +168,8 @@ int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
 /* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
  * runs on; abg_profile_get reports total milliseconds and launch count of one kernel
  * family ("hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep",
- * "walk", "rewalk", "contig_prep", "predict", "precommit", "commit", "popcount"). */
+ * "walk", "rewalk", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp",
+ * "pc_short", "pc_timemin", "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"). */
 int abg_profile_enable(abg_ctx* ctx, int on);
 int abg_profile_reset(abg_ctx* ctx);
 int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

@@ -197,8 +197,8 @@ def test_spaced_seed_device_logic_matches_oracle(k, mask, G):
 def test_parallel_commit_needs_several_passes_and_stays_exact():
     """A filter so small that false positives chain reads and contigs together: the fixed-point
     commit needs more than one pass per batch here, and must still equal the sequential order."""
-    k, counters = 25, 1 << 19
-    m1, m2 = synth.make_read_set(30000, 40.0, err=0.02, genome_seed=30, read_seed=34)
+    k, counters = 25, 1 << 17
+    m1, m2 = synth.make_read_set(8000, 30.0, err=0.02, genome_seed=30, read_seed=34)
     buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
     o = ob.Oracle(k, counters=counters)
     hc = HostCheck(k, counters, insert_batch=20000, claim_log2=14, p2_first=64)
