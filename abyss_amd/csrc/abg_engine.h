@@ -37,7 +37,7 @@ struct Config {
 	uint32_t wtab_log2 = 26;          // walker vertex table entries
 	uint32_t wclaim_log2 = 26;        // walker claim slots
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
-	uint64_t p2_first_batch = 4096;   // PASS 2 read batches grow geometrically from here
+	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
 	uint64_t p2_max_batch = 1ull << 21;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
@@ -1033,7 +1033,7 @@ class Engine {
 		be_.free(result_d);
 	}
 
-	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0; };
+	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0; };
 	Stats stats() const { return stats_; }
 
   private:
@@ -1384,6 +1384,7 @@ class Engine {
 		counters_.contig_id += oid;
 		counters_.bases_assembled += bases;
 		counters_.visited_reads += visited;
+		stats_.generated += (brk - c_begin) - visited;
 		cend_count_ += scal_h[3];
 		if (nshort) { free_tab(e.tcend); be_.free(e.short_keys); }
 		be_.free(e.off); be_.free(e.cnt); be_.free(e.cnt2); be_.free(e.cnt3); be_.free(e.active);

@@ -153,7 +153,8 @@ struct HipBackend {
 	}
 	~HipBackend()
 	{
-		if (ticket) hipFree(ticket);
+		if (ticket) free(ticket);
+		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
 		if (ev1) hipEventDestroy(ev1);
 		if (stream) hipStreamDestroy(stream);
@@ -167,14 +168,56 @@ struct HipBackend {
 			abort();
 		}
 	}
+	// Scratch buffers come and go with every batch; hipMalloc / hipFree cost far more than the
+	// kernels between them (and hipFree synchronises the device).  Blocks up to 256 MiB are
+	// rounded up to a power of two and recycled; all work is ordered on one stream, so a block
+	// may be handed out again while its previous user is still queued.
+	static constexpr size_t CACHE_MAX_BLOCK = 256ull << 20, CACHE_MAX_TOTAL = 8ull << 30;
+	std::map<size_t, std::vector<void*>> cache_free;
+	std::map<void*, size_t> cache_size;
+	size_t cache_held = 0;
 	void* alloc(size_t n)
 	{
 		void* p = nullptr;
 		hipSetDevice(device);
-		check(hipMalloc(&p, n ? n : 1), "hipMalloc");
+		if (n > CACHE_MAX_BLOCK) {
+			check(hipMalloc(&p, n), "hipMalloc");
+			return p;
+		}
+		size_t sz = 256;
+		while (sz < n) sz <<= 1;
+		auto it = cache_free.find(sz);
+		if (it != cache_free.end() && !it->second.empty()) {
+			p = it->second.back();
+			it->second.pop_back();
+			cache_held -= sz;
+			return p;
+		}
+		check(hipMalloc(&p, sz), "hipMalloc");
+		cache_size[p] = sz;
 		return p;
 	}
-	void free(void* p) { if (p) { hipStreamSynchronize(stream); hipFree(p); } }
+	void free(void* p)
+	{
+		if (!p) return;
+		auto it = cache_size.find(p);
+		if (it != cache_size.end() && cache_held + it->second <= CACHE_MAX_TOTAL) {
+			cache_free[it->second].push_back(p);
+			cache_held += it->second;
+			return;
+		}
+		if (it != cache_size.end()) cache_size.erase(it);
+		hipStreamSynchronize(stream);
+		hipFree(p);
+	}
+	void drop_cache()
+	{
+		hipStreamSynchronize(stream);
+		for (auto& kv : cache_free)
+			for (void* q : kv.second) { cache_size.erase(q); hipFree(q); }
+		cache_free.clear();
+		cache_held = 0;
+	}
 	void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
 	void h2d(void* d, const void* s, size_t n)
 	{
@@ -434,7 +477,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 	out->candidates = s.candidates;
 	out->walked = s.walked;
 	out->rewalked = s.rewalked;
-	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds;
+	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
 	return ABG_OK;
 }
 

@@ -177,6 +177,7 @@ int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* 
 typedef struct abg_stats {
 	uint64_t insert_rounds, walk_rounds, candidates, walked, rewalked, commit_breaks;
 	uint64_t commit_rounds; /* passes of the parallel commit (0: the ordered kernel ran) */
+	uint64_t generated;     /* candidates whose contigs were committed (parallel commit only) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

@@ -109,7 +109,7 @@ void hc_get_stats(void* h, abg_stats* out)
 {
 	auto s = ((Sess*)h)->eng->stats();
 	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
-	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds;
+	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
 }
 // exact modulo check: returns the number of mismatches between mod64 and the hardware %
 uint64_t hc_mod_check(uint64_t m, const uint64_t* hs, uint64_t n)
