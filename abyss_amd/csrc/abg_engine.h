@@ -386,6 +386,28 @@ ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uin
 {
 	return scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
 }
+// canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
+// rolled (NTC64, nthash.hpp:242-257,275-279); from scratch throughout under a spaced seed
+template <class Get, class Put>
+ABG_HD void kmer_hash_run(const Params& p, Get get, uint32_t j0, uint32_t j1, Put put)
+{
+	if (j0 >= j1) return;
+	const unsigned k = p.k;
+	if (p.mask) {
+		for (uint32_t j = j0; j < j1; j++) put(j, scratch_hash(p, [&](unsigned i) { return get(j + i); }));
+		return;
+	}
+	uint64_t fh, rh;
+	scratch_hashes(p, [&](unsigned i) { return get(j0 + i); }, fh, rh);
+	put(j0, rh < fh ? rh : fh);
+	for (uint32_t j = j0 + 1; j < j1; j++) {
+		const unsigned out = get(j - 1), in = get(j + k - 1);
+		fh = srol1(fh) ^ seed_of(in) ^ sel4(p.seed_k, out);
+		rh = sror1(rh ^ sel4(p.seedrc_k, in) ^ seed_of(3u - out));
+		put(j, rh < fh ? rh : fh);
+	}
+}
+constexpr uint32_t PREP_RUN = 8; // consecutive k-mers per lane
 template <int NW>
 struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave per candidate)
 	Params p; Batch b; const uint32_t* cand_read; const uint64_t* rkoff; uint64_t* rkh; uint32_t first;
@@ -394,7 +416,10 @@ struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave 
 		uint32_t c = first + (uint32_t)i;
 		uint64_t r = cand_read[c];
 		uint32_t nk = b.len[r] - p.k + 1;
-		for (uint32_t j = lane; j < nk; j += nlanes) rkh[rkoff[c] + j] = read_kmer_hash<NW>(p, b, r, j);
+		uint64_t* out = rkh + rkoff[c];
+		for (uint32_t j0 = lane * PREP_RUN; j0 < nk; j0 += nlanes * PREP_RUN)
+			kmer_hash_run(p, [&](unsigned q) { return batch_base(b, r, q); }, j0, j0 + PREP_RUN < nk ? j0 + PREP_RUN : nk,
+			    [&](uint32_t j, uint64_t h) { out[j] = h; });
 	}
 };
 template <int NW>
@@ -404,13 +429,12 @@ struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum m
 	{
 		ContigRec& rec = recs[first + i];
 		const uint8_t* seq = pool + rec.seq_off;
+		uint64_t* out = kh + rec.seq_off;
 		uint32_t cnk = rec.len - p.k + 1;
 		uint32_t cov = 0; // getSeqAbsoluteKmerCoverage (bloom-dbg.h:92-109): a pure function of the solid filter
-		for (uint32_t j = lane; j < cnk; j += nlanes) {
-			uint64_t h = seq_kmer_hash<NW>(p, seq, j);
-			kh[rec.seq_off + j] = h;
-			cov += solid_min_count(p, cnt, h);
-		}
+		for (uint32_t j0 = lane * PREP_RUN; j0 < cnk; j0 += nlanes * PREP_RUN)
+			kmer_hash_run(p, [&](unsigned q) { return (unsigned)seq[q]; }, j0, j0 + PREP_RUN < cnk ? j0 + PREP_RUN : cnk,
+			    [&](uint32_t j, uint64_t h) { out[j] = h; cov += solid_min_count(p, cnt, h); });
 		if (cov) atomic_add_u32(&rec.coverage, cov);
 	}
 };
@@ -672,13 +696,21 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 // sequential loop computes.  Costs 4 bytes per filter bit for T; without that memory the
 // engine uses the sequential kernel.
 constexpr uint32_t T_NEVER = 0xFFFFFFFFu;
+// T is not cleared between passes: a stamp carries the tag of the pass that wrote it in its
+// high bits, newer passes have SMALLER tags (they win atomicMin against anything older), and a
+// stamp with another tag reads as "never".  The array is cleared when the tags run out.
+constexpr uint32_t T_TIME_BITS = 22, T_TAGS = 1u << (32 - T_TIME_BITS); // positions < 2^22 (<= rec_cap records)
+ABG_HD uint32_t t_stamp(uint32_t tag, uint32_t time) { return (tag << T_TIME_BITS) | time; }
+// position recorded for this pass, or T_NEVER
+ABG_HD uint32_t t_read(uint32_t v, uint32_t tag) { return (v >> T_TIME_BITS) == tag ? (v & ((1u << T_TIME_BITS) - 1)) : T_NEVER; }
 struct ParCommit {
 	Params p; Batch b;
 	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
 	ContigRec* recs; const uint8_t* pool; uint8_t* result;
 	const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff; const uint8_t* read_flag;
 	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
-	uint32_t* T;           // [filter bits] time stamps
+	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp
+	uint32_t tag;          // tag of the current pass (smaller = newer, so a newer pass wins every atomicMin)
 	WalkTab cend;          // contigEndKmers (bloom-dbg.h:992), owner 0
 	WalkTab tcend;         // end k-mers of this range's inserted short contigs; meta = earliest position
 	uint32_t* off;         // [n + 1] commit position of each candidate's first contig
@@ -697,7 +729,7 @@ ABG_HD bool pc_bit_before(const ParCommit& e, uint64_t h, uint32_t time)
 	for (unsigned q = 0; q < e.p.nh; q++) {
 		uint64_t pos = pos_i(e.p, h, q);
 		bool set = ((e.vis32[pos >> 5] >> (pos & 31)) & 1u) != 0;
-		ok = ok & (set | (e.T[pos] < time));
+		ok = ok & (set | (t_read(e.T[pos], e.tag) < time));
 	}
 	return ok;
 }
@@ -740,7 +772,7 @@ struct FPcTimeMin { // T: one wave per candidate
 			const uint32_t cnk = rec.len - e.p.k + 1;
 			for (uint32_t j = lane; j < cnk; j += nlanes) {
 				uint64_t h = ch[j];
-				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(&e.T[pos_i(e.p, h, q)], rec.time);
+				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(&e.T[pos_i(e.p, h, q)], t_stamp(e.tag, rec.time));
 			}
 		}
 	}
@@ -852,7 +884,7 @@ struct FPcDecide { // one wave per candidate: re-decide the read and its contigs
 						for (uint32_t j = lane; j < cnk; j += nlanes)
 							for (unsigned q = 0; q < e.p.nh; q++) {
 								uint64_t pos = pos_i(e.p, ch[j], q);
-								mine = mine | (e.T[pos] == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
+								mine = mine | (t_read(e.T[pos], e.tag) == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
 							}
 						moves = !wave_all_lanes(!mine, nlanes);
 					}
@@ -1049,6 +1081,7 @@ class Engine {
 	MaskTab* mask_d_ = nullptr;
 	std::chrono::steady_clock::time_point dbg_t0_;
 	uint32_t* T_ = nullptr; // parallel commit: time stamp per filter bit
+	uint32_t t_tag_ = 0;    // next pass takes tag t_tag_ - 1; 0: clear T first
 	bool use_par_commit() const { return cfg_.par_commit && m_ * 4ull <= cfg_.par_commit_max_bytes; }
 	Counters counters_;
 	Stats stats_;
@@ -1303,7 +1336,7 @@ class Engine {
 			uint64_t need = cend_count_ + 2ull * (nrec - std::min(nord, rec_cap_));
 			while (need * 2 > cend_.mask + 1) grow_cend();
 		}
-		if (!T_) T_ = (uint32_t*)be_.alloc(m_ * 4ull);
+		if (!T_) { T_ = (uint32_t*)be_.alloc(m_ * 4ull); t_tag_ = 0; }
 		{
 			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
 			be_.launch_wave(n, f, "precommit");
@@ -1340,8 +1373,10 @@ class Engine {
 			be_.launch(nshort, f, "pc_short_keys");
 		}
 		// the fixed point
+		if (off[n] > (1u << T_TIME_BITS)) { fprintf(stderr, "abyss_amd: too many contig records in one commit\n"); abort(); }
 		for (uint32_t round = 0;; round++) {
-			be_.memset(e.T, 0xFF, m_ * 4ull);
+			if (t_tag_ == 0) { be_.memset(e.T, 0xFF, m_ * 4ull); t_tag_ = T_TAGS - 1; } // tag T_TAGS-1 is what 0xFF.. carries: never used
+			e.tag = --t_tag_;
 			if (nshort) {
 				be_.memset(e.tcend.hmin, 0xFF, (e.tcend.mask + 1) * 8);
 				FPcShort f{ e, 0 };
