@@ -1,0 +1,97 @@
+"""Properties of the HIP path at BASELINE.json's full size (configs[1]: 5 M x 2x150 bp, k=64, B=2G,
+H=4), where the oracle cannot follow.  The path is a deterministic restatement of a sequential
+algorithm, so its results must not depend on how the work was cut up:
+
+* the counting filter, the visited filter, the assembly counters and every unitig are identical
+  whether PASS 1 runs in 2^24- or 2^22-k-mer batches against a large or a small claim table, PASS 2
+  in the default batch schedule or another one, the commit as the parallel fixed point or as the
+  ordered single-workgroup loop;
+* assembling the same reads again yields nothing (every read is then entirely visited);
+* PASS 1 has no false negatives: every k-mer of a sample of reads has min count >= 1, and every
+  k-mer of every unitig is solid (min count >= kc) and visited.
+
+Exactness against the oracle / the reference binary is tested at sizes they finish in seconds
+(test_gpu_parity.py, test_gpu_cli.py); this file ties the full-size runs to those.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from abyss_amd import api  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+K, BLOOM, PAIRS, READ_LEN = 64, 2 << 30, 5_000_000, 150
+
+
+def _run(words, woff, lens, n_reads, env, monkeypatch, want_contigs, **tuning):
+    for key in ("ABG_PAR_COMMIT", "ABG_P2_FIRST_BATCH", "ABG_P2_MAX_BATCH", "ABG_DRAIN_THRESHOLD"):
+        monkeypatch.delenv(key, raising=False)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    g = api.BloomDBG(K, bloom_bytes=BLOOM, num_hashes=4, min_cov=2, **tuning)
+    g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
+    counters = g.counters()
+    _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False,
+                                   want_contigs=want_contigs)
+    digest = hashlib.sha1()
+    for c in contigs:
+        if not c.redundant:
+            digest.update(b"%d %d %d %d " % (c.contig_id, c.read_index, len(c.seq), c.coverage))
+            digest.update(c.seq)
+    return g, counters, contigs, digest.hexdigest()
+
+
+def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
+    import torch
+    import bench
+    device = torch.device("cuda:0")
+    genome_len = int(PAIRS * 2 * READ_LEN / 50.0)
+    words, woff, lens = bench.gen_packed_reads(genome_len, PAIRS, READ_LEN, 0.005, seed=42, device=device)
+    n_reads = 2 * PAIRS
+    torch.cuda.synchronize()
+
+    a, cnt_a, contigs_a, dig_a = _run(words, woff, lens, n_reads, {}, monkeypatch, True)
+    ca, sa = a.assembly_counters(), a.stats()
+    vis_a = a.visited()
+    assert sa["commit_rounds"] > 0 and ca["next_contig_id"] > 50_000
+
+    # PASS 1 sanity on a sample: no false negatives (every read k-mer was inserted at least once)
+    nonred = [c for c in contigs_a if not c.redundant]
+    assert len(nonred) == ca["next_contig_id"] and sum(len(c.seq) for c in nonred) == ca["bases_assembled"]
+    # every unitig k-mer is solid and, after the run, visited: assembling the unitigs themselves as
+    # reads finds every one of them ALL_KMERS_VISITED (result 5) or rejects it before (never "NOT_SOLID")
+    sample = nonred[:: max(1, len(nonred) // 2000)]
+    buf, off = api.concat_seqs([c.seq for c in sample])
+    res, new_contigs = a.assemble(buf, off)
+    assert set(np.unique(res)) <= {3, 5}, np.bincount(res)  # BLUNT_END (contig ends at a tip) or ALL_KMERS_VISITED
+    assert not [c for c in new_contigs if not c.redundant]
+
+    # idempotence: the same reads again -> nothing new, all solid reads are visited
+    before = a.assembly_counters()
+    _, again = a.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False)
+    after = a.assembly_counters()
+    assert not [c for c in again if not c.redundant]
+    assert after["next_contig_id"] == before["next_contig_id"] and after["bases_assembled"] == before["bases_assembled"]
+    assert np.array_equal(a.visited(), vis_a)
+    a.close()
+
+    # another way of cutting up the same work: small PASS 1 batches and claim table, another PASS 2
+    # schedule, fewer walkers in flight, the ordered commit kernel
+    b, cnt_b, contigs_b, dig_b = _run(words, woff, lens, n_reads,
+                                      {"ABG_PAR_COMMIT": "0", "ABG_P2_FIRST_BATCH": "50000", "ABG_P2_MAX_BATCH": "1500000",
+                                       "ABG_DRAIN_THRESHOLD": "100000"},
+                                      monkeypatch, True, insert_batch_kmers=1 << 22, claim_log2=26, walk_slots=1024)
+    assert b.stats()["commit_rounds"] == 0
+    assert np.array_equal(cnt_a, cnt_b)
+    cb = b.assembly_counters()
+    assert {k2: cb[k2] for k2 in ca} == ca
+    assert dig_a == dig_b
+    assert np.array_equal(vis_a, b.visited())
+    b.close()
