@@ -40,6 +40,7 @@ struct Config {
 	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
 	uint64_t p2_max_batch = 1ull << 21;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
+	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
@@ -1060,7 +1061,12 @@ class Engine {
 			assemble_range(b, done, bs, result_d, results_host, sink);
 			done += bs;
 			counters_.reads_processed += bs;
-			p2_batch_ = std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
+			// Batches grow geometrically up to p2_max_batch (larger ones walk too many reads of the
+			// same unitigs side by side).  A batch with few candidates, though, is bound by its
+			// slowest walker, not by throughput: while that lasts (the start, and the end of a read
+			// set, where nearly every read is already visited) the size keeps doubling.
+			if (last_candidates_ < cfg_.p2_starved) p2_batch_ = std::min<uint64_t>(p2_batch_ * 2, 8 * cfg_.p2_max_batch);
+			else p2_batch_ = std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 		}
 		be_.free(result_d);
 	}
@@ -1103,6 +1109,7 @@ class Engine {
 	uint64_t* kh_ = nullptr; uint64_t* rkh_ = nullptr; uint64_t* dbg_ = nullptr;
 	uint64_t cend_count_ = 0;
 	uint8_t* read_flag_ = nullptr;
+	uint64_t last_candidates_ = 0;
 	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	void ensure_insert()
@@ -1668,6 +1675,7 @@ class Engine {
 			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
 		}
 		stats_.candidates += cand.size();
+		last_candidates_ = cand.size();
 		if (!cand.empty()) run_rounds<NW>(v, cand, res_d, first, sink);
 		if (results_host) {
 			be_.d2h(results_host + first, res_d, n);
