@@ -47,7 +47,7 @@ _lib = None
 def symbols():
     """Every entry point include/abyss_amd.h declares."""
     return [
-        "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_filter_size",
+        "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_reset", "abg_filter_size",
         "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
         "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
@@ -73,6 +73,7 @@ def load(path: str | None = None):
     lib.abg_destroy.restype = None
     lib.abg_last_error.argtypes = [vp]
     lib.abg_last_error.restype = C.c_char_p
+    lib.abg_reset.argtypes = [vp]
     lib.abg_filter_size.argtypes = [vp, u64p]
     lib.abg_load_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
     lib.abg_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]

@@ -114,6 +114,10 @@ class BloomDBG:
             msg = self._lib.abg_last_error(self._ctx)
             raise AbyssAmdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
+    def reset(self) -> None:
+        """Empty filters and zero counters, keeping the device memory (abg_reset)."""
+        self._check(self._lib.abg_reset(self._ctx), "abg_reset")
+
     # ---- filter
     @property
     def size(self) -> int:

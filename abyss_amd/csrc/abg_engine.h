@@ -352,27 +352,21 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 
 template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
-	WalkEnv<NW> e; const uint32_t* list; bool use_fast;
-	// coop: called by all 64 lanes of a wavefront in lock step (HIP backend) or by one thread (serial)
+	WalkEnv<NW> e; const uint32_t* list;
+	// fast: fast_bytes of memory private to this walker (LDS on the device); coop: called by all
+	// 64 lanes of a wavefront in lock step (HIP backend) or by one thread (serial)
 	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes, bool coop)
 	{
-		if (use_fast && fast) {
-			// the environment goes to fast memory as well (see walk_read): every lane of a
-			// cooperative caller stores the same values
-			WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
-			const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
-			*env = e;
-			env->fast = (char*)fast + a;
-			env->fast_bytes = fast_bytes - a;
-			env->coop = coop;
-			walk_read<NW>(*env, list[i], slot);
-			return;
-		}
-		WalkEnv<NW> env = e;
-		env.fast = nullptr;
-		env.fast_bytes = 0;
-		env.coop = coop;
-		walk_read<NW>(env, list[i], slot);
+		// The environment goes to fast memory as well (see walk_read): handed by reference to
+		// out-of-line functions it would otherwise be a per-lane copy in scratch.  Every lane of a
+		// cooperative caller stores the same values.
+		WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
+		const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
+		*env = e;
+		env->fast = (char*)fast + a;
+		env->fast_bytes = fast_bytes - a;
+		env->coop = coop;
+		walk_read<NW>(*env, list[i], slot);
 	}
 };
 
@@ -1009,6 +1003,27 @@ class Engine {
 		free_insert();
 		free_walk();
 	}
+	// Back to the state right after construction -- empty filters, zero counters, empty
+	// contigEndKmers -- without giving any memory back (claim tables and time stamps are
+	// epoch-tagged and need no clearing).
+	void reset()
+	{
+		if (casc_.bits) be_.memset(casc_.bits, 0, casc_.levels * casc_.level_words * 4);
+		else be_.memset(cnt_, 0, m_);
+		be_.memset(vis_, 0, vis_bytes_);
+		be_.memset(cstate_, 0, sizeof(CommitState));
+		counters_ = Counters();
+		stats_ = Stats();
+		last_rounds_ = 0;
+		p2_batch_ = cfg_.p2_first_batch;
+		last_candidates_ = 0;
+		needed_frac_ = 1.0;
+		if (walk_ready_) {
+			be_.memset(cend_.hmin, 0xFF, (cend_.mask + 1) * 8);
+			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
+		}
+		cend_count_ = 0;
+	}
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	uint8_t* counters_dev() { return cnt_; }
@@ -1101,7 +1116,7 @@ class Engine {
 	WalkTab wtab_{}, cend_{};
 	uint32_t wtab_log2_ = 0;
 	uint32_t* wclaims_ = nullptr;
-	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; bool slow_frames_ = false; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
+	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
 	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
 	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
 	uint32_t* order_ = nullptr; uint32_t* order_n_ = nullptr;
@@ -1554,7 +1569,7 @@ class Engine {
 				env.claims = wclaims_;
 				env.owner_base = owner_next;
 				owner_next += nc;
-				FWalk<NW> fw{ env, list_d, !slow_frames_ };
+				FWalk<NW> fw{ env, list_d };
 				be_.launch_walkers(nc - base, fw, wslots_, "walk");
 				stats_.walked += nc - base;
 				dump("walk", nc - base);
@@ -1581,7 +1596,7 @@ class Engine {
 					env.claims = nullptr;
 					env.owner_base = owner_next;
 					owner_next += nc;
-					FWalk<NW> fw{ env, need_d, !slow_frames_ };
+					FWalk<NW> fw{ env, need_d };
 					if (debug) { uint32_t tmp; be_.d2h(&tmp, rec_used_, 4); dbg_t0_ = std::chrono::steady_clock::now(); }
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;

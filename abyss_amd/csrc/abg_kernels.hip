@@ -349,6 +349,14 @@ const char* abg_last_error(const abg_ctx* ctx)
 	if (ctx) return ctx->s.error.c_str();
 	return g_create_error.c_str();
 }
+int abg_reset(abg_ctx* ctx)
+{
+	if (!ctx) return ABG_EINVAL;
+	ctx->s.eng->reset();
+	ctx->s.be.sync();
+	return ABG_OK;
+}
+
 int abg_filter_size(const abg_ctx* ctx, uint64_t* counters)
 {
 	if (!ctx || !counters) return ABG_EINVAL;

@@ -280,7 +280,7 @@ struct WalkEnv {
 	uint32_t owner_base;       // owner ids of this launch are owner_base + candidate index
 	// per-slot scratch
 	TBFrame<NW>* tb_pool; VKey* tbk_pool; uint32_t tb_cap;
-	// fast per-walker memory (LDS on the device) for the trueBranch stack; NULL: use tb_pool
+	// fast memory private to the walker (LDS on the device): scratch, path state, trueBranch stack
 	void* fast; uint32_t fast_bytes;
 	VKey* la_pool;
 	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
@@ -618,29 +618,23 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	const unsigned k = p.k;
 	// The search scratch and the path state are handed by reference to out-of-line functions, so
 	// they live in memory.  As locals that is per-lane scratch: 64 copies per cooperative wave
-	// and a 256-byte transaction per dword touched.  With fast memory (LDS) available they are
-	// carved out of it instead: one copy per wave, read by broadcast.
-	SearchScratch<NW> sc_local;
-	WalkState<NW> w_local;
-	SearchScratch<NW>* scp = &sc_local;
-	WalkState<NW>* wp = &w_local;
+	// and a 256-byte transaction per dword touched.  They are carved out of the walker's fast
+	// memory (LDS on the device) instead: one copy per wave, read by broadcast; the rest of it
+	// is the fast tier of the trueBranch stack.
 	char* fast = (char*)e.fast;
 	uint32_t fast_bytes = e.fast_bytes;
-	if (fast) {
-		const uint32_t a = (uint32_t)((sizeof(SearchScratch<NW>) + 15) & ~15ull), b = (uint32_t)((sizeof(WalkState<NW>) + 15) & ~15ull);
-		scp = (SearchScratch<NW>*)fast;
-		wp = (WalkState<NW>*)(fast + a);
-		fast += a + b; fast_bytes -= a + b;
-	}
-	SearchScratch<NW>& sc = *scp;
-	WalkState<NW>& w = *wp;
+	const uint32_t sc_bytes = (uint32_t)((sizeof(SearchScratch<NW>) + 15) & ~15ull);
+	const uint32_t ws_bytes = (uint32_t)((sizeof(WalkState<NW>) + 15) & ~15ull);
+	SearchScratch<NW>& sc = *(SearchScratch<NW>*)fast;
+	WalkState<NW>& w = *(WalkState<NW>*)(fast + sc_bytes);
+	fast += sc_bytes + ws_bytes; fast_bytes -= sc_bytes + ws_bytes;
 	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_cap = e.tb_cap;
 	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
 	sc.la = sc.la_local;
-	if (fast) {
-		// the rest of the fast tier: trueBranch keys and frames side by side
+	{
+		// trueBranch keys and frames side by side
 		uint32_t cap = fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
 		sc.tbf_keys = (VKey*)fast;
 		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));

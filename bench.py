@@ -165,13 +165,18 @@ def main() -> int:
 
     g = None
     unitigs = bases = 0
+    setup_s = 0.0
 
     def step():
-        nonlocal g, unitigs, bases
-        if g is not None:
-            g.close()
-        g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local)
+        nonlocal g, unitigs, bases, setup_s
+        t_setup = time.perf_counter()
+        if g is None:
+            g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local)
+        else:
+            g.reset()  # empty filters, zero counters; the device memory is kept (abg_reset)
+        setup_s += time.perf_counter() - t_setup
         g.profile_enable(True)
+        g.profile_reset()
         g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
         # contigs stay on the device (no per-contig callback into Python): the unitig count and
         # their total length come from the assembly counters (AssemblyCounters.h:15-31)
@@ -251,6 +256,8 @@ def main() -> int:
             "roofline": roofline,
             "kernel_ms": {nm: {"ms": round(v[0], 3), "launches": v[1]} for nm, v in prof.items() if v[1]},
             "engine_stats": stats,
+            # part of every step: creating the filters (first step) or clearing them (abg_reset)
+            "setup_ms_per_step": round(setup_s / max(a.steps + a.warmup, 1) * 1e3, 1),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)

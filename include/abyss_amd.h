@@ -113,6 +113,11 @@ int abg_create(const abg_params* p, abg_ctx** out);
 void abg_destroy(abg_ctx* ctx);
 const char* abg_last_error(const abg_ctx* ctx); /* ctx may be NULL: error of the last failed abg_create */
 
+/* Empty filters, zero counters, empty contigEndKmers: the state right after abg_create, keeping the
+ * device memory (what destroying and re-creating the context would do, minus ~26 GB of hipFree /
+ * hipMalloc for a 2G filter).  Tuning and parameters are unchanged. */
+int abg_reset(abg_ctx* ctx);
+
 /* bloom.size() / sizeInBytes(): number of uint8 counters == number of visited bits */
 int abg_filter_size(const abg_ctx* ctx, uint64_t* counters);
 

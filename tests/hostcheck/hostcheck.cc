@@ -83,6 +83,7 @@ void* hc_create_cascade(unsigned k, unsigned nh, unsigned levels, uint64_t level
 }
 uint8_t* hc_cascade_level(void* h, unsigned l) { return ((Sess*)h)->eng->cascade_level_dev(l); }
 void hc_destroy(void* h) { delete (Sess*)h; }
+void hc_reset(void* h) { ((Sess*)h)->eng->reset(); }
 uint64_t hc_size(void* h) { return ((Sess*)h)->eng->size(); }
 uint8_t* hc_counters(void* h) { return ((Sess*)h)->eng->counters_dev(); }
 uint8_t* hc_visited(void* h) { return ((Sess*)h)->eng->visited_dev(); }

@@ -230,6 +230,21 @@ def test_ordered_commit_kernel_still_exact(monkeypatch):
     assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
 
 
+def test_reset_gives_a_fresh_context():
+    g = GoldenCase("k32")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], insert_batch=30000, claim_log2=16, p2_first=100)
+    for _ in range(2):
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+        hc.l.hc_reset.argtypes = [C.c_void_p]
+        hc.l.hc_reset(hc.h)
+        assert hc.counters().sum() == 0 and hc.visited().sum() == 0
+        assert hc.assembly_counters()["next_contig_id"] == 0
+
+
 def test_saturating_counters_and_duplicate_kmers():
     # heavy duplication: 300 copies of the same read saturate counters at 255
     # (CountingBloomFilter.hpp:146-149); homopolymers give runs of identical k-mers
