@@ -133,6 +133,7 @@ def main() -> int:
     ap.add_argument("--pairs", type=int, default=5_000_000, help="read pairs per GPU (configs[1]: 5 M)")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--bloom", type=str, default="2G")
+    ap.add_argument("--K", type=int, default=0, help="spaced seed of two K-mers (-K of abyss-bloom-dbg; configs[3]: --k 96 --K 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -171,7 +172,8 @@ def main() -> int:
         nonlocal g, unitigs, bases, setup_s
         t_setup = time.perf_counter()
         if g is None:
-            g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local)
+            g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local,
+                             spaced_seed=api.spaced_seed_kmer_pair(a.k, a.K) if a.K else None)
         else:
             g.reset()  # empty filters, zero counters; the device memory is kept (abg_reset)
         setup_s += time.perf_counter() - t_setup
@@ -248,8 +250,8 @@ def main() -> int:
             "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d, B=%s, H=4, 1xMI355X per rank"
-                       % (a.pairs, read_len, a.k, a.bloom),
+            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, 1xMI355X per rank"
+                       % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom),
                        "genome_bp": genome_len, "coverage": cov, "error_rate": err, "read_kmers": kmers,
                        "parallelism": "replicas x%d (filter not partitioned yet)" % world if world > 1 else "single GPU",
                        "unitigs": unitigs, "unitig_bp": bases},
