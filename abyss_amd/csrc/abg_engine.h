@@ -41,6 +41,7 @@ struct Config {
 	uint64_t p2_max_batch = 1ull << 21;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
+	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
@@ -347,6 +348,28 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
 		}
 		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
+	}
+};
+
+// A classification made against an older visited snapshot (see Engine::prefetch_classify) is
+// brought up to date: BLUNT_END / NOT_SOLID do not depend on the snapshot and "all k-mers
+// visited" is final once true, so only the candidates are tested again.
+template <int NW>
+struct FRefilter {
+	Params p; Batch b; const uint8_t* vis; uint8_t* result;
+	ABG_HDN void operator()(uint64_t r, uint32_t) const
+	{
+		if (result[r] != RES_CANDIDATE) return;
+		const unsigned k = p.k;
+		const uint32_t nk = b.len[r] - k + 1;
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!visited_contains(p, vis, vtx_hash(p, v))) return;
+		}
+		result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
 	}
 };
 
@@ -1000,6 +1023,7 @@ class Engine {
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
+		if (la_pool2_) be_.free(la_pool2_);
 		free_insert();
 		free_walk();
 	}
@@ -1071,19 +1095,40 @@ class Engine {
 		ensure_walk();
 		uint64_t done = 0;
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
+		full_b_ = &b; result_base_ = result_d; pre_n_ = 0;
 		while (done < b.n) {
 			uint64_t bs = std::min<uint64_t>(p2_batch_, b.n - done);
 			assemble_range(b, done, bs, result_d, results_host, sink);
 			done += bs;
 			counters_.reads_processed += bs;
-			// Batches grow geometrically up to p2_max_batch (larger ones walk too many reads of the
-			// same unitigs side by side).  A batch with few candidates, though, is bound by its
-			// slowest walker, not by throughput: while that lasts (the start, and the end of a read
-			// set, where nearly every read is already visited) the size keeps doubling.
-			if (last_candidates_ < cfg_.p2_starved) p2_batch_ = std::min<uint64_t>(p2_batch_ * 2, 8 * cfg_.p2_max_batch);
-			else p2_batch_ = std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
+			p2_batch_ = next_batch_size();
 		}
+		be_.sync_side();
+		full_b_ = nullptr; pre_n_ = 0; prefetch_ = nullptr;
 		be_.free(result_d);
+	}
+	// Batches grow geometrically up to p2_max_batch (larger ones walk too many reads of the same
+	// unitigs side by side).  A batch with few candidates, though, is bound by its slowest walker,
+	// not by throughput: while that lasts (the start, and the end of a read set, where nearly
+	// every read is already visited) the size keeps doubling.
+	uint64_t next_batch_size() const
+	{
+		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * 2, 8 * cfg_.p2_max_batch);
+		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
+	}
+	// Classification of the NEXT batch on the side stream, queued right before this batch's walkers
+	// so that it fills the machine while they thin out (a batch ends with its slowest walker).  It
+	// sees an older visited snapshot; FRefilter brings it up to date when its turn comes.
+	template <int NW>
+	void prefetch_classify(uint64_t next_first, uint64_t next_n)
+	{
+		if (!next_n || !cfg_.prefetch_classify) return;
+		if (!la_pool2_) la_pool2_ = (VKey*)be_.alloc((uint64_t)cslots2_ * LA_MAX_VISITED * sizeof(VKey));
+		Batch vn = *full_b_;
+		vn.woff += next_first; vn.len += next_first; vn.koff += next_first; vn.n = next_n;
+		FClassify<NW> f{ p_, vn, 0, cnt_, vis_, result_base_ + next_first, la_pool2_ };
+		be_.launch_slots_side(next_n, f, cslots2_, "classify");
+		pre_first_ = next_first; pre_n_ = next_n;
 	}
 
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0; };
@@ -1125,6 +1170,10 @@ class Engine {
 	uint64_t cend_count_ = 0;
 	uint8_t* read_flag_ = nullptr;
 	uint64_t last_candidates_ = 0;
+	const Batch* full_b_ = nullptr; uint8_t* result_base_ = nullptr; // the assemble_packed call in progress
+	uint64_t pre_first_ = 0, pre_n_ = 0;      // range classified ahead on the side stream
+	std::function<void()> prefetch_;
+	VKey* la_pool2_ = nullptr; uint32_t cslots2_ = 65536;
 	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	void ensure_insert()
@@ -1570,6 +1619,7 @@ class Engine {
 				env.owner_base = owner_next;
 				owner_next += nc;
 				FWalk<NW> fw{ env, list_d };
+				if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 				be_.launch_walkers(nc - base, fw, wslots_, "walk");
 				stats_.walked += nc - base;
 				dump("walk", nc - base);
@@ -1598,6 +1648,7 @@ class Engine {
 					owner_next += nc;
 					FWalk<NW> fw{ env, need_d };
 					if (debug) { uint32_t tmp; be_.d2h(&tmp, rec_used_, 4); dbg_t0_ = std::chrono::steady_clock::now(); }
+					if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
 					stats_.rewalked += nneed;
 					batch_rewalked += nneed;
@@ -1677,10 +1728,16 @@ class Engine {
 	void assemble_range_nw(const Batch& v, uint64_t first, uint64_t n, uint8_t* res_d,
 	    uint8_t* results_host, const std::function<void(const ContigOut&)>& sink)
 	{
-		{
+		if (pre_n_ == n && pre_first_ == first) {
+			be_.sync_side();
+			FRefilter<NW> f{ p_, v, vis_, res_d };
+			be_.launch(n, f, "reclassify");
+		} else {
+			be_.sync_side();
 			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_ };
 			be_.launch_slots(n, f, cslots_, "classify");
 		}
+		pre_n_ = 0;
 		std::vector<uint8_t> res(n);
 		be_.d2h(res.data(), res_d, n);
 		std::vector<uint32_t> cand;
@@ -1691,6 +1748,10 @@ class Engine {
 		}
 		stats_.candidates += cand.size();
 		last_candidates_ = cand.size();
+		if (full_b_ && first + n < full_b_->n) {
+			const uint64_t nf = first + n, nn = std::min<uint64_t>(next_batch_size(), full_b_->n - nf);
+			prefetch_ = [this, nf, nn]() { prefetch_classify<NW>(nf, nn); };
+		}
 		if (!cand.empty()) run_rounds<NW>(v, cand, res_d, first, sink);
 		if (results_host) {
 			be_.d2h(results_host + first, res_d, n);

@@ -131,6 +131,10 @@ struct HipBackend {
 	bool good = false;
 	std::string reason;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr; // side stream: work that may overlap the main stream's kernels (launch_side)
+	hipEvent_t ev2a = nullptr, ev2b = nullptr;
+	std::string side_name;
+	bool side_pending = false;
 	bool profiling = false;
 	std::map<std::string, ProfEntry> prof;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -147,6 +151,9 @@ struct HipBackend {
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint32_t)prop.multiProcessorCount;
 		if (hipStreamCreate(&stream) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		if (hipStreamCreate(&stream2) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		hipEventCreate(&ev2a);
+		hipEventCreate(&ev2b);
 		hipEventCreate(&ev0);
 		hipEventCreate(&ev1);
 		good = true;
@@ -157,6 +164,9 @@ struct HipBackend {
 		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
 		if (ev1) hipEventDestroy(ev1);
+		if (ev2a) hipEventDestroy(ev2a);
+		if (ev2b) hipEventDestroy(ev2b);
+		if (stream2) hipStreamDestroy(stream2);
 		if (stream) hipStreamDestroy(stream);
 	}
 	bool ok() const { return good; }
@@ -268,6 +278,38 @@ struct HipBackend {
 		begin(name);
 		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
 		end(name);
+	}
+	// The same on the side stream: it starts after everything queued on the main stream SO FAR
+	// and runs next to whatever the main stream queues afterwards (queue it BEFORE the kernel it
+	// is meant to overlap).  One at a time; sync_side() waits for it and books its time.
+	template <class F>
+	void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = (n + 63) / 64;
+		uint64_t cap = slots / 64 ? slots / 64 : 1;
+		if (blocks > cap) blocks = cap;
+		hipEventRecord(ev2a, stream);              // order after the main stream's queue
+		hipStreamWaitEvent(stream2, ev2a, 0);
+		hipEventRecord(ev2a, stream2);
+		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream2, f, n);
+		check(hipGetLastError(), name);
+		hipEventRecord(ev2b, stream2);
+		side_name = name;
+		side_pending = true;
+	}
+	void sync_side()
+	{
+		if (!side_pending) return;
+		check(hipEventSynchronize(ev2b), "hipEventSynchronize");
+		if (profiling) {
+			float ms = 0;
+			hipEventElapsedTime(&ms, ev2a, ev2b);
+			ProfEntry& p = prof[side_name];
+			p.ms += ms;
+			p.launches++;
+		}
+		side_pending = false;
 	}
 	template <class F>
 	void launch_wave(uint64_t n, F f, const char* name)

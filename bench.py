@@ -200,7 +200,7 @@ def main() -> int:
 
     # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
     names = ["hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep", "walk", "rewalk",
-             "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
+             "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names}
     stats = g.stats()

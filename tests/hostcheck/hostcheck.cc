@@ -34,6 +34,8 @@ struct SerialBackend {
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
+	template <class F> void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name) { launch_slots(n, f, slots, name); }
+	void sync_side() {}
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests
 	alignas(16) unsigned char fastbuf[2048];
 	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, (uint32_t)sizeof fastbuf, false); }
