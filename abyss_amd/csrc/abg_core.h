@@ -151,6 +151,8 @@ struct MaskTab {
 	uint8_t pos[MAX_K];               // the masked ('0') positions
 	uint64_t F[MAX_K][4];             // srol^(k-1-pos)(seed[b])    : term of base b in the forward hash
 	uint64_t R[MAX_K][4];             // srol^(pos)(seed[3-b])      : term of base b in the reverse hash
+	uint32_t nruns;                   // maximal runs [run_a, run_b) of masked positions
+	uint8_t run_a[MAX_K / 2], run_b[MAX_K / 2];
 };
 struct Params {
 	uint32_t k;        // k-mer size
@@ -190,9 +192,16 @@ inline Params make_params(uint32_t k, uint32_t nh, uint32_t kc, uint32_t trim, u
 // host-side construction of the spaced-seed table; `mask` is k characters of '0'/'1'
 inline void make_mask(const char* mask, uint32_t k, MaskTab& t, Params& p)
 {
-	t.k = k; t.nmasked = 0;
+	t.k = k; t.nmasked = 0; t.nruns = 0;
 	t.ones_prefix[0] = 0;
 	p.ident_fast = 0;
+	for (unsigned i = 0; i < k;) {
+		if (mask[i] == '1') { i++; continue; }
+		unsigned e = i;
+		while (e < k && mask[e] != '1') e++;
+		t.run_a[t.nruns] = (uint8_t)i; t.run_b[t.nruns] = (uint8_t)e; t.nruns++;
+		i = e;
+	}
 	for (int j = 0; j < MAX_NW; j++) p.care[j] = 0;
 	for (unsigned i = 0; i < k; i++) {
 		bool one = mask[i] == '1';
@@ -225,16 +234,25 @@ ABG_HD uint64_t pos_i(const Params& p, uint64_t h, unsigned i)
 
 // ------------------------------------------------------------ 2-bit k-mers
 // Base i lives in bits [2*(i%32), 2*(i%32)+2) of word i/32; bits past 2k are zero.
+// The template parameter NW of everything below encodes two things: the number of 64-bit
+// words of a k-mer (NW & 7, 1..6) and whether the code is built for a spaced seed (NW >= 8).
+// The spaced-seed build carries the masked-out hash terms in every vertex and calls the mask
+// helpers; the plain build has neither, so the headline path pays nothing for them (registers,
+// LDS frame size) -- the engine instantiates its kernels for NW and for NW_MASKED + NW and picks
+// at run time.
+constexpr int NW_MASKED = 8;
+template <int NW> constexpr int KW = NW & 7;
+template <int NW> constexpr bool MASKED_BUILD = NW >= NW_MASKED;
 template <int NW>
 struct Kmer {
-	uint64_t w[NW];
+	uint64_t w[KW<NW>];
 };
 template <int NW>
 ABG_HD unsigned kmer_get(const Kmer<NW>& s, unsigned i)
 {
 	unsigned r = 0;
 #pragma unroll
-	for (int j = 0; j < NW; j++)
+	for (int j = 0; j < KW<NW>; j++)
 		if ((int)(i >> 5) == j) r = (unsigned)(s.w[j] >> (2 * (i & 31))) & 3u;
 	return r;
 }
@@ -242,7 +260,7 @@ template <int NW>
 ABG_HD void kmer_set(Kmer<NW>& s, unsigned i, unsigned b)
 {
 #pragma unroll
-	for (int j = 0; j < NW; j++)
+	for (int j = 0; j < KW<NW>; j++)
 		if ((int)(i >> 5) == j) {
 			unsigned sh = 2 * (i & 31);
 			s.w[j] = (s.w[j] & ~(3ULL << sh)) | ((uint64_t)b << sh);
@@ -254,14 +272,14 @@ ABG_HD void kmer_shift(Kmer<NW>& s, unsigned k, int sense, unsigned b)
 {
 	if (sense == SENSE) {
 #pragma unroll
-		for (int j = 0; j < NW; j++) {
-			uint64_t hi = (j + 1 < NW) ? s.w[j + 1] : 0;
+		for (int j = 0; j < KW<NW>; j++) {
+			uint64_t hi = (j + 1 < KW<NW>) ? s.w[j + 1] : 0;
 			s.w[j] = (s.w[j] >> 2) | (hi << 62);
 		}
 		kmer_set(s, k - 1, b);
 	} else {
 #pragma unroll
-		for (int j = NW - 1; j >= 0; j--) {
+		for (int j = KW<NW> - 1; j >= 0; j--) {
 			uint64_t lo = (j > 0) ? s.w[j - 1] : 0;
 			s.w[j] = (s.w[j] << 2) | (lo >> 62);
 		}
@@ -269,7 +287,7 @@ ABG_HD void kmer_shift(Kmer<NW>& s, unsigned k, int sense, unsigned b)
 		// clear the base shifted past position k-1
 		unsigned top = k & 31;
 #pragma unroll
-		for (int j = 0; j < NW; j++) {
+		for (int j = 0; j < KW<NW>; j++) {
 			if (j == (int)(k >> 5)) s.w[j] = top ? (s.w[j] & ((1ULL << (2 * top)) - 1)) : 0;
 			else if (j > (int)(k >> 5)) s.w[j] = 0;
 		}
@@ -281,7 +299,7 @@ ABG_HD Kmer<NW> kmer_revcomp(const Kmer<NW>& s, unsigned k)
 {
 	Kmer<NW> r;
 #pragma unroll
-	for (int j = 0; j < NW; j++) r.w[j] = 0;
+	for (int j = 0; j < KW<NW>; j++) r.w[j] = 0;
 	for (unsigned i = 0; i < k; i++)
 		kmer_set(r, k - 1 - i, 3u - kmer_get(s, i));
 	return r;
@@ -305,42 +323,80 @@ ABG_HD bool kmer_equal(const Params& p, const Kmer<NW>& a, const Kmer<NW>& b)
 {
 	bool e = true;
 #pragma unroll
-	for (int j = 0; j < NW; j++) e = e && (((a.w[j] ^ b.w[j]) & p.care[j]) == 0);
+	for (int j = 0; j < KW<NW>; j++) e = e && (((a.w[j] ^ b.w[j]) & p.care[j]) == 0);
 	return e;
 }
 
 // ------------------------------------------------------------------ vertex
 // RollingBloomDBGVertex (RollingBloomDBG.h:33-38) with value semantics: the k-mer
 // and the forward / reverse-complement ntHash state of RollingHash (RollingHash.h:211-219).
+// Spaced-seed build only: XOR of the masked positions' terms in fh / rh, so that the strand
+// hashes maskHash would compute (nthash.hpp:537-547) are fh ^ df and rh ^ dr.
+template <bool M> struct VtxMask { uint64_t df, dr; };
+template <> struct VtxMask<false> {};
 template <int NW>
-struct Vtx {
+struct Vtx : VtxMask<MASKED_BUILD<NW>> {
 	Kmer<NW> s;
 	uint64_t fh, rh;
 };
+template <int NW> ABG_HD uint64_t vtx_df(const Vtx<NW>& v) { if constexpr (MASKED_BUILD<NW>) return v.df; else return 0; }
+template <int NW> ABG_HD uint64_t vtx_dr(const Vtx<NW>& v) { if constexpr (MASKED_BUILD<NW>) return v.dr; else return 0; }
+template <int NW> ABG_HD void vtx_set_d(Vtx<NW>& v, uint64_t df, uint64_t dr)
+{
+	if constexpr (MASKED_BUILD<NW>) { v.df = df; v.dr = dr; } else { (void)v; (void)df; (void)dr; }
+}
 // (fh, rh) of the identity below
 struct VKey { uint64_t fh, rh; };
-// The two strand hashes that make the canonical hash: the rolling (fh, rh) themselves, or,
-// under a spaced seed, maskHash's fsVal / rsVal (nthash.hpp:537-547): every masked
-// position's term XORed out.
+// XOR of the masked positions' terms of a k-mer, from scratch (O(masked positions))
 template <int NW>
-ABG_HD void strand_hashes(const Params& p, const Kmer<NW>& s, uint64_t fh, uint64_t rh, uint64_t& fs, uint64_t& rs)
+ABG_HD void masked_terms(const Params& p, const Kmer<NW>& s, uint64_t& df, uint64_t& dr)
 {
-	fs = fh; rs = rh;
+	df = 0; dr = 0;
 	if (p.mask) {
 		const MaskTab& m = *p.mask;
 		for (unsigned j = 0; j < m.nmasked; j++) {
 			unsigned b = kmer_get(s, m.pos[j]);
-			fs ^= m.F[j][b];
-			rs ^= m.R[j][b];
+			df ^= m.F[j][b];
+			dr ^= m.R[j][b];
 		}
 	}
+}
+// The same for the k-mer shifted one base in direction `sense`, from the unshifted k-mer's
+// terms in O(runs of masked positions): within a run every base moves one position, which
+// rotates its term by one bit, and the run gains a base at one end and loses one at the other
+// (the incoming base lands on an end of the k-mer, which a mask never covers, MaskedKmer.h:43).
+// srol1 / sror1 are bit permutations, hence linear over XOR.
+template <int NW>
+ABG_HD void masked_terms_shifted(const Params& p, const Kmer<NW>& old, uint64_t df, uint64_t dr, int sense,
+    uint64_t& ndf, uint64_t& ndr)
+{
+	const MaskTab& m = *p.mask;
+	const unsigned k = p.k;
+	for (unsigned r = 0; r < m.nruns; r++) {
+		// SENSE: position a leaves the run, position b enters it; ANTISENSE: b - 1 leaves, a - 1 enters
+		const unsigned ia = (sense == SENSE) ? m.run_a[r] : m.run_a[r] - 1u;
+		const unsigned ib = (sense == SENSE) ? m.run_b[r] : m.run_b[r] - 1u;
+		const unsigned xa = kmer_get(old, ia), xb = kmer_get(old, ib);
+		df ^= srol_n(seed_of(xa), k - 1 - ia) ^ srol_n(seed_of(xb), k - 1 - ib);
+		dr ^= srol_n(seed_of(3u - xa), ia) ^ srol_n(seed_of(3u - xb), ib);
+	}
+	ndf = (sense == SENSE) ? srol1(df) : sror1(df);
+	ndr = (sense == SENSE) ? sror1(dr) : srol1(dr);
+}
+// The two strand hashes that make the canonical hash: the rolling (fh, rh) themselves, or,
+// under a spaced seed, maskHash's fsVal / rsVal: every masked position's term XORed out.
+template <int NW>
+ABG_HD void strand_hashes(const Vtx<NW>& v, uint64_t& fs, uint64_t& rs)
+{
+	fs = v.fh ^ vtx_df(v); rs = v.rh ^ vtx_dr(v);
 }
 // canonical hash (RollingHash.h:28-31,74-79)
 template <int NW>
 ABG_HD uint64_t vtx_hash(const Params& p, const Vtx<NW>& v)
 {
+	(void)p;
 	uint64_t fs, rs;
-	strand_hashes(p, v.s, v.fh, v.rh, fs, rs);
+	strand_hashes(v, fs, rs);
 	return rs < fs ? rs : fs;
 }
 // Identity of a vertex under RollingBloomDBGVertex::operator== (RollingBloomDBG.h:92-159):
@@ -364,7 +420,7 @@ ABG_HD VKey vtx_ident(const Params& p, const Vtx<NW>& v)
 		return key;
 	}
 	uint64_t fs, rs;
-	strand_hashes(p, v.s, v.fh, v.rh, fs, rs);
+	strand_hashes(v, fs, rs);
 	bool canon = kmer_is_canonical(v.s, p.k);
 	key.fh = canon ? fs : rs;
 	key.rh = canon ? rs : fs;
@@ -413,6 +469,7 @@ ABG_HD void vtx_rehash(const Params& p, Vtx<NW>& v)
 	}
 	v.fh = fh;
 	v.rh = rh;
+	if constexpr (MASKED_BUILD<NW>) masked_terms(p, v.s, v.df, v.dr);
 }
 // Vertex::shift (RollingBloomDBG.h:55-63): RollingHash::rollRight / rollLeft
 // (RollingHash.h:88-124; NTC64 nthash.hpp:242-257,275-279; NTC64L :282-304).
@@ -420,6 +477,7 @@ template <int NW>
 ABG_HD void vtx_shift(const Params& p, Vtx<NW>& v, int sense, unsigned in)
 {
 	unsigned k = p.k;
+	if constexpr (MASKED_BUILD<NW>) masked_terms_shifted(p, v.s, v.df, v.dr, sense, v.df, v.dr);
 	if (sense == SENSE) {
 		unsigned out = kmer_get(v.s, 0);
 		v.fh = srol1(v.fh) ^ seed_of(in) ^ p.seed_k[out];
@@ -437,6 +495,7 @@ ABG_HD void vtx_revcomp(const Params& p, Vtx<NW>& v)
 {
 	v.s = kmer_revcomp(v.s, p.k);
 	uint64_t t = v.fh; v.fh = v.rh; v.rh = t;
+	if constexpr (MASKED_BUILD<NW>) { t = v.df; v.df = v.dr; v.dr = t; } // the mask is symmetric
 }
 template <int NW>
 ABG_HD bool vtx_equal(const Params& p, const Vtx<NW>& a, const Vtx<NW>& b)
@@ -684,11 +743,8 @@ template <int NW>
 ABG_HD void neighbour_mask_delta(const Params& p, const Vtx<NW>& u, int sense, uint64_t& df, uint64_t& dr)
 {
 	df = 0; dr = 0;
-	if (p.mask) {
-		Kmer<NW> sh = u.s;
-		kmer_shift(sh, p.k, sense, 0);
-		strand_hashes(p, sh, 0, 0, df, dr);
-	}
+	if constexpr (MASKED_BUILD<NW>) masked_terms_shifted(p, u.s, u.df, u.dr, sense, df, dr);
+	else (void)p;
 }
 // Returns a 4-bit mask (bit b = neighbour with base b exists) and the (rolling) hash pairs.
 template <int NW>
@@ -719,6 +775,7 @@ ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsi
     uint64_t fh, uint64_t rh)
 {
 	Vtx<NW> v = u;
+	if constexpr (MASKED_BUILD<NW>) masked_terms_shifted(p, u.s, u.df, u.dr, sense, v.df, v.dr);
 	kmer_shift(v.s, p.k, sense, b);
 	v.fh = fh;
 	v.rh = rh;
@@ -881,8 +938,9 @@ ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in
 		f.next = (uint8_t)(nx + 1);
 		Vtx<NW> fv;
 #pragma unroll
-		for (int j = 0; j < NW; j++) fv.s.w[j] = uni64<COOP>(f.v.s.w[j]);
+		for (int j = 0; j < KW<NW>; j++) fv.s.w[j] = uni64<COOP>(f.v.s.w[j]);
 		fv.fh = uni64<COOP>(f.v.fh); fv.rh = uni64<COOP>(f.v.rh);
+		vtx_set_d(fv, uni64<COOP>(vtx_df(f.v)), uni64<COOP>(vtx_dr(f.v)));
 		const Vtx<NW> w = nbr_vertex_lean(p, tabs, fv, sense, b);
 		const VKey wk = vtx_ident(p, w);
 		// visited.find(w): cooperative callers spread the scan over the lanes
@@ -936,8 +994,9 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 	auto uniform_vtx = [&](const Vtx<NW>& x) {
 		Vtx<NW> r;
 #pragma unroll
-		for (int j = 0; j < NW; j++) r.s.w[j] = uni64<COOP>(x.s.w[j]);
+		for (int j = 0; j < KW<NW>; j++) r.s.w[j] = uni64<COOP>(x.s.w[j]);
 		r.fh = uni64<COOP>(x.fh); r.rh = uni64<COOP>(x.rh);
+		vtx_set_d(r, uni64<COOP>(vtx_df(x)), uni64<COOP>(vtx_dr(x)));
 		return r;
 	};
 	int top = -1;
@@ -1075,7 +1134,7 @@ template <int NW, bool COOP>
 ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restrict__ cnt_in, const Vtx<NW>& u,
     const int dir_in, const unsigned trim_in, const unsigned mask_in, SearchScratch<NW>& sc)
 {
-	if (p_in.mask || p_in.nh > 4) return 0;
+	if (MASKED_BUILD<NW> || p_in.nh > 4) return 0;
 	const Params p = uniform_params<COOP>(p_in);
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
 	const int dir = (int)uni32<COOP>((uint32_t)dir_in);

@@ -1286,7 +1286,7 @@ class Engine {
 	}
 	void alloc_walk_scratch()
 	{
-		tb_pool_ = be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(TBFrame<MAX_NW>));
+		tb_pool_ = be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(TBFrame<NW_MASKED + MAX_NW>));
 		tbk_pool_ = (VKey*)be_.alloc((uint64_t)wslots_ * walk_tb_cap_ * sizeof(VKey));
 		lbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
 		rbuf_ = (uint8_t*)be_.alloc((uint64_t)wslots_ * walk_buf_cap_);
@@ -1345,7 +1345,7 @@ class Engine {
 		WalkEnv<NW> e;
 		e.p = p_; e.cnt = cnt_; e.batch = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.tab = wtab_; e.claims = nullptr; e.claim_mask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1); e.owner_base = 0;
-		// scratch strides are sized for TBFrame<MAX_NW>; a smaller NW fits more frames in them
+		// scratch strides are sized for the largest TBFrame; a smaller NW fits more frames in them
 		e.tb_pool = (TBFrame<NW>*)tb_pool_;
 		e.tbk_pool = tbk_pool_;
 		e.tb_cap = walk_tb_cap_;
@@ -1770,12 +1770,18 @@ class Engine {
 		Batch v = b;
 		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
 		uint8_t* res_d = result_d + first;
-		switch (p_.nw) {
+		// spaced seed: the build that carries the masked-out terms (see NW_MASKED, abg_core.h)
+		switch (p_.mask ? NW_MASKED + p_.nw : p_.nw) {
 		case 1: assemble_range_nw<1>(v, first, n, res_d, results_host, sink); break;
 		case 2: assemble_range_nw<2>(v, first, n, res_d, results_host, sink); break;
 		case 3: assemble_range_nw<3>(v, first, n, res_d, results_host, sink); break;
 		case 4: assemble_range_nw<4>(v, first, n, res_d, results_host, sink); break;
-		default: assemble_range_nw<6>(v, first, n, res_d, results_host, sink); break;
+		case 5: case 6: assemble_range_nw<6>(v, first, n, res_d, results_host, sink); break;
+		case NW_MASKED + 1: assemble_range_nw<NW_MASKED + 1>(v, first, n, res_d, results_host, sink); break;
+		case NW_MASKED + 2: assemble_range_nw<NW_MASKED + 2>(v, first, n, res_d, results_host, sink); break;
+		case NW_MASKED + 3: assemble_range_nw<NW_MASKED + 3>(v, first, n, res_d, results_host, sink); break;
+		case NW_MASKED + 4: assemble_range_nw<NW_MASKED + 4>(v, first, n, res_d, results_host, sink); break;
+		default: assemble_range_nw<NW_MASKED + 6>(v, first, n, res_d, results_host, sink); break;
 		}
 	}
 };

@@ -160,7 +160,7 @@ ABG_HD Kmer<NW> batch_kmer(const Batch& b, uint64_t r, uint32_t pos, unsigned k)
 {
 	Kmer<NW> s;
 #pragma unroll
-	for (int j = 0; j < NW; j++) s.w[j] = 0;
+	for (int j = 0; j < KW<NW>; j++) s.w[j] = 0;
 	for (unsigned i = 0; i < k; i++)
 		kmer_set(s, i, batch_base(b, r, pos + i));
 	return s;
@@ -317,7 +317,7 @@ ABG_HDN Vtx<NW> ws_vertex(const Params& p, const WalkState<NW>& w, uint32_t i)
 {
 	Vtx<NW> v;
 #pragma unroll
-	for (int j = 0; j < NW; j++) v.s.w[j] = 0;
+	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = 0;
 	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, ws_base(p, w, i + j));
 	vtx_rehash(p, v);
 	return v;
@@ -327,7 +327,7 @@ ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i)
 {
 	Vtx<NW> v;
 #pragma unroll
-	for (int j = 0; j < NW; j++) v.s.w[j] = 0;
+	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = 0;
 	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, seq[i + j]);
 	vtx_rehash(p, v);
 	return v;
@@ -375,8 +375,9 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 	uint32_t ext = uni32<COOP>(w.ext);
 	Vtx<NW> head;
 #pragma unroll
-	for (int j = 0; j < NW; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
+	for (int j = 0; j < KW<NW>; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
 	head.fh = uni64<COOP>(w.head.fh); head.rh = uni64<COOP>(w.head.rh);
+	vtx_set_d(head, uni64<COOP>(vtx_df(w.head)), uni64<COOP>(vtx_dr(w.head)));
 	VKey prev_key;
 	prev_key.fh = uni64<COOP>(w.prev_key.fh); prev_key.rh = uni64<COOP>(w.prev_key.rh);
 	// The rolling-hash tables as named scalars: an array in registers that is indexed at run time
@@ -405,21 +406,35 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 			if (sense == SENSE) { fh = fb_s ^ seed_of(b); rh = rb_s ^ pick(b, rm0, rm1, rm2, rm3); }
 			else { fh = fb_a ^ pick(b, sm0, sm1, sm2, sm3); rh = rb_a ^ seed_of(3u - b); }
 		};
+		// spaced seed: the masked-out terms the four neighbours of either side share
+		uint64_t df_s = 0, dr_s = 0, df_a = 0, dr_a = 0;
+		if constexpr (MASKED_BUILD<NW>) {
+			masked_terms_shifted(p, head.s, head.df, head.dr, SENSE, df_s, dr_s);
+			masked_terms_shifted(p, head.s, head.df, head.dr, ANTISENSE, df_a, dr_a);
+			df_s = uni64<COOP>(df_s); dr_s = uni64<COOP>(dr_s); df_a = uni64<COOP>(df_a); dr_a = uni64<COOP>(dr_a);
+		}
+		// canonical (masked) hash of that neighbour
+		auto nbr_hash_c = [&](int sense, unsigned b) -> uint64_t {
+			uint64_t fh, rh;
+			nbr(sense, b, fh, rh);
+			fh ^= (sense == SENSE) ? df_s : df_a;
+			rh ^= (sense == SENSE) ? dr_s : dr_a;
+			return rh < fh ? rh : fh;
+		};
 		// probe round over the 8 neighbours (q < 4: behind, q >= 4: ahead), in flight while the
 		// head enters the visited set (ExtendPath.h:650-658)
 		uint8_t my_c = 255; bool my_active = false;
 		if (COOP) {
 			const unsigned lane = lane_id(), q = lane >> 3, i = lane & 7;
-			uint64_t fh, rh;
-			nbr(q < 4 ? bsense : fsense, q & 3u, fh, rh);
+			const uint64_t h = nbr_hash_c(q < 4 ? bsense : fsense, q & 3u);
 			my_active = i < p.nh;
-			if (my_active) my_c = cnt[pos_i(p, rh < fh ? rh : fh, i)];
+			if (my_active) my_c = cnt[pos_i(p, h, i)];
 		}
 		const VKey hkey = vtx_ident(p, head);
 		ins = (int32_t)uni32<COOP>((uint32_t)wt_insert(tab, wt_key(hkey), owner, contig, COOP));
 		if (ins != WT_NEW) { why = LIN_INS; break; }
 		if (claims) {
-			const uint64_t hm = hkey.fh < hkey.rh ? hkey.fh : hkey.rh; // the canonical hash (no spaced seed here)
+			const uint64_t hm = hkey.fh < hkey.rh ? hkey.fh : hkey.rh; // the canonical hash: the smaller strand hash
 			uint32_t old = wu_atomic_min_u32(&claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask], claim_id, COOP);
 			if (uni32<COOP>(old) < claim_id && may_defer) { why = LIN_DEFER; break; }
 		}
@@ -430,11 +445,8 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 			for (unsigned q = 0; q < 8; q++)
 				if ((bad >> (8 * q)) & 0xFFu) m8 &= ~(1u << q);
 		} else {
-			for (unsigned q = 0; q < 8; q++) {
-				uint64_t fh, rh;
-				nbr(q < 4 ? bsense : fsense, q & 3u, fh, rh);
-				if (!solid_contains(p, cnt, rh < fh ? rh : fh)) m8 &= ~(1u << q);
-			}
+			for (unsigned q = 0; q < 8; q++)
+				if (!solid_contains(p, cnt, nbr_hash_c(q < 4 ? bsense : fsense, q & 3u))) m8 &= ~(1u << q);
 		}
 		const unsigned bmask = m8 & 0xFu, fmask = m8 >> 4;
 		why = LIN_GENERAL;
@@ -445,6 +457,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 		Vtx<NW> t = head;
 		kmer_shift(t.s, k, bsense, bb);
 		nbr(bsense, bb, t.fh, t.rh);
+		vtx_set_d(t, (bsense == SENSE) ? df_s : df_a, (bsense == SENSE) ? dr_s : dr_a);
 		if (!key_equal(vtx_ident(p, t), prev_key)) break;
 		// path.push_back(v) / push_front(v)
 		wu_st_u8(&buf[nbuf], (uint8_t)fb, COOP);
@@ -454,6 +467,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 		nbr(fsense, fb, nfh, nrh);
 		kmer_shift(head.s, k, fsense, fb);
 		head.fh = nfh; head.rh = nrh;
+		vtx_set_d(head, (fsense == SENSE) ? df_s : df_a, (fsense == SENSE) ? dr_s : dr_a);
 	}
 	w.head = head; w.prev_key = prev_key; w.ext = ext; w.ins = ins;
 	if (dir == FORWARD) w.nr = nbuf; else w.nl = nbuf;
@@ -478,8 +492,8 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	bool look_behind = false;
 	bool pending = false; // the head was pushed but not yet entered into `visited`
 	const bool split = sc.coop && p.nh <= 8;
-	// runs of simple steps go to walk_linear (no spaced seed; cooperative probes hold up to 8 hash functions)
-	const bool lean = !p.mask && (p.nh <= 8 || !sc.coop);
+	// runs of simple steps go to walk_linear (cooperative probes hold up to 8 hash functions)
+	const bool lean = p.nh <= 8 || !sc.coop;
 	int ins_given = -1; // walk_linear already inserted the head: what the insertion returned
 	int result;
 	for (;;) {
