@@ -40,6 +40,7 @@ struct Config {
 	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
 	uint64_t p2_max_batch = 1ull << 21;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
+	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
@@ -1113,7 +1114,7 @@ class Engine {
 	// every read is already visited) the size keeps doubling.
 	uint64_t next_batch_size() const
 	{
-		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * 2, 8 * cfg_.p2_max_batch);
+		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * cfg_.p2_starved_growth, 8 * cfg_.p2_max_batch);
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
 	// Classification of the NEXT batch on the side stream, queued right before this batch's walkers

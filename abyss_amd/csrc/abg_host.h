@@ -76,6 +76,7 @@ class Session {
 		if (const char* e = getenv("ABG_P2_MAX_BATCH")) cfg.p2_max_batch = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_PAR_COMMIT")) cfg.par_commit = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
+		if (const char* e = getenv("ABG_P2_STARVED_GROWTH")) cfg.p2_starved_growth = (uint32_t)std::max(2, atoi(e));
 		if (const char* e = getenv("ABG_P2_STARVED")) cfg.p2_starved = (uint32_t)atoi(e);
 		if (const char* e = getenv("ABG_P2_GROWTH")) cfg.p2_growth = (uint32_t)std::max(2, atoi(e));
 		if (const char* e = getenv("ABG_DRAIN_THRESHOLD")) cfg.drain_threshold = (uint32_t)strtoul(e, 0, 10);
