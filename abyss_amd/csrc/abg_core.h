@@ -1128,13 +1128,13 @@ ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned m
 // lanes each, so that one probe round trip advances all of them; a cooperative caller's
 // successor() thereby pays the depth of one branch instead of the sum over the branches, and
 // pays it without frame traffic.  Branches proven true are returned in true_mask; any other
-// outcome (a vertex with no or several neighbours ahead, more than four hash functions, a
-// spaced seed, chains longer than the key space) is left to the general search.
+// outcome (a vertex with no or several neighbours ahead, more than four hash functions, chains
+// longer than the key space) is left to the general search.
 template <int NW, bool COOP>
 ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restrict__ cnt_in, const Vtx<NW>& u,
     const int dir_in, const unsigned trim_in, const unsigned mask_in, SearchScratch<NW>& sc)
 {
-	if (MASKED_BUILD<NW> || p_in.nh > 4) return 0;
+	if (p_in.nh > 4) return 0;
 	const Params p = uniform_params<COOP>(p_in);
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
 	const int dir = (int)uni32<COOP>((uint32_t)dir_in);
@@ -1180,13 +1180,15 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 				else {
 					if (sub == 0) mykeys[depth] = key;
 					// the neighbours ahead: lane (b, i) of the group probes hash i of neighbour b
-					uint64_t fb, rb;
+					uint64_t fb, rb, ndf, ndr;
 					nbr_base(tabs, v, p.k, sense, fb, rb);
+					neighbour_mask_delta(p, v, sense, ndf, ndr); // spaced seed: the neighbours' masked-out terms
 					unsigned cm = 0;
 					if (COOP) {
 						const unsigned b = sub >> 2, i = sub & 3u;
 						uint64_t fh, rh;
 						nbr_hash(tabs, sense, fb, rb, b, fh, rh);
+						fh ^= ndf; rh ^= ndr;
 						bool bad = false;
 						if (i < p.nh) bad = cnt[pos_i(p, rh < fh ? rh : fh, i)] < p.kc;
 						const unsigned gb = (unsigned)((wave_ballot(bad) >> (16 * grp)) & 0xFFFFull);
@@ -1196,6 +1198,7 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 						for (unsigned q = 0; q < 4; q++) {
 							uint64_t fh, rh;
 							nbr_hash(tabs, sense, fb, rb, q, fh, rh);
+							fh ^= ndf; rh ^= ndr;
 							if (solid_contains(p, cnt, rh < fh ? rh : fh)) cm |= 1u << q;
 						}
 					}
