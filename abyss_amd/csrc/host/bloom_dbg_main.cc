@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <getopt.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -259,6 +260,23 @@ int main(int argc, char** argv)
 	Chunk chunk;
 	uint64_t counters = 0;
 	abg_filter_size(ctx, &counters);
+	// The reference reads its input twice (loadBloomFilter, then assemble).  When both passes run
+	// over the same files, the parsed records of pass 1 are kept for pass 2 as long as they fit in
+	// a quarter of the machine's memory: parsing is what the host spends its time on.
+	std::vector<Chunk> kept;
+	bool keep = prebuilt.empty();
+	for (int i = optind; i < argc; ++i) if (!strcmp(argv[i], ":") || !strcmp(argv[i], "-")) keep = false;
+	size_t kept_bytes = 0;
+	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE);
+	auto loaded = [&]() {
+		check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load");
+		if (keep) {
+			kept_bytes += chunk.seqs.size() + 48 * chunk.n();
+			if (kept_bytes > keep_limit) { keep = false; kept.clear(); kept.shrink_to_fit(); }
+			else { kept.push_back(std::move(chunk)); chunk = Chunk(); return; }
+		}
+		chunk.clear();
+	};
 	if (prebuilt.empty()) {
 		// PASS 1: loadBloomFilter, BloomIO.h:97-118 (a ":" argument separates load and assembly files)
 		for (int i = optind; i < argc; ++i) {
@@ -268,9 +286,9 @@ int main(int argc, char** argv)
 			uint64_t n = 0;
 			while (in.read(id, comment, seq)) {
 				chunk.add(id, seq); n++;
-				if (chunk.seqs.size() >= CHUNK_BASES) { check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load"); chunk.clear(); }
+				if (chunk.seqs.size() >= CHUNK_BASES) loaded();
 			}
-			if (chunk.n()) { check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load"); chunk.clear(); }
+			if (chunk.n()) loaded();
 			if (verbose) fprintf(stderr, "Loaded %llu reads from `%s` into Bloom filter\n", (unsigned long long)n, argv[i]);
 		}
 	} else {
@@ -300,13 +318,18 @@ int main(int argc, char** argv)
 	static const char* rr[] = { "NA", "SHORTER_THAN_K", "NON_ACGT", "BLUNT_END", "NOT_SOLID", "ALL_KMERS_VISITED", "ALL_BRANCH_KMERS_VISITED", "GENERATED_CONTIGS" };
 	Output o{ out, trace, &chunk, p.k };
 	std::vector<uint8_t> results;
-	auto flush = [&]() {
-		if (!chunk.n()) return;
-		results.assign(chunk.n(), 0);
-		check(abg_assemble_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n(), results.data(), on_contig, &o), ctx, "assemble");
-		if (readlog) for (size_t i = 0; i < chunk.n(); i++) fprintf(readlog, "%s\t%s\n", chunk.ids[i].c_str(), rr[results[i]]);
-		chunk.clear();
+	auto assemble = [&](Chunk& c) {
+		if (!c.n()) return;
+		o.chunk = &c;
+		results.assign(c.n(), 0);
+		check(abg_assemble_seqs(ctx, c.seqs.data(), c.off.data(), c.n(), results.data(), on_contig, &o), ctx, "assemble");
+		if (readlog) for (size_t i = 0; i < c.n(); i++) fprintf(readlog, "%s\t%s\n", c.ids[i].c_str(), rr[results[i]]);
 	};
+	auto flush = [&]() { assemble(chunk); chunk.clear(); };
+	if (keep && !kept.empty()) {
+		for (Chunk& c : kept) { assemble(c); c = Chunk(); }
+		first_asm = argc; // nothing left to read
+	}
 	for (int i = first_asm; i < argc; ++i) {
 		if (!strcmp(argv[i], ":")) continue;
 		abghost::FastaReader in(argv[i], ropt);

@@ -43,11 +43,14 @@ class FastaReader {
 			fprintf(stderr, "error: `%s': %s\n", path.c_str(), strerror(errno));
 			exit(EXIT_FAILURE);
 		}
+		setvbuf(m_f, nullptr, _IOFBF, 4u << 20); // one reader per stream: big buffer, unlocked reads
+		flockfile(m_f);
 		int c = peek();
 		if (c == EOF) fprintf(stderr, "%s:0: warning: file is empty\n", m_path.c_str());
 	}
 	~FastaReader()
 	{
+		if (m_f) funlockfile(m_f);
 		if (m_f && m_f != stdin) { if (m_pipe) pclose(m_f); else fclose(m_f); }
 		free(m_line_buf);
 	}
@@ -87,7 +90,7 @@ class FastaReader {
 			if (type == '>') {
 				while (peek() != '>' && peek() != '#' && getline(line)) s += line;
 			} else {
-				int c = getc(m_f);
+				int c = getc_unlocked(m_f);
 				if (c != '+') die("expected `+'");
 				getline(line);
 				getline(q);
@@ -131,7 +134,7 @@ class FastaReader {
 	unsigned m_line = 0;
 	char* m_line_buf = nullptr;
 	size_t m_line_cap = 0;
-	int peek() { int c = getc(m_f); if (c != EOF) ungetc(c, m_f); return c; }
+	int peek() { int c = getc_unlocked(m_f); if (c != EOF) ungetc(c, m_f); return c; }
 	bool getline(std::string& out)
 	{
 		ssize_t n = ::getline(&m_line_buf, &m_line_cap, m_f);
