@@ -151,7 +151,14 @@ struct HipBackend {
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint32_t)prop.multiProcessorCount;
 		if (hipStreamCreate(&stream) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
-		if (hipStreamCreate(&stream2) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		{
+			// the side stream only fills gaps: lowest priority (ABG_SIDE_PRIORITY=0 turns that off)
+			int lo = 0, hi = 0;
+			hipDeviceGetStreamPriorityRange(&lo, &hi);
+			const char* e = getenv("ABG_SIDE_PRIORITY");
+			const bool low = !e || atoi(e) != 0;
+			if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, low ? lo : hi) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		}
 		hipEventCreate(&ev2a);
 		hipEventCreate(&ev2b);
 		hipEventCreate(&ev0);
