@@ -1149,7 +1149,19 @@ class Engine {
 	std::chrono::steady_clock::time_point dbg_t0_;
 	uint32_t* T_ = nullptr; // parallel commit: time stamp per filter bit
 	uint32_t t_tag_ = 0;    // next pass takes tag t_tag_ - 1; 0: clear T first
-	bool use_par_commit() const { return cfg_.par_commit && m_ * 4ull <= cfg_.par_commit_max_bytes; }
+	// the parallel commit needs 4 bytes of time stamp per filter bit; without that memory (or when
+	// switched off) the ordered single-workgroup kernel runs
+	bool use_par_commit()
+	{
+		if (!cfg_.par_commit || m_ * 4ull > cfg_.par_commit_max_bytes || t_failed_) return false;
+		if (!T_) {
+			T_ = (uint32_t*)be_.try_alloc(m_ * 4ull);
+			t_tag_ = 0;
+			if (!T_) { t_failed_ = true; if (cfg_.verbose) fprintf(stderr, "abyss_amd: no memory for the parallel commit's time stamps, using the ordered kernel\n"); return false; }
+		}
+		return true;
+	}
+	bool t_failed_ = false;
 	Counters counters_;
 	Stats stats_;
 	uint64_t last_rounds_ = 0;
@@ -1408,7 +1420,6 @@ class Engine {
 			uint64_t need = cend_count_ + 2ull * (nrec - std::min(nord, rec_cap_));
 			while (need * 2 > cend_.mask + 1) grow_cend();
 		}
-		if (!T_) { T_ = (uint32_t*)be_.alloc(m_ * 4ull); t_tag_ = 0; }
 		{
 			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
 			be_.launch_wave(n, f, "precommit");

@@ -193,6 +193,14 @@ struct HipBackend {
 	std::map<size_t, std::vector<void*>> cache_free;
 	std::map<void*, size_t> cache_size;
 	size_t cache_held = 0;
+	// for optional big buffers: NULL instead of aborting when the device has no room
+	void* try_alloc(size_t n)
+	{
+		void* p = nullptr;
+		hipSetDevice(device);
+		if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		return p;
+	}
 	void* alloc(size_t n)
 	{
 		void* p = nullptr;

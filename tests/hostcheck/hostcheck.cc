@@ -26,6 +26,7 @@ struct SerialBackend {
 	bool ok() const { return true; }
 	std::string why() const { return ""; }
 	void* alloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
+	void* try_alloc(size_t n) { return malloc(n ? n : 1); }
 	void free(void* p) { ::free(p); }
 	void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
