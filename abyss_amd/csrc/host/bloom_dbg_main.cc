@@ -4,8 +4,7 @@
 // libabyss_amd.so (include/abyss_amd.h).  All assembly work happens on the GPU; this file
 // only parses options, reads sequence files and prints records.
 //
-// Not supported yet (the binary says so and exits 1): spaced seeds (-K, --qr-seed, -s),
-// -g/-C/-R auxiliary outputs, checkpoints, SAM/qseq input.
+// Not supported (the binary says so and exits 1): -g/-C/-R auxiliary outputs, checkpoints.
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 

@@ -2,16 +2,17 @@
 // Restates the FASTA / FASTQ behaviour of the reference's FastaReader::read
 // (DataLayer/FastaReader.cpp:130-421) as used by BloomDBG (flag FOLD_CASE): '#' comment
 // lines, Casava chastity filter, multi-line FASTA, masked-end trimming, case folding,
-// 3'/5' quality trimming (-q) and internal quality masking (-Q).  SAM / qseq / export
-// inputs are not supported by this binary (it stops with an error, as the reference does
-// for malformed input).  Compressed files are piped through the matching decompressor the
-// way Common/Uncompress.cpp does.
+// 3'/5' quality trimming (-q) and internal quality masking (-Q); SAM records (secondary and
+// QC-failed alignments skipped, reverse strand restored, /1 /2 suffixes) and qseq / export
+// lines (:215-352).  Colour-space reads are not supported.  Compressed files are piped through
+// the matching decompressor the way Common/Uncompress.cpp does.
 #pragma once
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace abghost {
 
@@ -63,7 +64,13 @@ class FastaReader {
 			while (peek() == '#') getline(line);
 			int type = peek();
 			if (type == EOF) return false;
-			if (type != '>' && type != '@') die("Expected either `>' or `@' (SAM, qseq and export input are not supported by this binary)");
+			unsigned qoff_default = 33;
+			if (type != '>' && type != '@') {
+				// a SAM, qseq or export line (FastaReader.cpp:256-352): no case folding, no masked-end trimming
+				int r = read_tabular(id, comment, s, q, qoff_default);
+				if (r == 0) continue; // record filtered out
+				return finish(s, q, qoff_default);
+			}
 			getline(header);
 			// ignore SAM headers
 			if (header.size() > 3 && header[0] == '@' && isalpha((unsigned char)header[1]) &&
@@ -107,26 +114,111 @@ class FastaReader {
 				if (!q.empty()) { q.erase(back); q.erase(0, front); }
 			}
 			for (auto& ch : s) ch = (char)toupper((unsigned char)ch); // FOLD_CASE
-			unsigned qoff = m_opt.qualityOffset > 0 ? (unsigned)m_opt.qualityOffset : 33u;
-			if (m_opt.qualityThreshold > 0 && !q.empty()) {
-				// keep [first base with q >= threshold, last such base]
-				int good = (int)qoff + m_opt.qualityThreshold;
-				size_t front = std::string::npos, back = 0;
-				for (size_t i = 0; i < q.size(); i++)
-					if ((unsigned char)q[i] >= good && (unsigned char)q[i] <= '~') { if (front == std::string::npos) front = i; back = i + 1; }
-				if (front == std::string::npos || front >= back) { s.erase(1); q.erase(1); }
-				else if (front > 0 || back < q.size()) { s.erase(back); s.erase(0, front); q.erase(back); q.erase(0, front); }
-			}
-			if (m_opt.internalQThreshold > 0 && !q.empty()) {
-				int good = (int)qoff + m_opt.internalQThreshold;
-				for (size_t i = 0; i < q.size(); i++)
-					if (!((unsigned char)q[i] >= good && (unsigned char)q[i] <= '~')) s[i] = 'N';
-			}
-			return true;
+			return finish(s, q, qoff_default);
 		}
 	}
 
   private:
+	// quality trimming / masking shared by every format (FastaReader.cpp:355-399)
+	bool finish(std::string& s, std::string& q, unsigned qoff_default)
+	{
+		unsigned qoff = m_opt.qualityOffset > 0 ? (unsigned)m_opt.qualityOffset : qoff_default;
+		if (m_opt.qualityThreshold > 0 && !q.empty()) {
+			// keep [first base with q >= threshold, last such base]
+			int good = (int)qoff + m_opt.qualityThreshold;
+			size_t front = std::string::npos, back = 0;
+			for (size_t i = 0; i < q.size(); i++)
+				if ((unsigned char)q[i] >= good && (unsigned char)q[i] <= '~') { if (front == std::string::npos) front = i; back = i + 1; }
+			if (front == std::string::npos || front >= back) { s.erase(1); q.erase(1); }
+			else if (front > 0 || back < q.size()) { s.erase(back); s.erase(0, front); q.erase(back); q.erase(0, front); }
+		}
+		if (m_opt.internalQThreshold > 0 && !q.empty()) {
+			int good = (int)qoff + m_opt.internalQThreshold;
+			for (size_t i = 0; i < q.size(); i++)
+				if (!((unsigned char)q[i] >= good && (unsigned char)q[i] <= '~')) s[i] = 'N';
+		}
+		return true;
+	}
+	static bool chaste(const std::string& f, bool& ok)
+	{
+		ok = true;
+		if (f == "1" || f == "Y") return true;
+		if (f == "0" || f == "N") return false;
+		ok = false;
+		return false;
+	}
+	static char complement(char c) // complementBaseChar, Common/Sequence.cpp:21-47
+	{
+		char rc;
+		switch (toupper((unsigned char)c)) {
+		case 'A': rc = 'T'; break; case 'C': rc = 'G'; break; case 'G': rc = 'C'; break; case 'T': rc = 'A'; break;
+		case 'N': rc = 'N'; break; case '.': rc = '.'; break; case 'M': rc = 'K'; break; case 'R': rc = 'Y'; break;
+		case 'W': rc = 'W'; break; case 'S': rc = 'S'; break; case 'Y': rc = 'R'; break; case 'K': rc = 'M'; break;
+		case 'V': rc = 'B'; break; case 'H': rc = 'D'; break; case 'D': rc = 'H'; break; case 'B': rc = 'V'; break;
+		default: fprintf(stderr, "error: unexpected character: `%c'\n", c); abort();
+		}
+		return islower((unsigned char)c) ? (char)tolower(rc) : rc;
+	}
+	// returns 1 with a record, 0 when the line was filtered out
+	int read_tabular(std::string& id, std::string& comment, std::string& s, std::string& q, unsigned& qoff_default)
+	{
+		std::string line;
+		getline(line);
+		std::vector<std::string> f;
+		{
+			size_t a = 0;
+			while (a <= line.size()) { // std::getline(in, field, '\t'): no empty last field after a trailing tab
+				size_t b = line.find('\t', a);
+				if (b == std::string::npos) { if (a < line.size()) f.push_back(line.substr(a)); break; }
+				f.push_back(line.substr(a, b - a));
+				a = b + 1;
+			}
+		}
+		if (f.size() >= 11 && (f[9].size() == f[10].size() || f[10] == "*")) { // SAM
+			unsigned flags = (unsigned)strtoul(f[1].c_str(), NULL, 0);
+			if (flags & 0x100) return 0;                         // FSECONDARY
+			if (m_opt.chastityFilter && (flags & 0x200)) return 0; // FQCFAIL
+			id = f[0];
+			char which = '0';
+			switch (flags & 0xc1) { // FPAIRED|FREAD1|FREAD2
+			case 0: case 1: break;
+			case 0x41: id += "/1"; which = '1'; break;
+			case 0x81: id += "/2"; which = '2'; break;
+			default: die(("invalid flags: `" + id + "'").c_str());
+			}
+			comment = (flags & 0x200) ? "0:Y:0:" : "0:N:0:";
+			comment[0] = which;
+			s = f[9]; q = f[10];
+			if (s == "*") s.clear();
+			if (q == "*") q.clear();
+			if (flags & 0x10) { // FREVERSE
+				std::string rc(s.rbegin(), s.rend());
+				for (auto& ch : rc) ch = complement(ch);
+				s = rc;
+				q.assign(q.rbegin(), q.rend());
+			}
+			qoff_default = 33;
+			if (!q.empty() && q.size() != s.size()) die("sequence and quality must be the same length");
+			return 1;
+		}
+		if (f.size() == 11 || f.size() == 22) { // qseq or export
+			bool ok;
+			bool ch = chaste(f.back(), ok);
+			if (!ok) die("chastity filter should be one of 0, 1, N or Y");
+			if (m_opt.chastityFilter && !ch) return 0;
+			id = f[0];
+			for (int i = 1; i < 6; i++) if (!f[i].empty()) { id += ':'; id += f[i]; }
+			if (!f[6].empty() && f[6] != "0") { id += '#'; id += f[6]; }
+			id += '/';
+			id += (f[7] == "3" ? std::string("2") : f[7]);
+			comment = f[7] + (ch ? ":N:0:" : ":Y:0:");
+			s = f[8]; q = f[9];
+			qoff_default = 64;
+			if (q.size() != s.size()) die("sequence and quality must be the same length");
+			return 1;
+		}
+		die("Expected either `>' or `@' or 11 fields");
+	}
 	std::string m_path;
 	ReaderOptions m_opt;
 	FILE* m_f = nullptr;

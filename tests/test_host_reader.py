@@ -25,6 +25,14 @@ def test_reader_matches_golden(i):
     assert run_mine(OPTS[i], inp) == open(os.path.join(GOLDEN, "reader_%d.tsv" % i), "rb").read()
 
 
+@pytest.mark.parametrize("tag,name", [("sam_", "reader_input.sam"), ("qseq_", "reader_input_qseq.txt"),
+                                      ("export_", "reader_input_export.txt")])
+@pytest.mark.parametrize("i", range(len(OPTS)))
+def test_tabular_formats_match_golden(tag, name, i):
+    inp = os.path.join(GOLDEN, name)
+    assert run_mine(OPTS[i], inp) == open(os.path.join(GOLDEN, "reader_%s%d.tsv" % (tag, i)), "rb").read()
+
+
 @pytest.mark.skipif(not os.path.exists(REF_READER), reason="reference build not present")
 def test_reader_matches_reference_live(tmp_path):
     import numpy as np
@@ -43,3 +51,50 @@ def test_reader_matches_reference_live(tmp_path):
     for opts in OPTS + [["-q", "15", "-Q", "20", "--no-chastity"]]:
         ref = subprocess.run([REF_READER] + opts + [str(p)], stdout=subprocess.PIPE, check=True).stdout
         assert run_mine(opts, str(p)) == ref, opts
+
+
+def _sam_and_qseq(tmp_path, seed=9):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+
+    def seq_qual(L, lo=33, hi=74):
+        seq = "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04], size=L))
+        qual = "".join(chr(int(x)) for x in rng.integers(lo, hi, size=L))
+        return seq, qual
+
+    sam = ["@HD\tVN:1.6\tSO:unsorted", "@SQ\tSN:chr1\tLN:1000", "@PG\tID:x\tPN:y"]
+    flag_choices = [0, 16, 65, 129, 81, 161, 97, 145, 256, 272, 512, 577, 1, 17, 0x41 | 0x200, 0x81 | 0x100]
+    for i in range(300):
+        L = int(rng.integers(1, 90))
+        seq, qual = seq_qual(L)
+        flag = int(rng.choice(flag_choices))
+        if rng.random() < 0.1:
+            qual = "*"
+        extra = ["NM:i:0", "BX:Z:ACGT-1"][: int(rng.integers(0, 3))]
+        sam.append("\t".join(["q%d" % i, str(flag), "chr1", "100", "60", "%dM" % L, "*", "0", "0", seq, qual] + extra))
+    (tmp_path / "x.sam").write_text("\n".join(sam) + "\n")
+
+    qseq, export = [], []
+    for i in range(200):
+        L = int(rng.integers(1, 80))
+        seq, qual = seq_qual(L, 64, 105)
+        seq = seq.replace("N", ".") if i % 7 == 0 else seq
+        read = str(int(rng.choice([1, 2, 3])))
+        index = str(int(rng.choice([0, 1, 7])))
+        filt = str(int(rng.integers(0, 2)))
+        qseq.append("\t".join(["M1", "42", "3", str(i % 9 + 1), str(1000 + i), str(2000 + i), index, read, seq, qual, filt]))
+        export.append("\t".join(["M2", "7", "1", str(i % 5 + 1), str(10 + i), str(20 + i), index if index != "0" else "", read, seq,
+                                 qual] + ["x"] * 11 + [["N", "Y"][int(filt)]]))
+    (tmp_path / "x_qseq.txt").write_text("\n".join(qseq) + "\n")
+    (tmp_path / "x_export.txt").write_text("\n".join(export) + "\n")
+    return [str(tmp_path / "x.sam"), str(tmp_path / "x_qseq.txt"), str(tmp_path / "x_export.txt")]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_READER), reason="reference build not present")
+def test_sam_qseq_export_match_reference_live(tmp_path):
+    """SAM, qseq and export input (DataLayer/FastaReader.cpp:256-352)."""
+    for path in _sam_and_qseq(tmp_path):
+        for opts in OPTS + [["-q", "15", "-Q", "20", "--no-chastity"]]:
+            ref = subprocess.run([REF_READER] + opts + [path], stdout=subprocess.PIPE, check=True).stdout
+            assert ref.count(b"\n") > 50
+            assert run_mine(opts, path) == ref, (path, opts)
