@@ -51,6 +51,7 @@ def symbols():
         "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
         "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
+        "abg_contains_seq",
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
     ]
 
@@ -74,6 +75,7 @@ def load(path: str | None = None):
     lib.abg_last_error.argtypes = [vp]
     lib.abg_last_error.restype = C.c_char_p
     lib.abg_reset.argtypes = [vp]
+    lib.abg_contains_seq.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint64, u64p]
     lib.abg_filter_size.argtypes = [vp, u64p]
     lib.abg_load_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
     lib.abg_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]

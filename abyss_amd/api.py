@@ -212,6 +212,16 @@ class BloomDBG:
                                            C.byref(n)), "abg_hash_seq")
         return pos[:n.value], hashes[:n.value]
 
+    def contains_seq(self, seq: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        """(positions, 0/1) of the valid k-mers of `seq` in the solid filter (writeCovTrack, bloom-dbg.h:1282-1334)."""
+        cap = max(len(seq), 1)
+        pos = np.zeros(cap, dtype=np.uint32)
+        val = np.zeros(cap, dtype=np.uint8)
+        n = C.c_uint64()
+        self._check(self._lib.abg_contains_seq(self._ctx, seq, len(seq), pos.ctypes.data, val.ctypes.data, cap,
+                                               C.byref(n)), "abg_contains_seq")
+        return pos[:n.value], val[:n.value]
+
     def profile_enable(self, on: bool = True) -> None:
         self._check(self._lib.abg_profile_enable(self._ctx, int(on)), "abg_profile_enable")
 

@@ -13,6 +13,10 @@
 
 namespace abg {
 
+struct FContainsSolid { // CountingBloomFilter::contains (CountingBloomFilter.hpp:190-196) for every op
+	Params p; const uint64_t* h0; const uint8_t* cnt; uint8_t* out;
+	ABG_HD void operator()(uint64_t t, uint32_t) const { out[t] = solid_contains(p, cnt, h0[t]) ? 1 : 0; }
+};
 struct FExpand { // RollingHash::getHashes (RollingHash.h:141-146) for every op
 	Params p; const uint64_t* h0; uint64_t* out;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
@@ -199,6 +203,52 @@ class Session {
 	}
 
 	// ------------------------------------------------------------------ probes
+	// valid k-mers of one sequence: positions and whether the solid filter contains them
+	// (writeCovTrack's loop, bloom-dbg.h:1297-1312)
+	int contains_seq(const char* seq, uint64_t len, uint32_t* pos_out, uint8_t* contains_out,
+	    uint64_t cap, uint64_t* n_out)
+	{
+		if (eng->cascade_mode()) return fail(ABG_EINVAL, "not available on a cascading filter");
+		const uint32_t k = cfg.k;
+		HostBatch hb;
+		std::vector<uint32_t> start;
+		std::string up(seq, len);
+		for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
+		valid_runs(up, runs_);
+		const uint32_t max_piece = 1u << 20;
+		for (auto& run : runs_) {
+			uint64_t pa = run.first, pb = run.second - 1 + k;
+			for (uint64_t q = pa; q + k <= pb;) {
+				uint64_t e = std::min<uint64_t>(pb, q + max_piece);
+				hb.add_ascii(up.data() + q, (uint32_t)(e - q), k);
+				start.push_back((uint32_t)q);
+				if (e == pb) break;
+				q = e - (k - 1);
+			}
+		}
+		uint64_t T = hb.koff.back();
+		*n_out = T;
+		if (!T) return ABG_OK;
+		DevBatch d = upload(hb);
+		uint64_t* h0 = (uint64_t*)be.alloc(T * 8);
+		uint8_t* c = (uint8_t*)be.alloc(T);
+		FHash fh{ eng->params(), d.b, h0 };
+		be.launch(T, fh, "hash");
+		FContainsSolid fc{ eng->params(), h0, eng->counters_dev(), c };
+		be.launch(T, fc, "contains");
+		std::vector<uint8_t> host(T);
+		be.d2h(host.data(), c, T);
+		uint64_t t = 0;
+		for (uint64_t s2 = 0; s2 < hb.n(); s2++)
+			for (uint32_t j = 0; j + k <= hb.len[s2]; j++, t++) {
+				if (t >= cap) continue;
+				if (pos_out) pos_out[t] = start[s2] + j;
+				if (contains_out) contains_out[t] = host[t];
+			}
+		be.free(h0); be.free(c);
+		release(d);
+		return ABG_OK;
+	}
 	int hash_seq(const char* seq, uint64_t len, uint32_t* pos_out, uint64_t* hashes_out,
 	    uint64_t cap, uint64_t* n_out)
 	{

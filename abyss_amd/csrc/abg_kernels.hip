@@ -406,6 +406,13 @@ const char* abg_last_error(const abg_ctx* ctx)
 	if (ctx) return ctx->s.error.c_str();
 	return g_create_error.c_str();
 }
+int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out, uint8_t* contains_out,
+    uint64_t cap, uint64_t* n_out)
+{
+	if (!ctx || !seq || !n_out) return ABG_EINVAL;
+	return ctx->s.contains_seq(seq, len, pos_out, contains_out, cap, n_out);
+}
+
 int abg_reset(abg_ctx* ctx)
 {
 	if (!ctx) return ABG_EINVAL;

@@ -4,7 +4,7 @@
 // libabyss_amd.so (include/abyss_amd.h).  All assembly work happens on the GPU; this file
 // only parses options, reads sequence files and prints records.
 //
-// Not supported (the binary says so and exits 1): -g/-C/-R auxiliary outputs, checkpoints.
+// Not supported (the binary says so and exits 1): -g (GraphViz dump), checkpoints.
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
@@ -158,7 +158,7 @@ int main(int argc, char** argv)
 {
 	abg_params p;
 	abg_params_init(&p);
-	std::string bloomPath, outputPath, tracePath, readLogPath;
+	std::string bloomPath, outputPath, tracePath, readLogPath, covTrackPath, refPath;
 	int verbose = 0;
 	bool die = false;
 	unsigned K = 0, qr = 0;
@@ -186,7 +186,9 @@ int main(int argc, char** argv)
 		case MIN_KMER_COV: p.min_cov = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
 		case QR_SEED: K = 0; spaced.clear(); qr = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
 		case READ_LOG: readLogPath = optarg; break;
-		case 'C': case 'g': case 'R': case CHECKPOINT: case KEEP_CHECKPOINT: case CHECKPOINT_PREFIX:
+		case 'C': covTrackPath = optarg; break;
+		case 'R': refPath = optarg; break;
+		case 'g': case CHECKPOINT: case KEEP_CHECKPOINT: case CHECKPOINT_PREFIX:
 			fprintf(stderr, PROGRAM ": option `-%c' is not supported by this build\n", c < 128 ? c : '-');
 			exit(EXIT_FAILURE);
 		}
@@ -199,6 +201,7 @@ int main(int argc, char** argv)
 	if (bloomPath.empty() && p.k == 0) { fprintf(stderr, PROGRAM ": missing mandatory option `-k'\n"); die = true; }
 	if (p.k > 0 && K > 0 && K > p.k / 2) { fprintf(stderr, PROGRAM ": value of `-K' must be <= k/2\n"); die = true; }
 	if (p.k > 0 && qr > 0 && (qr < 11 || qr > p.k / 2)) { fprintf(stderr, PROGRAM ": value of `--qr-seed' must be >= 11 and <= k/2\n"); die = true; }
+	if (!covTrackPath.empty() && refPath.empty()) { fprintf(stderr, PROGRAM ": you must specify a reference with `-R' when using `-C'\n"); die = true; } // bloom-dbg.cc:512-516
 	if (p.num_hashes > ABG_MAX_HASHES) { fprintf(stderr, PROGRAM ": number of hash functions (`-H`) must be <= %d\n", ABG_MAX_HASHES); die = true; }
 	if (argc - optind < 1) { fprintf(stderr, PROGRAM ": missing input file arguments\n"); die = true; }
 	if (die) { fprintf(stderr, "Try `%s --help' for more information.\n", PROGRAM); exit(EXIT_FAILURE); }
@@ -303,6 +306,31 @@ int main(int argc, char** argv)
 		    (unsigned long long)counters, (unsigned long long)counters, p.min_cov, (unsigned long long)filt,
 		    100.0 * pow((double)filt / (double)counters, p.num_hashes));
 		fprintf(stderr, "Trimming branches %u k-mers or shorter\n", trim);
+	}
+	// -C / -R: writeCovTrack (bloom-dbg.cc:200-201, bloom-dbg.h:1251-1334): a variableStep WIG with 1
+	// where the reference's k-mer is in the solid filter, 0 where it is not
+	if (!covTrackPath.empty() && !refPath.empty()) {
+		FILE* wig = fopen(covTrackPath.c_str(), "w");
+		if (!wig) { fprintf(stderr, "error: `%s': %s\n", covTrackPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		if (verbose) fprintf(stderr, "Writing 0/1 k-mer coverage track for `%s` to `%s`\n", refPath.c_str(), covTrackPath.c_str());
+		abghost::FastaReader ref(refPath, ropt);
+		std::vector<uint32_t> pos; std::vector<uint8_t> val;
+		while (ref.read(id, comment, seq)) {
+			pos.resize(seq.size() + 1); val.resize(seq.size() + 1);
+			uint64_t n = 0;
+			check(abg_contains_seq(ctx, seq.data(), seq.size(), pos.data(), val.data(), pos.size(), &n), ctx, "contains");
+			size_t blockStart = 1, blockLength = 0; unsigned blockVal = 0;
+			for (uint64_t i = 0; i < n; i++) {
+				if (i == 0 || val[i] != blockVal) {
+					if (i) fprintf(wig, "variableStep chrom=%s span=%zu\n%zu %u\n", id.c_str(), blockLength, blockStart, blockVal);
+					blockStart = (size_t)pos[i] + 1; blockLength = 1; blockVal = val[i]; // WIG coordinates are 1-based
+				} else {
+					blockLength++;
+				}
+			}
+			if (blockLength > 0) fprintf(wig, "variableStep chrom=%s span=%zu\n%zu %u\n", id.c_str(), blockLength, blockStart, blockVal);
+		}
+		fclose(wig);
 	}
 	// PASS 2: assemble, bloom-dbg.h:900-951,972-1089
 	FILE* trace = NULL; FILE* readlog = NULL;

@@ -170,6 +170,11 @@ int abg_set_counters(abg_ctx* ctx, const abg_counters* in); /* resume, Checkpoin
 int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
     uint64_t* hashes_out, uint64_t cap, uint64_t* n_out);
 
+/* goodKmerSet.contains() for every valid k-mer of one sequence, in RollingHashIterator order: the
+ * loop of writeCovTrack (-C / -R, bloom-dbg.h:1282-1334).  Writes at most cap entries. */
+int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
+    uint8_t* contains_out, uint64_t cap, uint64_t* n_out);
+
 /* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
  * runs on; abg_profile_get reports total milliseconds and launch count of one kernel
  * family ("hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep",

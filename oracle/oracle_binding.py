@@ -126,6 +126,13 @@ class Oracle:
         n = lib().orc_hash_seq(self._h, seq, len(seq), pos.ctypes.data, hashes.ctypes.data, cap)
         return pos[:n], hashes[:n]
 
+    def min_count(self, hashes: np.ndarray) -> np.ndarray:
+        """CountingBloomFilter::minCount for rows of num_hashes hash values (CountingBloomFilter.hpp:172-182)."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.zeros(len(hashes), dtype=np.uint8)
+        lib().orc_min_count(self._h, hashes.ctypes.data, len(hashes), out.ctypes.data)
+        return out
+
     def assemble(self, buf: bytes, offsets: np.ndarray):
         from abyss_amd.api import ContigRecord  # plain dataclass, no GPU code involved
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -98,6 +98,10 @@ int hc_assemble_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n,
 {
 	return ((Sess*)h)->assemble_seqs(seqs, off, n, results, cb, user);
 }
+int hc_contains_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint8_t* val, uint64_t cap, uint64_t* n)
+{
+	return ((Sess*)h)->contains_seq(seq, len, pos, val, cap, n);
+}
 int hc_hash_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint64_t* hashes, uint64_t cap, uint64_t* n)
 {
 	return ((Sess*)h)->hash_seq(seq, len, pos, hashes, cap, n);

@@ -49,7 +49,8 @@ def test_cli_option_errors(tmp_path):
                       (["-k32", "-b1M"], b"missing input file arguments"), (["-k32", "-b1M", "-K17", "r.fa"], b"must be <= k/2"),
                       (["-k32", "-b1M", "--qr-seed=7", "r.fa"], b"must be >= 11 and <= k/2"),
                       (["-k32", "-b1M", "-s101", "r.fa"], b"spaced seed must be exactly k bits long"),
-                      (["-k32", "-bXYZ", "r.fa"], b"invalid option")):
+                      (["-k32", "-bXYZ", "r.fa"], b"invalid option"),
+                      (["-k32", "-b1M", "-C", "x.wig", "r.fa"], b"you must specify a reference with `-R' when using `-C'")):
         r = subprocess.run([cli()] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and msg in r.stderr, (args, r.stderr)
     r = subprocess.run([cli(), "-k32", "-b1M", "nonexistent.fq"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -77,3 +78,25 @@ def test_cli_matches_reference_binary_on_fastq(tmp_path):
     rz = subprocess.run([cli(), "-k32", "-q3", "-b100M", "r1.fq.gz", "r2.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE)
     assert rz.returncode == 0 and rz.stdout == ref_out
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref/abyss-bloom-dbg did not travel with the snapshot")
+def test_cli_coverage_track_matches_reference_binary(tmp_path):
+    """-C / -R: the 0/1 k-mer coverage WIG of a reference (writeCovTrack, bloom-dbg.h:1251-1334)."""
+    h1, _ = synth.make_genome(60000, seed=11)
+    m1, m2 = synth.make_read_set(60000, 7.0, genome_seed=11, read_seed=12)
+    synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)
+    synth.write_fastq(str(tmp_path / "r2.fq"), m2, "r", 2)
+    g = synth.codes_to_ascii(h1[None, :])[0].tobytes()
+    with open(tmp_path / "ref.fa", "wb") as f:  # two records, lower case, a run of N, a short tail record
+        f.write(b">chrA some comment\n" + g[:30000] + b"\n>chrB\n" + g[30000:45000].lower() + b"NNNNNNNNNN" + g[45000:] +
+                b"\n>tiny\nACGTACGT\n")
+    args = ["-k40", "-b8M", "-R", "ref.fa", "r1.fq", "r2.fq"]
+    ref_out, _ = ob.run_ref(["-C", "cov_ref.wig"] + args, cwd=str(tmp_path), threads=1)
+    r = subprocess.run([cli(), "-j1", "-C", "cov_amd.wig"] + args, cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == ref_out
+    wig = open(tmp_path / "cov_ref.wig", "rb").read()
+    assert wig.count(b"variableStep") > 10 and b"chrB" in wig
+    assert open(tmp_path / "cov_amd.wig", "rb").read() == wig

@@ -230,6 +230,26 @@ def test_ordered_commit_kernel_still_exact(monkeypatch):
     assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
 
 
+def test_contains_seq_is_min_count_at_least_kc():
+    """abg_contains_seq (the -C / -R coverage track): goodKmerSet.contains() per valid k-mer."""
+    g = GoldenCase("k40_mixed")
+    kw = g.kwargs()
+    o = ob.Oracle(kw["k"], counters=g.meta["counters"], num_hashes=kw["num_hashes"], min_cov=kw["min_cov"])
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], insert_batch=50000, claim_log2=16)
+    o.load(g.buf, g.off)
+    hc.load(g.buf, g.off)
+    hc.l.hc_contains_seq.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    ref_like = b"".join(g.reads[:40]) + b"NNacgtn" + g.reads[50] + b"ACGTACGTAC" * 30
+    pos = np.zeros(len(ref_like), dtype=np.uint32)
+    val = np.zeros(len(ref_like), dtype=np.uint8)
+    n = C.c_uint64()
+    assert hc.l.hc_contains_seq(hc.h, ref_like, len(ref_like), pos.ctypes.data, val.ctypes.data, len(ref_like), C.byref(n)) == 0
+    po, ho = o.hash_seq(ref_like)
+    assert np.array_equal(po, pos[:n.value])
+    assert np.array_equal(o.min_count(ho) >= kw["min_cov"], val[:n.value].astype(bool))
+    assert 0 < val[:n.value].sum() < n.value
+
+
 def test_reset_gives_a_fresh_context():
     g = GoldenCase("k32")
     kw = g.kwargs()
