@@ -4,7 +4,7 @@
 // libabyss_amd.so (include/abyss_amd.h).  All assembly work happens on the GPU; this file
 // only parses options, reads sequence files and prints records.
 //
-// Not supported (the binary says so and exits 1): -g (GraphViz dump), checkpoints.
+// Not supported (the binary says so and exits 1): -g (GraphViz dump).
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
@@ -102,6 +102,7 @@ struct Chunk { // one batch of sequences for the C ABI
 
 struct Output {
 	FILE* out; FILE* trace; const Chunk* chunk; unsigned k;
+	FILE* checkpoint = NULL; // duplicate FASTA output for checkpoints (bloom-dbg.h:607-609,919-926)
 };
 static const char* ext_str(int c)
 {
@@ -113,7 +114,11 @@ static void on_contig(void* user, const abg_contig* c)
 	Output* o = (Output*)user;
 	const std::string& rid = o->chunk->ids[c->read_index];
 	if (!c->redundant) // printContig, bloom-dbg.h:455-487
+	{
 		fprintf(o->out, ">%llu %u %u read:%s\n%s\n", (unsigned long long)c->contig_id, c->length, c->coverage, rid.c_str(), c->seq);
+		if (o->checkpoint)
+			fprintf(o->checkpoint, ">%llu %u %u read:%s\n%s\n", (unsigned long long)c->contig_id, c->length, c->coverage, rid.c_str(), c->seq);
+	}
 	if (o->trace) { // ContigRecord operator<<, bloom-dbg.h:229-254
 		if (c->redundant) fputs("NA\t", o->trace); else fprintf(o->trace, "%llu\t", (unsigned long long)c->contig_id);
 		fprintf(o->trace, "%u\t%d\t%s\t", c->length, c->redundant, rid.c_str());
@@ -154,6 +159,114 @@ static std::string spaced_seed_qr_pair(unsigned k, unsigned len)
 	return seed;
 }
 
+// ---- Bloom files and checkpoints (BloomDBG/Checkpoint.h) ----------------------------------------
+static bool file_readable(const std::string& path) { FILE* f = fopen(path.c_str(), "rb"); if (f) fclose(f); return f != NULL; }
+static void copy_file(const std::string& from, const std::string& to) // copyFile, Common/IOUtil.h
+{
+	FILE* a = fopen(from.c_str(), "rb"); FILE* b = fopen(to.c_str(), "wb");
+	if (!a || !b) { fprintf(stderr, "error: `%s': %s\n", (a ? to : from).c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	char buf[1 << 16]; size_t n;
+	while ((n = fread(buf, 1, sizeof buf, a)) > 0) fwrite(buf, 1, n, b);
+	fclose(a); fclose(b);
+}
+// header + payload of a [BTLCountingBloomFilter_v1] / [BTLBloomFilter_v1] file
+// (CountingBloomFilter.hpp:262-329, BloomFilter.hpp:105-178)
+static void read_bloom_file(const std::string& path, const char* magic, uint64_t& size, unsigned& hn, unsigned& ks,
+    std::vector<uint8_t>& payload, bool bits)
+{
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) { fprintf(stderr, "error: `%s': %s\n", path.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	char* line = NULL; size_t cap = 0; ssize_t n;
+	if ((n = getline(&line, &cap, f)) <= 0 || strncmp(line, magic, strlen(magic))) {
+		fprintf(stderr, "ERROR: magic string does not match (likely version mismatch)\n"); exit(EXIT_FAILURE);
+	}
+	uint64_t bytes = 0; bool end = false;
+	size = 0; hn = 0; ks = 0;
+	while ((n = getline(&line, &cap, f)) > 0) {
+		if (!strncmp(line, "[HeaderEnd]", 11)) { end = true; break; }
+		char key[64]; unsigned long long v;
+		if (sscanf(line, " %63[A-Za-z] = %llu", key, &v) == 2) {
+			if (!strcmp(key, "BloomFilterSize")) size = v; else if (!strcmp(key, "HashNum")) hn = (unsigned)v;
+			else if (!strcmp(key, "KmerSize")) ks = (unsigned)v; else if (!strcmp(key, "BloomFilterSizeInBytes")) bytes = v;
+		}
+	}
+	if (!end || !size) { fprintf(stderr, "ERROR: pre-built bloom filter does not have the correct header end.\n"); exit(EXIT_FAILURE); }
+	payload.resize(bytes ? bytes : (bits ? size / 8 : size));
+	if (fread(payload.data(), 1, payload.size(), f) != payload.size()) { fprintf(stderr, "error: `%s': short read\n", path.c_str()); exit(EXIT_FAILURE); }
+	fclose(f); free(line);
+}
+static void write_counting_file(abg_ctx* ctx, const std::string& path, unsigned k, unsigned H) // operator<<, CountingBloomFilter.hpp:344-379
+{
+	uint64_t size = 0; abg_filter_size(ctx, &size);
+	std::vector<uint8_t> cnt(size);
+	if (abg_counters_export(ctx, cnt.data()) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(ctx)); exit(EXIT_FAILURE); }
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) { fprintf(stderr, "error: `%s': %s\n", path.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	fprintf(f, "[BTLCountingBloomFilter_v1]\n\tBloomFilterSize = %llu\n\tHashNum = %u\n\tKmerSize = %u\n"
+	           "\tBloomFilterSizeInBytes = %llu\n\tBitsPerCounter = 8\n[HeaderEnd]\n",
+	    (unsigned long long)size, H, k, (unsigned long long)size);
+	fwrite(cnt.data(), 1, cnt.size(), f);
+	fclose(f);
+}
+static void write_visited_file(abg_ctx* ctx, const std::string& path, unsigned k, unsigned H) // BloomFilter::writeHeader, BloomFilter.hpp:261-294
+{
+	uint64_t size = 0; abg_filter_size(ctx, &size);
+	std::vector<uint8_t> bits(size / 8);
+	if (abg_visited_export(ctx, bits.data()) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(ctx)); exit(EXIT_FAILURE); }
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) { fprintf(stderr, "error: `%s': %s\n", path.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	fprintf(f, "[BTLBloomFilter_v1]\n\tnEntry = 0\n\tdFPR = 0.0000000000000000\n\tEntry = 0\n"
+	           "\tBloomFilterSizeInBytes = %llu\n\tBloomFilterSize = %llu\n\tHashNum = %u\n\tKmerSize = %u\n[HeaderEnd]\n",
+	    (unsigned long long)(size / 8), (unsigned long long)size, H, k);
+	fwrite(bits.data(), 1, bits.size(), f);
+	fclose(f);
+}
+static const char CK_FASTA[] = ".contigs.fa", CK_COUNTERS[] = ".counters.tsv", CK_DBG[] = ".dbg.bloom",
+                  CK_VISITED[] = ".visited.bloom", CK_TMP[] = ".tmp";
+static bool checkpoint_exists(const std::string& prefix) // Checkpoint.h:130-144
+{
+	return file_readable(prefix + CK_FASTA) && file_readable(prefix + CK_DBG) && file_readable(prefix + CK_VISITED) &&
+	       file_readable(prefix + CK_COUNTERS);
+}
+static void do_rename(const std::string& a, const std::string& b, int verbose)
+{
+	if (verbose) fprintf(stderr, "\tMoving `%s' to `%s'\n", a.c_str(), b.c_str());
+	if (rename(a.c_str(), b.c_str()) != 0) { perror("Error renaming file"); abort(); }
+}
+// createCheckpoint, Checkpoint.h:31-127
+static void create_checkpoint(abg_ctx* ctx, const std::string& prefix, unsigned k, unsigned H, int verbose)
+{
+	if (verbose) fprintf(stderr, "Writing checkpoint data...\n");
+	const std::string dbg = prefix + CK_DBG, vis = prefix + CK_VISITED, cnt = prefix + CK_COUNTERS, fa = prefix + CK_FASTA;
+	if (verbose) fprintf(stderr, "\tWriting Bloom filter de Bruijn graph to `%s'\n", (dbg + CK_TMP).c_str());
+	write_counting_file(ctx, dbg + CK_TMP, k, H);
+	if (verbose) fprintf(stderr, "\tWriting visited k-mers Bloom to `%s'\n", (vis + CK_TMP).c_str());
+	write_visited_file(ctx, vis + CK_TMP, k, H);
+	if (verbose) fprintf(stderr, "\tWriting assembly counters to `%s'\n", (cnt + CK_TMP).c_str());
+	abg_counters c;
+	abg_get_counters(ctx, &c);
+	FILE* f = fopen((cnt + CK_TMP).c_str(), "w");
+	if (!f) { fprintf(stderr, "error: `%s': %s\n", (cnt + CK_TMP).c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	fprintf(f, "solid_reads\tprocessed_reads\tbases_assembled\tnext_contig_id\n%llu\t%llu\t%llu\t%llu\n", // AssemblyCounters.h:32-52
+	    (unsigned long long)c.solid_reads, (unsigned long long)c.reads_processed, (unsigned long long)c.bases_assembled,
+	    (unsigned long long)c.next_contig_id);
+	fclose(f);
+	if (verbose) fprintf(stderr, "\tCopying `%s to `%s'\n", (fa + CK_TMP).c_str(), fa.c_str());
+	copy_file(fa + CK_TMP, fa);
+	do_rename(dbg + CK_TMP, dbg, verbose);
+	do_rename(vis + CK_TMP, vis, verbose);
+	do_rename(cnt + CK_TMP, cnt, verbose);
+}
+static void remove_checkpoint(const std::string& prefix, int verbose) // removeCheckpointData, Checkpoint.h:245-281
+{
+	if (verbose) fprintf(stderr, "Removing checkpoint files...\n");
+	for (const char* ext : { CK_DBG, CK_VISITED, CK_COUNTERS, CK_FASTA })
+		for (const char* tmp : { "", CK_TMP }) {
+			std::string path = prefix + ext + tmp;
+			if (file_readable(path) && remove(path.c_str()) != 0) { perror("Error removing file"); abort(); }
+		}
+}
+
 int main(int argc, char** argv)
 {
 	abg_params p;
@@ -162,6 +275,7 @@ int main(int argc, char** argv)
 	int verbose = 0;
 	bool die = false;
 	unsigned K = 0, qr = 0;
+	uint64_t readsPerCheckpoint = 0; bool keepCheckpoint = false; std::string checkpointPrefix = "bloom-dbg-checkpoint";
 	std::string spaced;
 	for (int c; (c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1;) {
 		bool bad = false;
@@ -188,7 +302,10 @@ int main(int argc, char** argv)
 		case READ_LOG: readLogPath = optarg; break;
 		case 'C': covTrackPath = optarg; break;
 		case 'R': refPath = optarg; break;
-		case 'g': case CHECKPOINT: case KEEP_CHECKPOINT: case CHECKPOINT_PREFIX:
+		case CHECKPOINT: readsPerCheckpoint = strtoull(optarg, &end, 10); bad = *end; break;
+		case KEEP_CHECKPOINT: keepCheckpoint = true; break;
+		case CHECKPOINT_PREFIX: checkpointPrefix = optarg; break;
+		case 'g':
 			fprintf(stderr, PROGRAM ": option `-%c' is not supported by this build\n", c < 128 ? c : '-');
 			exit(EXIT_FAILURE);
 		}
@@ -222,25 +339,8 @@ int main(int argc, char** argv)
 	// -i: [BTLCountingBloomFilter_v1] header + raw counters (CountingBloomFilter.hpp:262-329,344-379)
 	std::vector<uint8_t> prebuilt;
 	if (!bloomPath.empty()) {
-		FILE* f = fopen(bloomPath.c_str(), "rb");
-		if (!f) { fprintf(stderr, "error: `%s': %s\n", bloomPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
-		char* line = NULL; size_t cap = 0; ssize_t n;
-		if ((n = getline(&line, &cap, f)) <= 0 || strncmp(line, "[BTLCountingBloomFilter_v1]", 27)) {
-			fprintf(stderr, "ERROR: magic string does not match (likely version mismatch)\n"); exit(EXIT_FAILURE);
-		}
-		uint64_t size = 0, bytes = 0; unsigned hn = 0, ks = 0; bool end = false;
-		while ((n = getline(&line, &cap, f)) > 0) {
-			if (!strncmp(line, "[HeaderEnd]", 11)) { end = true; break; }
-			char key[64]; unsigned long long v;
-			if (sscanf(line, " %63[A-Za-z] = %llu", key, &v) == 2) {
-				if (!strcmp(key, "BloomFilterSize")) size = v; else if (!strcmp(key, "HashNum")) hn = (unsigned)v;
-				else if (!strcmp(key, "KmerSize")) ks = (unsigned)v; else if (!strcmp(key, "BloomFilterSizeInBytes")) bytes = v;
-			}
-		}
-		if (!end || !size) { fprintf(stderr, "ERROR: pre-built bloom filter does not have the correct header end.\n"); exit(EXIT_FAILURE); }
-		prebuilt.resize(bytes ? bytes : size);
-		if (fread(prebuilt.data(), 1, prebuilt.size(), f) != prebuilt.size()) { fprintf(stderr, "error: `%s': short read\n", bloomPath.c_str()); exit(EXIT_FAILURE); }
-		fclose(f); free(line);
+		uint64_t size = 0; unsigned hn = 0, ks = 0;
+		read_bloom_file(bloomPath, "[BTLCountingBloomFilter_v1]", size, hn, ks, prebuilt, false);
 		p.k = ks; p.num_hashes = hn; p.counters = size; // bloom-dbg.cc:320-322
 	}
 	p.verbose = verbose;
@@ -279,7 +379,45 @@ int main(int argc, char** argv)
 		}
 		chunk.clear();
 	};
-	if (prebuilt.empty()) {
+	// --checkpoint=N (bloom-dbg.h:1012-1077, Checkpoint.h): the state is saved every N reads, and a
+	// run that finds a complete set of checkpoint files picks up from it (bloom-dbg.cc:546-547).
+	// (Resuming restores what the files hold: both filters, the four counters, the contigs so far;
+	// like the reference it starts with an empty contigEndKmers set.)
+	const bool ckpt = readsPerCheckpoint > 0;
+	const bool resume = ckpt && checkpoint_exists(checkpointPrefix);
+	uint64_t skip_reads = 0;
+	if (ckpt) keep = false;
+	if (resume) {
+		if (verbose) fprintf(stderr, "Resuming from last checkpoint...\n");
+		std::vector<uint8_t> payload; uint64_t size = 0; unsigned hn = 0, ks = 0;
+		if (verbose) fprintf(stderr, "\tReading Bloom filter de Bruijn graph from `%s'\n", (checkpointPrefix + CK_DBG).c_str());
+		read_bloom_file(checkpointPrefix + CK_DBG, "[BTLCountingBloomFilter_v1]", size, hn, ks, payload, false);
+		if (size != counters || hn != p.num_hashes || ks != p.k) { fprintf(stderr, PROGRAM ": checkpoint does not match -k/-b/-H\n"); exit(EXIT_FAILURE); }
+		check(abg_counters_import(ctx, payload.data()), ctx, "import");
+		if (verbose) fprintf(stderr, "\tReading reading visited k-mers Bloom from `%s'\n", (checkpointPrefix + CK_VISITED).c_str());
+		read_bloom_file(checkpointPrefix + CK_VISITED, "[BTLBloomFilter_v1]", size, hn, ks, payload, true);
+		if (size != counters) { fprintf(stderr, PROGRAM ": checkpoint does not match -k/-b/-H\n"); exit(EXIT_FAILURE); }
+		check(abg_visited_import(ctx, payload.data()), ctx, "import");
+		if (verbose) fprintf(stderr, "\tReading index of next input read from `%s'\n", (checkpointPrefix + CK_COUNTERS).c_str());
+		abg_counters c; memset(&c, 0, sizeof c);
+		{
+			FILE* f = fopen((checkpointPrefix + CK_COUNTERS).c_str(), "r");
+			unsigned long long a = 0, b = 0, d = 0, e = 0;
+			if (!f || fscanf(f, "%*[^\n]\n%llu\t%llu\t%llu\t%llu", &a, &b, &d, &e) != 4) { fprintf(stderr, "error: `%s': malformed\n", (checkpointPrefix + CK_COUNTERS).c_str()); exit(EXIT_FAILURE); }
+			fclose(f);
+			c.solid_reads = a; c.reads_processed = b; c.bases_assembled = d; c.next_contig_id = e;
+		}
+		check(abg_set_counters(ctx, &c), ctx, "counters");
+		skip_reads = c.reads_processed;
+		if (verbose) fprintf(stderr, "\tAdvancing to read index %llu in input reads...\n", (unsigned long long)skip_reads);
+		if (verbose) fprintf(stderr, "\tCopying `%s' to `%s'\n", (checkpointPrefix + CK_FASTA).c_str(), (checkpointPrefix + CK_FASTA + CK_TMP).c_str());
+		copy_file(checkpointPrefix + CK_FASTA, checkpointPrefix + CK_FASTA + CK_TMP);
+		if (verbose) fprintf(stderr, "\tOutputting previously assembled contigs from `%s'\n", (checkpointPrefix + CK_FASTA).c_str());
+		FILE* prev = fopen((checkpointPrefix + CK_FASTA).c_str(), "rb");
+		char buf[1 << 16]; size_t nb;
+		while (prev && (nb = fread(buf, 1, sizeof buf, prev)) > 0) fwrite(buf, 1, nb, out);
+		if (prev) fclose(prev);
+	} else if (prebuilt.empty()) {
 		// PASS 1: loadBloomFilter, BloomIO.h:97-118 (a ":" argument separates load and assembly files)
 		for (int i = optind; i < argc; ++i) {
 			if (!strcmp(argv[i], ":")) { first_asm = i + 1; break; }
@@ -344,6 +482,11 @@ int main(int argc, char** argv)
 	}
 	static const char* rr[] = { "NA", "SHORTER_THAN_K", "NON_ACGT", "BLUNT_END", "NOT_SOLID", "ALL_KMERS_VISITED", "ALL_BRANCH_KMERS_VISITED", "GENERATED_CONTIGS" };
 	Output o{ out, trace, &chunk, p.k };
+	if (ckpt) {
+		const std::string path = checkpointPrefix + CK_FASTA + CK_TMP;
+		if (!(o.checkpoint = fopen(path.c_str(), resume ? "a" : "w"))) { fprintf(stderr, "error: `%s': %s\n", path.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+	}
+	uint64_t untilCheckpoint = readsPerCheckpoint;
 	std::vector<uint8_t> results;
 	auto assemble = [&](Chunk& c) {
 		if (!c.n()) return;
@@ -361,11 +504,20 @@ int main(int argc, char** argv)
 		if (!strcmp(argv[i], ":")) continue;
 		abghost::FastaReader in(argv[i], ropt);
 		while (in.read(id, comment, seq)) {
+			if (skip_reads) { skip_reads--; continue; }
 			chunk.add(id, seq);
-			if (chunk.seqs.size() >= CHUNK_BASES) flush();
+			if (ckpt && --untilCheckpoint == 0) {
+				flush();
+				fflush(o.checkpoint);
+				create_checkpoint(ctx, checkpointPrefix, p.k, p.num_hashes, verbose);
+				untilCheckpoint = readsPerCheckpoint;
+			} else if (chunk.seqs.size() >= CHUNK_BASES) {
+				flush();
+			}
 		}
 	}
 	flush();
+	if (o.checkpoint) fclose(o.checkpoint);
 	if (verbose) {
 		abg_counters c;
 		abg_get_counters(ctx, &c);
@@ -375,6 +527,7 @@ int main(int argc, char** argv)
 		fprintf(stderr, "Assembled %llu bp in %llu contigs\nAssembly complete\n", (unsigned long long)c.bases_assembled,
 		    (unsigned long long)c.next_contig_id);
 	}
+	if (ckpt && !keepCheckpoint) remove_checkpoint(checkpointPrefix, verbose);
 	if (trace) fclose(trace);
 	if (readlog) fclose(readlog);
 	if (out != stdout) fclose(out); else fflush(stdout);

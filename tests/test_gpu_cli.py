@@ -100,3 +100,34 @@ def test_cli_coverage_track_matches_reference_binary(tmp_path):
     wig = open(tmp_path / "cov_ref.wig", "rb").read()
     assert wig.count(b"variableStep") > 10 and b"chrB" in wig
     assert open(tmp_path / "cov_amd.wig", "rb").read() == wig
+
+
+@pytest.mark.skipif(not ob.have_ref(), reason="oracle/_ref/abyss-bloom-dbg did not travel with the snapshot")
+def test_cli_checkpoints_match_reference_binary(tmp_path):
+    """--checkpoint=N --keep-checkpoint: the four checkpoint files (BloomDBG/Checkpoint.h) after the last
+    checkpoint, byte for byte; then a resumed run of ours continues from them."""
+    g = GoldenCase("k32")
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i, s in enumerate(g.reads):
+            f.write(b">r%d\n%s\n" % (i, s))
+    args = ["-k32", "-b4M", "--checkpoint=1500", "--keep-checkpoint"]
+    ref_out, _ = ob.run_ref(args + ["--checkpoint-prefix=ckr", "reads.fa"], cwd=str(tmp_path), threads=1)
+    r = subprocess.run([cli(), "-j1", "-v"] + args + ["--checkpoint-prefix=cka", "reads.fa"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == ref_out == g.fasta
+    assert b"Writing checkpoint data..." in r.stderr
+    for ext in (".dbg.bloom", ".visited.bloom", ".counters.tsv", ".contigs.fa", ".contigs.fa.tmp"):
+        assert open(tmp_path / ("cka" + ext), "rb").read() == open(tmp_path / ("ckr" + ext), "rb").read(), ext
+    assert open(tmp_path / "cka.counters.tsv").read().split("\n")[1].split("\t")[1] == "3000"
+    # resume: reads 0..2999 are skipped, their contigs come from the checkpoint, the rest is assembled
+    r2 = subprocess.run([cli(), "-j1", "-v"] + args + ["--checkpoint-prefix=cka", "reads.fa"], cwd=tmp_path,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert b"Resuming from last checkpoint..." in r2.stderr and b"Advancing to read index 3000" in r2.stderr
+    assert r2.stdout == g.fasta
+    # without --keep-checkpoint the files are removed at the end
+    r3 = subprocess.run([cli(), "-j1", "-k32", "-b4M", "--checkpoint=1500", "--checkpoint-prefix=ckx", "reads.fa"], cwd=tmp_path,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r3.returncode == 0 and r3.stdout == g.fasta
+    assert not [p for p in os.listdir(tmp_path) if p.startswith("ckx")]
