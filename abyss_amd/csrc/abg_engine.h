@@ -53,6 +53,16 @@ struct Counters { // AssemblyCounters.h:15-31
 	         contig_id = 0;
 };
 
+// ASCII -> base code 0..3 (A, C, G, T in either case), 0xFF + 3 for anything else: the low two
+// bits are what gets packed, bit 7 says "not a base"
+struct BaseCodes {
+	uint8_t t[256];
+	BaseCodes()
+	{
+		for (int i = 0; i < 256; i++) t[i] = 0xFF;
+		t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+	}
+};
 // Host-side staging of pure-ACGT sequences in the device layout (see Batch).
 struct HostBatch {
 	std::vector<uint32_t> words;
@@ -61,15 +71,25 @@ struct HostBatch {
 	std::vector<uint64_t> koff{ 0 };
 	void clear() { words.clear(); woff.assign(1, 0); len.clear(); koff.assign(1, 0); }
 	uint64_t n() const { return len.size(); }
-	// append one sequence of codes 0..3 given as ASCII ACGT (upper case); caller guarantees len >= k
+	// append one sequence given as ASCII; A/C/G/T in either case become 0..3, anything else
+	// becomes some base (callers only pass such characters where a spaced seed ignores them);
+	// the caller guarantees len >= k
 	void add_ascii(const char* s, uint32_t L, uint32_t k)
 	{
-		size_t w0 = words.size();
-		words.resize(w0 + (L + 15) / 16, 0);
-		for (uint32_t i = 0; i < L; i++) {
-			char ch = s[i];
-			uint32_t b = (ch == 'A') ? 0u : (ch == 'C') ? 1u : (ch == 'G') ? 2u : 3u;
-			words[w0 + (i >> 4)] |= b << (2 * (i & 15));
+		static const BaseCodes codes;
+		uint64_t w0 = words.size();
+		words.resize(w0 + (L + 15) / 16);
+		uint32_t* out = words.data() + w0;
+		uint32_t i = 0;
+		for (; i + 16 <= L; i += 16) {
+			uint32_t w = 0;
+			for (uint32_t j = 0; j < 16; j++) w |= (uint32_t)(codes.t[(unsigned char)s[i + j]] & 3u) << (2 * j);
+			*out++ = w;
+		}
+		if (i < L) {
+			uint32_t w = 0;
+			for (uint32_t j = 0; i + j < L; j++) w |= (uint32_t)(codes.t[(unsigned char)s[i + j]] & 3u) << (2 * j);
+			*out = w;
 		}
 		woff.push_back(words.size());
 		len.push_back(L);

@@ -102,15 +102,20 @@ class Session {
 			const char* s = seqs + off[i];
 			uint64_t L = off[i + 1] - off[i];
 			if (L < k) continue; // RollingHashIterator.h:37-40
-			up.assign(s, L);
-			for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
-			valid_runs(up, runs_);
+			// (case is folded by the code table; the upper-cased copy is only needed under a spaced seed)
+			const char* text = s;
+			if (!cfg.spaced_seed.empty()) {
+				up.assign(s, L);
+				for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
+				text = up.data();
+			}
+			valid_runs(text, L, runs_);
 			for (auto& run : runs_) {
 				// k-mers run.first .. run.second - 1 start in this piece
 				uint64_t pa = run.first, pb = run.second - 1 + k;
 				for (uint64_t q = pa; q + k <= pb;) {
 					uint64_t e = std::min<uint64_t>(pb, q + max_piece);
-					hb.add_ascii(up.data() + q, (uint32_t)(e - q), k);
+					hb.add_ascii(text + q, (uint32_t)(e - q), k);
 					if (e == pb) break;
 					q = e - (k - 1);
 				}
@@ -152,11 +157,10 @@ class Session {
 			const char* s = seqs + off[i];
 			uint64_t L = off[i + 1] - off[i];
 			if (L < k) { res[i] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
-			up.assign(s, L);
-			bool ok = true;
-			for (auto& ch : up) { ch = (char)toupper((unsigned char)ch); ok = ok && is_acgt(ch); }
-			if (!ok) { res[i] = RR_NON_ACGT; continue; }            // allACGT, bloom-dbg.h:808
-			hb.add_ascii(up.data(), (uint32_t)L, k);
+			uint8_t bad = 0;
+			for (uint64_t q = 0; q < L; q++) bad |= codes_.t[(unsigned char)s[q]];
+			if (bad & 0x80) { res[i] = RR_NON_ACGT; continue; }     // allACGT, bloom-dbg.h:808 (either case: the reader folds it)
+			hb.add_ascii(s, (uint32_t)L, k);
 			orig.push_back(i);
 		}
 		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
@@ -214,7 +218,7 @@ class Session {
 		std::vector<uint32_t> start;
 		std::string up(seq, len);
 		for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
-		valid_runs(up, runs_);
+		valid_runs(up.data(), up.size(), runs_);
 		const uint32_t max_piece = 1u << 20;
 		for (auto& run : runs_) {
 			uint64_t pa = run.first, pb = run.second - 1 + k;
@@ -257,7 +261,7 @@ class Session {
 		std::vector<uint32_t> start; // start position of each packed piece
 		std::string up(seq, len);
 		for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
-		valid_runs(up, runs_);
+		valid_runs(up.data(), up.size(), runs_);
 		for (auto& run : runs_) {
 			hb.add_ascii(up.data() + run.first, (uint32_t)(run.second - run.first + k - 1), k);
 			start.push_back((uint32_t)run.first);
@@ -291,24 +295,27 @@ class Session {
   private:
 	static bool is_acgt(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 	std::vector<std::pair<uint64_t, uint64_t>> runs_;
+	BaseCodes codes_;
 	std::vector<uint8_t> bad_;
 	// Maximal runs [first, second) of consecutive start positions of the k-mers
 	// RollingHashIterator yields for an upper-cased sequence (RollingHashIterator.h:35-97):
 	// those with an ACGT character at every position the spaced seed looks at (all of them
 	// without one).  A run of k-mers a..b-1 is the text [a, b - 1 + k); characters under a
 	// '0' may be anything (they are packed as some base and never contribute to a hash).
-	void valid_runs(const std::string& up, std::vector<std::pair<uint64_t, uint64_t>>& runs)
+	// (without a spaced seed `up` may be in either case; with one it must be upper case)
+	void valid_runs(const char* up, uint64_t L, std::vector<std::pair<uint64_t, uint64_t>>& runs)
 	{
 		runs.clear();
-		const uint64_t L = up.size(), k = cfg.k;
+		const uint64_t k = cfg.k;
 		if (L < k) return;
 		const uint64_t nk = L - k + 1;
 		if (cfg.spaced_seed.empty()) {
+			const uint8_t* t = codes_.t;
 			uint64_t a = 0;
 			while (a < L) {
-				while (a < L && !is_acgt(up[a])) a++;
+				while (a < L && (t[(unsigned char)up[a]] & 0x80)) a++;
 				uint64_t b = a;
-				while (b < L && is_acgt(up[b])) b++;
+				while (b < L && !(t[(unsigned char)up[b]] & 0x80)) b++;
 				if (b - a >= k) runs.emplace_back(a, b - k + 1);
 				a = b;
 			}
