@@ -34,7 +34,8 @@ struct Config {
 	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
 	uint64_t pool_cap = 1ull << 28;   // contig pool bytes
 	uint32_t rec_cap = 1u << 22;      // contig records per round
-	uint32_t wtab_log2 = 26;          // walker vertex table entries
+	uint32_t wtab_log2 = 26;          // walker vertex table entries (grown per launch to fit its walkers, up to:)
+	uint32_t wtab_log2_max = 31;
 	uint32_t wclaim_log2 = 26;        // walker claim slots
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
 	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
@@ -1193,6 +1194,7 @@ class Engine {
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{};
 	uint32_t wtab_log2_ = 0;
+	uint64_t wtab_per_walker_ = 2048; // planning figure: vertices one walker enters (config 2 averages ~1100)
 	uint32_t* wclaims_ = nullptr;
 	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
 	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
@@ -1560,6 +1562,20 @@ class Engine {
 		free_tab(cend_);
 		cend_ = bigger;
 	}
+	// The vertex table holds every vertex of every walker of one launch.  It is sized ahead for
+	// `nwalk` walkers at wtab_per_walker_ entries each (twice that, to keep probing short); a
+	// launch that fills it anyway reports overflow and the estimate doubles (run_rounds).
+	void ensure_wtab(uint64_t nwalk)
+	{
+		const uint64_t want = 2 * nwalk * wtab_per_walker_;
+		uint32_t log2 = wtab_log2_;
+		while ((1ull << log2) < want && log2 < cfg_.wtab_log2_max) log2++;
+		if (log2 == wtab_log2_) return;
+		free_tab(wtab_);
+		wtab_log2_ = log2;
+		alloc_tab(wtab_, wtab_log2_);
+		if (cfg_.verbose) fprintf(stderr, "abyss_amd: walker vertex table grown to 2^%u entries\n", wtab_log2_);
+	}
 	void clear_wtab()
 	{
 		be_.memset(wtab_.hmin, 0xFF, (wtab_.mask + 1) * 8);
@@ -1645,6 +1661,7 @@ class Engine {
 			// full by the first stage-2 launch instead.
 			const bool defer_stage = needed_frac_ < 0.5;
 			if (defer_stage) {
+				ensure_wtab(nc - base);
 				clear_wtab();
 				WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
 				env.claims = wclaims_;
@@ -1673,6 +1690,7 @@ class Engine {
 				be_.d2h(&nneed, need_n, 4);
 				if (nneed) {
 					if (owner_next > 0xF0000000u - nc) { overflow = true; break; } // owner ids exhausted: restart
+					ensure_wtab(nneed);
 					clear_wtab();
 					WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
 					env.claims = nullptr;
@@ -1710,6 +1728,7 @@ class Engine {
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.
 				if (committed == base) grow_walk_resources();
+				else wtab_per_walker_ *= 2; // most likely the vertex table: plan for longer walks from now on
 			}
 			base = committed;
 		}
