@@ -41,6 +41,7 @@ struct Config {
 	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
 	uint64_t p2_max_batch = 1ull << 21;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
+	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
@@ -1135,6 +1136,9 @@ class Engine {
 	// every read is already visited) the size keeps doubling.
 	uint64_t next_batch_size() const
 	{
+		// (a larger genome at the same read count leaves more of each batch unvisited: when a batch
+		// had more candidates than the walkers' tables should have to hold, the next one is halved)
+		if (last_candidates_ > cfg_.p2_crowded) return std::max<uint64_t>(p2_batch_ / 2, 1024);
 		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * cfg_.p2_starved_growth, 8 * cfg_.p2_max_batch);
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
