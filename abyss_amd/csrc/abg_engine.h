@@ -128,7 +128,10 @@ struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
 // nthash.hpp:242-257,275-279), stores the canonical hashes (64 contiguous bytes per lane) and
 // issues the H claims of every op right away, so the hashing ALU work hides under the
 // latency of the claim atomics.
-constexpr uint32_t HC_RUN = 8;
+#ifndef ABG_HC_RUN
+#define ABG_HC_RUN 8
+#endif
+constexpr uint32_t HC_RUN = ABG_HC_RUN;
 struct FHashClaim {
 	Params p; Batch b; uint64_t* h0; uint64_t T; uint64_t* claim; uint64_t cmask; uint32_t epoch;
 	ABG_HD void operator()(uint64_t g, uint32_t) const
@@ -1198,7 +1201,7 @@ class Engine {
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{};
 	uint32_t wtab_log2_ = 0;
-	uint64_t wtab_per_walker_ = 2048; // planning figure: vertices one walker enters (config 2 averages ~1100)
+	uint64_t wtab_per_walker_ = 1536; // planning figure: vertices one walker enters (config 2 averages ~1100)
 	uint32_t* wclaims_ = nullptr;
 	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
 	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
