@@ -45,6 +45,7 @@ struct Config {
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
+	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
@@ -1487,7 +1488,9 @@ class Engine {
 		// the fixed point
 		if (off[n] > (1u << T_TIME_BITS)) { fprintf(stderr, "abyss_amd: too many contig records in one commit\n"); abort(); }
 		for (uint32_t round = 0;; round++) {
-			if (t_tag_ == 0) { be_.memset(e.T, 0xFF, m_ * 4ull); t_tag_ = T_TAGS - 1; } // tag T_TAGS-1 is what 0xFF.. carries: never used
+			// (tag T_TAGS - 1 is what the cleared array carries: never handed out; cfg_.t_tags < T_TAGS only
+			// makes the clearing more frequent -- the tests use that to exercise it)
+			if (t_tag_ == 0) { be_.memset(e.T, 0xFF, m_ * 4ull); t_tag_ = std::min<uint32_t>(cfg_.t_tags, T_TAGS) - 1; }
 			e.tag = --t_tag_;
 			if (nshort) {
 				be_.memset(e.tcend.hmin, 0xFF, (e.tcend.mask + 1) * 8);

@@ -214,6 +214,22 @@ def test_parallel_commit_needs_several_passes_and_stays_exact():
     assert o.assembly_counters() == hc.assembly_counters()
 
 
+def test_time_stamp_tags_wrap_around(monkeypatch):
+    """The parallel commit's time stamps are cleared only when the pass tags run out (1024 passes);
+    ABG_T_TAGS=3 makes that happen every other pass."""
+    monkeypatch.setenv("ABG_T_TAGS", "3")
+    for name in ("k32", "k48_K16"):
+        g = GoldenCase(name)
+        kw = g.kwargs()
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=64, mask=mask_of(g))
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        assert hc.stats()["commit_rounds"] >= 6
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+
+
 def test_ordered_commit_kernel_still_exact(monkeypatch):
     """ABG_PAR_COMMIT=0 selects the single-workgroup ordered commit (the fallback when the time
     stamps of the parallel form do not fit in memory)."""
