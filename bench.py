@@ -140,13 +140,14 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)  # before the process group: RCCL binds the communicator to the current device
+    backend = os.environ.get("ABG_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm; ABG_BENCH_BACKEND=gloo lets the launch path be exercised on a
         # box with fewer GPUs than ranks (ranks then share devices)
-        dist.init_process_group(backend=os.environ.get("ABG_BENCH_BACKEND", "nccl"))
-    local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
     device = torch.device("cuda", local)
 
     mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30}
@@ -161,7 +162,7 @@ def main() -> int:
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
             torch.cuda.synchronize()
 
     g = None
@@ -267,7 +268,7 @@ def main() -> int:
     if g is not None:
         g.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
     return 0
 
