@@ -52,6 +52,8 @@ def symbols():
         "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
         "abg_contains_seq",
+        "abg_attach_comm", "abg_share_reads", "abg_rccl_unique_id", "abg_rccl_comm_create", "abg_rccl_comm_destroy",
+        "abg_dev_copy",
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
     ]
 
@@ -94,5 +96,11 @@ def load(path: str | None = None):
     lib.abg_profile_reset.argtypes = [vp]
     lib.abg_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
     lib.abg_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.abg_attach_comm.argtypes = [vp, vp]
+    lib.abg_share_reads.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
+    lib.abg_rccl_unique_id.argtypes = [vp]
+    lib.abg_rccl_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.abg_rccl_comm_destroy.argtypes = [vp]
+    lib.abg_dev_copy.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32]
     _lib = lib
     return lib

@@ -133,6 +133,20 @@ class BloomDBG:
     def load_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int) -> None:
         self._check(self._lib.abg_load_packed(self._ctx, words_ptr, woff_ptr, len_ptr, n), "abg_load_packed")
 
+    # ---- partitioned multi-GPU run (abyss_amd.dist)
+    def attach_comm(self, comm) -> None:
+        """Range-partition the counting filter over the ranks of `comm` (an abyss_amd.dist communicator).
+        `comm` must stay alive as long as this object."""
+        self._comm = comm
+        self._check(self._lib.abg_attach_comm(self._ctx, C.byref(comm.struct)), "abg_attach_comm")
+
+    def share_reads(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int) -> Tuple[int, int, int, int]:
+        """All-gather of the ranks' packed reads: (words, woff, len) device pointers and the total count."""
+        gw, go, gl, nt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self._lib.abg_share_reads(self._ctx, words_ptr, woff_ptr, len_ptr, n, C.byref(gw), C.byref(go),
+                                              C.byref(gl), C.byref(nt)), "abg_share_reads")
+        return gw.value, go.value, gl.value, nt.value
+
     def counting_stats(self) -> Tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.abg_counting_stats(self._ctx, C.byref(a), C.byref(b)), "abg_counting_stats")

@@ -133,8 +133,19 @@ struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
 #define ABG_HC_RUN 8
 #endif
 constexpr uint32_t HC_RUN = ABG_HC_RUN;
-struct FHashClaim {
+// DIST: the filter is range-partitioned over the ranks of a communicator (see Engine::Comm);
+// every rank hashes every op but claims only the counters in its own range [lo, lo + span).
+template <bool DIST>
+struct FHashClaimT {
 	Params p; Batch b; uint64_t* h0; uint64_t T; uint64_t* claim; uint64_t cmask; uint32_t epoch;
+	uint64_t lo, span;
+	ABG_HD void claim_all(uint64_t h, uint64_t v) const
+	{
+		for (unsigned i = 0; i < p.nh; i++) {
+			const uint64_t q = pos_i(p, h, i);
+			if (!DIST || q - lo < span) atomic_min_u64(&claim[q & cmask], v);
+		}
+	}
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
 		uint64_t t0 = g * HC_RUN;
@@ -152,9 +163,7 @@ struct FHashClaim {
 				// spaced seed: from scratch over the '1' positions (not the headline configuration)
 				uint64_t h = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
 				h0[t] = h;
-				uint64_t v = claim_val(epoch, (uint32_t)t);
-				for (unsigned i = 0; i < p.nh; i++)
-					atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
+				claim_all(h, claim_val(epoch, (uint32_t)t));
 				continue;
 			}
 			if (fresh) {
@@ -171,12 +180,11 @@ struct FHashClaim {
 			}
 			uint64_t h = rh < fh ? rh : fh;
 			h0[t] = h;
-			uint64_t v = claim_val(epoch, (uint32_t)t);
-			for (unsigned i = 0; i < p.nh; i++)
-				atomic_min_u64(&claim[pos_i(p, h, i) & cmask], v);
+			claim_all(h, claim_val(epoch, (uint32_t)t));
 		}
 	}
 };
+typedef FHashClaimT<false> FHashClaim;
 struct FClaim { // first round: every op claims its H counters
 	Params p; const uint64_t* h0; uint64_t* claim; uint64_t cmask; uint32_t epoch;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
@@ -250,6 +258,93 @@ struct FInsertRound {
 			uint64_t v2 = claim_val(epoch + 1, t);
 			for (unsigned j = 0; j < p.nh; j++)
 				atomic_min_u64(&claim_next[pos_i(p, h, j) & cmask], v2);
+		}
+	}
+};
+// ---- the same round when the counters are range-partitioned over R ranks (Engine::Comm).
+// Every rank runs every pending op but looks only at the counters it owns: FEvalDist folds
+// "holds the claim on all of my counters" and "minimum of my counters" into one byte per op,
+//   0 = some claim lost; 1..255 = min(local minimum + 1, 255); 255 also = "none of its counters is mine",
+// an all_reduce(MIN) over the ranks turns that into "0 = loser, else min(global minimum + 1, 255)",
+// and FApplyDist increments the owned counters equal to the global minimum (incrementMin,
+// CountingBloomFilter.hpp:135-162) or re-claims for the next round.  A counter c is bumped iff
+// c < 255 and c + 1 == r: for r <= 254 that is c == min; r == 255 leaves c == 254 == min (a
+// saturated minimum has no counter below 255 to match).
+struct FEvalDist {
+	Params p; const uint64_t* h0; const uint8_t* cnt; const uint32_t* pend;
+	const uint64_t* claim_cur; uint64_t cmask; uint32_t epoch; uint64_t lo, span; uint8_t* res;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t t = pend ? pend[i] : (uint32_t)i;
+		const uint64_t h = h0[t];
+		const uint64_t v = claim_val(epoch, t);
+		bool held = true, any = false;
+		unsigned mn = 255;
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint64_t q = pos_i(p, h, j);
+			if (q - lo >= span) continue;
+			any = true;
+			held = held & (claim_cur[q & cmask] == v);
+			const unsigned c = cnt[q];
+			mn = c < mn ? c : mn;
+		}
+		res[i] = (uint8_t)(!any ? 255u : !held ? 0u : (mn + 1 > 255 ? 255u : mn + 1));
+	}
+};
+struct FApplyDist {
+	Params p; const uint64_t* h0; uint8_t* cnt; const uint32_t* pend;
+	uint64_t* claim_next; uint64_t cmask; uint32_t epoch; uint64_t lo, span; const uint8_t* res; uint8_t* lost;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t t = pend ? pend[i] : (uint32_t)i;
+		const uint64_t h = h0[t];
+		const unsigned r = res[i];
+		lost[i] = r == 0;
+		if (r == 0) {
+			const uint64_t v2 = claim_val(epoch + 1, t);
+			for (unsigned j = 0; j < p.nh; j++) {
+				const uint64_t q = pos_i(p, h, j);
+				if (q - lo < span) atomic_min_u64(&claim_next[q & cmask], v2);
+			}
+			return;
+		}
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint64_t q = pos_i(p, h, j);
+			if (q - lo >= span) continue;
+			const unsigned c = cnt[q];
+			if (c < 255 && c + 1 == r) cnt[q] = (uint8_t)(c + 1);
+		}
+	}
+};
+// Hand-over to the single-workgroup tail (insert_drain): the few ops still pending touch
+// counters on every rank, so their current values are exchanged once (FDrainVals, then an
+// all_reduce(MAX): the owner contributes the value, everybody else 0), written over the local
+// non-authoritative copies together with the missing claims (FDrainLoad), and every rank runs
+// the same drain; only the counters a rank owns keep their meaning afterwards.
+struct FDrainVals {
+	Params p; const uint64_t* h0; const uint8_t* cnt; const uint32_t* pend; uint64_t lo, span; uint8_t* val;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint64_t h = h0[pend[i]];
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint64_t q = pos_i(p, h, j);
+			val[i * p.nh + j] = q - lo < span ? cnt[q] : (uint8_t)0;
+		}
+	}
+};
+struct FDrainLoad {
+	Params p; const uint64_t* h0; uint8_t* cnt; const uint32_t* pend; uint64_t lo, span; const uint8_t* val;
+	uint64_t* claim_cur; uint64_t cmask; uint32_t epoch;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t t = pend[i];
+		const uint64_t h = h0[t];
+		const uint64_t v = claim_val(epoch, t);
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint64_t q = pos_i(p, h, j);
+			if (q - lo < span) continue;
+			cnt[q] = val[i * p.nh + j]; // same value from every op that shares q
+			atomic_min_u64(&claim_cur[q & cmask], v);
 		}
 	}
 };
@@ -526,6 +621,7 @@ struct FPredict {
 	const uint64_t* rkoff; const uint64_t* rkh;
 	const uint32_t* claims; uint32_t claim_mask; uint32_t* need_list; uint32_t* need_n;
 	uint32_t first; uint32_t force;
+	uint32_t rank, world; // partitioned run: need_n[1] counts every needed candidate, the list holds the ones this rank walks
 	ABG_HDN void operator()(uint64_t i, uint32_t) const
 	{
 		uint32_t c = first + (uint32_t)i;
@@ -540,9 +636,40 @@ struct FPredict {
 			if (owner < c && status[owner] == WS_COMPLETE) continue;
 			covered = false;
 		}
-		if (!covered) need_list[atomic_add_u32(need_n, 1)] = c;
+		if (!covered) {
+			if (world > 1) {
+				atomic_add_u32(need_n + 1, 1);
+				if (c % world != rank) return;
+			}
+			need_list[atomic_add_u32(need_n, 1)] = c;
+		}
 	}
 };
+// Partitioned run: contig records gathered from the other ranks keep their rank-local numbering;
+// bring pool offsets and record links into the merged numbering.  Records [g_rec + rbase[q],
+// g_rec + rbase[q + 1]) came from rank q, whose pool block moved from g_pool to g_pool + pbase[q].
+constexpr int MAX_RANKS = 16;
+struct FRecFix {
+	ContigRec* recs; uint32_t g_rec; uint32_t world;
+	uint32_t rbase[MAX_RANKS + 1]; uint64_t pbase[MAX_RANKS + 1];
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint32_t q = 0;
+		while (q + 1 < world && i >= rbase[q + 1]) q++;
+		ContigRec& r = recs[g_rec + i];
+		r.seq_off += pbase[q];
+		if (r.next != REC_END) r.next += rbase[q];
+	}
+};
+struct FFirstFix { // first record of the candidates this rank walked in the launch
+	const uint32_t* list; uint32_t* first_rec; uint32_t delta;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = list[i];
+		if (first_rec[c] != REC_END) first_rec[c] += delta;
+	}
+};
+struct FAddU64 { uint64_t* a; uint64_t d; ABG_HD void operator()(uint64_t i, uint32_t) const { a[i] += d; } };
 
 // ---- ordered commit (outputContig, bloom-dbg.h:538-620), cooperative over T threads
 struct CommitState {
@@ -1034,7 +1161,8 @@ class Engine {
 			cnt_ = (uint8_t*)be_.alloc(8);
 			vis_bytes_ = 8;
 		} else {
-			cnt_ = (uint8_t*)be_.alloc(m_);
+			// (slack: the shards of a partitioned run are gathered in equal chunks of roundUp64(m / ranks))
+			cnt_ = (uint8_t*)be_.alloc(m_ + 64 * (MAX_RANKS + 1));
 			be_.memset(cnt_, 0, m_);
 			vis_bytes_ = (m_ / 8 + 4 + 3) & ~3ull;
 		}
@@ -1051,6 +1179,7 @@ class Engine {
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
 		if (la_pool2_) be_.free(la_pool2_);
+		free_shared();
 		free_insert();
 		free_walk();
 	}
@@ -1065,6 +1194,7 @@ class Engine {
 		be_.memset(cstate_, 0, sizeof(CommitState));
 		counters_ = Counters();
 		stats_ = Stats();
+		cnt_partial_ = false;
 		last_rounds_ = 0;
 		p2_batch_ = cfg_.p2_first_batch;
 		last_candidates_ = 0;
@@ -1077,7 +1207,74 @@ class Engine {
 	}
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
-	uint8_t* counters_dev() { return cnt_; }
+	// (a partitioned run leaves only the rank's own range current until the shards are gathered)
+	uint8_t* counters_dev() { gather_counters(); return cnt_; }
+
+	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
+	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
+	// positions [q * chunk, (q + 1) * chunk) -- and all-gathered for PASS 2; every rank sees every
+	// read (share_reads), so the op stream is replicated and only the state is partitioned.
+	struct Comm {
+		int rank = 0, world = 1;
+		bool stream_ordered = false;
+		void* user = nullptr;
+		int (*all_gather_v)(void*, void*, const uint64_t*, const uint64_t*, void*) = nullptr;
+		int (*all_reduce)(void*, void*, uint64_t, int32_t, int32_t, void*) = nullptr;
+	};
+	enum { DT_U8 = 0, DT_U32 = 1, DT_U64 = 2, OP_SUM = 0, OP_MAX = 1, OP_MIN = 2 };
+	bool attach_comm(const Comm& c)
+	{
+		if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || casc_.bits) return false;
+		comm_ = c;
+		uint64_t chunk = (m_ + c.world - 1) / c.world;
+		chunk = (chunk + 63) & ~63ull;
+		own_lo_ = std::min<uint64_t>(m_, (uint64_t)c.rank * chunk);
+		own_span_ = std::min<uint64_t>(m_, own_lo_ + chunk) - own_lo_;
+		own_chunk_ = chunk;
+		if (c.world > 1) cfg_.prefetch_classify = false; // every rank classifies its slice of a batch instead
+		return true;
+	}
+	bool dist() const { return comm_.world > 1; }
+	// All-gather of the ranks' packed read sets (rank-major order) into buffers the engine keeps
+	// until the next call: what every rank then hands to load_packed / assemble_packed.
+	Batch share_reads(const Batch& loc)
+	{
+		const uint32_t R = (uint32_t)comm_.world, me = (uint32_t)comm_.rank;
+		uint64_t w0 = 0, w1 = 0;
+		if (loc.n) { be_.d2h(&w0, loc.woff, 8); be_.d2h(&w1, loc.woff + loc.n, 8); }
+		std::vector<uint64_t> cnt(2 * R, 0);
+		cnt[2 * me] = loc.n; cnt[2 * me + 1] = w1 - w0;
+		host_all_reduce_sum(cnt.data(), 2 * R);
+		std::vector<uint64_t> nb(R + 1, 0), wb(R + 1, 0);
+		for (uint32_t q = 0; q < R; q++) { nb[q + 1] = nb[q] + cnt[2 * q]; wb[q + 1] = wb[q] + cnt[2 * q + 1]; }
+		free_shared();
+		sh_words_ = (uint32_t*)be_.alloc(wb[R] * 4 + 64);
+		sh_woff_ = (uint64_t*)be_.alloc((nb[R] + 1) * 8);
+		sh_len_ = (uint32_t*)be_.alloc(nb[R] * 4 + 4);
+		sh_koff_ = (uint64_t*)be_.alloc((nb[R] + 1) * 8);
+		if (loc.n) {
+			be_.d2d(sh_words_ + wb[me], loc.words + w0, (w1 - w0) * 4);
+			be_.d2d(sh_len_ + nb[me], loc.len, loc.n * 4);
+			be_.d2d(sh_woff_ + nb[me], loc.woff, loc.n * 8);
+			FAddU64 f{ sh_woff_ + nb[me], wb[me] - w0 };
+			be_.launch(loc.n, f, "share_fix");
+		}
+		std::vector<uint64_t> c(R), d(R);
+		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q + 1] * 4; d[q] = wb[q] * 4; }
+		c_all_gather_v(sh_words_, c.data(), d.data());
+		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q] * 4; d[q] = nb[q] * 4; }
+		c_all_gather_v(sh_len_, c.data(), d.data());
+		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q] * 8; d[q] = nb[q] * 8; }
+		c_all_gather_v(sh_woff_, c.data(), d.data());
+		be_.h2d(sh_woff_ + nb[R], &wb[R], 8);
+		// k-mer prefix sums (PASS 1 wants them on both sides)
+		sh_koff_h_.assign(nb[R] + 1, 0);
+		std::vector<uint32_t> len(nb[R]);
+		be_.d2h(len.data(), sh_len_, nb[R] * 4);
+		for (uint64_t i = 0; i < nb[R]; i++) sh_koff_h_[i + 1] = sh_koff_h_[i] + (len[i] >= p_.k ? len[i] - p_.k + 1 : 0);
+		be_.h2d(sh_koff_, sh_koff_h_.data(), (nb[R] + 1) * 8);
+		return Batch{ sh_words_, sh_woff_, sh_len_, sh_koff_, nb[R] };
+	}
 	bool cascade_mode() const { return casc_.bits != nullptr; }
 	uint32_t cascade_levels() const { return casc_.levels; }
 	uint8_t* cascade_level_dev(uint32_t l) { return (uint8_t*)(casc_.bits + (uint64_t)l * casc_.level_words); }
@@ -1089,6 +1286,7 @@ class Engine {
 
 	void popcounts(uint64_t* nonzero, uint64_t* filtered)
 	{
+		gather_counters();
 		be_.memset(scal_, 0, 16);
 		FPopcount f{ (const uint64_t*)cnt_, p_.kc, scal_ };
 		be_.launch(m_ / 8, f, "popcount");
@@ -1120,6 +1318,7 @@ class Engine {
 	    const std::function<void(const ContigOut&)>& sink)
 	{
 		ensure_walk();
+		gather_counters();
 		uint64_t done = 0;
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		full_b_ = &b; result_base_ = result_d; pre_n_ = 0;
@@ -1191,6 +1390,58 @@ class Engine {
 		return true;
 	}
 	bool t_failed_ = false;
+	// ---- partitioned run
+	Comm comm_;
+	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
+	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
+	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;
+	std::vector<uint64_t> sh_koff_h_;
+	uint8_t* dres_ = nullptr; uint8_t* dlost_ = nullptr; // PASS 1: one byte per pending op
+	uint32_t g_rec_ = 0; uint64_t g_pool_ = 0;           // PASS 2: records / pool bytes every rank holds
+  public:
+	const uint64_t* shared_koff_host() const { return sh_koff_h_.data(); }
+  private:
+	void free_shared()
+	{
+		if (!sh_words_) return;
+		be_.free(sh_words_); be_.free(sh_woff_); be_.free(sh_len_); be_.free(sh_koff_);
+		sh_words_ = nullptr;
+	}
+	void c_fail(const char* what) { fprintf(stderr, "abyss_amd: collective %s failed on rank %d\n", what, comm_.rank); abort(); }
+	// in place: rank q's part lives at buf + displs[q] (bytes); on return every rank holds all parts
+	void c_all_gather_v(void* buf, const uint64_t* counts, const uint64_t* displs)
+	{
+		if (!comm_.stream_ordered) be_.sync();
+		be_.begin("comm_all_gather");
+		if (comm_.all_gather_v(comm_.user, buf, counts, displs, be_.stream_handle())) c_fail("all_gather_v");
+		be_.end("comm_all_gather");
+	}
+	void c_all_reduce(void* buf, uint64_t n, int dtype, int op)
+	{
+		if (!n) return;
+		if (!comm_.stream_ordered) be_.sync();
+		be_.begin("comm_all_reduce");
+		if (comm_.all_reduce(comm_.user, buf, n, dtype, op, be_.stream_handle())) c_fail("all_reduce");
+		be_.end("comm_all_reduce");
+	}
+	void host_all_reduce_sum(uint64_t* v, uint32_t n)
+	{
+		uint64_t* d = (uint64_t*)be_.alloc(n * 8ull);
+		be_.h2d(d, v, n * 8ull);
+		c_all_reduce(d, n, DT_U64, OP_SUM);
+		be_.d2h(v, d, n * 8ull);
+		be_.free(d);
+	}
+	// the shards of the counting filter, gathered onto every rank (PASS 2 reads it at random)
+	void gather_counters()
+	{
+		if (!dist() || !cnt_partial_) return;
+		std::vector<uint64_t> c(comm_.world), d(comm_.world);
+		// equal chunks (one ring all-gather); the last one runs into the slack behind the m_ counters
+		for (int q = 0; q < comm_.world; q++) { d[q] = (uint64_t)q * own_chunk_; c[q] = own_chunk_; }
+		c_all_gather_v(cnt_, c.data(), d.data());
+		cnt_partial_ = false;
+	}
 	Counters counters_;
 	Stats stats_;
 	uint64_t last_rounds_ = 0;
@@ -1230,10 +1481,12 @@ class Engine {
 			pend_[i] = (uint32_t*)be_.alloc(nb * 4);
 		}
 		pend_n_ = (uint32_t*)be_.alloc(8);
+		if (dist()) { dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32)); dlost_ = (uint8_t*)be_.alloc(nb); }
 	}
 	void free_insert()
 	{
 		if (!h0_) return;
+		if (dres_) { be_.free(dres_); be_.free(dlost_); dres_ = nullptr; }
 		be_.free(h0_);
 		for (int i = 0; i < 2; i++) { be_.free(claim_[i]); be_.free(pend_[i]); }
 		be_.free(pend_n_);
@@ -1263,8 +1516,13 @@ class Engine {
 		}
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
+		if (dist()) {
+			insert_rounds_dist(v, T, cmask);
+			be_.free(kv_d);
+			return;
+		}
 		{
-			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_ };
+			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_, 0, 0 };
 			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
 		}
 		uint64_t npend = T;
@@ -1300,6 +1558,56 @@ class Engine {
 		}
 		epoch_++;
 		be_.free(kv_d);
+	}
+
+	// The reservation rounds of insert_range over a range-partitioned filter: the same rounds,
+	// every rank running every pending op against the counters it owns, one all_reduce(MIN) of a
+	// byte per op between "who holds all claims / what is the minimum" and "apply".  The list of
+	// losers is compacted in op order, so it is the same list on every rank.
+	void insert_rounds_dist(const Batch& v, uint64_t T, uint64_t cmask)
+	{
+		cnt_partial_ = true;
+		uint64_t* ccur = claim_[0];
+		uint64_t* cnext = claim_[1];
+		{
+			FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_ };
+			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
+		}
+		uint64_t npend = T;
+		const uint32_t* pin = nullptr;
+		uint32_t* pout = pend_[0];
+		while (npend) {
+			if (pin && npend <= cfg_.drain_threshold) {
+				uint8_t* val = dres_;
+				{ FDrainVals f{ p_, h0_, cnt_, pin, own_lo_, own_span_, val }; be_.launch(npend, f, "drain_vals"); }
+				c_all_reduce(val, npend * p_.nh, DT_U8, OP_MAX);
+				{ FDrainLoad f{ p_, h0_, cnt_, pin, own_lo_, own_span_, val, ccur, cmask, epoch_ }; be_.launch(npend, f, "drain_load"); }
+				uint32_t* other = (pin == pend_[0]) ? pend_[1] : pend_[0];
+				InsertDrainEnv de{ p_, h0_, cnt_, casc_, const_cast<uint32_t*>(pin), other, (uint32_t)npend,
+					ccur, cnext, cmask, epoch_, pend_n_ };
+				be_.launch_drain(de);
+				uint32_t r[2] = { 0, 0 };
+				be_.d2h(r, pend_n_, 8);
+				epoch_ += r[1];
+				last_rounds_ += r[1];
+				stats_.insert_rounds += r[1];
+				break;
+			}
+			{ FEvalDist f{ p_, h0_, cnt_, pin, ccur, cmask, epoch_, own_lo_, own_span_, dres_ }; be_.launch(npend, f, pin ? "insert_retry" : "insert_round"); }
+			c_all_reduce(dres_, npend, DT_U8, OP_MIN);
+			{ FApplyDist f{ p_, h0_, cnt_, pin, cnext, cmask, epoch_, own_lo_, own_span_, dres_, dlost_ }; be_.launch(npend, f, "insert_apply"); }
+			be_.compact_flagged(pin, dlost_, npend, pout, pend_n_);
+			uint32_t nn = 0;
+			be_.d2h(&nn, pend_n_, 4);
+			npend = nn;
+			std::swap(ccur, cnext);
+			pin = pout;
+			pout = (pout == pend_[0]) ? pend_[1] : pend_[0];
+			epoch_++;
+			last_rounds_++;
+			stats_.insert_rounds++;
+		}
+		epoch_++;
 	}
 
 	void ensure_walk()
@@ -1542,6 +1850,78 @@ class Engine {
 		return brk;
 	}
 
+	// Partitioned run: each rank walked its share of a launch's candidates and appended records and
+	// sequences after the merged ones ([g_rec_, ..) / [g_pool_, ..)).  Exchange them so that every
+	// rank holds every record, in rank order, and the per-candidate status / first record of all.
+	void merge_walk_results(const uint32_t* list_d, uint32_t nlist, uint32_t* status_d, uint32_t* first_d, uint32_t nc)
+	{
+		const uint32_t R = (uint32_t)comm_.world, me = (uint32_t)comm_.rank;
+		uint32_t lr = 0; uint64_t lp = 0;
+		be_.d2h(&lr, rec_used_, 4);
+		be_.d2h(&lp, pool_used_, 8);
+		lr = std::min(lr, rec_cap_); lp = std::min<uint64_t>(lp, pool_cap_);
+		std::vector<uint64_t> cnt(2 * R, 0);
+		cnt[2 * me] = lr - g_rec_; cnt[2 * me + 1] = lp - g_pool_;
+		host_all_reduce_sum(cnt.data(), 2 * R);
+		FRecFix fx;
+		fx.rbase[0] = 0; fx.pbase[0] = 0;
+		for (uint32_t q = 0; q < R; q++) {
+			fx.rbase[q + 1] = fx.rbase[q] + (uint32_t)cnt[2 * q];
+			fx.pbase[q + 1] = fx.pbase[q] + cnt[2 * q + 1];
+		}
+		const uint64_t tot_rec = fx.rbase[R], tot_pool = fx.pbase[R];
+		// room for everybody's results (contents are kept: earlier records are still to be committed)
+		if (g_rec_ + tot_rec > rec_cap_) {
+			uint32_t cap = rec_cap_;
+			while (g_rec_ + tot_rec > cap) cap *= 2;
+			recs_ = (ContigRec*)regrow(recs_, (uint64_t)rec_cap_ * sizeof(ContigRec), (uint64_t)cap * sizeof(ContigRec));
+			order_ = (uint32_t*)regrow(order_, (uint64_t)rec_cap_ * 4, (uint64_t)cap * 4);
+			rec_cap_ = cap;
+		}
+		if (g_pool_ + tot_pool > pool_cap_) {
+			uint64_t cap = pool_cap_;
+			while (g_pool_ + tot_pool > cap) cap *= 2;
+			pool_ = (uint8_t*)regrow(pool_, pool_cap_, cap);
+			kh_ = (uint64_t*)regrow(kh_, pool_cap_ * 8, cap * 8);
+			pool_cap_ = cap;
+		}
+		// own block to its place in the merged numbering
+		if (me && cnt[2 * me]) {
+			void* tmp = be_.alloc(cnt[2 * me] * sizeof(ContigRec));
+			be_.d2d(tmp, recs_ + g_rec_, cnt[2 * me] * sizeof(ContigRec));
+			be_.d2d(recs_ + g_rec_ + fx.rbase[me], tmp, cnt[2 * me] * sizeof(ContigRec));
+			be_.free(tmp);
+		}
+		if (me && cnt[2 * me + 1]) {
+			void* tmp = be_.alloc(cnt[2 * me + 1]);
+			be_.d2d(tmp, pool_ + g_pool_, cnt[2 * me + 1]);
+			be_.d2d(pool_ + g_pool_ + fx.pbase[me], tmp, cnt[2 * me + 1]);
+			be_.free(tmp);
+		}
+		std::vector<uint64_t> c(R), d(R);
+		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q] * sizeof(ContigRec); d[q] = (uint64_t)(g_rec_ + fx.rbase[q]) * sizeof(ContigRec); }
+		if (tot_rec) c_all_gather_v(recs_, c.data(), d.data());
+		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q + 1]; d[q] = g_pool_ + fx.pbase[q]; }
+		if (tot_pool) c_all_gather_v(pool_, c.data(), d.data());
+		if (tot_rec) {
+			fx.recs = recs_; fx.g_rec = g_rec_; fx.world = R;
+			be_.launch(tot_rec, fx, "merge_fix");
+		}
+		if (nlist && fx.rbase[me]) { FFirstFix f{ list_d, first_d, fx.rbase[me] }; be_.launch(nlist, f, "merge_fix"); }
+		c_all_reduce(status_d, nc, DT_U32, OP_MAX); // WS_NONE < WS_COMPLETE < WS_OVERFLOW; only the walking rank changed an entry
+		c_all_reduce(first_d, nc, DT_U32, OP_MIN);  // REC_END unless walked
+		g_rec_ += (uint32_t)tot_rec; g_pool_ += tot_pool;
+		be_.h2d(rec_used_, &g_rec_, 4);
+		be_.h2d(pool_used_, &g_pool_, 8);
+	}
+	void* regrow(void* old, uint64_t old_bytes, uint64_t new_bytes)
+	{
+		void* n = be_.alloc(new_bytes);
+		be_.d2d(n, old, old_bytes);
+		be_.free(old);
+		return n;
+	}
+
 	// hashes + coverage of the contig records produced since the last call (parallel)
 	template <int NW>
 	void prep_new_records(uint32_t& prepped)
@@ -1657,6 +2037,7 @@ class Engine {
 			be_.memset(pool_used_, 0, 8);
 			be_.memset(rec_used_, 0, 4);
 			be_.memset(order_n_, 0, 4);
+			g_rec_ = 0; g_pool_ = 0;
 			be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
 			uint32_t prepped = 0;
 			uint32_t owner_next = 0;
@@ -1669,7 +2050,7 @@ class Engine {
 			// candidates share unitigs; when most of them turned out to be needed in the previous
 			// batch they would only be walked twice, so it is skipped and everybody is walked in
 			// full by the first stage-2 launch instead.
-			const bool defer_stage = needed_frac_ < 0.5;
+			const bool defer_stage = needed_frac_ < 0.5 && !dist(); // (its claims are rank-local state)
 			if (defer_stage) {
 				ensure_wtab(nc - base);
 				clear_wtab();
@@ -1690,17 +2071,21 @@ class Engine {
 			uint64_t batch_rewalked = 0;
 			while (committed < nc) {
 				// stage 2: candidates without a result that lower reads will not cover
-				be_.memset(need_n, 0, 4);
+				be_.memset(need_n, 0, 8);
 				{
 					FPredict<NW> fp{ p_, b, cand_d, status_d, vis_, rkoff_d, rkh_, wclaims_, cmask,
-						need_d, need_n, committed, force };
+						need_d, need_n, committed, force, (uint32_t)comm_.rank, (uint32_t)comm_.world };
 					be_.launch(nc - committed, fp, "predict");
 				}
-				uint32_t nneed = 0;
-				be_.d2h(&nneed, need_n, 4);
-				if (nneed) {
+				// partitioned run: nneed = what this rank walks (every rank's c % world == rank share of the
+				// needed candidates), nneed_all = what all ranks walk together
+				uint32_t nn2[2] = { 0, 0 };
+				be_.d2h(nn2, need_n, 8);
+				uint32_t nneed = nn2[0];
+				const uint32_t nneed_all = dist() ? nn2[1] : nneed;
+				if (nneed_all) {
 					if (owner_next > 0xF0000000u - nc) { overflow = true; break; } // owner ids exhausted: restart
-					ensure_wtab(nneed);
+					ensure_wtab(std::max<uint32_t>(nneed, 1));
 					clear_wtab();
 					WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
 					env.claims = nullptr;
@@ -1710,9 +2095,10 @@ class Engine {
 					if (debug) { uint32_t tmp; be_.d2h(&tmp, rec_used_, 4); dbg_t0_ = std::chrono::steady_clock::now(); }
 					if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
-					stats_.rewalked += nneed;
-					batch_rewalked += nneed;
+					stats_.rewalked += nneed_all;
+					batch_rewalked += nneed_all;
 					dump("rewalk", nneed);
+					if (dist()) merge_walk_results(need_d, nneed, status_d, first_d, nc);
 					prep_new_records<NW>(prepped);
 				}
 				// stage 3: ordered commit as far as the results allow
@@ -1793,6 +2179,14 @@ class Engine {
 			be_.sync_side();
 			FRefilter<NW> f{ p_, v, vis_, res_d };
 			be_.launch(n, f, "reclassify");
+		} else if (dist()) {
+			// every rank classifies a slice of the batch; the verdicts are gathered
+			const uint64_t R = (uint64_t)comm_.world;
+			std::vector<uint64_t> c(R), d(R);
+			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
+			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_ };
+			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
+			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			be_.sync_side();
 			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_ };

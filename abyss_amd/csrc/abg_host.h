@@ -144,6 +144,25 @@ class Session {
 		return ABG_OK;
 	}
 
+	// ------------------------------------------------------------------ partitioned run
+	int attach_comm(const abg_comm& c)
+	{
+		if (!c.all_gather_v || !c.all_reduce) return fail(ABG_EINVAL, "communicator lacks a collective");
+		typename Engine<BE>::Comm ec;
+		ec.rank = c.rank; ec.world = c.world; ec.stream_ordered = c.stream_ordered != 0; ec.user = c.user;
+		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce;
+		if (!eng->attach_comm(ec)) return fail(ABG_EINVAL, "bad rank / world (at most " + std::to_string(MAX_RANKS) + " ranks; not available on a cascading filter)");
+		return ABG_OK;
+	}
+	int share_reads(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n,
+	    const uint32_t** g_words, const uint64_t** g_woff, const uint32_t** g_len, uint64_t* n_total)
+	{
+		Batch loc{ d_words, d_woff, d_len, d_woff, n };
+		Batch g = eng->share_reads(loc);
+		*g_words = g.words; *g_woff = g.woff; *g_len = g.len; *n_total = g.n;
+		return ABG_OK;
+	}
+
 	// ------------------------------------------------------------------ PASS 2
 	int assemble_seqs(const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
 	    abg_contig_cb cb, void* user)

@@ -10,6 +10,9 @@
 //
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include "abg_host.h"
 
@@ -168,6 +171,7 @@ struct HipBackend {
 	~HipBackend()
 	{
 		if (ticket) free(ticket);
+		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
 		if (ev1) hipEventDestroy(ev1);
@@ -257,6 +261,32 @@ struct HipBackend {
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+	void d2d(void* d, const void* s, size_t n)
+	{
+		if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D");
+	}
+	void* stream_handle() const { return (void*)stream; }
+	// out = the entries of `in` (or the indices 0..n-1 when in == NULL) whose flag is set, in
+	// order (the same list on every rank of a partitioned run); *count_dev = how many
+	void* cub_tmp = nullptr;
+	size_t cub_tmp_bytes = 0;
+	void compact_flagged(const uint32_t* in, const uint8_t* flags, uint64_t n, uint32_t* out, uint32_t* count_dev)
+	{
+		begin("compact");
+		size_t need = 0;
+		hipcub::CountingInputIterator<uint32_t> iota(0);
+		if (in) check(hipcub::DeviceSelect::Flagged(nullptr, need, in, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		else check(hipcub::DeviceSelect::Flagged(nullptr, need, iota, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		if (need > cub_tmp_bytes) {
+			if (cub_tmp) { hipStreamSynchronize(stream); hipFree(cub_tmp); }
+			cub_tmp_bytes = need * 2;
+			check(hipMalloc(&cub_tmp, cub_tmp_bytes), "hipMalloc");
+		}
+		size_t bytes = cub_tmp_bytes;
+		if (in) check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, in, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		else check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, iota, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		end("compact");
+	}
 	uint32_t max_slots() const { return cus * 8 * 256; }
 
 	void begin(const char*) { if (profiling) hipEventRecord(ev0, stream); }
@@ -364,6 +394,82 @@ struct HipBackend {
 };
 
 typedef abg::Session<HipBackend> Sess;
+
+// ---- RCCL communicator behind abg_comm.  librccl is opened at run time (the library stays
+// loadable where RCCL is not installed; single-GPU use never touches it).  Collectives are
+// enqueued on the engine's stream: no host synchronisation between a kernel, the exchange of
+// its output and the kernel that consumes it.
+struct RcclApi {
+	void* h = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclBroadcast) Broadcast = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string why;
+	bool load()
+	{
+		if (h) return true;
+		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+			h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (h) break;
+		}
+		if (!h) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
+#define ABG_SYM(f) f = (decltype(f))dlsym(h, "nccl" #f); if (!f) { why = "librccl lacks nccl" #f; h = nullptr; return false; }
+		ABG_SYM(GetUniqueId) ABG_SYM(CommInitRank) ABG_SYM(CommDestroy) ABG_SYM(AllReduce) ABG_SYM(AllGather)
+		ABG_SYM(Broadcast) ABG_SYM(GroupStart) ABG_SYM(GroupEnd) ABG_SYM(GetErrorString)
+#undef ABG_SYM
+		return true;
+	}
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+struct RcclComm { ncclComm_t comm = nullptr; int rank = 0, world = 1, device = 0; };
+
+int rccl_fail(ncclResult_t r, const char* what)
+{
+	fprintf(stderr, "abyss_amd: %s: %s\n", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+	return -1;
+}
+int rccl_all_gather_v(void* user, void* buf, const uint64_t* counts, const uint64_t* displs, void* stream)
+{
+	RcclComm* c = (RcclComm*)user;
+	hipStream_t st = (hipStream_t)stream;
+	bool uniform = true;
+	for (int q = 0; q < c->world; q++) uniform = uniform && counts[q] == counts[0] && displs[q] == displs[0] + (uint64_t)q * counts[0];
+	ncclResult_t r;
+	if (uniform) {
+		// in place: each rank's part already sits at recvbuff + rank * count
+		if (!counts[0]) return 0;
+		char* base = (char*)buf + displs[0];
+		r = g_rccl.AllGather(base + (uint64_t)c->rank * counts[0], base, counts[0], ncclUint8, c->comm, st);
+		return r == ncclSuccess ? 0 : rccl_fail(r, "ncclAllGather");
+	}
+	// ragged parts: one broadcast per rank, fused into a single group
+	r = g_rccl.GroupStart();
+	if (r != ncclSuccess) return rccl_fail(r, "ncclGroupStart");
+	for (int q = 0; q < c->world; q++) {
+		if (!counts[q]) continue;
+		char* part = (char*)buf + displs[q];
+		r = g_rccl.Broadcast(part, part, counts[q], ncclUint8, q, c->comm, st);
+		if (r != ncclSuccess) { g_rccl.GroupEnd(); return rccl_fail(r, "ncclBroadcast"); }
+	}
+	r = g_rccl.GroupEnd();
+	return r == ncclSuccess ? 0 : rccl_fail(r, "ncclGroupEnd");
+}
+int rccl_all_reduce(void* user, void* buf, uint64_t count, int32_t dtype, int32_t op, void* stream)
+{
+	RcclComm* c = (RcclComm*)user;
+	static const ncclDataType_t dt[3] = { ncclUint8, ncclUint32, ncclUint64 };
+	static const ncclRedOp_t ops[3] = { ncclSum, ncclMax, ncclMin };
+	if (dtype < 0 || dtype > 2 || op < 0 || op > 2) return -1;
+	ncclResult_t r = g_rccl.AllReduce(buf, buf, count, dt[dtype], ops[op], c->comm, (hipStream_t)stream);
+	return r == ncclSuccess ? 0 : rccl_fail(r, "ncclAllReduce");
+}
 
 std::mutex g_err_mutex;
 std::string g_create_error;
@@ -516,6 +622,64 @@ int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
 {
 	if (!ctx || !seq || !n_out) return ABG_EINVAL;
 	return ctx->s.hash_seq(seq, len, pos_out, hashes_out, cap, n_out);
+}
+int abg_attach_comm(abg_ctx* ctx, const abg_comm* comm)
+{
+	if (!ctx || !comm) return ABG_EINVAL;
+	return ctx->s.attach_comm(*comm);
+}
+int abg_share_reads(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len,
+    uint64_t n_local, const uint32_t** g_words, const uint64_t** g_woff, const uint32_t** g_len, uint64_t* n_total)
+{
+	if (!ctx || !g_words || !g_woff || !g_len || !n_total || (n_local && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
+	return ctx->s.share_reads(d_words, d_woff, d_len, n_local, g_words, g_woff, g_len, n_total);
+}
+int abg_rccl_unique_id(uint8_t id[128])
+{
+	static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+	if (!id) return ABG_EINVAL;
+	std::lock_guard<std::mutex> g(g_rccl_mutex);
+	if (!g_rccl.load()) { g_create_error = g_rccl.why; return ABG_ENODEV; }
+	ncclUniqueId u;
+	ncclResult_t r = g_rccl.GetUniqueId(&u);
+	if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return ABG_EINTERNAL; }
+	memcpy(id, &u, 128);
+	return ABG_OK;
+}
+int abg_rccl_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t device, abg_comm* out)
+{
+	if (!id || !out || world < 1 || rank < 0 || rank >= world) return ABG_EINVAL;
+	std::lock_guard<std::mutex> g(g_rccl_mutex);
+	if (!g_rccl.load()) { g_create_error = g_rccl.why; return ABG_ENODEV; }
+	if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return ABG_ENODEV; }
+	ncclUniqueId u;
+	memcpy(&u, id, 128);
+	RcclComm* c = new RcclComm;
+	c->rank = rank; c->world = world; c->device = device;
+	ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+	if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete c; return ABG_EINTERNAL; }
+	memset(out, 0, sizeof *out);
+	out->rank = rank; out->world = world; out->stream_ordered = 1; out->user = c;
+	out->all_gather_v = rccl_all_gather_v;
+	out->all_reduce = rccl_all_reduce;
+	return ABG_OK;
+}
+int abg_rccl_comm_destroy(abg_comm* comm)
+{
+	if (!comm || !comm->user || comm->all_reduce != rccl_all_reduce) return ABG_EINVAL;
+	RcclComm* c = (RcclComm*)comm->user;
+	if (c->comm) g_rccl.CommDestroy(c->comm);
+	delete c;
+	comm->user = nullptr;
+	return ABG_OK;
+}
+int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t kind)
+{
+	if (!ctx || (n && (!dst || !src)) || kind < 0 || kind > 2) return ABG_EINVAL;
+	if (kind == 0) ctx->s.be.h2d(dst, src, n);
+	else if (kind == 1) ctx->s.be.d2h(dst, src, n);
+	else { ctx->s.be.d2d(dst, src, n); ctx->s.be.sync(); }
+	return ABG_OK;
 }
 int abg_profile_enable(abg_ctx* ctx, int on)
 {

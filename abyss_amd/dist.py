@@ -1,0 +1,137 @@
+"""Communicators for the partitioned multi-GPU run (include/abyss_amd.h, ``abg_comm``).
+
+* ``RcclComm`` -- the product path: the library's own RCCL communicator
+  (``abg_rccl_comm_create``), collectives enqueued on the engine's HIP stream over xGMI.  The
+  128-byte unique id travels from rank 0 to the others through the torch.distributed process
+  group that launched the ranks (one process per GPU).
+* ``StagedTorchComm`` -- the same two collectives over ``torch.distributed`` with the buffers
+  staged through host memory.  It lets the partitioned algorithm run where RCCL cannot: on CPU
+  against tests/hostcheck (gloo, world_size 2) and with two ranks sharing one GPU (RCCL refuses
+  duplicate devices).  Test infrastructure; ``bench.py --comm staged`` exposes it for diagnosis.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+U8, U32, U64 = 0, 1, 2
+SUM, MAX, MIN = 0, 1, 2
+
+AGV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
+
+
+class CommStruct(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("stream_ordered", C.c_int32), ("reserved_", C.c_int32),
+                ("user", C.c_void_p), ("all_gather_v", AGV_FN), ("all_reduce", AR_FN)]
+
+
+class RcclComm:
+    """abg_rccl_comm_create over an id broadcast through torch.distributed."""
+
+    def __init__(self, device: int):
+        import torch
+        import torch.distributed as dist
+        self._lib = _lib.load()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            rc = self._lib.abg_rccl_unique_id(ident)
+            if rc != 0:
+                raise RuntimeError("abg_rccl_unique_id failed (%d): %s" % (rc, self._lib.abg_last_error(None).decode()))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", device) if dist.get_backend() == "nccl" else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self.struct = CommStruct()
+        rc = self._lib.abg_rccl_comm_create(ident, self.rank, self.world, device, C.byref(self.struct))
+        if rc != 0:
+            raise RuntimeError("abg_rccl_comm_create failed (%d): %s" % (rc, self._lib.abg_last_error(None).decode()))
+
+    def close(self):
+        if self.struct is not None:
+            self._lib.abg_rccl_comm_destroy(C.byref(self.struct))
+            self.struct = None
+
+
+class StagedTorchComm:
+    """all_gather_v / all_reduce of ``abg_comm`` through torch.distributed on host copies.
+    read(ptr, nbytes) -> uint8 array and write(ptr, uint8 array) move bytes between the
+    engine's memory space and the host (memmove for tests/hostcheck, abg_dev_copy for a GPU)."""
+
+    def __init__(self, read, write):
+        import torch.distributed as dist
+        self.read, self.write = read, write
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.calls = {"all_gather_v": 0, "all_reduce": 0, "bytes": 0}
+        self._agv = AGV_FN(self._all_gather_v)
+        self._ar = AR_FN(self._all_reduce)
+        self.struct = CommStruct(self.rank, self.world, 0, 0, None, self._agv, self._ar)
+
+    def _all_gather_v(self, _user, buf, counts, displs, _stream):
+        import torch
+        import torch.distributed as dist
+        try:
+            cnt = [int(counts[q]) for q in range(self.world)]
+            dsp = [int(displs[q]) for q in range(self.world)]
+            width = max(cnt)
+            if width == 0:
+                return 0
+            mine = np.zeros(width, dtype=np.uint8)
+            if cnt[self.rank]:
+                mine[:cnt[self.rank]] = self.read(buf + dsp[self.rank], cnt[self.rank])
+            parts = [torch.empty(width, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, torch.from_numpy(mine))
+            for q in range(self.world):
+                if q != self.rank and cnt[q]:
+                    self.write(buf + dsp[q], parts[q].numpy()[:cnt[q]])
+            self.calls["all_gather_v"] += 1
+            self.calls["bytes"] += sum(cnt)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C caller
+            print("StagedTorchComm.all_gather_v:", repr(e), flush=True)
+            return -1
+
+    def _all_reduce(self, _user, buf, count, dtype, op, _stream):
+        import torch
+        import torch.distributed as dist
+        try:
+            npdt = {U8: np.uint8, U32: np.uint32, U64: np.uint64}[dtype]
+            raw = self.read(buf, int(count) * np.dtype(npdt).itemsize).view(npdt)
+            # torch.distributed has no unsigned 32/64-bit reductions: widen (values here are far below 2^63)
+            t = torch.from_numpy(raw.copy() if dtype == U8 else raw.astype(np.int64))
+            dist.all_reduce(t, op={SUM: dist.ReduceOp.SUM, MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN}[op])
+            self.write(buf, np.ascontiguousarray(t.numpy().astype(npdt)).view(np.uint8))
+            self.calls["all_reduce"] += 1
+            self.calls["bytes"] += int(count) * np.dtype(npdt).itemsize
+            return 0
+        except Exception as e:
+            print("StagedTorchComm.all_reduce:", repr(e), flush=True)
+            return -1
+
+
+def host_memory_io():
+    """read/write for buffers that already live in host memory (tests/hostcheck)."""
+    def read(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n,)).copy()
+
+    def write(ptr, arr):
+        C.memmove(ptr, arr.ctypes.data, arr.size)
+    return read, write
+
+
+def device_memory_io(ctx):
+    """read/write through abg_dev_copy of the context `ctx` (an api.BloomDBG)."""
+    lib = _lib.load()
+
+    def read(ptr, n):
+        out = np.empty(n, dtype=np.uint8)
+        assert lib.abg_dev_copy(ctx._ctx, out.ctypes.data, ptr, n, 1) == 0
+        return out
+
+    def write(ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        assert lib.abg_dev_copy(ctx._ctx, ptr, arr.ctypes.data, arr.size, 0) == 0
+    return read, write

@@ -175,11 +175,68 @@ int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
 int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out,
     uint8_t* contains_out, uint64_t cap, uint64_t* n_out);
 
+/* ---- multi-GPU: one process per GPU, the filter range-partitioned over the ranks -----------
+ * Stands in for what the reference does across machines with MPI messages
+ * (Parallel/NetworkSequenceCollection.cpp: k-mers routed to the rank that owns them) and for
+ * its filter windows (`abyss-bloom build -w M/N`, Bloom/BloomFilterWindow.h:30-40: a filter
+ * split by position).  With a communicator attached, PASS 1 keeps the counting filter
+ * range-partitioned by position -- rank q owns counters [q*chunk, (q+1)*chunk), chunk =
+ * roundUp64(ceil(size / world)) -- every rank runs every k-mer op against the counters it owns
+ * and one all_reduce(MIN) of a byte per op per round decides winners and minima; the shards
+ * are all-gathered before PASS 2, whose walks are split over the ranks and whose results are
+ * merged before the (replicated) ordered commit.  Results are bit-identical to a single-GPU
+ * run over the concatenated read set.
+ *
+ * The communicator is a table of two collectives over buffers in the library's memory space
+ * (device memory): abg_rccl_comm_create() fills it with RCCL (stream-ordered, over xGMI);
+ * tests supply their own (e.g. gloo through host staging, abg_dev_copy).  Every rank must make
+ * the same sequence of abg_* calls with the same arguments (abg_share_reads excepted, which
+ * takes each rank's own reads). */
+enum abg_dtype { ABG_U8 = 0, ABG_U32 = 1, ABG_U64 = 2 };
+enum abg_redop { ABG_SUM = 0, ABG_MAX = 1, ABG_MIN = 2 };
+typedef struct abg_comm {
+	int32_t rank, world;
+	/* non-zero: the functions enqueue on `stream` (a hipStream_t) and return at once; zero: they
+	 * are called with that stream idle and return when the data is in place */
+	int32_t stream_ordered;
+	int32_t reserved_;
+	void* user;
+	/* in place: rank q's part is counts[q] bytes at buf + displs[q]; the caller's own part is
+	 * there already; on completion every rank holds every part.  Returns 0 on success. */
+	int (*all_gather_v)(void* user, void* buf, const uint64_t* counts, const uint64_t* displs, void* stream);
+	/* in place, element-wise over `count` elements of abg_dtype with abg_redop */
+	int (*all_reduce)(void* user, void* buf, uint64_t count, int32_t dtype, int32_t op, void* stream);
+} abg_comm;
+#define ABG_MAX_RANKS 16
+
+/* Switch the context to the partitioned run (before any load).  The table is copied; `user`
+ * must outlive the context.  world == 1 is allowed (and is the plain single-GPU path). */
+int abg_attach_comm(abg_ctx* ctx, const abg_comm* comm);
+
+/* All-gather of the ranks' packed read sets, in rank order, into device buffers the context
+ * owns (valid until the next call or abg_destroy): every rank then passes the returned
+ * pointers to abg_load_packed / abg_assemble_packed.  Input layout as abg_load_packed. */
+int abg_share_reads(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len,
+    uint64_t n_local, const uint32_t** g_words, const uint64_t** g_woff, const uint32_t** g_len,
+    uint64_t* n_total);
+
+/* RCCL communicator (librccl.so.1 is opened at run time).  Rank 0 makes the 128-byte id and
+ * hands it to the others by whatever channel launched the ranks (bench.py: the
+ * torch.distributed store); every rank then creates its communicator on its own device. */
+int abg_rccl_unique_id(uint8_t id[128]);
+int abg_rccl_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t device, abg_comm* out);
+int abg_rccl_comm_destroy(abg_comm* comm);
+
+/* hipMemcpy on the context's stream, synchronous: kind 0 = host to device, 1 = device to host,
+ * 2 = device to device (for communicators that stage through the host) */
+int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t kind);
+
 /* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
  * runs on; abg_profile_get reports total milliseconds and launch count of one kernel
  * family ("hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep",
  * "walk", "rewalk", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp",
- * "pc_short", "pc_timemin", "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"). */
+ * "pc_short", "pc_timemin", "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"; partitioned run:
+ * "insert_apply", "drain_vals", "drain_load", "merge_fix", "comm_all_reduce", "comm_all_gather"). */
 int abg_profile_enable(abg_ctx* ctx, int on);
 int abg_profile_reset(abg_ctx* ctx);
 int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

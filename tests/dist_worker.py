@@ -1,0 +1,171 @@
+"""Worker of tests/test_dist_partition.py: one rank of a partitioned run on the CPU.
+
+Every rank drives a tests/hostcheck session (the product's device logic executed serially)
+joined to the others by abyss_amd.dist.StagedTorchComm over gloo; rank 0 also runs the same
+input through the oracle (or compares with a golden reference run) and prints one JSON line.
+TEST INFRASTRUCTURE: launched with torch.distributed.run, world_size 2 or 3.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import oracle_binding as ob  # noqa: E402
+from abyss_amd import _lib, api, dist as adist, synth  # noqa: E402
+from test_hostcheck import HostCheck  # noqa: E402
+from util import GoldenCase, contig_tuple, mask_of  # noqa: E402
+
+
+class DistHostCheck(HostCheck):
+    def attach(self):
+        self.comm = adist.StagedTorchComm(*adist.host_memory_io())
+        self.l.hc_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+        assert self.l.hc_attach_comm(self.h, C.byref(self.comm.struct)) == 0
+        vp = C.c_void_p
+        self.l.hc_share_reads.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+        self.l.hc_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]
+        self.l.hc_assemble_packed.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, _lib.CONTIG_CB, vp]
+
+    def share(self, words, woff, lens):
+        gw, go, gl, nt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        assert self.l.hc_share_reads(self.h, words.ctypes.data, woff.ctypes.data, lens.ctypes.data, len(lens),
+                                     C.byref(gw), C.byref(go), C.byref(gl), C.byref(nt)) == 0
+        return gw, go, gl, nt.value
+
+    def load_packed(self, gw, go, gl, n):
+        assert self.l.hc_load_packed(self.h, gw, go, gl, n) == 0
+
+    def assemble_packed(self, gw, go, gl, n):
+        res = np.zeros(n, dtype=np.uint8)
+        out = []
+
+        def cb(_u, c):
+            c = c.contents
+            out.append(api.ContigRecord(c.contig_id, c.read_index, c.seq, c.coverage, bool(c.redundant), c.left_ext,
+                                        c.right_ext, c.left_code, c.right_code, c.seed_pos))
+        assert self.l.hc_assemble_packed(self.h, gw, go, gl, n, res.ctypes.data, _lib.CONTIG_CB(cb), None) == 0
+        return res, out
+
+
+def pack(codes):
+    """[n, L] base codes 0..3 -> (words, woff, len) in the packed layout of include/abyss_amd.h."""
+    n, L = codes.shape
+    wpr = (L + 15) // 16
+    pad = np.zeros((n, wpr * 16), dtype=np.uint64)
+    pad[:, :L] = codes
+    words = (pad.reshape(n, wpr, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=2).astype(np.uint32)
+    return np.ascontiguousarray(words.reshape(-1)), np.arange(n + 1, dtype=np.uint64) * np.uint64(wpr), np.full(n, L, dtype=np.uint32)
+
+
+def case_golden(name, rank, world):
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    hc = DistHostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=128, mask=mask_of(g))
+    hc.attach()
+    hc.load(g.buf, g.off)
+    fp = hc.counting_stats()[1]
+    results, contigs = hc.assemble(g.buf, g.off)
+    c = hc.assembly_counters()
+    ok = {
+        "filtered_popcount": fp == g.meta["filtered_popcount"],
+        "fasta": api.format_fasta(contigs, g.ids) == g.fasta,
+        "readlog": api.format_read_log(results, g.ids) == g.readlog,
+        "trace": api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace,
+        "counters": (c["reads_processed"], c["solid_reads"], c["visited_reads"]) == (g.meta["reads"], g.meta["solid_reads"], g.meta["visited_reads"]),
+    }
+    return ok, hc
+
+
+def case_oracle(k, G, counters, cov, err, insert_batch, rank, world, shared):
+    """Synthetic reads against the oracle.  shared: each rank holds a slice of the packed reads and
+    the ranks all-gather them (abg_share_reads) instead of every rank passing the whole set."""
+    m1, m2 = synth.make_read_set(G, cov, err=err, genome_seed=k, read_seed=k + 3)
+    codes = np.concatenate([m1, m2])
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(codes))
+    hc = DistHostCheck(k, counters, insert_batch=insert_batch, claim_log2=12, p2_first=64)
+    hc.attach()
+    if shared:
+        n = codes.shape[0]
+        a, b = n * rank // world, n * (rank + 1) // world
+        if rank == world - 1 and world > 2:
+            a = b  # a rank without reads of its own
+        elif rank == world - 2 and world > 2:
+            b = n
+        words, woff, lens = pack(codes[a:b])
+        gw, go, gl, nt = hc.share(words, woff, lens)
+        assert nt == n
+        hc.load_packed(gw, go, gl, nt)
+        cnt = hc.counters()
+        rh, ch = hc.assemble_packed(gw, go, gl, nt)
+    else:
+        hc.load(buf, off)
+        cnt = hc.counters()
+        rh, ch = hc.assemble(buf, off)
+    o = ob.Oracle(k, counters=counters)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    ok = {
+        "counting_filter": bool(np.array_equal(o.counters(), cnt)),
+        "saturated": int(cnt.max()),
+        "results": bool(np.array_equal(ro, rh)),
+        "contigs": [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch],
+        "visited": bool(np.array_equal(o.visited(), hc.visited())),
+        "assembly_counters": o.assembly_counters() == hc.assembly_counters(),
+        "n_contigs": len(co),
+    }
+    return ok, hc
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    what = sys.argv[1]
+    if what == "golden":
+        ok, hc = case_golden(sys.argv[2], rank, world)
+    elif what == "oracle":
+        ok, hc = case_oracle(33, 12000, 1 << 20, 25.0, 0.005, 20000, rank, world, shared=False)
+    elif what == "tiny_filter":
+        # a filter so small that counters saturate and every op conflicts with many others: long
+        # reservation chains, several rounds per batch, the distributed hand-over to the drain kernel
+        ok, hc = case_oracle(25, 6000, 1 << 13, 40.0, 0.02, 5000, rank, world, shared=False)
+    elif what == "saturate":
+        # PASS 1 only: 300 copies of one read saturate counters at 255 (CountingBloomFilter.hpp:146-149),
+        # homopolymers give runs of identical k-mers; batches of 1000 ops, 3 ranks
+        reads = [b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAATTTGGCC"] * 300 + [b"A" * 60, b"T" * 60, b"ACAC" * 20]
+        buf, off = api.concat_seqs(reads)
+        o = ob.Oracle(21, counters=4096)
+        hc = DistHostCheck(21, 4096, insert_batch=1000, claim_log2=8)
+        hc.attach()
+        o.load(buf, off)
+        hc.load(buf, off)
+        a, b = o.counters(), hc.counters()
+        ok = {"counting_filter": bool(np.array_equal(a, b)), "saturated": int(b.max())}
+    elif what == "shared":
+        ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=True)
+    else:
+        raise SystemExit("unknown case")
+    ok["stats"] = hc.stats()
+    ok["comm_calls"] = hc.comm.calls
+    # every rank must have reached the same verdicts
+    flat = json.dumps({k: v for k, v in ok.items() if k not in ("comm_calls",)}, sort_keys=True)
+    box = [None] * world
+    dist.all_gather_object(box, flat)
+    ok["ranks_agree"] = all(b == box[0] for b in box)
+    if rank == 0:
+        print("RESULT " + json.dumps(ok), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

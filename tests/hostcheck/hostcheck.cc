@@ -32,6 +32,17 @@ struct SerialBackend {
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	uint32_t max_slots() const { return 1; }
+	void d2d(void* d, const void* s, size_t n) { memmove(d, s, n); }
+	void sync() {}
+	void begin(const char*) {}
+	void end(const char*) {}
+	void* stream_handle() const { return nullptr; }
+	void compact_flagged(const uint32_t* in, const uint8_t* flags, uint64_t n, uint32_t* out, uint32_t* count)
+	{
+		uint32_t m = 0;
+		for (uint64_t i = 0; i < n; i++) if (flags[i]) out[m++] = in ? in[i] : (uint32_t)i;
+		*count = m;
+	}
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
@@ -105,6 +116,22 @@ int hc_contains_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint8
 int hc_hash_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint64_t* hashes, uint64_t cap, uint64_t* n)
 {
 	return ((Sess*)h)->hash_seq(seq, len, pos, hashes, cap, n);
+}
+// partitioned run (two or more hostcheck sessions, one per process, joined by a communicator)
+int hc_attach_comm(void* h, const abg_comm* c) { return ((Sess*)h)->attach_comm(*c); }
+int hc_share_reads(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n,
+    const uint32_t** gw, const uint64_t** gwoff, const uint32_t** glen, uint64_t* ntot)
+{
+	return ((Sess*)h)->share_reads(w, woff, len, n, gw, gwoff, glen, ntot);
+}
+int hc_load_packed(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n)
+{
+	return ((Sess*)h)->load_packed(w, woff, len, n);
+}
+int hc_assemble_packed(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n,
+    uint8_t* results, abg_contig_cb cb, void* user)
+{
+	return ((Sess*)h)->assemble_packed(w, woff, len, n, results, cb, user);
 }
 void hc_get_counters(void* h, abg_counters* out)
 {

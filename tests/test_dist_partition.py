@@ -1,0 +1,62 @@
+"""The partitioned multi-GPU run (include/abyss_amd.h: abg_attach_comm / abg_share_reads) on the
+CPU: N processes, each driving the product's device logic through tests/hostcheck, joined by a
+gloo communicator (abyss_amd.dist.StagedTorchComm).  The counting filter is range-partitioned
+over the ranks in PASS 1, gathered, the walks of PASS 2 are split and merged -- and everything
+must stay bit-identical to the reference's single sequential run (golden fixtures / oracle)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+_port = [29650]
+
+
+def run_ranks(world, *args, timeout=900):
+    _port[0] += 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_port[0]), WORKER, *args],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-3000:])
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+@pytest.mark.parametrize("name,world", [("k64", 2), ("k40_mixed", 3), ("k25_h3_kc3_t40", 2)])
+def test_partitioned_run_reproduces_reference_run(name, world):
+    out = run_ranks(world, "golden", name)
+    for key in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["comm_calls"]["all_reduce"] > 0 and out["comm_calls"]["all_gather_v"] > 0
+
+
+def test_partitioned_run_matches_oracle_world2():
+    out = run_ranks(2, "oracle")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["n_contigs"] > 10
+
+
+def test_partitioned_tiny_filter_long_chains_and_drain_world3():
+    out = run_ranks(3, "tiny_filter")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["stats"]["insert_rounds"] > 20
+
+
+def test_partitioned_counters_saturate_like_the_reference_world3():
+    out = run_ranks(3, "saturate")
+    assert out["counting_filter"] and out["ranks_agree"], out
+    assert out["saturated"] == 255
+
+
+def test_partitioned_run_on_gathered_read_shares_world3():
+    """Each rank holds a slice of the packed read set (one of them none at all); abg_share_reads
+    all-gathers them in rank order."""
+    out = run_ranks(3, "shared")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
