@@ -1231,10 +1231,15 @@ class Engine {
 		own_lo_ = std::min<uint64_t>(m_, (uint64_t)c.rank * chunk);
 		own_span_ = std::min<uint64_t>(m_, own_lo_ + chunk) - own_lo_;
 		own_chunk_ = chunk;
-		if (c.world > 1) cfg_.prefetch_classify = false; // every rank classifies its slice of a batch instead
+		// ABG_FORCE_DIST=1: take the partitioned code path with a single rank too (its kernels,
+		// compaction, merges and collectives, each of which is then an identity) -- for tests and for
+		// measuring what the partitioned path itself costs
+		const char* f = getenv("ABG_FORCE_DIST");
+		force_dist_ = f && atoi(f) != 0;
+		if (dist()) cfg_.prefetch_classify = false; // every rank classifies its slice of a batch instead
 		return true;
 	}
-	bool dist() const { return comm_.world > 1; }
+	bool dist() const { return comm_.world > 1 || force_dist_; }
 	// All-gather of the ranks' packed read sets (rank-major order) into buffers the engine keeps
 	// until the next call: what every rank then hands to load_packed / assemble_packed.
 	Batch share_reads(const Batch& loc)
@@ -1392,6 +1397,7 @@ class Engine {
 	bool t_failed_ = false;
 	// ---- partitioned run
 	Comm comm_;
+	bool force_dist_ = false;
 	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
 	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;

@@ -32,19 +32,24 @@ class CommStruct(C.Structure):
 class RcclComm:
     """abg_rccl_comm_create over an id broadcast through torch.distributed."""
 
-    def __init__(self, device: int):
-        import torch
-        import torch.distributed as dist
+    def __init__(self, device: int, single: bool = False):
+        """single: a communicator of one rank, no process group needed."""
         self._lib = _lib.load()
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if single:
+            self.rank, self.world = 0, 1
+        else:
+            import torch
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
         ident = (C.c_uint8 * 128)()
         if self.rank == 0:
             rc = self._lib.abg_rccl_unique_id(ident)
             if rc != 0:
                 raise RuntimeError("abg_rccl_unique_id failed (%d): %s" % (rc, self._lib.abg_last_error(None).decode()))
-        box = [bytes(ident)]
-        dist.broadcast_object_list(box, src=0, device=torch.device("cuda", device) if dist.get_backend() == "nccl" else None)
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        if not single:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, device=torch.device("cuda", device) if dist.get_backend() == "nccl" else None)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
         self.struct = CommStruct()
         rc = self._lib.abg_rccl_comm_create(ident, self.rank, self.world, device, C.byref(self.struct))
         if rc != 0:
@@ -61,9 +66,9 @@ class StagedTorchComm:
     read(ptr, nbytes) -> uint8 array and write(ptr, uint8 array) move bytes between the
     engine's memory space and the host (memmove for tests/hostcheck, abg_dev_copy for a GPU)."""
 
-    def __init__(self, read, write):
+    def __init__(self, read, write, group=None):
         import torch.distributed as dist
-        self.read, self.write = read, write
+        self.read, self.write, self.group = read, write, group
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.calls = {"all_gather_v": 0, "all_reduce": 0, "bytes": 0}
         self._agv = AGV_FN(self._all_gather_v)
@@ -83,7 +88,7 @@ class StagedTorchComm:
             if cnt[self.rank]:
                 mine[:cnt[self.rank]] = self.read(buf + dsp[self.rank], cnt[self.rank])
             parts = [torch.empty(width, dtype=torch.uint8) for _ in range(self.world)]
-            dist.all_gather(parts, torch.from_numpy(mine))
+            dist.all_gather(parts, torch.from_numpy(mine), group=self.group)
             for q in range(self.world):
                 if q != self.rank and cnt[q]:
                     self.write(buf + dsp[q], parts[q].numpy()[:cnt[q]])
@@ -102,7 +107,7 @@ class StagedTorchComm:
             raw = self.read(buf, int(count) * np.dtype(npdt).itemsize).view(npdt)
             # torch.distributed has no unsigned 32/64-bit reductions: widen (values here are far below 2^63)
             t = torch.from_numpy(raw.copy() if dtype == U8 else raw.astype(np.int64))
-            dist.all_reduce(t, op={SUM: dist.ReduceOp.SUM, MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN}[op])
+            dist.all_reduce(t, op={SUM: dist.ReduceOp.SUM, MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN}[op], group=self.group)
             self.write(buf, np.ascontiguousarray(t.numpy().astype(npdt)).view(np.uint8))
             self.calls["all_reduce"] += 1
             self.calls["bytes"] += int(count) * np.dtype(npdt).itemsize

@@ -7,10 +7,14 @@ conservative-update insert of every read k-mer into the counting Bloom filter), 
 (classify reads, walk unitigs, commit contigs in read order).  N = number of read k-mers,
 each counted once although both passes touch it.
 
-Workload at N=1: BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads,
-k=64, B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors).  With --gpus N every
-rank runs that workload on its own read set and filter (weak scaling; the filter is not
-yet partitioned across GPUs -- see DESIGN.md); value is the whole-job aggregate.
+Workload: BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads, k=64,
+B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors).  With --gpus N (one process per
+GPU) the SAME job is split over the ranks (strong scaling): every rank holds 1/N of the reads,
+the counting filter is range-partitioned by position over the ranks' HBM during PASS 1 (RCCL
+all_gather of the 2-bit reads, one all_reduce(MIN) of a byte per k-mer op and round), gathered
+for PASS 2, whose walks are split over the ranks and merged before the ordered commit
+(DESIGN.md section 7); the unitigs are bit-identical to the 1-GPU run.  --mode replicas runs
+N independent copies of the job instead (weak scaling, no collective on the data path).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -38,7 +42,7 @@ METRIC = "Mk-mers/s inserted+extended (abyss-bloom-dbg, k=64); unitig bit-exact"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, seed: int, device):
+def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, seed: int, device, read_seed=None):
     """Synthetic read set generated on the GPU in the packed layout of include/abyss_amd.h:
     2 bits per base, 16 bases per uint32 word, each read on a word boundary.  File order of
     the reference: all mate-1 reads, then all mate-2 reads (BloomIO.h:102-115)."""
@@ -46,7 +50,7 @@ def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, s
     g1 = torch.from_numpy(h1).to(device)
     g2 = torch.from_numpy(h2).to(device)
     gen = torch.Generator(device=device)
-    gen.manual_seed(seed * 1000003 + 7)
+    gen.manual_seed((seed if read_seed is None else read_seed) * 1000003 + 7)
     wpr = (read_len + 15) // 16
     words = torch.empty((2 * n_pairs, wpr), dtype=torch.int32, device=device)
     shifts = (2 * torch.arange(16, device=device, dtype=torch.int64))
@@ -135,6 +139,10 @@ def main() -> int:
     ap.add_argument("--bloom", type=str, default="2G")
     ap.add_argument("--K", type=int, default=0, help="spaced seed of two K-mers (-K of abyss-bloom-dbg; configs[3]: --k 96 --K 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
+                    help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
+    ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
+                    help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,8 +162,42 @@ def main() -> int:
     bloom_bytes = int(float(a.bloom[:-1]) * mult[a.bloom[-1].upper()]) if a.bloom[-1].isalpha() else int(a.bloom)
     read_len, cov, err = 150, 50.0, 0.005
     genome_len = int(a.pairs * 2 * read_len / cov)
-    words, woff, lens = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42 + rank, device=device)
-    n_reads = 2 * a.pairs
+    partitioned = world > 1 and a.mode == "partitioned"
+    comm = None
+    comm_note = ""
+    if world == 1 and os.environ.get("ABG_FORCE_DIST", "0") not in ("", "0"):
+        # the partitioned code path on one rank (every collective an identity): what that path costs by itself
+        from abyss_amd import dist as adist
+        partitioned = True
+        comm = adist.RcclComm(local, single=True)
+        comm_note = "ABG_FORCE_DIST: partitioned code path on a single rank"
+    elif partitioned:
+        from abyss_amd import dist as adist
+        if a.comm == "rccl":
+            # the library's own RCCL communicator; its id travels through the process group.  If RCCL
+            # cannot be brought up on ANY rank, all ranks fall back to independent replicas together.
+            try:
+                comm = adist.RcclComm(local)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                comm_note = "rccl communicator failed (%r): replicas instead" % (e,)
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int32, device=device if backend == "nccl" else None)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm, partitioned = None, False
+                comm_note = comm_note or "rccl communicator failed on another rank: replicas instead"
+    if partitioned:
+        # one job: rank r holds the r-th block of the read set (same genome on every rank)
+        pairs_local = a.pairs // world + (1 if rank < a.pairs % world else 0)
+        words, woff, lens = gen_packed_reads(genome_len, pairs_local, read_len, err, seed=42, device=device,
+                                             read_seed=42 + 7919 * rank)
+        n_reads = 2 * pairs_local
+    else:
+        words, woff, lens = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42 + rank, device=device)
+        n_reads = 2 * a.pairs
     kmers = n_reads * (read_len - a.k + 1)
     torch.cuda.synchronize()
 
@@ -169,53 +211,86 @@ def main() -> int:
     unitigs = bases = 0
     setup_s = 0.0
 
-    def step():
-        nonlocal g, unitigs, bases, setup_s
+    def step(profile=True):
+        nonlocal g, unitigs, bases, setup_s, comm
         t_setup = time.perf_counter()
         if g is None:
             g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local,
                              spaced_seed=api.spaced_seed_kmer_pair(a.k, a.K) if a.K else None)
+            if partitioned:
+                if comm is None:  # --comm staged
+                    comm = adist.StagedTorchComm(*adist.device_memory_io(g), group=dist.new_group(backend="gloo"))
+                g.attach_comm(comm)
         else:
             g.reset()  # empty filters, zero counters; the device memory is kept (abg_reset)
         setup_s += time.perf_counter() - t_setup
-        g.profile_enable(True)
-        g.profile_reset()
-        g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
+        g.profile_enable(profile)
+        if profile:
+            g.profile_reset()
+        if partitioned:
+            # part of the step: all-gather of the ranks' 2-bit reads (every rank runs every k-mer op
+            # against the counters it owns, so it needs every read)
+            rw, ro, rl, rn = g.share_reads(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
+        else:
+            rw, ro, rl, rn = words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads
+        g.load_packed(rw, ro, rl, rn)
         # contigs stay on the device (no per-contig callback into Python): the unitig count and
         # their total length come from the assembly counters (AssemblyCounters.h:15-31)
-        g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False,
-                          want_contigs=False)
+        g.assemble_packed(rw, ro, rl, rn, want_results=False, want_contigs=False)
         c = g.assembly_counters()
         unitigs, bases = c["next_contig_id"], c["bases_assembled"]
 
+    # N = 1: every launch of the timed steps is bracketed by HIP events (the roofline numbers are
+    # measured live).  Partitioned: the events would put a host synchronisation behind every
+    # launch and collective, so the per-kernel split comes from the warm-up steps instead.
+    timed_profile = not partitioned
     for _ in range(a.warmup):
         step()
+    warm_prof = None
+    if partitioned and a.warmup and g is not None:
+        warm_prof = True
     barrier()
     t0 = time.perf_counter()
+    names = ["hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
+             "insert_drain", "classify", "read_prep", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
+             "share_fix",
+             "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
+             "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
+    prof = {nm: g.profile_get(nm) for nm in names} if (warm_prof and g is not None) else None
     for _ in range(a.steps):
-        step()
+        step(profile=timed_profile)
     barrier()
     elapsed = time.perf_counter() - t0
     red_dev = device if (world > 1 and dist.get_backend() == "nccl") else None
     elapsed, total_kmers = aggregate(elapsed, kmers, a.steps, world, red_dev)
 
     # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
-    names = ["hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep", "walk", "rewalk",
-             "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
-             "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
-    prof = {nm: g.profile_get(nm) for nm in names}
+    if prof is None:
+        prof = {nm: g.profile_get(nm) for nm in names}
     stats = g.stats()
+    ranks_agree = None
+    if partitioned and world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, (unitigs, bases, stats["insert_rounds"], stats["candidates"]))
+        ranks_agree = all(b == box[0] for b in box)
+    kmers_all = kmers  # k-mer ops one rank runs per step (all of the job's when partitioned: the op stream is replicated)
+    if partitioned:
+        kmers_all = 2 * a.pairs * (read_len - a.k + 1)
     H = 4
     per_kmer_bases = (read_len / 4.0) / (read_len - a.k + 1)
     unitig_kmers = max(bases - unitigs * (a.k - 1), 0)
     # Algorithmic bytes of one step per kernel family (SURVEY.md 8d terms):
     # per read k-mer for the streaming kernels, per unitig k-mer for the walk and the commit.
+    # Partitioned: a rank hashes every op of the job but touches only its 1/world of the claim slots
+    # and counters, classifies 1/world of the reads and walks 1/world of the candidates.
+    share = 1.0 / world if partitioned else 1.0
     alg_total = {
-        "hash_claim": (per_kmer_bases + 8 + H * 8) * kmers,      # 2-bit bases, hash out, H claim slots
-        "insert_round": (8 + H * 8 + 2 * H) * kmers,             # hash, H claims, H counter reads + writes
-        "classify": (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers,
-        "rewalk": 8 * H * unitig_kmers,                          # 8 neighbour queries x H per unitig k-mer
-        "walk": 8 * H * unitig_kmers,
+        "hash_claim": (per_kmer_bases + 8 + H * 8 * share) * kmers_all,   # 2-bit bases, hash out, H claim slots
+        "insert_round": ((8 + H * 8 * share + H * share + 1) if partitioned  # hash, owned claims + counters, verdict byte
+                         else (8 + H * 8 + 2 * H)) * kmers_all,             # hash, H claims, H counter reads + writes
+        "classify": (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share,
+        "rewalk": 8 * H * unitig_kmers * share,                  # 8 neighbour queries x H per unitig k-mer
+        "walk": 8 * H * unitig_kmers * share,
         "commit": 3 * H * unitig_kmers,                          # redundancy test + insertion + coverage
         "pc_timemin": 4 * H * unitig_kmers,                      # one 4-byte time stamp per (k-mer, hash)
         "pc_decide": 8 * H * unitig_kmers,                       # time stamp + filter word per (k-mer, hash)
@@ -231,7 +306,7 @@ def main() -> int:
     dom = max(per_kernel, key=lambda nm: prof[nm][0])
     traffic = None
     tsrc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tsrc) and a.pairs == 5_000_000:
+    if os.path.exists(tsrc) and a.pairs == 5_000_000 and world == 1:
         # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) of
         # this same command, committed with the profile; KB units, per launch like `achieved`
         t = json.load(open(tsrc)).get({"rewalk": "k_walkers", "walk": "k_walkers", "commit": "k_commit",
@@ -250,11 +325,17 @@ def main() -> int:
         out = {
             "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, 1xMI355X per rank"
-                       % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom),
-                       "genome_bp": genome_len, "coverage": cov, "error_rate": err, "read_kmers": kmers,
-                       "parallelism": "replicas x%d (filter not partitioned yet)" % world if world > 1 else "single GPU",
+            "higher_is_better": True, "scaling": "strong" if partitioned else "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
+                       % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom,
+                          "one job over %d MI355X" % world if partitioned else "1xMI355X per rank"),
+                       "genome_bp": genome_len, "coverage": cov, "error_rate": err,
+                       "read_kmers": kmers_all if partitioned else kmers,
+                       "parallelism": ("filter range-partitioned over %d ranks in PASS 1 (%s), gathered for PASS 2; walks split"
+                                       % (world, "RCCL all_gather + all_reduce on the engine's stream" if a.comm == "rccl"
+                                          else "torch.distributed on host copies")) if partitioned
+                       else ("replicas x%d (independent jobs)" % world if world > 1 else "single GPU"),
                        "unitigs": unitigs, "unitig_bp": bases},
             "roofline": roofline,
             "kernel_ms": {nm: {"ms": round(v[0], 3), "launches": v[1]} for nm, v in prof.items() if v[1]},
@@ -262,11 +343,18 @@ def main() -> int:
             # part of every step: creating the filters (first step) or clearing them (abg_reset)
             "setup_ms_per_step": round(setup_s / max(a.steps + a.warmup, 1) * 1e3, 1),
         }
+        if partitioned:
+            out["config"]["ranks_agree"] = ranks_agree
+            out["kernel_ms_note"] = "rank 0, last warm-up step (the timed steps run without per-launch events)"
+        if comm_note:
+            out["config"]["note"] = comm_note
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)
         print(json.dumps(out))
     if g is not None:
         g.close()
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
     if world > 1:
         dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
