@@ -1,5 +1,4 @@
-"""The N>1 path of bench.py (one process per GPU, replicas: no collective on the data path):
-the whole-job aggregation (MAX of the timed region, SUM of units) under torch.distributed with
+"""The N>1 path of bench.py (one process per GPU): the whole-job aggregation (MAX of the timed region, SUM of units) under torch.distributed with
 world_size 2 on the gloo backend, and the JSON contract of the bench line."""
 import json
 import os
