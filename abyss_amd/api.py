@@ -100,6 +100,7 @@ class BloomDBG:
 
     def close(self):
         if getattr(self, "_ctx", None):
+            self.free_device()
             self._lib.abg_destroy(self._ctx)
             self._ctx = None
 
@@ -146,6 +147,22 @@ class BloomDBG:
         self._check(self._lib.abg_share_reads(self._ctx, words_ptr, woff_ptr, len_ptr, n, C.byref(gw), C.byref(go),
                                               C.byref(gl), C.byref(nt)), "abg_share_reads")
         return gw.value, go.value, gl.value, nt.value
+
+    def to_device(self, arr: np.ndarray) -> int:
+        """Copy a host array into device memory of this context's GPU (abg_dev_alloc + abg_dev_copy);
+        returns the device pointer, released by free_device() or close()."""
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._check(self._lib.abg_dev_alloc(self._ctx, max(arr.nbytes, 1), C.byref(p)), "abg_dev_alloc")
+        self._check(self._lib.abg_dev_copy(self._ctx, p, arr.ctypes.data, arr.nbytes, 0), "abg_dev_copy")
+        self._dev = getattr(self, "_dev", [])
+        self._dev.append(p.value)
+        return p.value
+
+    def free_device(self) -> None:
+        for p in getattr(self, "_dev", []):
+            self._lib.abg_dev_free(self._ctx, p)
+        self._dev = []
 
     def counting_stats(self) -> Tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()

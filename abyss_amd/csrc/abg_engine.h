@@ -2088,7 +2088,7 @@ class Engine {
 				uint32_t nn2[2] = { 0, 0 };
 				be_.d2h(nn2, need_n, 8);
 				uint32_t nneed = nn2[0];
-				const uint32_t nneed_all = dist() ? nn2[1] : nneed;
+				const uint32_t nneed_all = comm_.world > 1 ? nn2[1] : nneed; // (FPredict counts need_n[1] only when it filters)
 				if (nneed_all) {
 					if (owner_next > 0xF0000000u - nc) { overflow = true; break; } // owner ids exhausted: restart
 					ensure_wtab(std::max<uint32_t>(nneed, 1));

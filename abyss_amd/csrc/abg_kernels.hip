@@ -415,7 +415,7 @@ struct RcclApi {
 	{
 		if (h) return true;
 		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-			h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			h = dlopen(name, RTLD_NOW | RTLD_LOCAL); // (never global: a second copy of RCCL, e.g. torch's, must not bind to this one)
 			if (h) break;
 		}
 		if (!h) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
@@ -671,6 +671,19 @@ int abg_rccl_comm_destroy(abg_comm* comm)
 	if (c->comm) g_rccl.CommDestroy(c->comm);
 	delete c;
 	comm->user = nullptr;
+	return ABG_OK;
+}
+int abg_dev_alloc(abg_ctx* ctx, uint64_t bytes, void** out)
+{
+	if (!ctx || !out) return ABG_EINVAL;
+	*out = ctx->s.be.try_alloc(bytes);
+	if (!*out) { ctx->s.error = "device allocation failed"; return ABG_ENOMEM; }
+	return ABG_OK;
+}
+int abg_dev_free(abg_ctx* ctx, void* ptr)
+{
+	if (!ctx) return ABG_EINVAL;
+	if (ptr) { ctx->s.be.sync(); hipFree(ptr); }
 	return ABG_OK;
 }
 int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t kind)

@@ -61,6 +61,22 @@ class RcclComm:
             self.struct = None
 
 
+class LocalComm:
+    """A communicator of one rank whose collectives are identities (no transport at all): with
+    ABG_FORCE_DIST=1 it drives the partitioned code path in a single process."""
+
+    def __init__(self):
+        self.rank, self.world = 0, 1
+        self.calls = {"all_gather_v": 0, "all_reduce": 0}
+        self._agv = AGV_FN(lambda *_a: self._count("all_gather_v"))
+        self._ar = AR_FN(lambda *_a: self._count("all_reduce"))
+        self.struct = CommStruct(0, 1, 0, 0, None, self._agv, self._ar)
+
+    def _count(self, what):
+        self.calls[what] += 1
+        return 0
+
+
 class StagedTorchComm:
     """all_gather_v / all_reduce of ``abg_comm`` through torch.distributed on host copies.
     read(ptr, nbytes) -> uint8 array and write(ptr, uint8 array) move bytes between the

@@ -145,6 +145,8 @@ def main() -> int:
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
 
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # no version banner on stdout next to the JSON line
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -350,7 +352,11 @@ def main() -> int:
             out["config"]["note"] = comm_note
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)
-        print(json.dumps(out))
+        # whatever native libraries buffered on stdout (RCCL's version banner) goes out first: the
+        # JSON line stays a line of its own
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     if g is not None:
         g.close()
     if comm is not None and hasattr(comm, "close"):

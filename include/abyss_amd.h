@@ -230,6 +230,10 @@ int abg_rccl_comm_destroy(abg_comm* comm);
 /* hipMemcpy on the context's stream, synchronous: kind 0 = host to device, 1 = device to host,
  * 2 = device to device (for communicators that stage through the host) */
 int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t kind);
+/* device memory on the context's GPU for callers that stage packed reads themselves (the *_packed
+ * entry points take device pointers); release with abg_dev_free before abg_destroy */
+int abg_dev_alloc(abg_ctx* ctx, uint64_t bytes, void** out);
+int abg_dev_free(abg_ctx* ctx, void* ptr);
 
 /* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
  * runs on; abg_profile_get reports total milliseconds and launch count of one kernel

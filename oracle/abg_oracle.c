@@ -1449,6 +1449,155 @@ orc_in_mask(const orc_ctx* c, const char* kmer)
 	return m;
 }
 
+/* ------------------------------------------------------------ -g: outputGraph */
+
+/* trimSeq (bloom-dbg.h:399-451): the longest run of consecutive k-mers contained in the solid
+ * filter; the first such run wins a tie (strictly greater).  RollingHashIterator skips k-mers
+ * over non-ACGT characters, and a jump in position ends a run (:422). */
+typedef struct {
+	const orc_ctx* c;
+	size_t prev, start, len, best_start, best_len;
+} trim_state;
+#define TRIM_UNSET ((size_t)-1)
+static int
+cb_trim(void* u, size_t pos, const vtx* v)
+{
+	trim_state* t = (trim_state*)u;
+	int good = vertex_exists(t->c, v);
+	if (!good || (t->prev != TRIM_UNSET && pos - t->prev > 1)) {
+		if (t->start != TRIM_UNSET && t->len > t->best_len) {
+			t->best_len = t->len;
+			t->best_start = t->start;
+		}
+		t->start = TRIM_UNSET;
+		t->len = 0;
+	}
+	if (good) {
+		if (t->start == TRIM_UNSET)
+			t->start = pos;
+		t->len++;
+	}
+	t->prev = pos;
+	return 0;
+}
+
+typedef struct {
+	char* buf;
+	size_t n, cap;
+	orc_text_cb cb;
+	void* user;
+} text_out;
+static void
+text_flush(text_out* o)
+{
+	if (o->n && o->cb)
+		o->cb(o->user, o->buf, o->n);
+	o->n = 0;
+}
+static void
+text_put(text_out* o, const char* s, size_t n)
+{
+	if (o->n + n > o->cap)
+		text_flush(o);
+	memcpy(o->buf + o->n, s, n);
+	o->n += n;
+}
+
+/* breadthFirstSearchImpl (Graph/BreadthFirstSearch.h:93-167) with one start vertex, a colour map
+ * shared by all searches (DefaultColorMap: white unless present) and GraphvizBFSVisitor
+ * (bloom-dbg.h:1097-1159): examine_edge prints "\tU -> V;\n" for every out-edge of a dequeued
+ * vertex, discover_vertex prints "\tV;\n" when the target was white.  A search runs until its
+ * queue is empty, so every vertex it discovered is black afterwards: "non-white" is all the
+ * colour map has to remember, and a start vertex that is not white is not even enqueued. */
+static void
+graph_bfs(const orc_ctx* c, vset* seen, const vtx* start, text_out* o, uint64_t* nodes, uint64_t* edges)
+{
+	unsigned k = c->k;
+	if (vset_contains(c, seen, start))
+		return; /* black (:126-128) */
+	size_t qcap = 1024, qh = 0, qn = 0;
+	vtx* q = (vtx*)malloc(qcap * sizeof(vtx));
+	vset_insert(c, seen, start);
+	(*nodes)++;
+	text_put(o, "\t", 1); text_put(o, start->s, k); text_put(o, ";\n", 2);
+	q[qn++] = *start;
+	while (qh < qn) {
+		vtx u = q[qh++];
+		for (int b = 0; b < 4; b++) { /* out_edge_iterator, RollingBloomDBG.h:299-330 */
+			vtx v;
+			vtx_neighbour(c, &u, SENSE, BASE_CHARS[b], &v);
+			if (!vertex_exists(c, &v))
+				continue;
+			(*edges)++;
+			text_put(o, "\t", 1); text_put(o, u.s, k); text_put(o, " -> ", 4); text_put(o, v.s, k); text_put(o, ";\n", 2);
+			if (vset_insert(c, seen, &v)) {
+				(*nodes)++;
+				text_put(o, "\t", 1); text_put(o, v.s, k); text_put(o, ";\n", 2);
+				if (qn == qcap) {
+					if (qh > qcap / 2) {
+						memmove(q, q + qh, (qn - qh) * sizeof(vtx));
+						qn -= qh; qh = 0;
+					} else {
+						qcap *= 2;
+						q = (vtx*)realloc(q, qcap * sizeof(vtx));
+					}
+				}
+				q[qn++] = v;
+			}
+		}
+	}
+	free(q);
+}
+
+/* outputGraph (bloom-dbg.h:1171-1242), without the "digraph g {" / "}" frame the visitor's
+ * constructor and destructor print.  Sequences as FastaReader(FOLD_CASE) hands them over. */
+void
+orc_output_graph(const orc_ctx* c, const char* seqs, const uint64_t* offsets, uint64_t n,
+    orc_text_cb cb, void* user, uint64_t* nodes_out, uint64_t* edges_out)
+{
+	unsigned k = c->k;
+	vset seen;
+	vset_init(&seen);
+	text_out o = { (char*)malloc(1 << 20), 0, 1 << 20, cb, user };
+	uint64_t nodes = 0, edges = 0;
+	for (uint64_t i = 0; i < n; i++) {
+		const char* seq = seqs + offsets[i];
+		size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+		if (len < k)
+			continue; /* trimSeq :406-409 */
+		trim_state t = { c, TRIM_UNSET, TRIM_UNSET, 0, TRIM_UNSET, 0 };
+		foreach_kmer(c, seq, len, cb_trim, &t);
+		if (t.start != TRIM_UNSET && t.len > t.best_len) { /* :439-442 */
+			t.best_len = t.len;
+			t.best_start = t.start;
+		}
+		if (t.best_len == 0)
+			continue;
+		/* seq = seq.substr(maxMatchStart, maxMatchLen + k - 1); FastaReader folded the case */
+		char first[ORC_MAX_KMER + 1], last[ORC_MAX_KMER + 1];
+		for (unsigned j = 0; j < k; j++) {
+			first[j] = (char)toupper((unsigned char)seq[t.best_start + j]);
+			last[j] = (char)toupper((unsigned char)seq[t.best_start + t.best_len - 1 + j]);
+		}
+		first[k] = last[k] = 0;
+		vtx start, rc;
+		vtx_init(c, &start, first);
+		graph_bfs(c, &seen, &start, &o, &nodes, &edges);
+		/* reverseComplement(seq).substr(0, k) = reverse complement of the last k-mer, hashed afresh (:1223-1225) */
+		char rcs[ORC_MAX_KMER + 1];
+		for (unsigned j = 0; j < k; j++)
+			rcs[j] = complement_base(last[k - 1 - j]);
+		rcs[k] = 0;
+		vtx_init(c, &rc, rcs);
+		graph_bfs(c, &seen, &rc, &o, &nodes, &edges);
+	}
+	text_flush(&o);
+	free(o.buf);
+	vset_free(&seen);
+	if (nodes_out) *nodes_out = nodes;
+	if (edges_out) *edges_out = edges;
+}
+
 /* ---------------------------------------------------- HashAgnosticCascadingBloom */
 struct orc_cascade {
 	orc_ctx* hasher;   /* k, H and the k-mer iterator (its own filters are unused) */

@@ -117,6 +117,10 @@ int orc_successor(const orc_ctx*, const char* kmer, int dir, unsigned trim, unsi
     char* succ_out);
 /* neighbours present in the solid filter, bit i = BASE_CHARS[i] (RollingBloomDBG.h:302-427) */
 unsigned orc_out_mask(const orc_ctx*, const char* kmer);
+/* -g: outputGraph (bloom-dbg.h:1171-1242): the lines between "digraph g {" and "}", handed over in chunks */
+typedef void (*orc_text_cb)(void* user, const char* text, size_t len);
+void orc_output_graph(const orc_ctx*, const char* seqs, const uint64_t* offsets, uint64_t n,
+    orc_text_cb cb, void* user, uint64_t* nodes_out, uint64_t* edges_out);
 unsigned orc_in_mask(const orc_ctx*, const char* kmer);
 
 /* HashAgnosticCascadingBloom (Bloom/HashAgnosticCascadingBloom.h:26-182) as built by

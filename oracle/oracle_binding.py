@@ -32,6 +32,9 @@ OCB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(OContig))
 _lib = None
 
 
+TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_size_t)
+
+
 def ensure_built() -> None:
     if not os.path.exists(LIB) or not os.path.exists(CLI):
         subprocess.run(["make", "-C", HERE, "oracle"], check=True, stdout=subprocess.DEVNULL)
@@ -72,6 +75,8 @@ def lib():
         l.orc_successor.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint, C.c_uint, C.c_char_p]
         l.orc_out_mask.argtypes = [vp, C.c_char_p]
         l.orc_in_mask.argtypes = [vp, C.c_char_p]
+        l.orc_output_graph.argtypes = [vp, C.c_char_p, vp, C.c_uint64, TEXT_CB, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        l.orc_output_graph.restype = None
         l.orc_seed_kmer_pair.argtypes = [C.c_uint, C.c_uint, C.c_char_p]
         l.orc_seed_qr.argtypes = [C.c_uint, C.c_char_p]
         l.orc_seed_qr_pair.argtypes = [C.c_uint, C.c_uint, C.c_char_p]
@@ -160,6 +165,16 @@ class Oracle:
         lib().orc_counters_get(self._h, *[C.byref(x) for x in v])
         names = ("solid_reads", "visited_reads", "reads_processed", "bases_assembled", "next_contig_id")
         return {n: x.value for n, x in zip(names, v)}
+
+    def output_graph(self, buf: bytes, offsets: np.ndarray):
+        """-g (outputGraph, bloom-dbg.h:1171-1242): (GraphViz text incl. the digraph frame, nodes, edges)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        parts = [b"digraph g {\n"]
+        cb = TEXT_CB(lambda _u, p, n: parts.append(C.string_at(p, n)))
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().orc_output_graph(self._h, buf, offsets.ctypes.data, len(offsets) - 1, cb, None, C.byref(a), C.byref(b))
+        parts.append(b"}\n")
+        return b"".join(parts), a.value, b.value
 
     def look_ahead(self, kmer: bytes, direction: int, depth: int) -> bool:
         return bool(lib().orc_look_ahead(self._h, kmer, direction, depth))

@@ -60,3 +60,27 @@ def test_partitioned_run_on_gathered_read_shares_world3():
     out = run_ranks(3, "shared")
     for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
         assert out[key], (key, out)
+
+
+@pytest.mark.parametrize("name", ["k64", "k40_mixed"])
+def test_partitioned_code_path_on_a_single_rank(name, monkeypatch):
+    """ABG_FORCE_DIST=1 with a one-rank communicator (identity collectives): the partitioned kernels,
+    the compaction, the drain hand-over and the merge of walk results in one process."""
+    import ctypes as C
+    from abyss_amd import api, dist as adist
+    from test_hostcheck import HostCheck
+    from util import GoldenCase, mask_of
+    monkeypatch.setenv("ABG_FORCE_DIST", "1")
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, p2_first=128, mask=mask_of(g))
+    comm = adist.LocalComm()
+    hc.l.hc_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+    assert hc.l.hc_attach_comm(hc.h, C.byref(comm.struct)) == 0
+    hc.load(g.buf, g.off)
+    assert hc.counting_stats()[1] == g.meta["filtered_popcount"]
+    results, contigs = hc.assemble(g.buf, g.off)
+    assert api.format_fasta(contigs, g.ids) == g.fasta
+    assert api.format_read_log(results, g.ids) == g.readlog
+    assert comm.calls["all_reduce"] > 0 and comm.calls["all_gather_v"] > 0

@@ -48,7 +48,6 @@ def test_rccl_single_rank_partitioned_path_reproduces_reference_run(name, force_
 
 def test_rccl_single_rank_share_reads_and_oracle(force_dist):
     """abg_share_reads + packed entry points on the partitioned path, against the oracle."""
-    import torch
     k, counters = 64, 1 << 24
     m1, m2 = synth.make_read_set(120000, 30.0)
     codes = np.concatenate([m1, m2])
@@ -58,14 +57,14 @@ def test_rccl_single_rank_share_reads_and_oracle(force_dist):
     pad = np.zeros((n, wpr * 16), dtype=np.uint64)
     pad[:, :L] = codes
     words = (pad.reshape(n, wpr, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=2).astype(np.uint32)
-    dw = torch.from_numpy(words.view(np.int32).reshape(-1)).cuda()
-    do = torch.from_numpy((np.arange(n + 1, dtype=np.int64) * wpr)).cuda()
-    dl = torch.full((n,), L, dtype=torch.int32).cuda()
     g = api.BloomDBG(k, counters=counters, insert_batch_kmers=1 << 20, claim_log2=24)
+    dw = g.to_device(words.reshape(-1))
+    do = g.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(wpr))
+    dl = g.to_device(np.full(n, L, dtype=np.uint32))
     comm = adist.RcclComm(0, single=True)
     g.attach_comm(comm)
     g.profile_enable(True)
-    gw, go, gl, nt = g.share_reads(dw.data_ptr(), do.data_ptr(), dl.data_ptr(), n)
+    gw, go, gl, nt = g.share_reads(dw, do, dl, n)
     assert nt == n
     g.load_packed(gw, go, gl, nt)
     o = ob.Oracle(k, counters=counters)
