@@ -40,6 +40,7 @@ class Stats(C.Structure):
 
 
 CONTIG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Contig))
+TEXT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_uint64)
 
 _lib = None
 
@@ -53,7 +54,7 @@ def symbols():
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
         "abg_contains_seq",
         "abg_attach_comm", "abg_share_reads", "abg_rccl_unique_id", "abg_rccl_comm_create", "abg_rccl_comm_destroy",
-        "abg_dev_copy", "abg_dev_alloc", "abg_dev_free",
+        "abg_dev_copy", "abg_dev_alloc", "abg_dev_free", "abg_output_graph_seqs",
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
     ]
 
@@ -102,6 +103,7 @@ def load(path: str | None = None):
     lib.abg_rccl_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.abg_rccl_comm_destroy.argtypes = [vp]
     lib.abg_dev_copy.argtypes = [vp, vp, vp, C.c_uint64, C.c_int32]
+    lib.abg_output_graph_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64, TEXT_CB, vp, u64p, u64p]
     lib.abg_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     lib.abg_dev_free.argtypes = [vp, vp]
     _lib = lib

@@ -223,6 +223,19 @@ class BloomDBG:
                     "abg_assemble_packed")
         return results, contigs
 
+    def output_graph(self, buf: bytes, offsets: np.ndarray, frame: bool = True) -> Tuple[bytes, int, int]:
+        """-g: outputGraph (bloom-dbg.h:1171-1242) over these sequences: (GraphViz text, nodes, edges).
+        The visited-vertex set carries over between calls; frame=False leaves out "digraph g {" / "}"."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        parts = [b"digraph g {\n"] if frame else []
+        cb = _lib.TEXT_CB(lambda _u, p, n: parts.append(C.string_at(p, n)))
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.abg_output_graph_seqs(self._ctx, buf, offsets.ctypes.data, len(offsets) - 1, cb, None,
+                                                    C.byref(a), C.byref(b)), "abg_output_graph_seqs")
+        if frame:
+            parts.append(b"}\n")
+        return b"".join(parts), a.value, b.value
+
     def assembly_counters(self) -> dict:
         c = _lib.Counters()
         self._check(self._lib.abg_get_counters(self._ctx, C.byref(c)), "abg_get_counters")

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace abg {
@@ -671,6 +672,101 @@ struct FFirstFix { // first record of the candidates this rank walked in the lau
 };
 struct FAddU64 { uint64_t* a; uint64_t d; ABG_HD void operator()(uint64_t i, uint32_t) const { a[i] += d; } };
 
+// ---- -g: outputGraph (bloom-dbg.h:1171-1242)
+// trimSeq (bloom-dbg.h:399-451) on one clean segment: the longest run of consecutive k-mers the
+// solid filter contains; the first such run wins a tie (a later one must be strictly longer).
+template <int NW>
+struct FTrimRun {
+	Params p; Batch b; const uint8_t* cnt; uint32_t* best_start; uint32_t* best_len;
+	ABG_HDN void operator()(uint64_t r, uint32_t) const
+	{
+		const unsigned k = p.k;
+		const uint32_t nk = b.len[r] - k + 1;
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		uint32_t bs = 0, bl = 0, cs = 0, cl = 0;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (solid_contains(p, cnt, vtx_hash(p, v))) {
+				if (!cl) cs = j;
+				cl++;
+			} else {
+				if (cl > bl) { bl = cl; bs = cs; }
+				cl = 0;
+			}
+		}
+		if (cl > bl) { bl = cl; bs = cs; }
+		best_start[r] = bs;
+		best_len[r] = bl;
+	}
+};
+// The breadth-first searches of outputGraph as ONE sequential walk (a single lane: the output IS
+// the visiting order).  breadthFirstSearchImpl (Graph/BreadthFirstSearch.h:93-167) with a colour
+// map shared by all searches: every search drains its queue, so "seen before" is all the map has
+// to say, a start vertex seen before is skipped, and the order in which vertices leave the queue
+// is the order in which they were discovered.  Per vertex leaving the queue one byte is recorded:
+// bits 0-3 = out-edge to the successor ending in A, C, G, T exists (examine_edge), bits 4-7 = that
+// successor was new (discover_vertex).  The host replays k-mer strings from that (abg_host.h).
+// Resumable: when the node buffer or the vertex table is about to run out the walk stops, the
+// host enlarges it and launches again.
+struct GraphState {
+	uint64_t s_next;   // next start vertex
+	uint64_t head, count; // queue = nodes[head, count)
+	uint64_t tab_used; // entries in the seen table
+	uint64_t edges;
+	uint32_t stop;     // 0 finished, 1 node buffer full, 2 table full
+	uint32_t pad_;
+};
+template <int NW>
+struct FGraphBfs {
+	Params p; const uint8_t* cnt; Batch starts; uint64_t nstarts; WalkTab tab; uint64_t tab_limit;
+	Vtx<NW>* nodes; uint64_t node_cap; uint8_t* ev; uint8_t* start_used; GraphState* st;
+	ABG_HDN void operator()(uint64_t, uint32_t) const
+	{
+		GraphState s = *st;
+		s.stop = 0;
+		while (!s.stop) {
+			while (s.head < s.count && !s.stop) {
+				if (s.count + 4 > node_cap) { s.stop = 1; break; }
+				if (s.tab_used + 4 > tab_limit) { s.stop = 2; break; }
+				const Vtx<NW> u = nodes[s.head];
+				unsigned e = 0;
+				for (unsigned b = 0; b < 4; b++) { // out_edge_iterator, RollingBloomDBG.h:299-330
+					Vtx<NW> w = neighbour_vertex(p, u, SENSE, b);
+					if (!solid_contains(p, cnt, vtx_hash(p, w))) continue;
+					e |= 1u << b;
+					s.edges++;
+					const VKey key = vtx_key(p, w);
+					if (wt_find(tab, key, 0) != WT_EMPTY) continue;
+					wt_insert(tab, key, 0, 0);
+					s.tab_used++;
+					nodes[s.count++] = w;
+					e |= 16u << b;
+				}
+				ev[s.head++] = (uint8_t)e;
+			}
+			if (s.stop || s.s_next >= nstarts) break;
+			if (s.count + 1 > node_cap) { s.stop = 1; break; }
+			if (s.tab_used + 1 > tab_limit) { s.stop = 2; break; }
+			Vtx<NW> v;
+			v.s = batch_kmer<NW>(starts, s.s_next, 0, p.k);
+			vtx_rehash(p, v);
+			const VKey key = vtx_key(p, v);
+			if (wt_find(tab, key, 0) != WT_EMPTY) {
+				start_used[s.s_next] = 0; // not white: nothing printed, nothing queued (:117-131)
+			} else {
+				wt_insert(tab, key, 0, 0);
+				s.tab_used++;
+				nodes[s.count++] = v;
+				start_used[s.s_next] = 1;
+			}
+			s.s_next++;
+		}
+		*st = s;
+	}
+};
+
 // ---- ordered commit (outputContig, bloom-dbg.h:538-620), cooperative over T threads
 struct CommitState {
 	Counters counters;
@@ -1179,6 +1275,7 @@ class Engine {
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
 		if (la_pool2_) be_.free(la_pool2_);
+		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
 		free_insert();
 		free_walk();
@@ -1204,6 +1301,7 @@ class Engine {
 			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
 		}
 		cend_count_ = 0;
+		if (gtab_.hmin) { free_tab(gtab_); gtab_ = WalkTab{ nullptr, nullptr, nullptr, 0 }; gtab_used_ = 0; }
 	}
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
@@ -1299,6 +1397,33 @@ class Engine {
 		be_.d2h(out, scal_, 16);
 		*nonzero = out[0];
 		*filtered = out[1];
+	}
+
+	// ---- -g: per clean segment, the longest run of solid k-mers (trimSeq)
+	void trim_runs(const Batch& b, uint32_t* best_start_h, uint32_t* best_len_h)
+	{
+		if (!b.n) return;
+		gather_counters();
+		uint32_t* bs = (uint32_t*)be_.alloc(b.n * 4);
+		uint32_t* bl = (uint32_t*)be_.alloc(b.n * 4);
+		dispatch_nw([&](auto nw) {
+			FTrimRun<decltype(nw)::value> f{ p_, b, cnt_, bs, bl };
+			be_.launch(b.n, f, "graph_trim");
+		});
+		be_.d2h(best_start_h, bs, b.n * 4);
+		be_.d2h(best_len_h, bl, b.n * 4);
+		be_.free(bs); be_.free(bl);
+	}
+	// ---- -g: the breadth-first searches from `starts` (sequences of k bases) in order; ev gets one
+	// byte per vertex in discovery order, used one flag per start (see FGraphBfs).  The set of seen
+	// vertices carries over between calls (the reference's colour map spans all input files).
+	void graph_bfs(const Batch& starts, std::vector<uint8_t>& ev, std::vector<uint8_t>& used, uint64_t* edges)
+	{
+		ev.clear(); used.assign(starts.n, 0);
+		*edges = 0;
+		if (!starts.n) return;
+		gather_counters();
+		dispatch_nw([&](auto nw) { graph_bfs_nw<decltype(nw)::value>(starts, ev, used, edges); });
 	}
 
 	// ---- PASS 1 on a device-resident packed batch (ops are inserted in batch order).
@@ -1475,6 +1600,74 @@ class Engine {
 	std::function<void()> prefetch_;
 	VKey* la_pool2_ = nullptr; uint32_t cslots2_ = 65536;
 	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
+
+	// ---- -g state: the vertices seen by any search so far
+	WalkTab gtab_{ nullptr, nullptr, nullptr, 0 };
+	uint64_t gtab_used_ = 0;
+	// the build of the device code for this k (and for a spaced seed: see NW_MASKED, abg_core.h)
+	template <class F>
+	void dispatch_nw(F&& f)
+	{
+		switch (p_.mask ? NW_MASKED + p_.nw : p_.nw) {
+		case 1: f(std::integral_constant<int, 1>()); break;
+		case 2: f(std::integral_constant<int, 2>()); break;
+		case 3: f(std::integral_constant<int, 3>()); break;
+		case 4: f(std::integral_constant<int, 4>()); break;
+		case 5: case 6: f(std::integral_constant<int, 6>()); break;
+		case NW_MASKED + 1: f(std::integral_constant<int, NW_MASKED + 1>()); break;
+		case NW_MASKED + 2: f(std::integral_constant<int, NW_MASKED + 2>()); break;
+		case NW_MASKED + 3: f(std::integral_constant<int, NW_MASKED + 3>()); break;
+		case NW_MASKED + 4: f(std::integral_constant<int, NW_MASKED + 4>()); break;
+		default: f(std::integral_constant<int, NW_MASKED + 6>()); break;
+		}
+	}
+	template <int NW>
+	void graph_bfs_nw(const Batch& starts, std::vector<uint8_t>& ev, std::vector<uint8_t>& used, uint64_t* edges)
+	{
+		if (!gtab_.hmin) { alloc_tab(gtab_, 16); gtab_used_ = 0; }
+		uint64_t node_cap = 1ull << 16;
+		Vtx<NW>* nodes = (Vtx<NW>*)be_.alloc(node_cap * sizeof(Vtx<NW>));
+		uint8_t* ev_d = (uint8_t*)be_.alloc(node_cap);
+		uint8_t* used_d = (uint8_t*)be_.alloc(starts.n);
+		GraphState* st_d = (GraphState*)be_.alloc(sizeof(GraphState));
+		GraphState st;
+		memset(&st, 0, sizeof st);
+		st.tab_used = gtab_used_;
+		be_.h2d(st_d, &st, sizeof st);
+		for (;;) {
+			FGraphBfs<NW> f{ p_, cnt_, starts, starts.n, gtab_, (gtab_.mask + 1) / 2, nodes, node_cap, ev_d, used_d, st_d };
+			be_.launch(1, f, "graph_bfs");
+			be_.d2h(&st, st_d, sizeof st);
+			if (st.stop == 1) {
+				nodes = (Vtx<NW>*)regrow(nodes, node_cap * sizeof(Vtx<NW>), 2 * node_cap * sizeof(Vtx<NW>));
+				ev_d = (uint8_t*)regrow(ev_d, node_cap, 2 * node_cap);
+				node_cap *= 2;
+			} else if (st.stop == 2) {
+				uint32_t log2 = 1;
+				while ((1ull << log2) < gtab_.mask + 1) log2++;
+				WalkTab bigger{};
+				alloc_tab(bigger, log2 + 1);
+				uint32_t* failed = (uint32_t*)be_.alloc(8);
+				be_.memset(failed, 0, 4);
+				FRehash fr{ gtab_, bigger, failed };
+				be_.launch(gtab_.mask + 1, fr, "rehash");
+				uint32_t bad = 0;
+				be_.d2h(&bad, failed, 4);
+				be_.free(failed);
+				if (bad) { fprintf(stderr, "abyss_amd: graph table rehash failed\n"); abort(); }
+				free_tab(gtab_);
+				gtab_ = bigger;
+			} else {
+				break;
+			}
+		}
+		gtab_used_ = st.tab_used;
+		ev.resize(st.count);
+		be_.d2h(ev.data(), ev_d, st.count);
+		be_.d2h(used.data(), used_d, starts.n);
+		*edges = st.edges;
+		be_.free(nodes); be_.free(ev_d); be_.free(used_d); be_.free(st_d);
+	}
 
 	void ensure_insert()
 	{

@@ -226,6 +226,114 @@ class Session {
 		return ABG_OK;
 	}
 
+	// ------------------------------------------------------------------ -g
+	// outputGraph (bloom-dbg.h:1171-1242) over sequences as FastaReader(FOLD_CASE) hands them over:
+	// the GraphViz lines between "digraph g {" and "}", delivered in chunks.  trimSeq and the
+	// searches run on the device (FTrimRun, FGraphBfs); the host turns the recorded visiting order
+	// back into k-mer strings: a successor's k-mer is its parent's shifted by one base.
+	// (Under a spaced seed, a non-ACGT character beneath a '0' of a START k-mer would be printed by
+	// the reference as it stands in the read; here it comes out as 'N' -- the one known deviation.)
+	int output_graph_seqs(const char* seqs, const uint64_t* off, uint64_t n, abg_text_cb cb, void* user,
+	    uint64_t* nodes_out, uint64_t* edges_out)
+	{
+		if (eng->cascade_mode()) return fail(ABG_EINVAL, "not available on a cascading filter");
+		const uint32_t k = cfg.k;
+		HostBatch hb;
+		struct Seg { uint64_t read; uint64_t start; };
+		std::vector<Seg> segs;
+		std::string up;
+		for (uint64_t i = 0; i < n; i++) {
+			const char* s = seqs + off[i];
+			const uint64_t L = off[i + 1] - off[i];
+			if (L < k) continue; // trimSeq :406-409
+			const char* text = s;
+			if (!cfg.spaced_seed.empty()) {
+				up.assign(s, L);
+				for (auto& ch : up) ch = (char)toupper((unsigned char)ch);
+				text = up.data();
+			}
+			valid_runs(text, L, runs_);
+			for (auto& run : runs_) { // k-mers run.first .. run.second - 1; a gap between runs ends a match (:422)
+				hb.add_ascii(text + run.first, (uint32_t)(run.second - run.first + k - 1), k);
+				segs.push_back(Seg{ i, run.first });
+			}
+		}
+		std::vector<uint32_t> bs(segs.size()), bl(segs.size());
+		if (!segs.empty()) {
+			DevBatch d = upload(hb);
+			eng->trim_runs(d.b, bs.data(), bl.data());
+			release(d);
+		}
+		// per read: the first longest run over its segments; start vertices = its first k-mer and the
+		// reverse complement of its last k-mer (:1217-1226)
+		HostBatch starts;
+		std::vector<std::string> start_kmers;
+		auto fold = [](char c) { c = (char)toupper((unsigned char)c); return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N'; };
+		auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; };
+		for (size_t a = 0; a < segs.size();) {
+			size_t b = a;
+			uint32_t best = 0; uint64_t best_pos = 0;
+			for (; b < segs.size() && segs[b].read == segs[a].read; b++)
+				if (bl[b] > best) { best = bl[b]; best_pos = segs[b].start + bs[b]; }
+			if (best) {
+				const char* s = seqs + off[segs[a].read];
+				std::string first(k, 'N'), rc(k, 'N');
+				for (uint32_t j = 0; j < k; j++) {
+					first[j] = fold(s[best_pos + j]);
+					rc[j] = comp(fold(s[best_pos + best - 1 + (k - 1 - j)]));
+				}
+				starts.add_ascii(first.data(), k, k);
+				starts.add_ascii(rc.data(), k, k);
+				start_kmers.push_back(first);
+				start_kmers.push_back(rc);
+			}
+			a = b;
+		}
+		std::vector<uint8_t> ev, used;
+		uint64_t edges = 0;
+		if (starts.n()) {
+			DevBatch d = upload(starts);
+			eng->graph_bfs(d.b, ev, used, &edges);
+			release(d);
+		}
+		// replay
+		std::string out;
+		out.reserve(1 << 20);
+		auto flush = [&]() { if (cb && !out.empty()) cb(user, out.data(), out.size()); out.clear(); };
+		std::vector<std::string> queue; // discovered vertices in order; `head` walks it
+		size_t head = 0;
+		uint64_t node = 0;
+		static const char BASES[] = "ACGT";
+		for (size_t si = 0; si < start_kmers.size(); si++) {
+			if (!used[si]) continue;
+			out += '\t'; out += start_kmers[si]; out += ";\n";
+			queue.clear(); head = 0;
+			queue.push_back(start_kmers[si]);
+			while (head < queue.size()) {
+				const std::string u = queue[head++];
+				if (node >= ev.size()) return fail(ABG_EINTERNAL, "graph replay ran past the device's record");
+				const unsigned e = ev[node++];
+				for (unsigned b2 = 0; b2 < 4; b2++) {
+					if (!((e >> b2) & 1)) continue;
+					std::string v = u.substr(1);
+					v += BASES[b2];
+					out += '\t'; out += u; out += " -> "; out += v; out += ";\n";
+					if ((e >> (4 + b2)) & 1) {
+						out += '\t'; out += v; out += ";\n";
+						queue.push_back(std::move(v));
+					}
+				}
+				if (out.size() >= (1u << 20)) flush();
+				if (head >= (1u << 16) && head * 2 > queue.size()) { queue.erase(queue.begin(), queue.begin() + head); head = 0; }
+			}
+		}
+		if (node != ev.size()) return fail(ABG_EINTERNAL, "graph replay does not match the device's record");
+		flush();
+		if (nodes_out) *nodes_out = ev.size();
+		if (edges_out) *edges_out = edges;
+		return ABG_OK;
+	}
+
 	// ------------------------------------------------------------------ probes
 	// valid k-mers of one sequence: positions and whether the solid filter contains them
 	// (writeCovTrack's loop, bloom-dbg.h:1297-1312)

@@ -694,6 +694,12 @@ int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t k
 	else { ctx->s.be.d2d(dst, src, n); ctx->s.be.sync(); }
 	return ABG_OK;
 }
+int abg_output_graph_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
+    abg_text_cb cb, void* user, uint64_t* nodes, uint64_t* edges)
+{
+	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
+	return ctx->s.output_graph_seqs(seqs, offsets, n, cb, user, nodes, edges);
+}
 int abg_profile_enable(abg_ctx* ctx, int on)
 {
 	if (!ctx) return ABG_EINVAL;

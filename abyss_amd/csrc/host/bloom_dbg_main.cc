@@ -4,7 +4,7 @@
 // libabyss_amd.so (include/abyss_amd.h).  All assembly work happens on the GPU; this file
 // only parses options, reads sequence files and prints records.
 //
-// Not supported (the binary says so and exits 1): -g (GraphViz dump).
+// Every option of the reference's table is served, -g (GraphViz dump, abg_output_graph_seqs) included.
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
@@ -271,7 +271,7 @@ int main(int argc, char** argv)
 {
 	abg_params p;
 	abg_params_init(&p);
-	std::string bloomPath, outputPath, tracePath, readLogPath, covTrackPath, refPath;
+	std::string bloomPath, outputPath, tracePath, readLogPath, covTrackPath, refPath, graphPath;
 	int verbose = 0;
 	bool die = false;
 	unsigned K = 0, qr = 0;
@@ -305,9 +305,7 @@ int main(int argc, char** argv)
 		case CHECKPOINT: readsPerCheckpoint = strtoull(optarg, &end, 10); bad = *end; break;
 		case KEEP_CHECKPOINT: keepCheckpoint = true; break;
 		case CHECKPOINT_PREFIX: checkpointPrefix = optarg; break;
-		case 'g':
-			fprintf(stderr, PROGRAM ": option `-%c' is not supported by this build\n", c < 128 ? c : '-');
-			exit(EXIT_FAILURE);
+		case 'g': graphPath = optarg; break;
 		}
 		if (bad) { // bloom-dbg.cc:472-475
 			fprintf(stderr, PROGRAM ": invalid option: `-%c%s'\n", (char)c, optarg);
@@ -469,6 +467,37 @@ int main(int argc, char** argv)
 			if (blockLength > 0) fprintf(wig, "variableStep chrom=%s span=%zu\n%zu %u\n", id.c_str(), blockLength, blockStart, blockVal);
 		}
 		fclose(wig);
+	}
+	// -g: outputGraph (bloom-dbg.cc:203-211, bloom-dbg.h:1171-1242) over the assembly input files.  (The
+	// reference writes it after the assembly; it reads nothing but the solid filter, so the order is free.)
+	if (!graphPath.empty()) {
+		FILE* gv = fopen(graphPath.c_str(), "w");
+		if (!gv) { fprintf(stderr, "error: `%s': %s\n", graphPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		if (verbose) fprintf(stderr, "Generating GraphViz output...\n");
+		fputs("digraph g {\n", gv);
+		uint64_t nodes = 0, edges = 0, nreads = 0;
+		Chunk gc;
+		auto graph = [&]() {
+			if (!gc.n()) return;
+			uint64_t a = 0, b = 0;
+			check(abg_output_graph_seqs(ctx, gc.seqs.data(), gc.off.data(), gc.n(),
+			    [](void* u, const char* text, uint64_t len) { fwrite(text, 1, len, (FILE*)u); }, gv, &a, &b), ctx, "graph");
+			nodes += a; edges += b;
+			gc.clear();
+		};
+		for (int i = first_asm; i < argc; ++i) {
+			if (!strcmp(argv[i], ":")) continue;
+			abghost::FastaReader in(argv[i], ropt);
+			while (in.read(id, comment, seq)) {
+				gc.add(id, seq); nreads++;
+				if (gc.seqs.size() >= CHUNK_BASES) graph();
+			}
+		}
+		graph();
+		fputs("}\n", gv);
+		if (fclose(gv)) { fprintf(stderr, "error: `%s': %s\n", graphPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
+		if (verbose) fprintf(stderr, "processed %llu reads (k-mers visited: %llu, edges visited: %llu)\nGraphViz generation complete\n",
+		    (unsigned long long)nreads, (unsigned long long)nodes, (unsigned long long)edges);
 	}
 	// PASS 2: assemble, bloom-dbg.h:900-951,972-1089
 	FILE* trace = NULL; FILE* readlog = NULL;

@@ -235,6 +235,18 @@ int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t k
 int abg_dev_alloc(abg_ctx* ctx, uint64_t bytes, void** out);
 int abg_dev_free(abg_ctx* ctx, void* ptr);
 
+/* -g -- outputGraph (BloomDBG/bloom-dbg.h:1171-1242): for every sequence, trimSeq (:399-451) and a
+ * breadth-first search over the solid filter's de Bruijn graph from its first k-mer and from the
+ * reverse complement of its last one (Graph/BreadthFirstSearch.h:93-167), printing
+ * GraphvizBFSVisitor's lines (:1097-1159): "\tKMER;\n" when a vertex is discovered, "\tU -> V;\n"
+ * for every out-edge of a visited vertex.  cb receives that text in chunks, WITHOUT the
+ * "digraph g {" / "}" frame; nodes / edges (may be NULL) receive the visitor's counters for this
+ * call.  The set of visited vertices carries over between calls (abg_reset clears it), so a read
+ * stream may be fed in chunks, as with abg_assemble_seqs. */
+typedef void (*abg_text_cb)(void* user, const char* text, uint64_t len);
+int abg_output_graph_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
+    abg_text_cb cb, void* user, uint64_t* nodes, uint64_t* edges);
+
 /* kernel timing: when enabled, every launch is bracketed by HIP events on the stream it
  * runs on; abg_profile_get reports total milliseconds and launch count of one kernel
  * family ("hash_claim", "insert_round", "insert_retry", "insert_drain", "classify", "read_prep",

@@ -133,6 +133,11 @@ int hc_assemble_packed(void* h, const uint32_t* w, const uint64_t* woff, const u
 {
 	return ((Sess*)h)->assemble_packed(w, woff, len, n, results, cb, user);
 }
+int hc_output_graph_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n, abg_text_cb cb, void* user,
+    uint64_t* nodes, uint64_t* edges)
+{
+	return ((Sess*)h)->output_graph_seqs(seqs, off, n, cb, user, nodes, edges);
+}
 void hc_get_counters(void* h, abg_counters* out)
 {
 	abg::Counters c = ((Sess*)h)->eng->counters();

@@ -43,6 +43,25 @@ def test_cli_reproduces_golden(name, tmp_path):
     assert b"Assembly complete" in r.stderr
 
 
+def test_cli_graphviz_dump(tmp_path):
+    """`-g FILE` (bloom-dbg.cc:203-211): the GraphViz file against the one the reference wrote."""
+    import hashlib
+    import json
+    from util import GOLDEN
+    g = GoldenCase("k32")
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i, s in enumerate(g.reads):
+            f.write(b">r%d\n%s\n" % (i, s))
+    r = subprocess.run([cli()] + g.meta["options"] + ["-j1", "-v", "-g", "g.dot", "reads.fa"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == g.fasta
+    ref = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))["k32"]
+    dot = open(tmp_path / "g.dot", "rb").read()
+    assert len(dot) == ref["bytes"] and hashlib.sha256(dot).hexdigest() == ref["sha256"]
+    assert ("(k-mers visited: %d, edges visited: %d)" % (ref["nodes"], ref["edges"])).encode() in r.stderr
+
+
 def test_cli_option_errors(tmp_path):
     (tmp_path / "r.fa").write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
     for args, msg in ((["-k32", "r.fa"], b"missing mandatory option `-b'"), (["-b1M", "r.fa"], b"missing mandatory option `-k'"),

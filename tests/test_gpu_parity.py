@@ -191,3 +191,25 @@ def test_export_import_roundtrip_and_idempotence():
     # every output unitig consists of solid k-mers only: re-loading the unitigs' k-mers into
     # the assembled filter of a third context leaves all reads that were visited, visited
     assert np.array_equal(g.counters(), cnt)
+
+
+@pytest.mark.parametrize("name", ["k64", "k40_mixed", "k48_K16"])
+def test_graphviz_dump_matches_reference(name):
+    """-g (abg_output_graph_seqs): trimSeq + the breadth-first searches on the device against the file
+    the unmodified reference wrote for the same reads (tests/golden/make_graph_golden.py)."""
+    import hashlib
+    import json
+    import os
+    from util import GOLDEN, mask_of
+    g0 = GoldenCase(name)
+    kw = g0.kwargs()
+    g = api.BloomDBG(kw["k"], counters=g0.meta["counters"], num_hashes=kw["num_hashes"], min_cov=kw["min_cov"],
+                     trim=kw["trim"], spaced_seed=mask_of(g0), claim_log2=22)
+    g.load(g0.buf, g0.off)
+    text, nodes, edges = g.output_graph(g0.buf, g0.off)
+    ref = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))[name]
+    assert (len(text), nodes, edges) == (ref["bytes"], ref["nodes"], ref["edges"])
+    assert hashlib.sha256(text).hexdigest() == ref["sha256"]
+    again, n2, e2 = g.output_graph(g0.buf, g0.off, frame=False)
+    assert again == b"" and (n2, e2) == (0, 0)
+    g.close()

@@ -83,6 +83,18 @@ class HostCheck:
         assert self.l.hc_hash_seq(self.h, seq, len(seq), pos.ctypes.data, hashes.ctypes.data, cap, C.byref(n)) == 0
         return pos[:n.value], hashes[:n.value]
 
+    def output_graph(self, buf, off, frame=True):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        parts = [b"digraph g {\n"] if frame else []
+        cb = _lib.TEXT_CB(lambda _u, p, n: parts.append(C.string_at(p, n)))
+        a, b = C.c_uint64(), C.c_uint64()
+        self.l.hc_output_graph_seqs.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, _lib.TEXT_CB, C.c_void_p,
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        assert self.l.hc_output_graph_seqs(self.h, buf, off.ctypes.data, len(off) - 1, cb, None, C.byref(a), C.byref(b)) == 0
+        if frame:
+            parts.append(b"}\n")
+        return b"".join(parts), a.value, b.value
+
     def assembly_counters(self):
         c = _lib.Counters()
         self.l.hc_get_counters(self.h, C.byref(c))
@@ -326,3 +338,40 @@ def test_chunked_calls_equal_single_call():
         results_all.append(r)
     assert api.format_fasta(contigs_all, g.ids) == g.fasta
     assert api.format_read_log(np.concatenate(results_all), g.ids) == g.readlog
+
+
+@pytest.mark.parametrize("name", ["k32", "k40_mixed", "k48_K16", "k25_h3_kc3_t40"])
+def test_graphviz_dump_device_logic_matches_reference(name):
+    """-g: trimSeq + the breadth-first searches (FTrimRun, FGraphBfs) and the host's replay against the
+    file the unmodified reference wrote (SHA-256, size, visitor counters); the vertex table and the node
+    buffer start small, so both grow on the way."""
+    import hashlib
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, mask=mask_of(g))
+    hc.load(g.buf, g.off)
+    text, nodes, edges = hc.output_graph(g.buf, g.off)
+    ref = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))[name]
+    assert (len(text), nodes, edges) == (ref["bytes"], ref["nodes"], ref["edges"])
+    assert hashlib.sha256(text).hexdigest() == ref["sha256"]
+
+
+def test_graphviz_dump_in_chunks_equals_single_call():
+    """The visited-vertex set carries over between calls like the reference's colour map over files."""
+    g = GoldenCase("k32")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], insert_batch=50000, claim_log2=16)
+    hc.load(g.buf, g.off)
+    whole, n1, e1 = hc.output_graph(g.buf, g.off, frame=False)
+    hc2 = HostCheck(kw["k"], g.meta["counters"], insert_batch=50000, claim_log2=16)
+    hc2.load(g.buf, g.off)
+    parts, nn, ee = [], 0, 0
+    cut = [0, 1, 50, 51, 1000, g.n]
+    for a, b in zip(cut, cut[1:]):
+        t, n, e = hc2.output_graph(g.buf[int(g.off[a]):int(g.off[b])], g.off[a:b + 1] - g.off[a], frame=False)
+        parts.append(t); nn += n; ee += e
+    assert b"".join(parts) == whole and (nn, ee) == (n1, e1)
+    # nothing is printed twice: a second pass over the same reads finds every start vertex black
+    again, n2, e2 = hc2.output_graph(g.buf, g.off, frame=False)
+    assert again == b"" and (n2, e2) == (0, 0)

@@ -12,7 +12,7 @@ import pytest
 
 import oracle_binding as ob
 from abyss_amd import api
-from util import GOLDEN, GoldenCase
+from util import GOLDEN, GoldenCase, mask_of
 
 ALL_CASES = ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k96", "k48_K16", "k50_qr11"]
 
@@ -115,3 +115,38 @@ def test_iterator_skips_non_acgt():
     assert len(o.hash_seq(b"")[0]) == 0
     pos2, h2 = o.hash_seq(b"acgtnacgt")
     assert list(pos2) == [0, 5]
+
+
+GRAPH_GOLDEN = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))
+
+
+@pytest.mark.parametrize("name", ["k32", "k64", "k40_mixed", "k48_K16", "k25_h3_kc3_t40"])
+def test_oracle_graphviz_dump_matches_reference(name):
+    """-g (outputGraph, bloom-dbg.h:1171-1242): the oracle's GraphViz text against the SHA-256 / size /
+    visitor counters of the file the unmodified reference wrote for the same reads
+    (tests/golden/make_graph_golden.py)."""
+    import hashlib
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    m = mask_of(g)
+    o = ob.Oracle(kw["k"], counters=g.meta["counters"], num_hashes=kw["num_hashes"], min_cov=kw["min_cov"],
+                  mask=m.encode() if m else None)
+    o.load(g.buf, g.off)
+    text, nodes, edges = o.output_graph(g.buf, g.off)
+    ref = GRAPH_GOLDEN[name]
+    assert (len(text), nodes, edges) == (ref["bytes"], ref["nodes"], ref["edges"])
+    assert hashlib.sha256(text).hexdigest() == ref["sha256"]
+
+
+def test_oracle_graphviz_dump_small_case_in_full():
+    import gzip
+    g = GoldenCase("k32")
+    kw = g.kwargs()
+    o = ob.Oracle(kw["k"], counters=g.meta["counters"])
+    buf, off = api.concat_seqs(g.reads[:300])
+    o.load(buf, off)
+    text, nodes, edges = o.output_graph(buf, off)
+    ref = gzip.open(os.path.join(GOLDEN, "k32_first300.graph.dot.gz"), "rb").read()
+    assert text == ref
+    assert (nodes, edges) == (GRAPH_GOLDEN["k32_first300"]["nodes"], GRAPH_GOLDEN["k32_first300"]["edges"])
+    assert text.startswith(b"digraph g {\n\t") and text.endswith(b";\n}\n")
