@@ -13,6 +13,7 @@
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include "abg_host.h"
 
@@ -414,6 +415,9 @@ struct RcclApi {
 	bool load()
 	{
 		if (h) return true;
+		// RCCL logs (its version banner included) go to stdout unless told otherwise -- the stream the
+		// host binary writes its FASTA to
+		setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
 		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
 			h = dlopen(name, RTLD_NOW | RTLD_LOCAL); // (never global: a second copy of RCCL, e.g. torch's, must not bind to this one)
 			if (h) break;
@@ -425,6 +429,14 @@ struct RcclApi {
 #undef ABG_SYM
 		return true;
 	}
+};
+// RCCL prints a version banner to stdout when a communicator is created -- the stream the host
+// binary writes its FASTA to and bench.py its JSON line.  While RCCL initialises, descriptor 1
+// points at stderr; the banner (sitting in stdio's buffer) is flushed there before 1 comes back.
+struct StdoutToStderr {
+	int saved;
+	StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+	~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
@@ -641,6 +653,7 @@ int abg_rccl_unique_id(uint8_t id[128])
 	std::lock_guard<std::mutex> g(g_rccl_mutex);
 	if (!g_rccl.load()) { g_create_error = g_rccl.why; return ABG_ENODEV; }
 	ncclUniqueId u;
+	StdoutToStderr quiet;
 	ncclResult_t r = g_rccl.GetUniqueId(&u);
 	if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return ABG_EINTERNAL; }
 	memcpy(id, &u, 128);
@@ -656,7 +669,11 @@ int abg_rccl_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int
 	memcpy(&u, id, 128);
 	RcclComm* c = new RcclComm;
 	c->rank = rank; c->world = world; c->device = device;
-	ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+	ncclResult_t r;
+	{
+		StdoutToStderr quiet;
+		r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+	}
 	if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete c; return ABG_EINTERNAL; }
 	memset(out, 0, sizeof *out);
 	out->rank = rank; out->world = world; out->stream_ordered = 1; out->user = c;

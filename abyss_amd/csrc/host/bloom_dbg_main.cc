@@ -8,6 +8,9 @@
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +37,8 @@ static const char USAGE_MESSAGE[] =
     "  -b  --bloom-size=N           overall memory budget in bytes; suffixes k, M, G [required]\n"
     "      --chastity / --no-chastity   discard unchaste reads [default] / keep them\n"
     "      --help                   display this help and exit\n"
+    "      --gpus=N                 [extension] spread the job over N MI355X of this node: the counting\n"
+    "                               filter is range-partitioned over them (RCCL over xGMI), output as on one\n"
     "  -H  --num-hashes=N           number of Bloom filter hash functions [4]\n"
     "  -i  --input-bloom=FILE       load the counting Bloom filter from FILE\n"
     "  -j, --threads=N              accepted for compatibility (the GPU does the work)\n"
@@ -50,7 +55,7 @@ static const char USAGE_MESSAGE[] =
     "  -v, --verbose                display verbose output\n"
     "      --version                output version information and exit\n";
 
-enum { OPT_HELP = 1, OPT_VERSION, QR_SEED, MIN_KMER_COV, CHECKPOINT, KEEP_CHECKPOINT, CHECKPOINT_PREFIX, READ_LOG };
+enum { OPT_HELP = 1, OPT_VERSION, QR_SEED, MIN_KMER_COV, CHECKPOINT, KEEP_CHECKPOINT, CHECKPOINT_PREFIX, READ_LOG, OPT_GPUS };
 static abghost::ReaderOptions ropt;
 static const char shortopts[] = "b:C:g:H:i:j:k:K:o:q:Q:R:s:t:T:v";
 static const struct option longopts[] = {
@@ -58,7 +63,7 @@ static const struct option longopts[] = {
 	{ "cov-track", required_argument, NULL, 'C' }, { "chastity", no_argument, &ropt.chastityFilter, 1 },
 	{ "no-chastity", no_argument, &ropt.chastityFilter, 0 }, { "checkpoint", required_argument, NULL, CHECKPOINT },
 	{ "keep-checkpoint", no_argument, NULL, KEEP_CHECKPOINT }, { "checkpoint-prefix", required_argument, NULL, CHECKPOINT_PREFIX },
-	{ "graph", required_argument, NULL, 'g' }, { "num-hashes", required_argument, NULL, 'H' },
+	{ "graph", required_argument, NULL, 'g' }, { "gpus", required_argument, NULL, OPT_GPUS }, { "num-hashes", required_argument, NULL, 'H' },
 	{ "input-bloom", required_argument, NULL, 'i' }, { "help", no_argument, NULL, OPT_HELP },
 	{ "threads", required_argument, NULL, 'j' }, { "trim-masked", no_argument, &ropt.trimMasked, 1 },
 	{ "no-trim-masked", no_argument, &ropt.trimMasked, 0 }, { "kmer", required_argument, NULL, 'k' },
@@ -272,6 +277,7 @@ int main(int argc, char** argv)
 	abg_params p;
 	abg_params_init(&p);
 	std::string bloomPath, outputPath, tracePath, readLogPath, covTrackPath, refPath, graphPath;
+	unsigned gpus = 1;
 	int verbose = 0;
 	bool die = false;
 	unsigned K = 0, qr = 0;
@@ -306,6 +312,7 @@ int main(int argc, char** argv)
 		case KEEP_CHECKPOINT: keepCheckpoint = true; break;
 		case CHECKPOINT_PREFIX: checkpointPrefix = optarg; break;
 		case 'g': graphPath = optarg; break;
+		case OPT_GPUS: gpus = (unsigned)strtoul(optarg, &end, 10); bad = *end || gpus < 1 || gpus > ABG_MAX_RANKS; break;
 		}
 		if (bad) { // bloom-dbg.cc:472-475
 			fprintf(stderr, PROGRAM ": invalid option: `-%c%s'\n", (char)c, optarg);
@@ -341,9 +348,51 @@ int main(int argc, char** argv)
 		read_bloom_file(bloomPath, "[BTLCountingBloomFilter_v1]", size, hn, ks, prebuilt, false);
 		p.k = ks; p.num_hashes = hn; p.counters = size; // bloom-dbg.cc:320-322
 	}
+	// --gpus N [extension]: one process per GPU.  The ranks are forked BEFORE anything touches the HIP
+	// runtime; rank 0 makes the RCCL id and pipes it to the others; every rank then reads the same
+	// input and makes the same library calls (the library partitions the filter and splits the
+	// device work, include/abyss_amd.h); only rank 0 writes output.
+	unsigned rank = 0;
+	std::vector<pid_t> children;
+	abg_comm comm;
+	memset(&comm, 0, sizeof comm);
+	const bool use_comm = gpus > 1 || (getenv("ABG_FORCE_DIST") && atoi(getenv("ABG_FORCE_DIST")));
+	if (gpus > 1 && readsPerCheckpoint) { fprintf(stderr, PROGRAM ": --checkpoint is not available with --gpus\n"); exit(EXIT_FAILURE); }
+	if (use_comm) {
+		std::vector<int> rd(gpus, -1), wr(gpus, -1);
+		for (unsigned r = 1; r < gpus; r++) {
+			int fd[2];
+			if (pipe(fd)) { perror("pipe"); exit(EXIT_FAILURE); }
+			rd[r] = fd[0]; wr[r] = fd[1];
+		}
+		fflush(NULL);
+		for (unsigned r = 1; r < gpus; r++) {
+			pid_t pid = fork();
+			if (pid < 0) { perror("fork"); exit(EXIT_FAILURE); }
+			if (pid == 0) { rank = r; children.clear(); break; }
+			children.push_back(pid);
+		}
+		uint8_t ident[128];
+		if (rank == 0) {
+			if (abg_rccl_unique_id(ident) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
+			for (unsigned r = 1; r < gpus; r++)
+				if (write(wr[r], ident, sizeof ident) != (ssize_t)sizeof ident) { perror("write"); exit(EXIT_FAILURE); }
+		} else {
+			if (read(rd[rank], ident, sizeof ident) != (ssize_t)sizeof ident) { fprintf(stderr, PROGRAM ": rank %u did not receive the communicator id\n", rank); exit(EXIT_FAILURE); }
+			// the other ranks compute along and stay silent
+			if (!getenv("ABG_RANK_STDERR")) { if (!freopen("/dev/null", "w", stderr)) exit(EXIT_FAILURE); }
+			if (!outputPath.empty()) outputPath = "/dev/null";
+			if (!freopen("/dev/null", "w", stdout)) exit(EXIT_FAILURE);
+			for (std::string* path : { &tracePath, &readLogPath, &covTrackPath, &graphPath }) if (!path->empty()) *path = "/dev/null";
+		}
+		for (unsigned r = 1; r < gpus; r++) { close(rd[r]); close(wr[r]); }
+		if (abg_rccl_comm_create(ident, (int32_t)rank, (int32_t)gpus, (int32_t)rank, &comm) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
+		p.device = (int32_t)rank;
+	}
 	p.verbose = verbose;
 	abg_ctx* ctx = NULL;
 	if (abg_create(&p, &ctx) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
+	if (use_comm) check(abg_attach_comm(ctx, &comm), ctx, "communicator");
 	const uint32_t trim = p.trim == 0xFFFFFFFFu ? p.k : p.trim;
 	if (verbose) {
 		fprintf(stderr, "Assembling with k-mer size %u\n", p.k);
@@ -561,5 +610,12 @@ int main(int argc, char** argv)
 	if (readlog) fclose(readlog);
 	if (out != stdout) fclose(out); else fflush(stdout);
 	abg_destroy(ctx);
-	return EXIT_SUCCESS;
+	if (use_comm) abg_rccl_comm_destroy(&comm);
+	int status = EXIT_SUCCESS;
+	for (pid_t pid : children) {
+		int st = 0;
+		if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = EXIT_FAILURE;
+	}
+	if (status != EXIT_SUCCESS) fprintf(stderr, PROGRAM ": a rank of the multi-GPU run failed\n");
+	return status;
 }

@@ -145,8 +145,7 @@ def main() -> int:
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
 
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"  # no version banner on stdout next to the JSON line
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # RCCL's banner / logs: not on stdout next to the JSON line
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

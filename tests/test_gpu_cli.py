@@ -62,6 +62,26 @@ def test_cli_graphviz_dump(tmp_path):
     assert ("(k-mers visited: %d, edges visited: %d)" % (ref["nodes"], ref["edges"])).encode() in r.stderr
 
 
+def test_cli_partitioned_code_path_on_one_rank(tmp_path):
+    """ABG_FORCE_DIST=1: the host binary creates the library's RCCL communicator (one rank), attaches
+    it and runs the partitioned code path (what `--gpus N` does on every rank) -- same files as ever."""
+    g = GoldenCase("k40_mixed")
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i, s in enumerate(g.reads):
+            f.write(b">r%d\n%s\n" % (i, s))
+    r = subprocess.run([cli()] + g.meta["options"] + ["-j1", "-v", "--gpus=1", "--read-log=rl.tsv", "-T", "tr.tsv", "reads.fa"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ABG_FORCE_DIST="1"))
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == g.fasta
+    assert open(tmp_path / "rl.tsv", "rb").read() == g.readlog
+    assert strip_length_column(open(tmp_path / "tr.tsv", "rb").read()) == g.trace
+    assert ("popcount                = %d" % g.meta["filtered_popcount"]).encode() in r.stderr
+    # more ranks than GPUs on the box: every rank must fail cleanly, not hang
+    r = subprocess.run([cli()] + g.meta["options"] + ["--gpus=64", "reads.fa"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"invalid option" in r.stderr
+
+
 def test_cli_option_errors(tmp_path):
     (tmp_path / "r.fa").write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
     for args, msg in ((["-k32", "r.fa"], b"missing mandatory option `-b'"), (["-b1M", "r.fa"], b"missing mandatory option `-k'"),
