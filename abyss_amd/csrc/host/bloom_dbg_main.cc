@@ -11,7 +11,9 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +43,7 @@ static const char USAGE_MESSAGE[] =
     "                               filter is range-partitioned over them (RCCL over xGMI), output as on one\n"
     "  -H  --num-hashes=N           number of Bloom filter hash functions [4]\n"
     "  -i  --input-bloom=FILE       load the counting Bloom filter from FILE\n"
-    "  -j, --threads=N              accepted for compatibility (the GPU does the work)\n"
+    "  -j, --threads=N              host threads parsing FASTQ input [all, up to 16]; the GPU does the assembly\n"
     "      --trim-masked / --no-trim-masked\n"
     "  -k, --kmer=N                 the size of a k-mer [<=192]\n"
     "      --kc=N                   ignore k-mers having a count < N [2]\n"
@@ -278,6 +280,7 @@ int main(int argc, char** argv)
 	abg_params_init(&p);
 	std::string bloomPath, outputPath, tracePath, readLogPath, covTrackPath, refPath, graphPath;
 	unsigned gpus = 1;
+	unsigned threads = 0; // -j: host threads parsing FASTQ (the GPU does the assembly); 0 = as many as the machine has, up to 16
 	int verbose = 0;
 	bool die = false;
 	unsigned K = 0, qr = 0;
@@ -291,7 +294,7 @@ int main(int argc, char** argv)
 		case 'b': bad = !si_to_bytes(optarg, &p.bloom_bytes); break;
 		case 'H': p.num_hashes = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
 		case 'i': bloomPath = optarg; break;
-		case 'j': (void)strtoul(optarg, &end, 10); bad = *end; break;
+		case 'j': threads = (unsigned)strtoul(optarg, &end, 10); bad = *end; break;
 		case 'k': p.k = (uint32_t)strtoul(optarg, &end, 10); bad = *end; break;
 		case 'K': qr = 0; spaced.clear(); K = (unsigned)strtoul(optarg, &end, 10); bad = *end; break; // resetSpacedSeedParams, AssemblyParams.h:96-100
 		case 'o': outputPath = optarg; break;
@@ -327,6 +330,8 @@ int main(int argc, char** argv)
 	if (p.num_hashes > ABG_MAX_HASHES) { fprintf(stderr, PROGRAM ": number of hash functions (`-H`) must be <= %d\n", ABG_MAX_HASHES); die = true; }
 	if (argc - optind < 1) { fprintf(stderr, PROGRAM ": missing input file arguments\n"); die = true; }
 	if (die) { fprintf(stderr, "Try `%s --help' for more information.\n", PROGRAM); exit(EXIT_FAILURE); }
+	if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	threads = std::min(threads, 64u);
 
 	// initGlobals (bloom-dbg.cc:214-233) + SpacedSeed.h:18-75
 	std::string mask;
@@ -469,7 +474,7 @@ int main(int argc, char** argv)
 		for (int i = optind; i < argc; ++i) {
 			if (!strcmp(argv[i], ":")) { first_asm = i + 1; break; }
 			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
-			abghost::FastaReader in(argv[i], ropt);
+			abghost::SequenceReader in(argv[i], ropt, threads);
 			uint64_t n = 0;
 			while (in.read(id, comment, seq)) {
 				chunk.add(id, seq); n++;
@@ -536,7 +541,7 @@ int main(int argc, char** argv)
 		};
 		for (int i = first_asm; i < argc; ++i) {
 			if (!strcmp(argv[i], ":")) continue;
-			abghost::FastaReader in(argv[i], ropt);
+			abghost::SequenceReader in(argv[i], ropt, threads);
 			while (in.read(id, comment, seq)) {
 				gc.add(id, seq); nreads++;
 				if (gc.seqs.size() >= CHUNK_BASES) graph();
@@ -580,7 +585,7 @@ int main(int argc, char** argv)
 	}
 	for (int i = first_asm; i < argc; ++i) {
 		if (!strcmp(argv[i], ":")) continue;
-		abghost::FastaReader in(argv[i], ropt);
+		abghost::SequenceReader in(argv[i], ropt, threads);
 		while (in.read(id, comment, seq)) {
 			if (skip_reads) { skip_reads--; continue; }
 			chunk.add(id, seq);

@@ -8,6 +8,9 @@
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
+#include <algorithm>
+#include <thread>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -106,7 +109,7 @@ int main(int argc, char** argv)
 	std::vector<uint64_t> off{ 0 };
 	for (int i = optind; i < argc; i++) { // BloomDBG::loadFile for each file, bloom.cc:596-597,613-614
 		if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
-		abghost::FastaReader in(argv[i], ropt);
+		abghost::SequenceReader in(argv[i], ropt, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
 		while (in.read(id, comment, seq)) {
 			seqs += seq; off.push_back(seqs.size());
 			if (seqs.size() >= (256u << 20)) { check(abg_load_seqs(ctx, seqs.data(), off.data(), off.size() - 1), ctx, "load"); seqs.clear(); off.assign(1, 0); }

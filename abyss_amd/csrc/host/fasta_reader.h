@@ -11,8 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <future>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sys/stat.h>
 
 namespace abghost {
 
@@ -49,12 +54,21 @@ class FastaReader {
 		int c = peek();
 		if (c == EOF) fprintf(stderr, "%s:0: warning: file is empty\n", m_path.c_str());
 	}
+	// over a stream the caller opened (e.g. fmemopen on a block of a file: SequenceReader below);
+	// `first_line` = number of lines before it in the file `path`, for error messages
+	FastaReader(FILE* f, const std::string& path, unsigned first_line, const ReaderOptions& o)
+	    : m_path(path), m_opt(o), m_f(f), m_line(first_line)
+	{
+		flockfile(m_f);
+	}
 	~FastaReader()
 	{
 		if (m_f) funlockfile(m_f);
 		if (m_f && m_f != stdin) { if (m_pipe) pclose(m_f); else fclose(m_f); }
 		free(m_line_buf);
 	}
+	FastaReader(const FastaReader&) = delete;
+	FastaReader& operator=(const FastaReader&) = delete;
 	// next record; false at end of file
 	bool read(std::string& id, std::string& comment, std::string& s)
 	{
@@ -241,6 +255,191 @@ class FastaReader {
 		fprintf(stderr, "%s:%u: error: %s\n", m_path.c_str(), m_line, msg);
 		exit(EXIT_FAILURE);
 	}
+};
+
+// FASTQ files parsed by several threads.  Parsing is what the host binary spends its time on once
+// the kernels are fast (a single thread reads ~330 MB/s); records are independent, so a window of
+// the file is cut into blocks at record boundaries and every block is parsed by the SAME
+// FastaReader logic (over fmemopen), which keeps the reference's semantics -- chastity filter,
+// trimming, masking, case folding -- by construction.  Records come out in file order.
+// A FASTQ record starts at a line beginning with '@' whose second-next line begins with '+': a
+// quality line may begin with '@', but then the line after it is a header and the one after that a
+// sequence, which cannot begin with '+'.  Anything that is not a plain file beginning with '@'
+// (FASTA, SAM/qseq/export, compressed input, stdin) goes through the sequential reader.
+class SequenceReader {
+  public:
+	SequenceReader(const std::string& path, const ReaderOptions& o, unsigned threads) : m_path(path), m_opt(o), m_threads(threads)
+	{
+		bool plain = threads > 1 && path != "-";
+		for (const char* ext : { ".gz", ".bz2", ".xz", ".zst" }) {
+			size_t n = strlen(ext);
+			if (path.size() > n && path.compare(path.size() - n, n, ext) == 0) plain = false;
+		}
+		if (plain) {
+			m_f = fopen(path.c_str(), "rb");
+			if (m_f) {
+				struct stat st;
+				int c = getc(m_f);
+				if (c != EOF) ungetc(c, m_f);
+				if (fstat(fileno(m_f), &st) != 0 || !S_ISREG(st.st_mode) || c != '@') { fclose(m_f); m_f = nullptr; }
+			}
+		}
+		if (!m_f) m_seq = new FastaReader(path, o); // (also reports a missing file the reference's way)
+		else m_window = std::min<size_t>((size_t)threads * (32u << 20), (size_t)1 << 30);
+		if (const char* e = getenv("ABG_READER_WINDOW")) m_window = std::max<size_t>(64, strtoull(e, nullptr, 10)); // tests: many small windows
+	}
+	~SequenceReader()
+	{
+		if (m_next.valid()) m_next.wait();
+		delete m_seq;
+		if (m_f) fclose(m_f);
+	}
+	SequenceReader(const SequenceReader&) = delete;
+	SequenceReader& operator=(const SequenceReader&) = delete;
+	bool read(std::string& id, std::string& comment, std::string& s)
+	{
+		if (m_seq) return m_seq->read(id, comment, s);
+		for (;;) {
+			while (m_block < m_blocks.size()) {
+				Block& b = m_blocks[m_block];
+				if (m_rec < b.seq_end.size()) {
+					const size_t i = m_rec++;
+					id.assign(b.ids, i ? b.id_end[i - 1] : 0, b.id_end[i] - (i ? b.id_end[i - 1] : 0));
+					comment.assign(b.comments, i ? b.com_end[i - 1] : 0, b.com_end[i] - (i ? b.com_end[i - 1] : 0));
+					s.assign(b.seqs, i ? b.seq_end[i - 1] : 0, b.seq_end[i] - (i ? b.seq_end[i - 1] : 0));
+					return true;
+				}
+				m_block++; m_rec = 0;
+			}
+			// the next window was being parsed while the caller worked on this one (GPU calls included)
+			if (!m_next.valid()) m_next = std::async(std::launch::async, [this]() { return parse_window(); });
+			Window w = m_next.get();
+			if (!w.ok) return false;
+			m_blocks = std::move(w.blocks); m_block = 0; m_rec = 0;
+			m_next = std::async(std::launch::async, [this]() { return parse_window(); });
+		}
+	}
+
+  private:
+	struct Block {
+		std::string ids, comments, seqs;
+		std::vector<size_t> id_end, com_end, seq_end;
+	};
+	// start of the first record at or after `from` (a line start), or `end` if there is none
+	static size_t next_record(const char* p, size_t from, size_t end)
+	{
+		size_t a = from;
+		if (a > 0 && p[a - 1] != '\n') { // move to a line start
+			const char* nl = (const char*)memchr(p + a, '\n', end - a);
+			if (!nl) return end;
+			a = (size_t)(nl - p) + 1;
+		}
+		while (a < end) {
+			const char* n1 = (const char*)memchr(p + a, '\n', end - a);
+			if (!n1) return end;
+			if (p[a] == '@') {
+				const size_t l1 = (size_t)(n1 - p) + 1;
+				const char* n2 = l1 < end ? (const char*)memchr(p + l1, '\n', end - l1) : nullptr;
+				if (!n2) return end;
+				const size_t l2 = (size_t)(n2 - p) + 1;
+				if (l2 < end && p[l2] == '+') return a;
+				if (l2 >= end) return end;
+			}
+			a = (size_t)(n1 - p) + 1;
+		}
+		return end;
+	}
+	// start of the LAST record that begins in p[0, end) (0 if none begins after offset 0)
+	static size_t last_record(const char* p, size_t end)
+	{
+		size_t probe = end > (1u << 20) ? end - (1u << 20) : 0;
+		for (;;) {
+			size_t r = next_record(p, probe, end), last = 0;
+			while (r < end) { last = r; r = next_record(p, r + 1, end); }
+			if (last > 0 || probe == 0) return last;
+			probe = probe > (16u << 20) ? probe - (16u << 20) : 0;
+		}
+	}
+	struct Window { std::vector<Block> blocks; bool ok = false; };
+	// reads and parses the next window (runs on a background thread; touches only m_f, m_buf, m_eof, m_lines)
+	Window parse_window()
+	{
+		Window w;
+		size_t end = 0;
+		for (;;) {
+			if (!m_eof) { // the unparsed tail of the previous window, then fresh bytes
+				const size_t have = m_buf.size();
+				m_buf.resize(have + m_window);
+				const size_t got = fread(&m_buf[have], 1, m_window, m_f);
+				m_buf.resize(have + got);
+				if (got < m_window) m_eof = true;
+			}
+			if (m_buf.empty()) return w;
+			end = m_buf.size();
+			if (m_eof) break; // everything that is left is parsed
+			// the last record that starts in the buffer may be cut short: it waits for the next window
+			const size_t cut = last_record(m_buf.data(), end);
+			if (cut > 0) { end = cut; break; }
+			// (no second record start in sight yet: read on)
+		}
+		const char* p = m_buf.data();
+		std::vector<size_t> start{ 0 };
+		for (unsigned t = 1; t < m_threads; t++) {
+			const size_t r = next_record(p, end / m_threads * t, end);
+			if (r > start.back() && r < end) start.push_back(r);
+		}
+		start.push_back(end);
+		const size_t nb = start.size() - 1;
+		w.blocks.resize(nb);
+		std::vector<size_t> nlines(nb, 0);
+		std::vector<unsigned> line0(nb, m_lines);
+		std::vector<std::thread> pool;
+		for (size_t b = 0; b < nb; b++) // line numbers for error messages
+			pool.emplace_back([&, b]() {
+				const char* q = p + start[b];
+				const char* e = p + start[b + 1];
+				size_t n = 0;
+				for (const char* x = q; x < e && (x = (const char*)memchr(x, '\n', (size_t)(e - x))) != nullptr; x++) n++;
+				nlines[b] = n;
+			});
+		for (auto& t : pool) t.join();
+		pool.clear();
+		for (size_t b = 1; b < nb; b++) line0[b] = line0[b - 1] + (unsigned)nlines[b - 1];
+		for (size_t b = 0; b < nb; b++)
+			pool.emplace_back([&, b]() {
+				const size_t len = start[b + 1] - start[b];
+				if (!len) return;
+				FILE* f = fmemopen((void*)(p + start[b]), len, "r");
+				if (!f) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
+				FastaReader r(f, m_path, line0[b], m_opt);
+				Block out; // (filled locally: neighbouring Blocks share cache lines)
+				out.seqs.reserve(len / 2);
+				std::string id, comment, s;
+				while (r.read(id, comment, s)) {
+					out.ids += id; out.id_end.push_back(out.ids.size());
+					out.comments += comment; out.com_end.push_back(out.comments.size());
+					out.seqs += s; out.seq_end.push_back(out.seqs.size());
+				}
+				w.blocks[b] = std::move(out);
+			});
+		for (auto& t : pool) t.join();
+		m_lines = line0[nb - 1] + (unsigned)nlines[nb - 1];
+		m_buf.erase(0, end); // what was not parsed stays for the next window
+		w.ok = true;
+		return w;
+	}
+	std::string m_path;
+	ReaderOptions m_opt;
+	unsigned m_threads;
+	FastaReader* m_seq = nullptr;
+	FILE* m_f = nullptr;
+	size_t m_window = 0;
+	bool m_eof = false;
+	std::string m_buf;
+	unsigned m_lines = 0;
+	std::vector<Block> m_blocks;
+	size_t m_block = 0, m_rec = 0;
+	std::future<Window> m_next;
 };
 
 } // namespace abghost

@@ -8,16 +8,27 @@ int main(int argc, char** argv)
 {
 	abghost::ReaderOptions o;
 	const char* path = NULL;
+	unsigned threads = 1;
+	bool count_only = false;
 	for (int i = 1; i < argc; i++) {
 		if (!strcmp(argv[i], "-q")) o.qualityThreshold = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-Q")) o.internalQThreshold = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--no-chastity")) o.chastityFilter = 0;
 		else if (!strcmp(argv[i], "--no-trim-masked")) o.trimMasked = 0;
 		else if (!strcmp(argv[i], "--illumina-quality")) o.qualityOffset = 64;
+		else if (!strcmp(argv[i], "-j")) threads = (unsigned)atoi(argv[++i]); // SequenceReader: blocks parsed in parallel
+		else if (!strcmp(argv[i], "--count")) count_only = true;
 		else path = argv[i];
 	}
-	abghost::FastaReader in(path, o);
+	abghost::SequenceReader in(path, o, threads);
 	std::string id, comment, seq;
-	while (in.read(id, comment, seq)) printf("%s\t%s\n", id.c_str(), seq.c_str());
+	unsigned long long n = 0, bases = 0, sum = 0;
+	while (in.read(id, comment, seq)) {
+		if (!count_only) { printf("%s\t%s\n", id.c_str(), seq.c_str()); continue; }
+		n++; bases += seq.size();
+		for (char c : id) sum = sum * 131 + (unsigned char)c;
+		for (char c : seq) sum = sum * 131 + (unsigned char)c;
+	}
+	if (count_only) printf("%llu records, %llu bases, checksum %llu\n", n, bases, sum);
 	return 0;
 }

@@ -52,7 +52,7 @@ def test_cli_graphviz_dump(tmp_path):
     with open(tmp_path / "reads.fa", "wb") as f:
         for i, s in enumerate(g.reads):
             f.write(b">r%d\n%s\n" % (i, s))
-    r = subprocess.run([cli()] + g.meta["options"] + ["-j1", "-v", "-g", "g.dot", "reads.fa"], cwd=tmp_path,
+    r = subprocess.run([cli()] + g.meta["options"] + ["-j4", "-v", "-g", "g.dot", "reads.fa"], cwd=tmp_path,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == g.fasta
@@ -66,10 +66,10 @@ def test_cli_partitioned_code_path_on_one_rank(tmp_path):
     """ABG_FORCE_DIST=1: the host binary creates the library's RCCL communicator (one rank), attaches
     it and runs the partitioned code path (what `--gpus N` does on every rank) -- same files as ever."""
     g = GoldenCase("k40_mixed")
-    with open(tmp_path / "reads.fa", "wb") as f:
+    with open(tmp_path / "reads.fa", "wb") as f:  # FASTQ, parsed by 4 threads (-j4)
         for i, s in enumerate(g.reads):
-            f.write(b">r%d\n%s\n" % (i, s))
-    r = subprocess.run([cli()] + g.meta["options"] + ["-j1", "-v", "--gpus=1", "--read-log=rl.tsv", "-T", "tr.tsv", "reads.fa"],
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+    r = subprocess.run([cli()] + g.meta["options"] + ["-j4", "-v", "--gpus=1", "--read-log=rl.tsv", "-T", "tr.tsv", "reads.fa"],
                        cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ABG_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout == g.fasta

@@ -98,3 +98,47 @@ def test_sam_qseq_export_match_reference_live(tmp_path):
             ref = subprocess.run([REF_READER] + opts + [path], stdout=subprocess.PIPE, check=True).stdout
             assert ref.count(b"\n") > 50
             assert run_mine(opts, path) == ref, (path, opts)
+
+
+@pytest.mark.parametrize("i", range(len(OPTS)))
+def test_parallel_reader_matches_golden(i, monkeypatch):
+    """SequenceReader: the file cut into blocks at record boundaries, each parsed by the same FastaReader
+    logic on its own thread (-j 4), here with windows of 600 bytes so that records straddle windows."""
+    inp = os.path.join(GOLDEN, "reader_input.fq")
+    want = open(os.path.join(GOLDEN, "reader_%d.tsv" % i), "rb").read()
+    assert run_mine(OPTS[i] + ["-j", "4"], inp) == want
+    monkeypatch.setenv("ABG_READER_WINDOW", "600")
+    assert run_mine(OPTS[i] + ["-j", "3"], inp) == want
+    monkeypatch.setenv("ABG_READER_WINDOW", "64")  # smaller than a record: the reader reads on
+    assert run_mine(OPTS[i] + ["-j", "8"], inp) == want
+
+
+def test_parallel_reader_on_quality_lines_starting_with_at_and_plus(tmp_path, monkeypatch):
+    """A quality line may begin with '@' or '+' (and a '+' line may repeat the id): the block boundaries must
+    still fall on record starts.  Sequential reader == parallel reader for every window / thread count."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(3000):
+        L = int(rng.integers(1, 160))
+        seq = "".join(rng.choice(list("ACGTacgtN"), p=[.22, .22, .22, .22, .02, .02, .02, .02, .04], size=L))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 74, size=L))
+        r = rng.random()
+        if r < 0.2:
+            qual = "@" + qual[1:]
+        elif r < 0.4:
+            qual = "+" + qual[1:]
+        casava = ["", " 1:N:0:ACGT", " 2:Y:0:ACGT"][int(rng.integers(0, 3))]
+        plus = "+" if rng.random() < 0.7 else "+read%d" % i
+        lines.append("@read%d%s\n%s\n%s\n%s\n" % (i, casava, seq, plus, qual))
+    p = tmp_path / "x.fq"
+    p.write_text("".join(lines))
+    for opts in ([], ["-q", "3"], ["-q", "15", "-Q", "20", "--no-chastity"]):
+        want = run_mine(opts, str(p))
+        assert want.count(b"\n") > 1500
+        for window, j in ((None, 2), (None, 7), ("5000", 4), ("100000", 16), ("300", 5)):
+            if window:
+                monkeypatch.setenv("ABG_READER_WINDOW", window)
+            else:
+                monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
+            assert run_mine(opts + ["-j", str(j)], str(p)) == want, (opts, window, j)
