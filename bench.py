@@ -250,14 +250,14 @@ def main() -> int:
     warm_prof = None
     if partitioned and a.warmup and g is not None:
         warm_prof = True
-    barrier()
-    t0 = time.perf_counter()
     names = ["hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
              "insert_drain", "classify", "read_prep", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
              "share_fix",
              "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names} if (warm_prof and g is not None) else None
+    barrier()
+    t0 = time.perf_counter()
     for _ in range(a.steps):
         step(profile=timed_profile)
     barrier()
@@ -304,6 +304,9 @@ def main() -> int:
             # bytes per launch / average launch duration == total bytes / total duration
             gbs = total / 1e9 / (ms / 1e3)
             per_kernel[nm] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / n, "launches": n}
+    if not per_kernel:
+        # (partitioned run without a warm-up step: no per-launch events were taken -- see timed_profile)
+        per_kernel = {"walk": {"achieved": None, "frac": None, "avg_launch_ms": None, "launches": 0}}
     dom = max(per_kernel, key=lambda nm: prof[nm][0])
     traffic = None
     tsrc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
