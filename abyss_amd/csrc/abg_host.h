@@ -10,6 +10,7 @@
 #include <cmath>
 #include <map>
 #include <string>
+#include <thread>
 
 namespace abg {
 
@@ -97,33 +98,42 @@ class Session {
 		// longest piece handed to the device as one sequence; longer ACGT runs are cut into
 		// pieces overlapping by k-1 bases, which yields the same k-mers in the same order
 		const uint32_t max_piece = (uint32_t)std::min<uint64_t>(1u << 20, cfg.insert_batch_kmers + k - 1);
-		HostBatch hb;
-		std::string up;
-		for (uint64_t i = 0; i < n; i++) {
-			const char* s = seqs + off[i];
-			uint64_t L = off[i + 1] - off[i];
-			if (L < k) continue; // RollingHashIterator.h:37-40
-			// (case is folded by the code table; the upper-cased copy is only needed under a spaced seed)
-			const char* text = s;
-			if (!cfg.spaced_seed.empty()) {
-				up.assign(s, L);
-				for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
-				text = up.data();
-			}
-			valid_runs(text, L, runs_);
-			for (auto& run : runs_) {
-				// k-mers run.first .. run.second - 1 start in this piece
-				uint64_t pa = run.first, pb = run.second - 1 + k;
-				for (uint64_t q = pa; q + k <= pb;) {
-					uint64_t e = std::min<uint64_t>(pb, q + max_piece);
-					hb.add_ascii(text + q, (uint32_t)(e - q), k);
-					if (e == pb) break;
-					q = e - (k - 1);
+		// packing is host work per base: the reads are split over threads, every thread packs its
+		// range into a batch of its own, and the batches are joined in order
+		const std::vector<uint64_t> cut = split_reads(off, n);
+		std::vector<HostBatch> parts(cut.size() - 1);
+		run_parts(parts.size(), [&](size_t t) {
+			HostBatch& hb = parts[t];
+			std::string up;
+			std::vector<std::pair<uint64_t, uint64_t>> runs;
+			std::vector<uint8_t> bad;
+			for (uint64_t i = cut[t]; i < cut[t + 1]; i++) {
+				const char* s = seqs + off[i];
+				uint64_t L = off[i + 1] - off[i];
+				if (L < k) continue; // RollingHashIterator.h:37-40
+				// (case is folded by the code table; the upper-cased copy is only needed under a spaced seed)
+				const char* text = s;
+				if (!cfg.spaced_seed.empty()) {
+					up.assign(s, L);
+					for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
+					text = up.data();
+				}
+				valid_runs(text, L, runs, bad);
+				for (auto& run : runs) {
+					// k-mers run.first .. run.second - 1 start in this piece
+					uint64_t pa = run.first, pb = run.second - 1 + k;
+					for (uint64_t q = pa; q + k <= pb;) {
+						uint64_t e = std::min<uint64_t>(pb, q + max_piece);
+						hb.add_ascii(text + q, (uint32_t)(e - q), k);
+						if (e == pb) break;
+						q = e - (k - 1);
+					}
 				}
 			}
-			if (hb.koff.back() >= cfg.insert_batch_kmers) { flush_load(hb); hb.clear(); }
-		}
-		if (hb.n()) flush_load(hb);
+		});
+		HostBatch joined;
+		const HostBatch& hb = join_parts(parts, joined);
+		if (hb.n()) flush_load(hb); // (the engine cuts it into ordered-insert batches of insert_batch_kmers)
 		return ABG_OK;
 	}
 	int load_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
@@ -169,20 +179,26 @@ class Session {
 	{
 		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
 		const uint32_t k = cfg.k;
-		HostBatch hb;
 		std::vector<uint64_t> orig; // packed index -> caller index
 		std::vector<uint8_t> res(n, (uint8_t)RR_UNINITIALIZED);
-		std::string up;
-		for (uint64_t i = 0; i < n; i++) {
-			const char* s = seqs + off[i];
-			uint64_t L = off[i + 1] - off[i];
-			if (L < k) { res[i] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
-			uint8_t bad = 0;
-			for (uint64_t q = 0; q < L; q++) bad |= codes_.t[(unsigned char)s[q]];
-			if (bad & 0x80) { res[i] = RR_NON_ACGT; continue; }     // allACGT, bloom-dbg.h:808 (either case: the reader folds it)
-			hb.add_ascii(s, (uint32_t)L, k);
-			orig.push_back(i);
-		}
+		const std::vector<uint64_t> cut = split_reads(off, n);
+		std::vector<HostBatch> parts(cut.size() - 1);
+		std::vector<std::vector<uint64_t>> origs(parts.size());
+		run_parts(parts.size(), [&](size_t t) {
+			for (uint64_t i = cut[t]; i < cut[t + 1]; i++) {
+				const char* s = seqs + off[i];
+				uint64_t L = off[i + 1] - off[i];
+				if (L < k) { res[i] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
+				uint8_t bad = 0;
+				for (uint64_t q = 0; q < L; q++) bad |= codes_.t[(unsigned char)s[q]];
+				if (bad & 0x80) { res[i] = RR_NON_ACGT; continue; }     // allACGT, bloom-dbg.h:808 (either case: the reader folds it)
+				parts[t].add_ascii(s, (uint32_t)L, k);
+				origs[t].push_back(i);
+			}
+		});
+		HostBatch joined;
+		const HostBatch& hb = join_parts(parts, joined);
+		for (auto& o : origs) orig.insert(orig.end(), o.begin(), o.end());
 		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
 		// ones rejected above; the engine counts the ones it sees
 		Counters c0 = eng->counters();
@@ -431,7 +447,8 @@ class Session {
 	// without one).  A run of k-mers a..b-1 is the text [a, b - 1 + k); characters under a
 	// '0' may be anything (they are packed as some base and never contribute to a hash).
 	// (without a spaced seed `up` may be in either case; with one it must be upper case)
-	void valid_runs(const char* up, uint64_t L, std::vector<std::pair<uint64_t, uint64_t>>& runs)
+	void valid_runs(const char* up, uint64_t L, std::vector<std::pair<uint64_t, uint64_t>>& runs) { valid_runs(up, L, runs, bad_); }
+	void valid_runs(const char* up, uint64_t L, std::vector<std::pair<uint64_t, uint64_t>>& runs, std::vector<uint8_t>& bad_) const
 	{
 		runs.clear();
 		const uint64_t k = cfg.k;
@@ -463,6 +480,52 @@ class Session {
 			runs.emplace_back(j, e);
 			j = e;
 		}
+	}
+	// ---- host threads (packing): reads [0, n) cut into ranges of about equal size in bases
+	static unsigned host_threads()
+	{
+		if (const char* e = getenv("ABG_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+		return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	}
+	static std::vector<uint64_t> split_reads(const uint64_t* off, uint64_t n)
+	{
+		const uint64_t bases = n ? off[n] - off[0] : 0;
+		unsigned T = host_threads();
+		if (bases < (8u << 20)) T = 1; // not worth a thread
+		if (const char* e = getenv("ABG_HOST_SPLIT")) T = (unsigned)std::max(1, atoi(e)); // tests: split small inputs too
+		std::vector<uint64_t> cut{ 0 };
+		for (unsigned t = 1; t < T; t++) {
+			const uint64_t want = off[0] + bases / T * t;
+			uint64_t i = (uint64_t)(std::lower_bound(off, off + n + 1, want) - off);
+			if (i > cut.back() && i < n) cut.push_back(i);
+		}
+		cut.push_back(n);
+		return cut;
+	}
+	template <class F>
+	static void run_parts(size_t nparts, F f)
+	{
+		if (nparts <= 1) { if (nparts) f(0); return; }
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < nparts; t++) pool.emplace_back([&f, t]() { f(t); });
+		for (auto& th : pool) th.join();
+	}
+	// the parts' batches one after the other (a single part is used as it is)
+	static const HostBatch& join_parts(std::vector<HostBatch>& parts, HostBatch& joined)
+	{
+		if (parts.size() == 1) return parts[0];
+		size_t words = 0, reads = 0;
+		for (auto& p : parts) { words += p.words.size(); reads += p.n(); }
+		joined.words.reserve(words); joined.woff.reserve(reads + 1); joined.len.reserve(reads); joined.koff.reserve(reads + 1);
+		for (auto& p : parts) {
+			const uint64_t wbase = joined.words.size(), kbase = joined.koff.back();
+			joined.words.insert(joined.words.end(), p.words.begin(), p.words.end());
+			joined.len.insert(joined.len.end(), p.len.begin(), p.len.end());
+			for (size_t i = 1; i < p.woff.size(); i++) joined.woff.push_back(p.woff[i] + wbase);
+			for (size_t i = 1; i < p.koff.size(); i++) joined.koff.push_back(p.koff[i] + kbase);
+			p = HostBatch(); // give the memory back as we go
+		}
+		return joined;
 	}
 	struct DevBatch { Batch b; void* words; void* woff; void* len; void* koff; };
 	DevBatch upload(const HostBatch& hb)

@@ -375,3 +375,21 @@ def test_graphviz_dump_in_chunks_equals_single_call():
     # nothing is printed twice: a second pass over the same reads finds every start vertex black
     again, n2, e2 = hc2.output_graph(g.buf, g.off, frame=False)
     assert again == b"" and (n2, e2) == (0, 0)
+
+
+@pytest.mark.parametrize("name,split", [("k40_mixed", 7), ("k48_K16", 3), ("k25_h3_kc3_t40", 16)])
+def test_host_packing_on_several_threads_is_invisible(name, split, monkeypatch):
+    """The host packs reads into the 2-bit device layout on several threads (ranges of reads, joined in
+    order); ABG_HOST_SPLIT forces that on inputs this small.  Reads with Ns, lower case and short reads
+    included (k40_mixed)."""
+    monkeypatch.setenv("ABG_HOST_SPLIT", str(split))
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, p2_first=128, mask=mask_of(g))
+    hc.load(g.buf, g.off)
+    assert hc.counting_stats()[1] == g.meta["filtered_popcount"]
+    results, contigs = hc.assemble(g.buf, g.off)
+    assert api.format_fasta(contigs, g.ids) == g.fasta
+    assert api.format_read_log(results, g.ids) == g.readlog
+    assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
