@@ -42,14 +42,19 @@ class RcclComm:
             import torch.distributed as dist
             self.rank, self.world = dist.get_rank(), dist.get_world_size()
         ident = (C.c_uint8 * 128)()
+        err = ""
         if self.rank == 0:
             rc = self._lib.abg_rccl_unique_id(ident)
             if rc != 0:
-                raise RuntimeError("abg_rccl_unique_id failed (%d): %s" % (rc, self._lib.abg_last_error(None).decode()))
+                err = "abg_rccl_unique_id failed (%d): %s" % (rc, self._lib.abg_last_error(None).decode())
         if not single:
-            box = [bytes(ident)]
+            # (a failure on rank 0 travels with the id, so that every rank raises instead of waiting for it)
+            box = [(bytes(ident), err)]
             dist.broadcast_object_list(box, src=0, device=torch.device("cuda", device) if dist.get_backend() == "nccl" else None)
-            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0][0])
+            err = box[0][1]
+        if err:
+            raise RuntimeError(err)
         self.struct = CommStruct()
         rc = self._lib.abg_rccl_comm_create(ident, self.rank, self.world, device, C.byref(self.struct))
         if rc != 0:
