@@ -34,6 +34,20 @@ def test_partitioned_run_reproduces_reference_run(name, world):
     assert out["comm_calls"]["all_reduce"] > 0 and out["comm_calls"]["all_gather_v"] > 0
 
 
+def test_partitioned_run_on_eight_ranks():
+    """The node size the design targets (8 x MI355X): golden run, long reservation chains on an odd
+    number of ranks, gathered read shares with an empty rank."""
+    out = run_ranks(8, "golden", "k32")
+    for key in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "ranks_agree"):
+        assert out[key], (key, out)
+    out = run_ranks(5, "tiny_filter")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    out = run_ranks(8, "shared")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+
+
 def test_partitioned_run_matches_oracle_world2():
     out = run_ranks(2, "oracle")
     for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
