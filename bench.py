@@ -141,6 +141,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
                     help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="partitioned mode: the fixed --pairs / --bloom job over N ranks (strong), or a job N times as big "
+                         "(--pairs and --bloom per rank: the shape of BASELINE.json configs[2])")
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
@@ -162,8 +165,14 @@ def main() -> int:
     mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30}
     bloom_bytes = int(float(a.bloom[:-1]) * mult[a.bloom[-1].upper()]) if a.bloom[-1].isalpha() else int(a.bloom)
     read_len, cov, err = 150, 50.0, 0.005
-    genome_len = int(a.pairs * 2 * read_len / cov)
     partitioned = world > 1 and a.mode == "partitioned"
+    single = (a.pairs, bloom_bytes, a.bloom)
+    if partitioned and a.scaling == "weak":
+        # one job, N times the reads, genome and filter of the single-GPU workload
+        a.pairs *= world
+        bloom_bytes *= world
+        a.bloom = "%dx%s" % (world, a.bloom)
+    genome_len = int(a.pairs * 2 * read_len / cov)
     comm = None
     comm_note = ""
     if world == 1 and os.environ.get("ABG_FORCE_DIST", "0") not in ("", "0"):
@@ -190,6 +199,8 @@ def main() -> int:
                     comm.close()
                 comm, partitioned = None, False
                 comm_note = comm_note or "rccl communicator failed on another rank: replicas instead"
+                a.pairs, bloom_bytes, a.bloom = single
+                genome_len = int(a.pairs * 2 * read_len / cov)
     if partitioned:
         # one job: rank r holds the r-th block of the read set (same genome on every rank)
         pairs_local = a.pairs // world + (1 if rank < a.pairs % world else 0)
@@ -329,7 +340,7 @@ def main() -> int:
         out = {
             "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if partitioned else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling if partitioned else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
                        % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom,
