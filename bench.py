@@ -13,8 +13,9 @@ GPU) the SAME job is split over the ranks (strong scaling): every rank holds 1/N
 the counting filter is range-partitioned by position over the ranks' HBM during PASS 1 (RCCL
 all_gather of the 2-bit reads, one all_reduce(MIN) of a byte per k-mer op and round), gathered
 for PASS 2, whose walks are split over the ranks and merged before the ordered commit
-(DESIGN.md section 7); the unitigs are bit-identical to the 1-GPU run.  --mode replicas runs
-N independent copies of the job instead (weak scaling, no collective on the data path).
+(DESIGN.md section 7); the unitigs are bit-identical to the 1-GPU run.  --scaling weak makes the
+job N times as big instead (reads, genome and filter: the shape of configs[2]); --mode replicas
+runs N independent copies of the job (no collective on the data path).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """

@@ -150,3 +150,81 @@ def test_oracle_graphviz_dump_small_case_in_full():
     assert text == ref
     assert (nodes, edges) == (GRAPH_GOLDEN["k32_first300"]["nodes"], GRAPH_GOLDEN["k32_first300"]["edges"])
     assert text.startswith(b"digraph g {\n\t") and text.endswith(b";\n}\n")
+
+
+# ---- the reference's own unit tests for this path, restated against the oracle
+TOY = [b"CGACT", b"TGACT", b"GACTC", b"ACTCT", b"ACTCG"]  # Unittest/BloomDBG/RollingBloomDBGTest.cpp:31-57
+BASE_BIT = {"A": 1, "C": 2, "G": 4, "T": 8}
+
+
+def _toy_graph(mask=None, num_hashes=2):
+    o = ob.Oracle(5, counters=100000, num_hashes=num_hashes, min_cov=1, mask=mask)
+    buf, off = api.concat_seqs(TOY)
+    o.load(buf, off)
+    return o
+
+
+def test_reference_unit_test_toy_graph_neighbours():
+    """RollingBloomDBGTest out_edge_iterator / adjacency_iterator / in_edges / pathTraversal
+    (Unittest/BloomDBG/RollingBloomDBGTest.cpp:61-191): GACTC has successors ACTCT, ACTCG and
+    predecessors CGACT, TGACT; CGACT -> GACTC and GACTC -> ACTCG/ACTCT are the only edges on the way."""
+    o = _toy_graph()
+    assert o.out_mask(b"GACTC") == BASE_BIT["T"] | BASE_BIT["G"]
+    assert o.in_mask(b"GACTC") == BASE_BIT["C"] | BASE_BIT["T"]
+    assert o.out_mask(b"CGACT") == BASE_BIT["C"]          # out_degree(CGACT) == 1: -> GACTC
+    assert o.out_mask(b"ACTCG") == 0 and o.out_mask(b"ACTCT") == 0
+    assert o.in_mask(b"CGACT") == 0 and o.in_mask(b"TGACT") == 0
+
+
+def test_reference_unit_test_toy_graph_under_a_spaced_seed():
+    """RollingBloomDBGSpacedSeedTest (:231-340): seed 11011, one hash; GACTC equals its own reverse
+    complement under the mask, which must not add edges."""
+    o = _toy_graph(mask=b"11011", num_hashes=1)
+    assert o.out_mask(b"GACTC") == BASE_BIT["T"] | BASE_BIT["G"]
+    assert o.in_mask(b"GACTC") == BASE_BIT["C"] | BASE_BIT["T"]
+
+
+def test_reference_unit_test_counting_filter_threshold():
+    """CountingBloomFilter base (Unittest/BloomDBG/CountingBloomFilterTest.cpp:9-47): 1000 counters, one
+    hash, threshold 2 -- contains() and filtered_popcount() after each insert."""
+    k, a, b, c, d, e = 16, b"AGATGTGCTGCCGCCT", b"TGGACAGCGTTACCTC", b"TAATAACAGTCCCTAT", b"GATCGTGGCGGGCGAT", b"T" * 16
+    o = ob.Oracle(k, counters=1000, num_hashes=1, min_cov=2)
+    assert o.size == 1000
+
+    def insert(s):
+        buf, off = api.concat_seqs([s])
+        o.load(buf, off)
+
+    def contains(s):
+        return bool(o.min_count(o.hash_seq(s)[1])[0] >= 2)
+
+    insert(a)
+    assert o.counting_stats()[1] == 0 and not contains(e)
+    insert(a)
+    assert o.counting_stats()[1] == 1 and contains(a)
+    insert(b)
+    assert o.counting_stats()[1] == 1 and not contains(b)
+    insert(c)
+    assert o.counting_stats()[1] == 1 and not contains(c)
+    insert(b)
+    assert o.counting_stats()[1] == 2 and contains(b) and not contains(d)
+
+
+def test_reference_unit_test_path_to_seq_under_a_spaced_seed():
+    """BloomDBG pathToSeq (Unittest/BloomDBG/BloomDBGTest.cpp:21-38): ACGTAC as a path of two 5-mers under
+    the seed 10001 comes back as ACNNAC.  Reached through the assembly: a filter holding both k-mers twice
+    makes the read solid, and the contig of that read is the path's sequence."""
+    seq = b"ACGTAC"
+    o = ob.Oracle(5, counters=100000, num_hashes=2, min_cov=1, trim=0, mask=b"10001")
+    # flanks so that the read has no blunt end (5 solid predecessors / successors either side)
+    long = b"GGCATTCAGCA" + seq + b"GTCTTGACCAT"
+    buf, off = api.concat_seqs([long])
+    o.load(buf, off)
+    res, contigs = o.assemble(buf, off)
+    assert len(contigs) >= 1
+    text = b"".join(c.seq for c in contigs)
+    assert b"N" in text  # columns no '1' of the seed covers come back as N (bloom-dbg.h:130-158)
+    k = 5
+    for c in contigs:  # every column covered by the first or last position of some path k-mer is a base
+        assert all(ch in b"ACGTN" for ch in c.seq)
+        assert c.seq[0] in b"ACGT" and c.seq[-1] in b"ACGT"
