@@ -8,6 +8,7 @@
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
 
+#include <csignal>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -59,6 +60,26 @@ static const char USAGE_MESSAGE[] =
 
 enum { OPT_HELP = 1, OPT_VERSION, QR_SEED, MIN_KMER_COV, CHECKPOINT, KEEP_CHECKPOINT, CHECKPOINT_PREFIX, READ_LOG, OPT_GPUS };
 static abghost::ReaderOptions ropt;
+// --gpus: the other ranks.  If one of them dies, the rest would wait for it in a collective for
+// ever: the SIGCHLD handler of rank 0 takes the whole job down instead.
+static pid_t g_children[ABG_MAX_RANKS];
+static volatile sig_atomic_t g_nchildren = 0, g_children_left = 0;
+static void on_sigchld(int)
+{
+	int st;
+	pid_t pid;
+	while ((pid = waitpid(-1, &st, WNOHANG)) > 0) {
+		bool mine = false;
+		for (int i = 0; i < g_nchildren; i++) mine = mine || g_children[i] == pid;
+		if (!mine) continue;
+		g_children_left--;
+		if (WIFEXITED(st) && WEXITSTATUS(st) == 0) continue;
+		static const char msg[] = "abyss-bloom-dbg: a rank of the multi-GPU run failed\n";
+		if (write(2, msg, sizeof msg - 1)) {}
+		for (int i = 0; i < g_nchildren; i++) kill(g_children[i], SIGKILL);
+		_exit(EXIT_FAILURE);
+	}
+}
 static const char shortopts[] = "b:C:g:H:i:j:k:K:o:q:Q:R:s:t:T:v";
 static const struct option longopts[] = {
 	{ "bloom-size", required_argument, NULL, 'b' }, { "min-coverage", required_argument, NULL, 'c' },
@@ -371,11 +392,23 @@ int main(int argc, char** argv)
 			rd[r] = fd[0]; wr[r] = fd[1];
 		}
 		fflush(NULL);
+		if (gpus > 1) {
+			struct sigaction sa;
+			memset(&sa, 0, sizeof sa);
+			sa.sa_handler = on_sigchld;
+			sa.sa_flags = SA_RESTART;
+			sigaction(SIGCHLD, &sa, NULL);
+		}
 		for (unsigned r = 1; r < gpus; r++) {
+			sigset_t block, old;
+			sigemptyset(&block); sigaddset(&block, SIGCHLD);
+			sigprocmask(SIG_BLOCK, &block, &old); // the child is on the list before its exit can be seen
 			pid_t pid = fork();
 			if (pid < 0) { perror("fork"); exit(EXIT_FAILURE); }
-			if (pid == 0) { rank = r; children.clear(); break; }
+			if (pid == 0) { rank = r; children.clear(); g_nchildren = 0; signal(SIGCHLD, SIG_DFL); sigprocmask(SIG_SETMASK, &old, NULL); break; }
 			children.push_back(pid);
+			g_children[g_nchildren] = pid; g_nchildren = g_nchildren + 1; g_children_left = g_children_left + 1;
+			sigprocmask(SIG_SETMASK, &old, NULL);
 		}
 		uint8_t ident[128];
 		if (rank == 0) {
@@ -383,6 +416,8 @@ int main(int argc, char** argv)
 			for (unsigned r = 1; r < gpus; r++)
 				if (write(wr[r], ident, sizeof ident) != (ssize_t)sizeof ident) { perror("write"); exit(EXIT_FAILURE); }
 		} else {
+			// (only rank 0 holds the writing ends: if it dies before sending, the read below sees end of file)
+			for (unsigned r = 1; r < gpus; r++) { close(wr[r]); wr[r] = -1; }
 			if (read(rd[rank], ident, sizeof ident) != (ssize_t)sizeof ident) { fprintf(stderr, PROGRAM ": rank %u did not receive the communicator id\n", rank); exit(EXIT_FAILURE); }
 			// the other ranks compute along and stay silent
 			if (!getenv("ABG_RANK_STDERR")) { if (!freopen("/dev/null", "w", stderr)) exit(EXIT_FAILURE); }
@@ -390,7 +425,7 @@ int main(int argc, char** argv)
 			if (!freopen("/dev/null", "w", stdout)) exit(EXIT_FAILURE);
 			for (std::string* path : { &tracePath, &readLogPath, &covTrackPath, &graphPath }) if (!path->empty()) *path = "/dev/null";
 		}
-		for (unsigned r = 1; r < gpus; r++) { close(rd[r]); close(wr[r]); }
+		for (unsigned r = 1; r < gpus; r++) { close(rd[r]); if (wr[r] >= 0) close(wr[r]); }
 		if (abg_rccl_comm_create(ident, (int32_t)rank, (int32_t)gpus, (int32_t)rank, &comm) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
 		p.device = (int32_t)rank;
 	}
@@ -616,11 +651,7 @@ int main(int argc, char** argv)
 	if (out != stdout) fclose(out); else fflush(stdout);
 	abg_destroy(ctx);
 	if (use_comm) abg_rccl_comm_destroy(&comm);
-	int status = EXIT_SUCCESS;
-	for (pid_t pid : children) {
-		int st = 0;
-		if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = EXIT_FAILURE;
-	}
-	if (status != EXIT_SUCCESS) fprintf(stderr, PROGRAM ": a rank of the multi-GPU run failed\n");
-	return status;
+	// (the handler reaps the other ranks and ends the job if one of them fails)
+	while (rank == 0 && g_children_left > 0) usleep(1000);
+	return EXIT_SUCCESS;
 }

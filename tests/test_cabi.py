@@ -51,3 +51,22 @@ def test_rejects_bad_parameters():
         ctx = C.c_void_p()
         assert lib.abg_create(C.byref(p), C.byref(ctx)) == -1
         assert lib.abg_last_error(None)
+
+
+def test_host_binary_multi_gpu_launch_fails_cleanly_without_devices(tmp_path):
+    """`abyss-bloom-dbg --gpus 2` forks one process per GPU before touching the HIP runtime; where there
+    is no GPU (this container) every rank must give up with a message and exit 1 -- nobody waits for ever."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    from abyss_amd import build
+    exe = build.build_cli()
+    (tmp_path / "r.fa").write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([exe, "-k32", "-b1M", "--gpus=2", "r.fa"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and r.stdout == b""
+    r = subprocess.run([exe, "-k32", "-b1M", "--gpus=2", "--checkpoint=100", "r.fa"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"--checkpoint is not available with --gpus" in r.stderr
