@@ -278,10 +278,18 @@ class SequenceReader {
 		if (plain) {
 			m_f = fopen(path.c_str(), "rb");
 			if (m_f) {
+				// a regular file whose first record is a 4-line FASTQ record ('@' header, '+' on the third
+				// line); a SAM file also begins with '@' (its @HD / @SQ header) but fails the second test
 				struct stat st;
-				int c = getc(m_f);
-				if (c != EOF) ungetc(c, m_f);
-				if (fstat(fileno(m_f), &st) != 0 || !S_ISREG(st.st_mode) || c != '@') { fclose(m_f); m_f = nullptr; }
+				bool fastq = fstat(fileno(m_f), &st) == 0 && S_ISREG(st.st_mode);
+				if (fastq) {
+					m_buf.resize(1u << 16);
+					m_buf.resize(fread(&m_buf[0], 1, m_buf.size(), m_f)); // (stays in the buffer: the first window starts with it)
+					const size_t l1 = m_buf.find('\n');
+					const size_t l2 = l1 == std::string::npos ? l1 : m_buf.find('\n', l1 + 1);
+					fastq = !m_buf.empty() && m_buf[0] == '@' && l2 != std::string::npos && l2 + 1 < m_buf.size() && m_buf[l2 + 1] == '+';
+				}
+				if (!fastq) { fclose(m_f); m_f = nullptr; m_buf.clear(); }
 			}
 		}
 		if (!m_f) m_seq = new FastaReader(path, o); // (also reports a missing file the reference's way)
