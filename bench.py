@@ -341,7 +341,8 @@ def main() -> int:
         out = {
             "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": a.scaling if partitioned else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling if (partitioned or (world == 1 and a.mode == "partitioned")) else "weak",
+            "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
                        % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom,
