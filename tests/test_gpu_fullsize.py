@@ -30,12 +30,14 @@ pytestmark = pytest.mark.gpu
 K, BLOOM, PAIRS, READ_LEN = 64, 2 << 30, 5_000_000, 150
 
 
-def _run(words, woff, lens, n_reads, env, monkeypatch, want_contigs, **tuning):
-    for key in ("ABG_PAR_COMMIT", "ABG_P2_FIRST_BATCH", "ABG_P2_MAX_BATCH", "ABG_DRAIN_THRESHOLD"):
+def _run(words, woff, lens, n_reads, env, monkeypatch, want_contigs, comm=None, **tuning):
+    for key in ("ABG_PAR_COMMIT", "ABG_P2_FIRST_BATCH", "ABG_P2_MAX_BATCH", "ABG_DRAIN_THRESHOLD", "ABG_FORCE_DIST"):
         monkeypatch.delenv(key, raising=False)
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     g = api.BloomDBG(K, bloom_bytes=BLOOM, num_hashes=4, min_cov=2, **tuning)
+    if comm is not None:
+        g.attach_comm(comm)
     g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
     counters = g.counters()
     _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads, want_results=False,
@@ -95,3 +97,17 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
     assert dig_a == dig_b
     assert np.array_equal(vis_a, b.visited())
     b.close()
+
+    # and the partitioned code path of the multi-GPU run on one rank: evaluate /
+    # all_reduce / apply rounds with the compacted loser lists, the drain hand-over, split classification,
+    # merged walk results -- every collective an identity (abyss_amd.dist.LocalComm)
+    from abyss_amd import dist as adist
+    comm = adist.LocalComm()
+    c, cnt_c, contigs_c, dig_c = _run(words, woff, lens, n_reads, {"ABG_FORCE_DIST": "1"}, monkeypatch, True, comm=comm)
+    assert comm.calls["all_reduce"] > 100 and comm.calls["all_gather_v"] > 0
+    assert np.array_equal(cnt_a, cnt_c)
+    cc = c.assembly_counters()
+    assert {k2: cc[k2] for k2 in ca} == ca
+    assert dig_a == dig_c
+    assert np.array_equal(vis_a, c.visited())
+    c.close()
