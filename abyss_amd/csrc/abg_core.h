@@ -304,6 +304,58 @@ ABG_HD Kmer<NW> kmer_revcomp(const Kmer<NW>& s, unsigned k)
 		kmer_set(r, k - 1 - i, 3u - kmer_get(s, i));
 	return r;
 }
+// The same without a loop over the bases: reverse the 2-bit groups of every word (and the word
+// order), complement, then move the k bases down over the unused high positions.
+ABG_HD uint64_t rc_word(uint64_t x)
+{
+	x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+	x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+	return ~__builtin_bswap64(x);
+}
+template <int NW>
+ABG_HD Kmer<NW> kmer_revcomp_fast(const Kmer<NW>& s, unsigned k)
+{
+	constexpr int W = KW<NW>;
+	uint64_t t[W];
+#pragma unroll
+	for (int j = 0; j < W; j++) t[j] = rc_word(s.w[W - 1 - j]);
+	// base i now sits at position 32 W - 1 - i; it belongs at k - 1 - i
+	const unsigned sh = (32u * W - k) * 2u, ws = sh >> 6, bs = sh & 63u;
+	Kmer<NW> r;
+#pragma unroll
+	for (int j = 0; j < W; j++) {
+		uint64_t lo = 0, hi = 0;
+#pragma unroll
+		for (int q = 0; q < W; q++) {
+			if (q == j + (int)ws) lo = t[q];
+			if (q == j + (int)ws + 1) hi = t[q];
+		}
+		r.w[j] = bs ? ((lo >> bs) | (hi << (64u - bs))) : lo;
+	}
+	return r;
+}
+// The k-mer starting at base `pos` of a packed sequence (16 bases per 32-bit word, the sequence
+// starting at word `woff`): only the words holding bases [pos, pos + k) are read.
+template <int NW>
+ABG_HD Kmer<NW> window_kmer(const uint32_t* __restrict__ words, uint64_t woff, uint32_t pos, unsigned k)
+{
+	Kmer<NW> s;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) {
+		s.w[j] = 0;
+		if (32u * j >= k) continue;
+		const unsigned nb = k - 32u * j < 32u ? k - 32u * j : 32u; // bases of this word
+		const uint32_t b0 = pos + 32u * j;
+		const uint64_t q = woff + (b0 >> 4);
+		const unsigned sh = 2u * (b0 & 15u), need = sh + 2u * nb;  // bits [sh, need) of words q, q + 1, q + 2
+		uint64_t lo = words[q];
+		if (need > 32) lo |= (uint64_t)words[q + 1] << 32;
+		uint64_t v = lo >> sh;
+		if (need > 64) v |= (uint64_t)words[q + 2] << (64u - sh);
+		s.w[j] = nb < 32 ? (v & ((1ULL << (2u * nb)) - 1)) : v;
+	}
+	return s;
+}
 // LightweightKmer::isCanonical (LightweightKmer.h:88-101): compares only the first
 // k/2 bases with the complement of the mirrored ones; ties count as canonical.
 template <int NW>
@@ -456,6 +508,28 @@ ABG_HD uint64_t scratch_hash(const Params& p, Get get)
 	uint64_t fh, rh;
 	scratch_hashes(p, get, fh, rh);
 	return rh < fh ? rh : fh;
+}
+// NTF64 / NTR64 base forms (nthash.hpp:220-239) of a k-mer held in words, without a spaced seed:
+// the loops of vtx_rehash with the bases taken off the words as they come
+template <int NW>
+ABG_HD void kmer_hashes(const Kmer<NW>& s, unsigned k, uint64_t& fh_out, uint64_t& rh_out)
+{
+	uint64_t fh = 0, rh = 0;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) {
+		if (32u * j >= k) continue;
+		const unsigned nb = k - 32u * j < 32u ? k - 32u * j : 32u;
+		uint64_t x = s.w[j];
+		for (unsigned i = 0; i < nb; i++) { fh = srol1(fh) ^ seed_of((unsigned)x & 3u); x >>= 2; }
+	}
+#pragma unroll
+	for (int j = KW<NW> - 1; j >= 0; j--) {
+		if (32u * j >= k) continue;
+		const unsigned nb = k - 32u * j < 32u ? k - 32u * j : 32u;
+		uint64_t x = s.w[j] << (64u - 2u * nb);
+		for (unsigned i = 0; i < nb; i++) { rh = srol1(rh) ^ seed_of(3u - (unsigned)(x >> 62)); x <<= 2; }
+	}
+	fh_out = fh; rh_out = rh;
 }
 // RollingHash::reset: the rolling (unmasked) state of a vertex
 template <int NW>

@@ -47,6 +47,8 @@ struct Config {
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
+	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
+	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
 	int verbose = 0;
@@ -493,6 +495,32 @@ struct FRefilter {
 			if (!visited_contains(p, vis, vtx_hash(p, v))) return;
 		}
 		result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
+	}
+};
+
+// The guide of the walkers' bulk steps (Guide, abg_walk.h): every k-mer of every `stride`-th read
+// that may be solid (the first of its H counters says so: one probe drops nearly all k-mers with a
+// sequencing error) leaves a hint "this k-mer is k-mer j of the read at word offset woff" in the
+// slot of its canonical hash.  Plain stores: whichever read wrote last serves as the guide.
+template <int NW>
+struct FGuideBuild {
+	Params p; Batch b; const uint8_t* cnt; uint64_t* tab; uint64_t mask; uint32_t stride;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint64_t r = i * stride;
+		const uint32_t L = b.len[r];
+		if (L < p.k) return;
+		const uint32_t nk = L - p.k + 1;
+		const uint64_t woff = b.woff[r];
+		if (nk > GUIDE_MAX_NK || woff > GUIDE_MAX_WOFF) return;
+		for (uint32_t j = lane; j < nk; j += nlanes) {
+			const Kmer<NW> s = window_kmer<NW>(b.words, woff, j, p.k);
+			uint64_t fh, rh;
+			kmer_hashes(s, p.k, fh, rh);
+			const uint64_t hm = rh < fh ? rh : fh;
+			if (cnt[pos_i(p, hm, 0)] < p.kc) continue;
+			tab[guide_slot(hm, mask)] = guide_pack(woff, j, nk, guide_tag(hm));
+		}
 	}
 };
 
@@ -1275,6 +1303,7 @@ class Engine {
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
 		if (la_pool2_) be_.free(la_pool2_);
+		if (guide_tab_) be_.free(guide_tab_);
 		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
 		free_insert();
@@ -1301,6 +1330,7 @@ class Engine {
 			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
 		}
 		cend_count_ = 0;
+		if (wstats_) be_.memset(wstats_, 0, WSTAT_N * 8);
 		if (gtab_.hmin) { free_tab(gtab_); gtab_ = WalkTab{ nullptr, nullptr, nullptr, 0 }; gtab_used_ = 0; }
 	}
 	const Params& params() const { return p_; }
@@ -1460,6 +1490,7 @@ class Engine {
 	{
 		ensure_walk();
 		gather_counters();
+		build_guide(b);
 		uint64_t done = 0;
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		full_b_ = &b; result_base_ = result_d; pre_n_ = 0;
@@ -1472,7 +1503,39 @@ class Engine {
 		}
 		be_.sync_side();
 		full_b_ = nullptr; pre_n_ = 0; prefetch_ = nullptr;
+		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);
+	}
+	// The guide of the bulk steps for the reads of one assemble_packed call (see FGuideBuild).  Even k
+	// without a spaced seed only (walk_bulk); sized to the sampled reads' k-mers, of which the solid
+	// ones -- a genome's worth -- stay.
+	void build_guide(const Batch& b)
+	{
+		guide_.tab = nullptr; guide_slots_ = 0;
+		if (!cfg_.guide_stride || p_.mask || !p_.ident_fast || p_.nh > 8 || !b.n) return;
+		const uint64_t sampled = (b.n + cfg_.guide_stride - 1) / cfg_.guide_stride;
+		uint64_t nwords = 0;
+		be_.d2h(&nwords, b.woff + b.n, 8);
+		const uint64_t bases = nwords * 16, minus = b.n * (uint64_t)(p_.k - 1);
+		const uint64_t kmers = (bases > minus ? bases - minus : b.n) / cfg_.guide_stride;
+		uint32_t log2 = 16;
+		while ((1ull << log2) < kmers && log2 < cfg_.guide_log2_max) log2++;
+		if (!guide_tab_ || log2 != guide_log2_) {
+			if (guide_tab_) be_.free(guide_tab_);
+			guide_tab_ = (uint64_t*)be_.try_alloc(8ull << log2);
+			guide_log2_ = log2;
+			if (!guide_tab_) { if (cfg_.verbose) fprintf(stderr, "abyss_amd: no memory for the walkers' guide table, walking step by step\n"); return; }
+		}
+		be_.memset(guide_tab_, 0, 8ull << log2);
+		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
+		dispatch_nw([&](auto nw) {
+			if constexpr (!MASKED_BUILD<decltype(nw)::value>) {
+				FGuideBuild<decltype(nw)::value> f{ p_, b, cnt_, guide_tab_, guide_.mask, cfg_.guide_stride };
+				be_.launch_wave(sampled, f, "guide_build");
+			}
+		});
+		guide_.tab = guide_tab_;
+		guide_slots_ = guide_.mask + 1;
 	}
 	// Batches grow geometrically up to p2_max_batch (larger ones walk too many reads of the same
 	// unitigs side by side).  A batch with few candidates, though, is bound by its slowest walker,
@@ -1501,8 +1564,19 @@ class Engine {
 		pre_first_ = next_first; pre_n_ = next_n;
 	}
 
-	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0; };
-	Stats stats() const { return stats_; }
+	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
+	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0; };
+	Stats stats()
+	{
+		Stats s = stats_;
+		if (wstats_) {
+			uint64_t v[WSTAT_N];
+			be_.d2h(v, wstats_, sizeof v);
+			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS];
+		}
+		s.guide_slots = guide_slots_;
+		return s;
+	}
 
   private:
 	BE& be_;
@@ -1592,6 +1666,8 @@ class Engine {
 	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
 	// PASS 2 resources
+	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
+	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{};
 	uint32_t wtab_log2_ = 0;
@@ -1831,6 +1907,8 @@ class Engine {
 		alloc_tab(wtab_, wtab_log2_);
 		wclaims_ = (uint32_t*)be_.alloc(4ull << cfg_.wclaim_log2);
 		la_pool_ = (VKey*)be_.alloc((uint64_t)std::max(wslots_, cslots_) * LA_MAX_VISITED * sizeof(VKey));
+		bulk_pool_ = (BulkScratch*)be_.alloc((uint64_t)wslots_ * sizeof(BulkScratch));
+		if (!wstats_) { wstats_ = (uint64_t*)be_.alloc(WSTAT_N * 8); be_.memset(wstats_, 0, WSTAT_N * 8); }
 		walk_tb_cap_ = cfg_.tb_cap;
 		walk_buf_cap_ = cfg_.buf_cap;
 		alloc_walk_scratch();
@@ -1868,7 +1946,8 @@ class Engine {
 	{
 		if (!walk_ready_) return;
 		free_tab(cend_); free_tab(wtab_);
-		be_.free(wclaims_); be_.free(la_pool_);
+		be_.free(wclaims_); be_.free(la_pool_); be_.free(bulk_pool_);
+		if (wstats_) { be_.free(wstats_); wstats_ = nullptr; }
 		free_walk_scratch();
 		be_.free(pool_); be_.free(kh_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
 		be_.free(order_); be_.free(order_n_);
@@ -1912,6 +1991,7 @@ class Engine {
 		e.tb_cap = walk_tb_cap_;
 		e.fast = nullptr; e.fast_bytes = 0; e.dbg = dbg_; e.coop = false;
 		e.la_pool = la_pool_;
+		e.guide = guide_; e.bulk_pool = bulk_pool_; e.wstats = wstats_;
 		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
 		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
 		e.recs = recs_; e.rec_cap = rec_cap_; e.rec_used = rec_used_;

@@ -32,11 +32,15 @@ ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
 	return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect,
 	    (unsigned long long)val);
 }
+ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { return atomicCAS(p, expect, val); }
 ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v)
 {
 	return (uint64_t)atomicMin((unsigned long long*)p, (unsigned long long)v);
 }
+// lanes of one wavefront exchanging data through memory they share (LDS or global): everything
+// written before is visible to the wave's other lanes after
+ABG_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
 {
@@ -54,6 +58,8 @@ ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
 	if (old == expect) *p = val;
 	return old;
 }
+ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { uint32_t o = *p; if (o == expect) *p = val; return o; }
+ABG_HD void wave_sync() {}
 ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
 ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -242,6 +248,48 @@ ABG_HD uint64_t wt_find(const WalkTab& t, const VKey& key, uint32_t owner)
 	return WT_EMPTY;
 }
 
+
+// ---------------------------------------------------------------- read-guided bulk steps
+// A unitig walk is a dependent chain -- every step needs the previous head -- but where the path
+// runs along a READ the chain is known ahead: the read's next k-mers are a prediction of the next
+// heads, and whether each predicted head really is the unique continuation can be checked for all
+// of them at once (the same 8 x H probes per vertex the step-by-step walk would issue, one vertex
+// per lane).  The guide table maps the canonical hash of a k-mer of a sample of the reads to where
+// that k-mer sits in the packed reads.  It is a direct-mapped, lossy table of HINTS: a wrong, stale
+// or missing entry only costs time, because every hint is verified against the head's k-mer and
+// every predicted step against the solid filter before it is taken (walk_bulk).
+struct Guide {
+	const uint64_t* tab;    // [mask + 1] hints (0 = none), see guide_pack
+	uint64_t mask;
+	const uint32_t* words;  // the packed reads the hints point into
+	uint64_t nwords;
+};
+constexpr uint32_t GUIDE_MAX_NK = 256; // k-mers of a sequence that can serve as a guide
+ABG_HD uint64_t guide_slot(uint64_t hm, uint64_t mask)
+{
+	uint64_t x = hm * 0x9E3779B97F4A7C15ULL;
+	x ^= x >> 29;
+	return x & mask;
+}
+ABG_HD uint32_t guide_tag(uint64_t hm) { return (uint32_t)(hm >> 56); }
+// valid bit | tag (8) | k-mers of the read - 1 (8) | k-mer index (8) | word offset of the read (39)
+ABG_HD uint64_t guide_pack(uint64_t woff, uint32_t pos, uint32_t nk, uint32_t tag)
+{
+	return (1ULL << 63) | ((uint64_t)(tag & 0xFFu) << 55) | ((uint64_t)(nk - 1) << 47) | ((uint64_t)pos << 39) | woff;
+}
+constexpr uint64_t GUIDE_MAX_WOFF = (1ULL << 39) - 1;
+constexpr uint32_t BULK_LANES = 64, BULK_MIN = 4;
+struct BulkScratch {
+	VKey key[BULK_LANES];         // identity of every predicted vertex
+	uint8_t good[BULK_LANES];     // the vertex is new to the walker, simple, and continues as predicted
+	uint8_t fbase[BULK_LANES];    // its one neighbour ahead
+	uint32_t dup[2 * BULK_LANES]; // open-addressing set of the chunk's identities (lane + 1)
+	uint32_t dupstop;             // first position that repeats an earlier vertex of the chunk
+	uint32_t full;                // the vertex table has no room
+	uint64_t hw[MAX_NW], hfh, hrh; // hand-over of the new head
+};
+enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_N = 8 };
+
 // ------------------------------------------------------------- walker output
 enum WalkStatus : uint32_t {
 	WS_NONE = 0,      // not walked yet
@@ -286,6 +334,9 @@ struct WalkEnv {
 	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
 	uint64_t* dbg;             // optional [ncand][8] per-walker work counters (profiling aid)
 	bool coop;                 // the walker is a whole wavefront in lock step
+	Guide guide;               // read-guided bulk steps (tab == NULL: off)
+	BulkScratch* bulk_pool;    // [slots] scratch of the bulk steps when the fast memory has no room for it
+	uint64_t* wstats;          // [WSTAT_N] work counters summed over all walkers
 	// contig output
 	uint8_t* pool; uint64_t pool_cap; uint64_t* pool_used;
 	ContigRec* recs; uint32_t rec_cap; uint32_t* rec_used;
@@ -303,6 +354,11 @@ struct WalkState {
 	VKey prev_key;    // identity of the vertex before it
 	uint32_t ext;     // vertices appended by this extendPath call so far
 	int32_t ins;      // LIN_INS: what the insertion of `head` into the visited set returned
+	// read-guided bulk steps (walk_bulk)
+	BulkScratch* bulk;     // NULL: off
+	uint32_t bulk_skip;    // the head is known not to start a bulk step (the last one stopped at it)
+	uint32_t bulk_overflow; // the vertex table filled up during a bulk step
+	uint32_t n_bulk_calls, n_bulk_steps, n_lin_steps; // work counters of this walker
 };
 template <int NW>
 ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
@@ -342,6 +398,206 @@ ABG_HD uint64_t dbg_clock(const uint64_t* dbg)
 	(void)dbg; return 0;
 #endif
 }
+// One bulk step of walk_linear.  Entered like its loop: w.head is pushed but not yet entered into
+// the visited set; `hint` is the guide entry of its canonical hash.  If the hint's read really
+// holds the head, its following k-mers (up to the end of the read, at most 64) are examined one
+// per lane exactly as walk_linear examines one head per iteration -- visited.insert(v) would be
+// new (ExtendPath.h:650-658), v has one neighbour either side and the one behind is the previous
+// vertex (extendPathBySingleVertex at successor()'s level 0, ExtendPath.h:314-362,403-459) -- plus
+// "the one ahead is the read's next k-mer", and the longest prefix of vertices that all pass is
+// taken: entered into the visited set, their bases appended, the head moved on.  Returns the
+// number of steps taken (0: nothing done, nothing changed).  A vertex that repeats an earlier one
+// of the same chunk ends the prefix (the step-by-step code then sees the cycle).
+template <int NW, bool COOP>
+ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir_in, const uint32_t owner_in,
+    const uint32_t contig_in, const uint64_t hint_in)
+{
+	if constexpr (MASKED_BUILD<NW>) {
+		(void)e; (void)w; (void)dir_in; (void)owner_in; (void)contig_in; (void)hint_in;
+		return 0;
+	} else {
+	const Params p = uniform_params<COOP>(e.p);
+	const unsigned k = p.k;
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(e.cnt);
+	const uint32_t* __restrict__ gwords = uniptr<COOP>(e.guide.words);
+	const uint64_t gnwords = uni64<COOP>(e.guide.nwords);
+	WalkTab tab;
+	tab.hmin = uniptr<COOP>(e.tab.hmin); tab.hmax = uniptr<COOP>(e.tab.hmax); tab.meta = uniptr<COOP>(e.tab.meta);
+	tab.mask = uni64<COOP>(e.tab.mask);
+	const uint64_t hint = uni64<COOP>(hint_in);
+	const uint64_t woff = hint & GUIDE_MAX_WOFF;
+	const uint32_t pos = (uint32_t)(hint >> 39) & 0xFFu, nk = ((uint32_t)(hint >> 47) & 0xFFu) + 1u;
+	if (pos >= nk || woff + ((nk + k - 1 + 15) >> 4) > gnwords) return 0; // (a stale or mangled hint)
+	const int dir = (int)uni32<COOP>((uint32_t)dir_in);
+	const uint32_t owner = uni32<COOP>(owner_in), contig = uni32<COOP>(contig_in);
+	const int fsense = (dir == FORWARD) ? SENSE : ANTISENSE, bsense = (dir == FORWARD) ? ANTISENSE : SENSE;
+	Vtx<NW> head;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
+	// does the read hold the head at `pos`, and on which strand?
+	bool same = true, anti = true;
+	{
+		const Kmer<NW> rk = window_kmer<NW>(gwords, woff, pos, k);
+		const Kmer<NW> hr = kmer_revcomp_fast(head.s, k);
+#pragma unroll
+		for (int j = 0; j < KW<NW>; j++) {
+			const uint64_t x = uni64<COOP>(rk.w[j]);
+			same = same & (x == head.s.w[j]);
+			anti = anti & (x == hr.w[j]);
+		}
+	}
+	if (!same && !anti) return 0;
+	const bool up = (fsense == SENSE) == same; // the walk runs towards higher k-mer indices of the read
+	uint8_t* buf = uniptr<COOP>(dir == FORWARD ? w.rbuf : w.lbuf);
+	const uint32_t nbuf = uni32<COOP>(dir == FORWARD ? w.nr : w.nl), buf_cap = uni32<COOP>(e.buf_cap);
+	uint32_t n = up ? nk - pos : pos + 1u;
+	if (n > BULK_LANES) n = BULK_LANES;
+	if (nbuf >= buf_cap) return 0;
+	if (n > buf_cap - nbuf) n = buf_cap - nbuf;
+	if (n < BULK_MIN) return 0;
+	BulkScratch& bs = *uniptr<COOP>(w.bulk);
+	VKey prev_key;
+	prev_key.fh = uni64<COOP>(w.prev_key.fh); prev_key.rh = uni64<COOP>(w.prev_key.rh);
+	const uint64_t sk0 = p.seed_k[0], sk1 = p.seed_k[1], sk2 = p.seed_k[2], sk3 = p.seed_k[3];
+	const uint64_t rk0 = p.seedrc_k[0], rk1 = p.seedrc_k[1], rk2 = p.seedrc_k[2], rk3 = p.seedrc_k[3];
+	const uint64_t sm0 = p.seed_km1[0], sm1 = p.seed_km1[1], sm2 = p.seed_km1[2], sm3 = p.seed_km1[3];
+	const uint64_t rm0 = p.seedrc_km1[0], rm1 = p.seedrc_km1[1], rm2 = p.seedrc_km1[2], rm3 = p.seedrc_km1[3];
+	const uint32_t lane0 = COOP ? lane_id() : 0u, lstep = COOP ? BULK_LANES : 1u;
+	// the k-mer of position l of the chunk, in the walker's orientation, and its strand hashes
+	auto vertex_at = [&](uint32_t l, Kmer<NW>& s, uint64_t& fh, uint64_t& rh) {
+		s = window_kmer<NW>(gwords, woff, up ? pos + l : pos - l, k);
+		if (!same) s = kmer_revcomp_fast(s, k);
+		kmer_hashes(s, k, fh, rh);
+	};
+	// hashes of the neighbour of (s, fh, rh) with base b in direction sense (neighbour_hashes)
+	auto nbr = [&](const Kmer<NW>& s, uint64_t fh, uint64_t rh, int sense, unsigned b, uint64_t& nfh, uint64_t& nrh) {
+		if (sense == SENSE) {
+			const unsigned out = (unsigned)s.w[0] & 3u;
+			nfh = srol1(fh) ^ pick4(out, sk0, sk1, sk2, sk3) ^ seed_of(b);
+			nrh = sror1(rh ^ seed_of(3u - out)) ^ pick4(b, rm0, rm1, rm2, rm3);
+		} else {
+			const unsigned out = kmer_get(s, k - 1);
+			nfh = sror1(fh ^ seed_of(out)) ^ pick4(b, sm0, sm1, sm2, sm3);
+			nrh = (srol1(rh) ^ pick4(out, rk0, rk1, rk2, rk3)) ^ seed_of(3u - b);
+		}
+	};
+	for (uint32_t l = lane0; l < 2 * BULK_LANES; l += lstep) bs.dup[l] = 0;
+	if (lane0 == 0) { bs.dupstop = n; bs.full = 0; }
+	// ---- every predicted vertex: identity, "new to the walker", "simple", "continues as predicted"
+	Kmer<NW> my_s; uint64_t my_fh = 0, my_rh = 0;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
+	for (uint32_t l = lane0; l < n; l += lstep) {
+		vertex_at(l, my_s, my_fh, my_rh);
+		VKey key; // vtx_ident for even k without a mask: the ordered pair of the strand hashes
+		key.fh = my_rh < my_fh ? my_rh : my_fh;
+		key.rh = my_rh < my_fh ? my_fh : my_rh;
+		bs.key[l] = key;
+		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
+		for (unsigned base = 0; base < p.nh; base += 4) {
+			uint8_t c[8][4];
+#pragma unroll
+			for (unsigned q = 0; q < 8; q++) {
+				uint64_t nfh, nrh;
+				nbr(my_s, my_fh, my_rh, q < 4 ? bsense : fsense, q & 3u, nfh, nrh);
+				const uint64_t h = nrh < nfh ? nrh : nfh;
+#pragma unroll
+				for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
+			}
+#pragma unroll
+			for (unsigned q = 0; q < 8; q++) {
+#pragma unroll
+				for (unsigned i = 0; i < 4; i++) bad |= (c[q][i] < p.kc ? 1u : 0u) << q;
+			}
+		}
+		const uint64_t fs = wt_find(tab, wt_key(key), owner);
+		bool ok = fs == WT_EMPTY || (uint32_t)ld_coherent(&tab.meta[fs]) == WT_TOMB;
+		const unsigned bmask = ~bad & 0xFu, fmask = (~bad >> 4) & 0xFu;
+		ok = ok && bmask != 0 && !(bmask & (bmask - 1)) && fmask != 0 && !(fmask & (fmask - 1));
+		const unsigned bb = (bmask & 1u) ? 0u : (bmask & 2u) ? 1u : (bmask & 4u) ? 2u : 3u;
+		const unsigned fb = (fmask & 1u) ? 0u : (fmask & 2u) ? 1u : (fmask & 4u) ? 2u : 3u;
+		if (l == 0) {
+			// the one vertex behind the head must be the previous vertex of the path; for the later
+			// positions it is: position l - 1 is a neighbour behind position l and is solid (it passed)
+			uint64_t tfh, trh;
+			nbr(my_s, my_fh, my_rh, bsense, bb, tfh, trh);
+			VKey tk;
+			tk.fh = trh < tfh ? trh : tfh; tk.rh = trh < tfh ? tfh : trh;
+			ok = ok && key_equal(tk, prev_key);
+		}
+		if (l + 1 < n) {
+			// the read's next k-mer adds this base at the walking end
+			const uint32_t rb_pos = up ? pos + l + k : pos - l - 1u;
+			const unsigned rb = (gwords[woff + (rb_pos >> 4)] >> (2u * (rb_pos & 15u))) & 3u;
+			ok = ok && fb == (same ? rb : 3u - rb);
+		}
+		bs.good[l] = ok ? 1 : 0;
+		bs.fbase[l] = (uint8_t)fb;
+	}
+	wave_sync();
+	// ---- a vertex that repeats an earlier one of the chunk (a cycle within the read) stops the prefix
+	for (uint32_t l = lane0; l < n; l += lstep) {
+		const VKey key = bs.key[l];
+		uint32_t slot = (uint32_t)((key.fh ^ (key.fh >> 32) ^ key.rh) * 0x9E3779B9u >> 16) & (2 * BULK_LANES - 1);
+		for (;;) {
+			const uint32_t old = cas_u32(&bs.dup[slot], 0u, l + 1u);
+			if (old == 0) break;
+			if (key_equal(bs.key[old - 1], key)) { atomic_min_u32(&bs.dupstop, old - 1 > l ? old - 1 : l); break; }
+			slot = (slot + 1) & (2 * BULK_LANES - 1);
+		}
+	}
+	wave_sync();
+	uint32_t m = 0;
+	if (COOP) {
+		const uint64_t g = wave_ballot(lane0 < n && bs.good[lane0 < n ? lane0 : 0] != 0);
+		const uint64_t ng = ~g;
+		m = ng ? (uint32_t)__builtin_ctzll(ng) : 64u;
+		if (m > n) m = n;
+	} else {
+		while (m < n && bs.good[m]) m++;
+	}
+	{
+		const uint32_t ds = uni32<COOP>(ld_coherent(&bs.dupstop));
+		if (ds < m) m = ds;
+	}
+	if (m == 0) return 0;
+	// ---- take the m steps
+	for (uint32_t l = lane0; l < m; l += lstep) {
+		const int ins = wt_insert(tab, wt_key(bs.key[l]), owner, contig, false);
+		if (ins != WT_NEW) bs.full = 1; // (not new can only mean: no room)
+		buf[nbuf + l] = bs.fbase[l];
+		if (l == m - 1) {
+			// the new head: the neighbour ahead of the last vertex taken
+			if (!COOP) vertex_at(l, my_s, my_fh, my_rh);
+			uint64_t nfh, nrh;
+			const unsigned fb = bs.fbase[l];
+			nbr(my_s, my_fh, my_rh, fsense, fb, nfh, nrh);
+			kmer_shift(my_s, k, fsense, fb);
+#pragma unroll
+			for (int j = 0; j < KW<NW>; j++) bs.hw[j] = my_s.w[j];
+			bs.hfh = nfh; bs.hrh = nrh;
+		}
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // the table entries are there for whoever looks next
+#endif
+	wave_sync();
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) w.head.s.w[j] = uni64<COOP>(bs.hw[j]);
+	w.head.fh = uni64<COOP>(bs.hfh); w.head.rh = uni64<COOP>(bs.hrh);
+	{
+		const VKey pk = bs.key[m - 1];
+		w.prev_key.fh = uni64<COOP>(pk.fh); w.prev_key.rh = uni64<COOP>(pk.rh);
+	}
+	w.ext += m;
+	if (dir == FORWARD) w.nr = nbuf + m; else w.nl = nbuf + m;
+	w.bulk_skip = m < n ? 1u : 0u; // the vertex the prefix stopped at goes through the step-by-step code
+	if (uni32<COOP>(ld_coherent(&bs.full))) w.bulk_overflow = 1;
+	w.n_bulk_calls++; w.n_bulk_steps += m;
+	return m;
+	}
+}
+
 // The unbranched stretch of extendPath as a loop of its own.  A step is "simple" when the head,
 // newly entered into the visited set, has exactly one neighbour on either side and the one
 // behind it is the vertex the path came from: then successor() answers at its level 0 in both
@@ -354,7 +610,8 @@ ABG_HD uint64_t dbg_clock(const uint64_t* dbg)
 // Entered with w.head pushed but not yet entered into the visited set.
 enum { LIN_GENERAL = 0, // w.head is in the visited set; its step is not simple
        LIN_INS = 1,     // inserting w.head returned w.ins (not WT_NEW); nothing else was done for it
-       LIN_DEFER = 2 }; // w.head collides with the claim of a lower-numbered walker
+       LIN_DEFER = 2,   // w.head collides with the claim of a lower-numbered walker
+       LIN_OVERFLOW = 3 }; // the vertex table filled up (during a bulk step)
 template <int NW, bool COOP>
 ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir_in, const uint32_t owner_in,
     const uint32_t contig_in, const uint32_t claim_id_in, const bool may_defer_in)
@@ -393,7 +650,37 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 	const unsigned k = p.k;
 	uint32_t why;
 	int32_t ins = WT_NEW;
+	// read-guided bulk steps (walk_bulk): even k without a mask (the identity of a vertex is then
+	// the ordered pair of its strand hashes), private walks only
+	const uint64_t* __restrict__ gtab = uniptr<COOP>(e.guide.tab);
+	const uint64_t gmask = uni64<COOP>(e.guide.mask);
+	const bool bulk_on = !MASKED_BUILD<NW> && gtab != nullptr && uniptr<COOP>(w.bulk) != nullptr && claims == nullptr &&
+	                     p.ident_fast != 0 && p.nh <= 8;
+	uint32_t bulk_skip = 0, lin_steps = 0;
 	for (;;) {
+		if (bulk_on) {
+			if (!bulk_skip) {
+				const uint64_t hm = head.rh < head.fh ? head.rh : head.fh;
+				const uint64_t hint = uni64<COOP>(gtab[guide_slot(hm, gmask)]);
+				if ((hint >> 63) && ((uint32_t)(hint >> 55) & 0xFFu) == guide_tag(hm)) {
+					w.head = head; w.prev_key = prev_key; w.ext = ext;
+					if (dir == FORWARD) w.nr = nbuf; else w.nl = nbuf;
+					const uint32_t took = uni32<COOP>(walk_bulk<NW, COOP>(e, w, dir, owner, contig, hint));
+					if (took) {
+#pragma unroll
+						for (int j = 0; j < KW<NW>; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
+						head.fh = uni64<COOP>(w.head.fh); head.rh = uni64<COOP>(w.head.rh);
+						prev_key.fh = uni64<COOP>(w.prev_key.fh); prev_key.rh = uni64<COOP>(w.prev_key.rh);
+						ext = uni32<COOP>(w.ext);
+						nbuf = uni32<COOP>(dir == FORWARD ? w.nr : w.nl);
+						bulk_skip = uni32<COOP>(w.bulk_skip);
+						if (uni32<COOP>(w.bulk_overflow)) { why = LIN_OVERFLOW; break; }
+						continue;
+					}
+				}
+			}
+			bulk_skip = 0;
+		}
 		// rolling states of the head shifted one base either way, before the incoming base is
 		// added (neighbour_hashes; NTC64 / NTC64L, nthash.hpp:242-304)
 		const unsigned out_s = kmer_get(head.s, 0), out_a = kmer_get(head.s, k - 1);
@@ -461,7 +748,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 		if (!key_equal(vtx_ident(p, t), prev_key)) break;
 		// path.push_back(v) / push_front(v)
 		wu_st_u8(&buf[nbuf], (uint8_t)fb, COOP);
-		nbuf++; ext++;
+		nbuf++; ext++; lin_steps++;
 		prev_key = hkey;
 		uint64_t nfh, nrh;
 		nbr(fsense, fb, nfh, nrh);
@@ -471,6 +758,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 	}
 	w.head = head; w.prev_key = prev_key; w.ext = ext; w.ins = ins;
 	if (dir == FORWARD) w.nr = nbuf; else w.nl = nbuf;
+	w.n_lin_steps += lin_steps;
 	return why;
 }
 
@@ -504,6 +792,7 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 			head = w.head; prev_key = w.prev_key; ext = w.ext;
 			n = w.nl + 1 + w.nr;
 			if (why == LIN_DEFER) { *abort = WS_DEFERRED; return -1; }
+			if (why == LIN_OVERFLOW) { *abort = WS_OVERFLOW; return -1; }
 			if (why == LIN_INS) {
 				ins_given = w.ins;
 			} else {
@@ -654,6 +943,11 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
 		sc.tbf_cap = cap - 1;
 	}
+	// the scratch of the bulk steps shares the fast tier of the trueBranch stack (no search is
+	// running while the unbranched loop is)
+	w.bulk = nullptr;
+	if (e.guide.tab) w.bulk = fast_bytes >= sizeof(BulkScratch) ? (BulkScratch*)fast : (e.bulk_pool ? e.bulk_pool + slot : nullptr);
+	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
 	sc.overflow = 0;
 	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0;
 	sc.coop = e.coop;
@@ -831,6 +1125,11 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	}
 	e.first_rec[c] = first;
 	e.status[c] = abort_status ? abort_status : (uint32_t)WS_COMPLETE;
+	if (e.wstats) {
+		wu_atomic_add_u64(&e.wstats[WSTAT_BULK_CALLS], w.n_bulk_calls, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_BULK_STEPS], w.n_bulk_steps, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_LIN_STEPS], w.n_lin_steps, sc.coop);
+	}
 	if (e.dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
 		const uint64_t t_end = wall_clock64();

@@ -261,6 +261,9 @@ typedef struct abg_stats {
 	uint64_t insert_rounds, walk_rounds, candidates, walked, rewalked, commit_breaks;
 	uint64_t commit_rounds; /* passes of the parallel commit (0: the ordered kernel ran) */
 	uint64_t generated;     /* candidates whose contigs were committed (parallel commit only) */
+	uint64_t bulk_calls, bulk_steps; /* read-guided bulk steps of the walkers: calls that advanced, vertices taken */
+	uint64_t lin_steps;     /* unbranched steps taken one at a time */
+	uint64_t guide_slots;   /* slots of the guide table of the last abg_assemble_* call (0: none) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

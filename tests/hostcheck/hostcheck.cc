@@ -61,6 +61,31 @@ struct SerialBackend {
 
 typedef abg::Session<SerialBackend> Sess;
 
+// k-mer helpers of the bulk steps against the per-base forms: window_kmer vs batch_kmer,
+// kmer_revcomp_fast vs kmer_revcomp, kmer_hashes vs vtx_rehash.  `words` holds one packed sequence
+// of `len` bases.  Returns the number of mismatches.
+template <int NW>
+static uint64_t selftest_kmer_nw(unsigned k, const uint32_t* words, uint32_t len)
+{
+	abg::Params p = abg::make_params(k, 4, 2, k, 1024);
+	const uint64_t woff[2] = { 0, (len + 15) / 16 };
+	const uint64_t koff[2] = { 0, len - k + 1 };
+	abg::Batch b{ words, woff, &len, koff, 1 };
+	uint64_t bad = 0;
+	for (uint32_t j = 0; j + k <= len; j++) {
+		abg::Vtx<NW> v;
+		v.s = abg::batch_kmer<NW>(b, 0, j, k);
+		abg::vtx_rehash(p, v);
+		const abg::Kmer<NW> w = abg::window_kmer<NW>(words, 0, j, k);
+		uint64_t fh, rh;
+		abg::kmer_hashes(w, k, fh, rh);
+		const abg::Kmer<NW> r0 = abg::kmer_revcomp(v.s, k), r1 = abg::kmer_revcomp_fast(v.s, k);
+		for (int q = 0; q < abg::KW<NW>; q++) bad += (w.w[q] != v.s.w[q]) + (r0.w[q] != r1.w[q]);
+		bad += (fh != v.fh) + (rh != v.rh);
+	}
+	return bad;
+}
+
 } // namespace
 
 extern "C" {
@@ -150,6 +175,17 @@ void hc_get_stats(void* h, abg_stats* out)
 	auto s = ((Sess*)h)->eng->stats();
 	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
 	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
+	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots;
+}
+uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)
+{
+	switch ((k + 31) / 32) {
+	case 1: return selftest_kmer_nw<1>(k, words, len);
+	case 2: return selftest_kmer_nw<2>(k, words, len);
+	case 3: return selftest_kmer_nw<3>(k, words, len);
+	case 4: return selftest_kmer_nw<4>(k, words, len);
+	default: return selftest_kmer_nw<6>(k, words, len);
+	}
 }
 // exact modulo check: returns the number of mismatches between mod64 and the hardware %
 uint64_t hc_mod_check(uint64_t m, const uint64_t* hs, uint64_t n)
