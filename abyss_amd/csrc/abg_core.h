@@ -937,6 +937,186 @@ ABG_HD Vtx<NW> nbr_vertex_lean(const Params& p, const SeedTabs& t, const Vtx<NW>
 	return make_neighbour(p, v, sense, b, fh, rh);
 }
 
+// --------------------------------------------------------------- atomics
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint64_t ld_coherent(const uint64_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD uint32_t ld_coherent(const uint32_t* p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD void st_coherent(uint64_t* p, uint64_t v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
+{
+	return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect,
+	    (unsigned long long)val);
+}
+ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { return atomicCAS(p, expect, val); }
+ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v)
+{
+	return (uint64_t)atomicMin((unsigned long long*)p, (unsigned long long)v);
+}
+// lanes of one wavefront exchanging data through memory they share (LDS or global): everything
+// written before is visible to the wave's other lanes after
+ABG_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
+{
+	return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
+}
+ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+#else
+// serial execution (tests/hostcheck): one item at a time, plain memory
+ABG_HD uint64_t ld_coherent(const uint64_t* p) { return *p; }
+ABG_HD uint32_t ld_coherent(const uint32_t* p) { return *p; }
+ABG_HD void st_coherent(uint64_t* p, uint64_t v) { *p = v; }
+ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
+{
+	uint64_t old = *p;
+	if (old == expect) *p = val;
+	return old;
+}
+ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { uint32_t o = *p; if (o == expect) *p = val; return o; }
+ABG_HD void wave_sync() {}
+ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
+ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = o + v; return o; }
+ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+#endif
+
+// Append slots for a one-item-per-lane kernel: every lane of the wave that `want`s a slot
+// gets a distinct index from *counter with ONE atomic per wavefront (ballot + prefix popcount)
+// instead of one same-address atomic per lane.  Must be reached by all active lanes together.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
+{
+	const uint64_t m = __ballot(want ? 1 : 0);
+	if (m == 0) return 0;
+	const unsigned lane = __lane_id();
+	const int leader = __ffsll((unsigned long long)m) - 1;
+	uint32_t base = 0;
+	if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+	base = (uint32_t)__shfl((int)base, leader);
+	return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+#else
+ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
+{
+	if (!want) return 0;
+	uint32_t o = *counter; *counter = o + 1; return o;
+}
+#endif
+
+// Atomics issued by a cooperative caller (a whole wavefront in lock step, see
+// abg_core.h): lane 0 performs the operation, every lane receives its result.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t expect, uint64_t val, bool coop)
+{
+	if (!coop) return cas_u64(p, expect, val);
+	uint64_t r = 0;
+	if (__lane_id() == 0) r = cas_u64(p, expect, val);
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+}
+ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop) return atomic_min_u32(p, v);
+	uint32_t r = 0;
+	if (__lane_id() == 0) r = atomic_min_u32(p, v);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop) return atomic_add_u32(p, v);
+	uint32_t r = 0;
+	if (__lane_id() == 0) r = atomic_add_u32(p, v);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool coop)
+{
+	if (!coop) return atomic_add_u64(p, v);
+	uint64_t r = 0;
+	if (__lane_id() == 0) r = atomic_add_u64(p, v);
+	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+}
+// write-through stores do not coalesce across lanes: one lane stores for the wave
+ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) st_coherent(p, v);
+}
+ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) *p = v;
+}
+ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool coop)
+{
+	if (!coop || __lane_id() == 0) *p = v;
+}
+#else
+ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool) { st_coherent(p, v); }
+ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool) { *p = v; }
+ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool) { *p = v; }
+ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
+ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool) { return atomic_min_u32(p, v); }
+ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool) { return atomic_add_u32(p, v); }
+ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool) { return atomic_add_u64(p, v); }
+#endif
+
+// ---------------------------------------------------------------- read-guided bulk steps
+// A unitig walk is a dependent chain -- every step needs the previous head -- but where the path
+// runs along a READ the chain is known ahead: the read's next k-mers are a prediction of the next
+// heads, and whether each predicted head really is the unique continuation can be checked for all
+// of them at once (the same 8 x H probes per vertex the step-by-step walk would issue, one vertex
+// per lane).  The guide table maps the canonical hash of a k-mer of a sample of the reads to where
+// that k-mer sits in the packed reads.  It is a direct-mapped, lossy table of HINTS: a wrong, stale
+// or missing entry only costs time, because every hint is verified against the head's k-mer and
+// every predicted step against the solid filter before it is taken (walk_bulk).
+struct Guide {
+	const uint64_t* tab;    // [mask + 1] hints (0 = none), see guide_pack
+	uint64_t mask;
+	const uint32_t* words;  // the packed reads the hints point into
+	uint64_t nwords;
+};
+constexpr uint32_t GUIDE_MAX_NK = 256; // k-mers of a sequence that can serve as a guide
+ABG_HD uint64_t guide_slot(uint64_t hm, uint64_t mask)
+{
+	uint64_t x = hm * 0x9E3779B97F4A7C15ULL;
+	x ^= x >> 29;
+	return x & mask;
+}
+ABG_HD uint32_t guide_tag(uint64_t hm) { return (uint32_t)(hm >> 56); }
+// valid bit | tag (8) | k-mers of the read - 1 (8) | k-mer index (8) | word offset of the read (39)
+ABG_HD uint64_t guide_pack(uint64_t woff, uint32_t pos, uint32_t nk, uint32_t tag)
+{
+	return (1ULL << 63) | ((uint64_t)(tag & 0xFFu) << 55) | ((uint64_t)(nk - 1) << 47) | ((uint64_t)pos << 39) | woff;
+}
+constexpr uint64_t GUIDE_MAX_WOFF = (1ULL << 39) - 1;
+constexpr uint32_t BULK_LANES = 64, BULK_MIN = 4;
+struct BulkScratch {
+	VKey key[BULK_LANES];         // identity of every predicted vertex
+	uint8_t good[BULK_LANES];     // the vertex is new to the walker, simple, and continues as predicted
+	uint8_t fbase[BULK_LANES];    // its one neighbour ahead
+	uint32_t dup[2 * BULK_LANES]; // open-addressing set of the chunk's identities (lane + 1)
+	uint32_t dupstop;             // first position that repeats an earlier vertex of the chunk
+	uint32_t full;                // the vertex table has no room
+	uint64_t hw[MAX_NW], hfh, hrh; // hand-over of the new head
+	// chain_bulk: where each of the (up to four) branches of a successor() call stands
+	struct Chain { uint64_t w[MAX_NW], fh, rh; uint32_t depth, state; } chain[4];
+};
+enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide has nothing more to say
+       CB_TRUE = 1,      // trueBranch answers true
+       CB_NOT_CHAIN = 2, // a vertex with no or several neighbours ahead: the general search decides
+       CB_NONE = 3 };    // not examined
+enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_N = 8 };
+
 // ------------------------------------------------------------ search scratch
 // Explicit stacks for the reference's recursive searches.  One SearchScratch per
 // concurrently running searcher (GPU thread); capacities are fixed at launch and
@@ -974,6 +1154,11 @@ struct SearchScratch {
 	uint64_t dbg_search;
 	uint64_t dbg_nodes;    // trueBranch calls entered (frames pushed)
 	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
+	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
+	BulkScratch* bulk;
+	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
+	uint64_t dbg_chain;    // profiling aid: clock ticks in chain_true_branches (when dbg_on)
+	uint32_t dbg_on;
 	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
 	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
 	VKey* la_visited;      // [LA_MAX_VISITED]
@@ -1194,6 +1379,195 @@ ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned m
 	vout = make_neighbour(p, u, (dir == FORWARD) ? SENSE : ANTISENSE, b, fh, rh);
 	return ER_LENGTH_LIMIT;
 }
+// chain_true_branches' descent along ONE branch, a read's worth of vertices at a time.  The
+// sequential rule (see chain_true_branches): at vertex v, `depth` edges down the branch -- v among
+// the chain's earlier vertices or depth >= trim: true; otherwise v joins the chain, and with
+// exactly one neighbour ahead the descent goes on there, else the branch is no plain chain.  Where
+// a guide read holds v, its following k-mers predict the next vertices: one lane each computes
+// their identities and their neighbours ahead, and the rule is then applied to all of them in
+// order.  Updates (v, depth, keys[0, depth)); returns CB_TRUE, CB_NOT_CHAIN, or CB_ACTIVE when the
+// guide has no (more) advice for v.  Even k without a mask only (identity = ordered strand hashes).
+template <int NW> struct SearchScratch;
+// (state goes in and out through bs.chain[gi]: vertex, depth, and on return the verdict)
+template <int NW, bool COOP>
+ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_in, SearchScratch<NW>& sc,
+    const unsigned gi_in, const int sense_in, const unsigned trim_in, VKey* keys_in)
+{
+	if constexpr (MASKED_BUILD<NW>) {
+		(void)p_in; (void)cnt_in; (void)sc; (void)gi_in; (void)sense_in; (void)trim_in; (void)keys_in;
+		return CB_ACTIVE;
+	} else {
+	const Params p = uniform_params<COOP>(p_in);
+	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
+	Guide g;
+	g.tab = uniptr<COOP>(sc.guide.tab); g.mask = uni64<COOP>(sc.guide.mask);
+	g.words = uniptr<COOP>(sc.guide.words); g.nwords = uni64<COOP>(sc.guide.nwords);
+	BulkScratch& bs = *uniptr<COOP>(sc.bulk);
+	const unsigned gi = uni32<COOP>(gi_in), trim = uni32<COOP>(trim_in);
+	const int sense = (int)uni32<COOP>((uint32_t)sense_in);
+	VKey* const keys = uniptr<COOP>(keys_in);
+	Vtx<NW> v;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = uni64<COOP>(bs.chain[gi].w[j]);
+	v.fh = uni64<COOP>(bs.chain[gi].fh); v.rh = uni64<COOP>(bs.chain[gi].rh);
+	uint32_t depth_io = uni32<COOP>(bs.chain[gi].depth);
+	auto done = [&](uint32_t d, uint32_t st) -> uint32_t {
+#pragma unroll
+		for (int j = 0; j < KW<NW>; j++) bs.chain[gi].w[j] = v.s.w[j];
+		bs.chain[gi].fh = v.fh; bs.chain[gi].rh = v.rh; bs.chain[gi].depth = d; bs.chain[gi].state = st;
+		return st;
+	};
+	const unsigned k = p.k;
+	const uint64_t sk0 = p.seed_k[0], sk1 = p.seed_k[1], sk2 = p.seed_k[2], sk3 = p.seed_k[3];
+	const uint64_t rk0 = p.seedrc_k[0], rk1 = p.seedrc_k[1], rk2 = p.seedrc_k[2], rk3 = p.seedrc_k[3];
+	const uint64_t sm0 = p.seed_km1[0], sm1 = p.seed_km1[1], sm2 = p.seed_km1[2], sm3 = p.seed_km1[3];
+	const uint64_t rm0 = p.seedrc_km1[0], rm1 = p.seedrc_km1[1], rm2 = p.seedrc_km1[2], rm3 = p.seedrc_km1[3];
+	const uint32_t lane0 = COOP ? lane_id() : 0u, lstep = COOP ? BULK_LANES : 1u;
+	uint32_t depth = depth_io;
+	for (;;) {
+		if (depth >= trim) return done(depth, CB_TRUE);
+		const uint64_t hm = v.rh < v.fh ? v.rh : v.fh;
+		const uint64_t hint = uni64<COOP>(g.tab[guide_slot(hm, g.mask)]);
+		if (!(hint >> 63) || ((uint32_t)(hint >> 55) & 0xFFu) != guide_tag(hm)) break;
+		const uint64_t woff = hint & GUIDE_MAX_WOFF;
+		const uint32_t pos = (uint32_t)(hint >> 39) & 0xFFu, nk = ((uint32_t)(hint >> 47) & 0xFFu) + 1u;
+		if (pos >= nk || woff + ((nk + k - 1 + 15) >> 4) > g.nwords) break;
+		bool same = true, anti = true;
+		{
+			const Kmer<NW> rk = window_kmer<NW>(g.words, woff, pos, k);
+			const Kmer<NW> hr = kmer_revcomp_fast(v.s, k);
+#pragma unroll
+			for (int j = 0; j < KW<NW>; j++) {
+				const uint64_t x = uni64<COOP>(rk.w[j]);
+				same = same & (x == v.s.w[j]);
+				anti = anti & (x == hr.w[j]);
+			}
+		}
+		if (!same && !anti) break;
+		const bool up = (sense == SENSE) == same;
+		uint32_t n = up ? nk - pos : pos + 1u;
+		if (n > BULK_LANES) n = BULK_LANES;
+		if (n > trim - depth + 1u) n = trim - depth + 1u;
+		if (n < 2) break;
+		auto vertex_at = [&](uint32_t l, Kmer<NW>& s, uint64_t& fh, uint64_t& rh) {
+			s = window_kmer<NW>(g.words, woff, up ? pos + l : pos - l, k);
+			if (!same) s = kmer_revcomp_fast(s, k);
+			kmer_hashes(s, k, fh, rh);
+		};
+		auto nbr = [&](const Kmer<NW>& s, uint64_t fh, uint64_t rh, unsigned b, uint64_t& nfh, uint64_t& nrh) {
+			if (sense == SENSE) {
+				const unsigned out = (unsigned)s.w[0] & 3u;
+				nfh = srol1(fh) ^ pick4(out, sk0, sk1, sk2, sk3) ^ seed_of(b);
+				nrh = sror1(rh ^ seed_of(3u - out)) ^ pick4(b, rm0, rm1, rm2, rm3);
+			} else {
+				const unsigned out = kmer_get(s, k - 1);
+				nfh = sror1(fh ^ seed_of(out)) ^ pick4(b, sm0, sm1, sm2, sm3);
+				nrh = (srol1(rh) ^ pick4(out, rk0, rk1, rk2, rk3)) ^ seed_of(3u - b);
+			}
+		};
+		for (uint32_t l = lane0; l < 2 * BULK_LANES; l += lstep) bs.dup[l] = 0;
+		if (lane0 == 0) bs.dupstop = n;
+		Kmer<NW> my_s; uint64_t my_fh = 0, my_rh = 0;
+#pragma unroll
+		for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
+		for (uint32_t l = lane0; l < n; l += lstep) {
+			vertex_at(l, my_s, my_fh, my_rh);
+			VKey key;
+			key.fh = my_rh < my_fh ? my_rh : my_fh;
+			key.rh = my_rh < my_fh ? my_fh : my_rh;
+			bs.key[l] = key;
+			unsigned bad = 0; // bit q: the neighbour ahead with base q is not in the solid filter
+			for (unsigned base = 0; base < p.nh; base += 4) {
+				uint8_t c[4][4];
+#pragma unroll
+				for (unsigned q = 0; q < 4; q++) {
+					uint64_t nfh, nrh;
+					nbr(my_s, my_fh, my_rh, q, nfh, nrh);
+					const uint64_t h = nrh < nfh ? nrh : nfh;
+#pragma unroll
+					for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
+				}
+#pragma unroll
+				for (unsigned q = 0; q < 4; q++) {
+#pragma unroll
+					for (unsigned i = 0; i < 4; i++) bad |= (c[q][i] < p.kc ? 1u : 0u) << q;
+				}
+			}
+			bool hit = false; // visited.find(v) among the chain's vertices before this chunk
+			for (uint32_t i = 0; i < depth; i++) hit = hit | key_equal(keys[i], key);
+			const unsigned cm = ~bad & 0xFu;
+			const bool single = cm != 0 && !(cm & (cm - 1));
+			const unsigned fb = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u;
+			bool pred = true; // the one neighbour ahead is the read's next k-mer
+			if (l + 1 < n) {
+				const uint32_t rb_pos = up ? pos + l + k : pos - l - 1u;
+				const unsigned rb = (g.words[woff + (rb_pos >> 4)] >> (2u * (rb_pos & 15u))) & 3u;
+				pred = fb == (same ? rb : 3u - rb);
+			}
+			bs.good[l] = (uint8_t)((single ? 1u : 0u) | (pred ? 2u : 0u) | (hit ? 4u : 0u));
+			bs.fbase[l] = (uint8_t)fb;
+		}
+		wave_sync();
+		for (uint32_t l = lane0; l < n; l += lstep) {
+			const VKey key = bs.key[l];
+			uint32_t slot = (uint32_t)((key.fh ^ (key.fh >> 32) ^ key.rh) * 0x9E3779B9u >> 16) & (2 * BULK_LANES - 1);
+			for (;;) {
+				const uint32_t old = cas_u32(&bs.dup[slot], 0u, l + 1u);
+				if (old == 0) break;
+				if (key_equal(bs.key[old - 1], key)) { atomic_min_u32(&bs.dupstop, old - 1 > l ? old - 1 : l); break; }
+				slot = (slot + 1) & (2 * BULK_LANES - 1);
+			}
+		}
+		wave_sync();
+		// the rule, in order: T = first position that answers true, B = first one that is no chain
+		// vertex, C = first one after which the read stops predicting
+		uint32_t T = n, B = n, C = n - 1;
+		{
+			const uint32_t ds = uni32<COOP>(ld_coherent(&bs.dupstop));
+			if (COOP) {
+				const unsigned f = lane0 < n ? (unsigned)bs.good[lane0] : 3u;
+				const uint64_t bt = wave_ballot(lane0 < n && ((f & 4u) || lane0 == ds || depth + lane0 >= trim));
+				const uint64_t bb = wave_ballot(lane0 < n && !(f & 1u));
+				const uint64_t bc = wave_ballot(lane0 < n && !(f & 2u));
+				if (bt) T = (uint32_t)__builtin_ctzll(bt);
+				if (bb) B = (uint32_t)__builtin_ctzll(bb);
+				if (bc) C = (uint32_t)__builtin_ctzll(bc);
+			} else {
+				for (uint32_t l = 0; l < n; l++) {
+					const unsigned f = bs.good[l];
+					if (T == n && ((f & 4u) || l == ds || depth + l >= trim)) T = l;
+					if (B == n && !(f & 1u)) B = l;
+					if (C == n - 1 && !(f & 2u)) C = l;
+				}
+			}
+		}
+		if (T <= B && T <= C) { sc.n_chain_steps += T; return done(depth + T, CB_TRUE); }
+		if (B <= C) { sc.n_chain_steps += B; return done(depth + B, CB_NOT_CHAIN); }
+		sc.n_chain_steps += C + 1;
+		// positions 0..C join the chain; the descent goes on at the neighbour ahead of position C
+		for (uint32_t l = lane0; l <= C; l += lstep) {
+			keys[depth + l] = bs.key[l];
+			if (l == C) {
+				if (!COOP) vertex_at(l, my_s, my_fh, my_rh);
+				uint64_t nfh, nrh;
+				const unsigned fb = bs.fbase[l];
+				nbr(my_s, my_fh, my_rh, fb, nfh, nrh);
+				kmer_shift(my_s, k, sense, fb);
+#pragma unroll
+				for (int j = 0; j < KW<NW>; j++) bs.hw[j] = my_s.w[j];
+				bs.hfh = nfh; bs.hrh = nrh;
+			}
+		}
+		wave_sync();
+#pragma unroll
+		for (int j = 0; j < KW<NW>; j++) v.s.w[j] = uni64<COOP>(bs.hw[j]);
+		v.fh = uni64<COOP>(bs.hfh); v.rh = uni64<COOP>(bs.hrh);
+		depth += C + 1;
+	}
+	return done(depth, CB_ACTIVE);
+	}
+}
+
 // trueBranch for the common shape of a real branch: a chain.  While every vertex reached has
 // exactly one neighbour ahead, trueBranch's recursion (ExtendPath.h:174-244) is a straight
 // descent that answers true as soon as it meets a vertex of the chain again (visited.find) or
@@ -1222,6 +1596,8 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 	if (!keys || trim > per_chain) return 0;
 	const unsigned lane = COOP ? lane_id() : 0u;
 	const unsigned ngroups = COOP ? 4u : 1u;
+	BulkScratch* const bulk = uniptr<COOP>(sc.bulk);
+	const bool use_guide = !MASKED_BUILD<NW> && uniptr<COOP>(sc.guide.tab) != nullptr && bulk != nullptr && p.ident_fast != 0;
 	unsigned true_mask = 0;
 	// serial callers take the branches one after the other (group 0); cooperative ones all at once
 	for (unsigned first = 0; first < 4; first += ngroups) {
@@ -1243,6 +1619,43 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 		}
 		VKey* const mykeys = keys + (uint64_t)grp * per_chain;
 		unsigned depth = 0;
+		if (use_guide) {
+			// read-guided descent first: one branch at a time, the whole wave on it (chain_bulk);
+			// the lock-step loop below carries on from wherever the guide leaves a branch
+			BulkScratch& bs = *bulk;
+			for (unsigned g = 0; g < ngroups; g++) {
+				unsigned gb = 4, seen3 = 0;
+#pragma unroll
+				for (unsigned b = 0; b < 4; b++)
+					if ((mask >> b) & 1u) { if (seen3 == first + g) gb = b; seen3++; }
+				bs.chain[g].state = CB_NONE;
+				if (gb >= 4) continue;
+				{
+					uint64_t fb, rb, fh, rh;
+					nbr_base(tabs, u, p.k, sense, fb, rb);
+					nbr_hash(tabs, sense, fb, rb, gb, fh, rh);
+					const Vtx<NW> gv = make_neighbour(p, u, sense, gb, fh, rh);
+#pragma unroll
+					for (int j = 0; j < KW<NW>; j++) bs.chain[g].w[j] = gv.s.w[j];
+					bs.chain[g].fh = gv.fh; bs.chain[g].rh = gv.rh; bs.chain[g].depth = 0;
+				}
+				wave_sync();
+				chain_bulk<NW, COOP>(p_in, cnt_in, sc, g, sense, trim, keys + (uint64_t)g * per_chain);
+			}
+			wave_sync();
+			if (active) {
+				const BulkScratch::Chain& cs = bs.chain[grp];
+				const uint32_t st = cs.state;
+				if (st != CB_NONE) {
+#pragma unroll
+					for (int j = 0; j < KW<NW>; j++) v.s.w[j] = cs.w[j];
+					v.fh = cs.fh; v.rh = cs.rh; depth = cs.depth;
+					if (st == CB_TRUE) { is_true = true; active = false; }
+					else if (st == CB_NOT_CHAIN) active = false;
+				}
+			}
+			wave_sync();
+		}
 		while (COOP ? wave_any(active) : active) {
 			if (active) {
 				const VKey key = vtx_ident(p, v);
@@ -1327,9 +1740,15 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	unsigned depth_of[4] = { 0, 0, 0, 0 }; // per edge: trim if true at trim, else D
 	if (trim > 0 && (mask & (mask - 1))) {
 		// branches that are plain chains are settled together (see chain_true_branches)
+#if defined(__HIP_DEVICE_COMPILE__)
+		const uint64_t tc0 = sc.dbg_on ? wall_clock64() : 0;
+#endif
 		const unsigned chain_true = (trim > 1) ? (sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
 		                                                  : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc))
 		                                       : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (sc.dbg_on) sc.dbg_chain += wall_clock64() - tc0;
+#endif
 		unsigned tb = 0;
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;

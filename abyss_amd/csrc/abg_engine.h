@@ -443,6 +443,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		SearchScratch<NW> sc;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
+		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
@@ -1565,14 +1566,14 @@ class Engine {
 	}
 
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
-	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0; };
+	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
 		if (wstats_) {
 			uint64_t v[WSTAT_N];
 			be_.d2h(v, wstats_, sizeof v);
-			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS];
+			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 		}
 		s.guide_slots = guide_slots_;
 		return s;
@@ -2295,29 +2296,32 @@ class Engine {
 			be_.launch_wave(nc, f, "read_prep");
 		}
 		const bool debug = getenv("ABG_WALK_DEBUG") != nullptr;
-		if (debug) { dbg_ = (uint64_t*)be_.alloc(nc * 64ull); }
+		if (debug) { dbg_ = (uint64_t*)be_.alloc(nc * 128ull); }
 		auto dump = [&](const char* what, uint32_t nwalk) {
 			if (!debug) return;
-			std::vector<uint64_t> d(nc * 8ull);
-			be_.d2h(d.data(), dbg_, nc * 64ull);
+			std::vector<uint64_t> d(nc * 16ull);
+			be_.d2h(d.data(), dbg_, nc * 128ull);
 			const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0_).count();
-			fprintf(stderr, "[walkdbg] launch+copy wall %.1f ms; ", wall_ms);
-			uint64_t best = 0, bi = 0, sum_t = 0, sum_steps = 0, sum_nodes = 0, sum_succ = 0, sum_la = 0, nn = 0;
+			uint64_t best = 0, bi = 0, nn = 0, sum[16] = { 0 };
 			for (uint32_t i = 0; i < nc; i++) {
-				const uint64_t* x = &d[i * 8ull];
+				const uint64_t* x = &d[i * 16ull];
 				if (!x[0]) continue;
-				nn++; sum_t += x[0]; sum_steps += x[1]; sum_nodes += x[2]; sum_la += x[3]; sum_succ += x[4];
+				nn++;
+				for (int q = 0; q < 16; q++) sum[q] += x[q];
 				if (x[0] > best) { best = x[0]; bi = i; }
 			}
-			const uint64_t* x = &d[bi * 8ull];
-			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu | sum: t=%.1fms steps=%llu search_ticks=%llu search_calls=%llu tbnodes=%llu | slowest: t=%.2fms steps=%llu search_ticks=%llu search_calls=%llu tbnodes=%llu x=%llu contigs=%llu st=%llu\n",
-			    what, nwalk, (unsigned long long)nn, sum_t / 1e5, (unsigned long long)sum_steps, (unsigned long long)sum_nodes,
-			    (unsigned long long)sum_la, (unsigned long long)sum_succ, x[0] / 1e5, (unsigned long long)x[1],
-			    (unsigned long long)x[2], (unsigned long long)x[3], (unsigned long long)x[4], (unsigned long long)x[5],
-			    (unsigned long long)x[6], (unsigned long long)x[7]);
-			be_.memset(dbg_, 0, nc * 64ull);
+			auto line = [&](const char* tag, const uint64_t* x) {
+				fprintf(stderr, "[walkdbg]   %s: t=%.2fms (search %.2f [chains %.2f] in %llu calls, %llu tbnodes; linear %.2f of which bulk %.2f in %llu tries / %llu hits / %llu steps; post %.2f) steps=%llu contigs=%llu\n",
+				    tag, x[0] / 1e5, x[2] / 1e5, x[12] / 1e5, (unsigned long long)x[3], (unsigned long long)x[4], x[8] / 1e5, x[5] / 1e5,
+				    (unsigned long long)x[9], (unsigned long long)x[10], (unsigned long long)x[11], x[7] / 1e5,
+				    (unsigned long long)x[1], (unsigned long long)x[6]);
+			};
+			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu launch+copy wall %.1f ms\n", what, nwalk, (unsigned long long)nn, wall_ms);
+			line("sum", sum);
+			line("slowest", &d[bi * 16ull]);
+			be_.memset(dbg_, 0, nc * 128ull);
 		};
-		if (debug) be_.memset(dbg_, 0, nc * 64ull);
+		if (debug) be_.memset(dbg_, 0, nc * 128ull);
 		uint32_t base = 0; // candidates [0, base) are accounted for
 		while (base < nc) {
 			stats_.rounds++;

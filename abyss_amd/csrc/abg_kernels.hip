@@ -750,7 +750,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 	out->walked = s.walked;
 	out->rewalked = s.rewalked;
 	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
-	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots;
+	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps;
 	return ABG_OK;
 }
 

@@ -13,139 +13,6 @@
 
 namespace abg {
 
-// --------------------------------------------------------------- atomics
-#if defined(__HIP_DEVICE_COMPILE__)
-ABG_HD uint64_t ld_coherent(const uint64_t* p)
-{
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-ABG_HD uint32_t ld_coherent(const uint32_t* p)
-{
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-ABG_HD void st_coherent(uint64_t* p, uint64_t v)
-{
-	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
-{
-	return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect,
-	    (unsigned long long)val);
-}
-ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { return atomicCAS(p, expect, val); }
-ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
-ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v)
-{
-	return (uint64_t)atomicMin((unsigned long long*)p, (unsigned long long)v);
-}
-// lanes of one wavefront exchanging data through memory they share (LDS or global): everything
-// written before is visible to the wave's other lanes after
-ABG_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
-{
-	return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
-}
-ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
-#else
-// serial execution (tests/hostcheck): one item at a time, plain memory
-ABG_HD uint64_t ld_coherent(const uint64_t* p) { return *p; }
-ABG_HD uint32_t ld_coherent(const uint32_t* p) { return *p; }
-ABG_HD void st_coherent(uint64_t* p, uint64_t v) { *p = v; }
-ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
-{
-	uint64_t old = *p;
-	if (old == expect) *p = val;
-	return old;
-}
-ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { uint32_t o = *p; if (o == expect) *p = val; return o; }
-ABG_HD void wave_sync() {}
-ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
-ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
-ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
-ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = o + v; return o; }
-ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
-#endif
-
-// Append slots for a one-item-per-lane kernel: every lane of the wave that `want`s a slot
-// gets a distinct index from *counter with ONE atomic per wavefront (ballot + prefix popcount)
-// instead of one same-address atomic per lane.  Must be reached by all active lanes together.
-#if defined(__HIP_DEVICE_COMPILE__)
-ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
-{
-	const uint64_t m = __ballot(want ? 1 : 0);
-	if (m == 0) return 0;
-	const unsigned lane = __lane_id();
-	const int leader = __ffsll((unsigned long long)m) - 1;
-	uint32_t base = 0;
-	if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-	base = (uint32_t)__shfl((int)base, leader);
-	return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-}
-#else
-ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
-{
-	if (!want) return 0;
-	uint32_t o = *counter; *counter = o + 1; return o;
-}
-#endif
-
-// Atomics issued by a cooperative caller (a whole wavefront in lock step, see
-// abg_core.h): lane 0 performs the operation, every lane receives its result.
-#if defined(__HIP_DEVICE_COMPILE__)
-ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t expect, uint64_t val, bool coop)
-{
-	if (!coop) return cas_u64(p, expect, val);
-	uint64_t r = 0;
-	if (__lane_id() == 0) r = cas_u64(p, expect, val);
-	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
-	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
-}
-ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool coop)
-{
-	if (!coop) return atomic_min_u32(p, v);
-	uint32_t r = 0;
-	if (__lane_id() == 0) r = atomic_min_u32(p, v);
-	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-}
-ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool coop)
-{
-	if (!coop) return atomic_add_u32(p, v);
-	uint32_t r = 0;
-	if (__lane_id() == 0) r = atomic_add_u32(p, v);
-	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-}
-ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool coop)
-{
-	if (!coop) return atomic_add_u64(p, v);
-	uint64_t r = 0;
-	if (__lane_id() == 0) r = atomic_add_u64(p, v);
-	return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
-	       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
-}
-// write-through stores do not coalesce across lanes: one lane stores for the wave
-ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool coop)
-{
-	if (!coop || __lane_id() == 0) st_coherent(p, v);
-}
-ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool coop)
-{
-	if (!coop || __lane_id() == 0) *p = v;
-}
-ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool coop)
-{
-	if (!coop || __lane_id() == 0) *p = v;
-}
-#else
-ABG_HD void wu_st_coherent(uint64_t* p, uint64_t v, bool) { st_coherent(p, v); }
-ABG_HD void wu_st_u32(uint32_t* p, uint32_t v, bool) { *p = v; }
-ABG_HD void wu_st_u8(uint8_t* p, uint8_t v, bool) { *p = v; }
-ABG_HD uint64_t wu_cas_u64(uint64_t* p, uint64_t e, uint64_t v, bool) { return cas_u64(p, e, v); }
-ABG_HD uint32_t wu_atomic_min_u32(uint32_t* p, uint32_t v, bool) { return atomic_min_u32(p, v); }
-ABG_HD uint32_t wu_atomic_add_u32(uint32_t* p, uint32_t v, bool) { return atomic_add_u32(p, v); }
-ABG_HD uint64_t wu_atomic_add_u64(uint64_t* p, uint64_t v, bool) { return atomic_add_u64(p, v); }
-#endif
-
 // ---------------------------------------------------------- packed read batch
 // Sequences are pure ACGT, 2 bits per base, 16 bases per 32-bit word, each sequence
 // starting on a word boundary.
@@ -249,47 +116,6 @@ ABG_HD uint64_t wt_find(const WalkTab& t, const VKey& key, uint32_t owner)
 }
 
 
-// ---------------------------------------------------------------- read-guided bulk steps
-// A unitig walk is a dependent chain -- every step needs the previous head -- but where the path
-// runs along a READ the chain is known ahead: the read's next k-mers are a prediction of the next
-// heads, and whether each predicted head really is the unique continuation can be checked for all
-// of them at once (the same 8 x H probes per vertex the step-by-step walk would issue, one vertex
-// per lane).  The guide table maps the canonical hash of a k-mer of a sample of the reads to where
-// that k-mer sits in the packed reads.  It is a direct-mapped, lossy table of HINTS: a wrong, stale
-// or missing entry only costs time, because every hint is verified against the head's k-mer and
-// every predicted step against the solid filter before it is taken (walk_bulk).
-struct Guide {
-	const uint64_t* tab;    // [mask + 1] hints (0 = none), see guide_pack
-	uint64_t mask;
-	const uint32_t* words;  // the packed reads the hints point into
-	uint64_t nwords;
-};
-constexpr uint32_t GUIDE_MAX_NK = 256; // k-mers of a sequence that can serve as a guide
-ABG_HD uint64_t guide_slot(uint64_t hm, uint64_t mask)
-{
-	uint64_t x = hm * 0x9E3779B97F4A7C15ULL;
-	x ^= x >> 29;
-	return x & mask;
-}
-ABG_HD uint32_t guide_tag(uint64_t hm) { return (uint32_t)(hm >> 56); }
-// valid bit | tag (8) | k-mers of the read - 1 (8) | k-mer index (8) | word offset of the read (39)
-ABG_HD uint64_t guide_pack(uint64_t woff, uint32_t pos, uint32_t nk, uint32_t tag)
-{
-	return (1ULL << 63) | ((uint64_t)(tag & 0xFFu) << 55) | ((uint64_t)(nk - 1) << 47) | ((uint64_t)pos << 39) | woff;
-}
-constexpr uint64_t GUIDE_MAX_WOFF = (1ULL << 39) - 1;
-constexpr uint32_t BULK_LANES = 64, BULK_MIN = 4;
-struct BulkScratch {
-	VKey key[BULK_LANES];         // identity of every predicted vertex
-	uint8_t good[BULK_LANES];     // the vertex is new to the walker, simple, and continues as predicted
-	uint8_t fbase[BULK_LANES];    // its one neighbour ahead
-	uint32_t dup[2 * BULK_LANES]; // open-addressing set of the chunk's identities (lane + 1)
-	uint32_t dupstop;             // first position that repeats an earlier vertex of the chunk
-	uint32_t full;                // the vertex table has no room
-	uint64_t hw[MAX_NW], hfh, hrh; // hand-over of the new head
-};
-enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_N = 8 };
-
 // ------------------------------------------------------------- walker output
 enum WalkStatus : uint32_t {
 	WS_NONE = 0,      // not walked yet
@@ -332,7 +158,7 @@ struct WalkEnv {
 	void* fast; uint32_t fast_bytes;
 	VKey* la_pool;
 	uint8_t* lbuf_pool; uint8_t* rbuf_pool; uint32_t buf_cap;
-	uint64_t* dbg;             // optional [ncand][8] per-walker work counters (profiling aid)
+	uint64_t* dbg;             // optional [ncand][16] per-walker work counters (profiling aid)
 	bool coop;                 // the walker is a whole wavefront in lock step
 	Guide guide;               // read-guided bulk steps (tab == NULL: off)
 	BulkScratch* bulk_pool;    // [slots] scratch of the bulk steps when the fast memory has no room for it
@@ -359,6 +185,8 @@ struct WalkState {
 	uint32_t bulk_skip;    // the head is known not to start a bulk step (the last one stopped at it)
 	uint32_t bulk_overflow; // the vertex table filled up during a bulk step
 	uint32_t n_bulk_calls, n_bulk_steps, n_lin_steps; // work counters of this walker
+	uint32_t n_bulk_tries;
+	uint64_t t_bulk, t_lin, t_post; // profiling aid (ABG_WALK_DEBUG): clock ticks in walk_bulk / walk_linear / after the extensions
 };
 template <int NW>
 ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
@@ -578,10 +406,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 			bs.hfh = nfh; bs.hrh = nrh;
 		}
 	}
-#if defined(__HIP_DEVICE_COMPILE__)
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // the table entries are there for whoever looks next
-#endif
-	wave_sync();
+	wave_sync(); // (write-through stores, acknowledged: the table entries are there for whoever looks next)
 #pragma unroll
 	for (int j = 0; j < KW<NW>; j++) w.head.s.w[j] = uni64<COOP>(bs.hw[j]);
 	w.head.fh = uni64<COOP>(bs.hfh); w.head.rh = uni64<COOP>(bs.hrh);
@@ -665,7 +490,9 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 				if ((hint >> 63) && ((uint32_t)(hint >> 55) & 0xFFu) == guide_tag(hm)) {
 					w.head = head; w.prev_key = prev_key; w.ext = ext;
 					if (dir == FORWARD) w.nr = nbuf; else w.nl = nbuf;
+					const uint64_t tb0 = dbg_clock(e.dbg);
 					const uint32_t took = uni32<COOP>(walk_bulk<NW, COOP>(e, w, dir, owner, contig, hint));
+					if (e.dbg) { w.t_bulk += dbg_clock(e.dbg) - tb0; w.n_bulk_tries++; }
 					if (took) {
 #pragma unroll
 						for (int j = 0; j < KW<NW>; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
@@ -787,8 +614,10 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	for (;;) {
 		if (pending && lean) {
 			w.head = head; w.prev_key = prev_key; w.ext = ext;
+			const uint64_t tl0 = dbg_clock(e.dbg);
 			const uint32_t why = sc.coop ? walk_linear<NW, true>(e, w, dir, owner, contig, claim_id, may_defer)
 			                             : walk_linear<NW, false>(e, w, dir, owner, contig, claim_id, may_defer);
+			if (e.dbg) w.t_lin += dbg_clock(e.dbg) - tl0;
 			head = w.head; prev_key = w.prev_key; ext = w.ext;
 			n = w.nl + 1 + w.nr;
 			if (why == LIN_DEFER) { *abort = WS_DEFERRED; return -1; }
@@ -936,6 +765,16 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	sc.tb_cap = e.tb_cap;
 	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
 	sc.la = sc.la_local;
+	// the scratch of the read-guided bulk steps (walk_bulk, chain_bulk): in fast memory when that
+	// leaves the trueBranch stack a decent fast tier, else in the walker's global scratch
+	w.bulk = nullptr;
+	if (e.guide.tab) {
+		const uint32_t bb = (uint32_t)((sizeof(BulkScratch) + 15) & ~15ull);
+		if (fast_bytes >= bb + 64u * (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey))) { w.bulk = (BulkScratch*)fast; fast += bb; fast_bytes -= bb; }
+		else if (e.bulk_pool) w.bulk = e.bulk_pool + slot;
+	}
+	sc.guide = e.guide; sc.bulk = w.bulk;
+	if (!w.bulk) sc.guide.tab = nullptr;
 	{
 		// trueBranch keys and frames side by side
 		uint32_t cap = fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
@@ -943,13 +782,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
 		sc.tbf_cap = cap - 1;
 	}
-	// the scratch of the bulk steps shares the fast tier of the trueBranch stack (no search is
-	// running while the unbranched loop is)
-	w.bulk = nullptr;
-	if (e.guide.tab) w.bulk = fast_bytes >= sizeof(BulkScratch) ? (BulkScratch*)fast : (e.bulk_pool ? e.bulk_pool + slot : nullptr);
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
+	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0;
 	sc.overflow = 0;
-	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0;
+	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1000,6 +836,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (rcode < 0) break;
 		uint32_t n = w.nl + 1 + w.nr;
 		total_steps += n;
+		const uint64_t tp0 = dbg_clock(e.dbg);
 
 		const bool tip = is_tip(n, lcode, rcode, p.trim);
 		if (tip && e.claims) {
@@ -1018,7 +855,9 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			if (off + need > e.pool_cap) { abort_status = WS_OVERFLOW; break; }
 			uint8_t* S = e.pool + off + 1;
 			uint64_t slen = (uint64_t)n + k - 1;
-			for (uint64_t j = 0; j < slen; j++) S[j] = (uint8_t)ws_base(p, w, (uint32_t)j);
+			// (a cooperative caller's lanes copy 64 bases at a time)
+			for (uint64_t j = sc.coop ? lane_id() : 0u; j < slen; j += sc.coop ? 64u : 1u) S[j] = (uint8_t)ws_base(p, w, (uint32_t)j);
+			wave_sync();
 			int64_t lo = 0, hi = (int64_t)n; // path = vertices [lo, hi) over S
 			// ---- trimBranchKmers (bloom-dbg.h:723-757)
 			Vtx<NW> popped[2]; bool popped_earlier[2]; int npopped = 0;
@@ -1122,6 +961,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			}
 		}
 		contig++;
+		if (e.dbg) w.t_post += dbg_clock(e.dbg) - tp0;
 	}
 	e.first_rec[c] = first;
 	e.status[c] = abort_status ? abort_status : (uint32_t)WS_COMPLETE;
@@ -1129,6 +969,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		wu_atomic_add_u64(&e.wstats[WSTAT_BULK_CALLS], w.n_bulk_calls, sc.coop);
 		wu_atomic_add_u64(&e.wstats[WSTAT_BULK_STEPS], w.n_bulk_steps, sc.coop);
 		wu_atomic_add_u64(&e.wstats[WSTAT_LIN_STEPS], w.n_lin_steps, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_CHAIN_STEPS], sc.n_chain_steps, sc.coop);
 	}
 	if (e.dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1136,9 +977,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 #else
 		const uint64_t t_end = 0;
 #endif
-		uint64_t* d = e.dbg + (uint64_t)c * 8;
+		uint64_t* d = e.dbg + (uint64_t)c * 16;
 		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
-		d[4] = sc.dbg_nodes; d[5] = 0; d[6] = contig; d[7] = abort_status;
+		d[4] = sc.dbg_nodes; d[5] = w.t_bulk; d[6] = contig; d[7] = w.t_post;
+		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
 	}
 }
 

@@ -264,6 +264,7 @@ typedef struct abg_stats {
 	uint64_t bulk_calls, bulk_steps; /* read-guided bulk steps of the walkers: calls that advanced, vertices taken */
 	uint64_t lin_steps;     /* unbranched steps taken one at a time */
 	uint64_t guide_slots;   /* slots of the guide table of the last abg_assemble_* call (0: none) */
+	uint64_t chain_steps;   /* branch-chain vertices settled a read at a time (successor()'s trueBranch chains) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

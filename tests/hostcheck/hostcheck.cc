@@ -48,9 +48,13 @@ struct SerialBackend {
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
 	template <class F> void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name) { launch_slots(n, f, slots, name); }
 	void sync_side() {}
-	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests
-	alignas(16) unsigned char fastbuf[2048];
-	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, (uint32_t)sizeof fastbuf, false); }
+	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests;
+	// HC_FAST_BYTES=16384 gives the walkers what the device gives them (the chain searches and the
+	// bulk scratch then live in it as they do in LDS)
+	alignas(16) unsigned char fastbuf[16384];
+	uint32_t fast_bytes = 2048;
+	SerialBackend() { if (const char* e = getenv("HC_FAST_BYTES")) fast_bytes = (uint32_t)std::min<long>(sizeof fastbuf, std::max<long>(1024, atol(e))); }
+	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false); }
 	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
@@ -175,7 +179,7 @@ void hc_get_stats(void* h, abg_stats* out)
 	auto s = ((Sess*)h)->eng->stats();
 	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
 	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
-	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots;
+	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps;
 }
 uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)
 {
