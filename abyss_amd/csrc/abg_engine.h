@@ -45,7 +45,8 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
-	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
+	uint32_t pipeline_depth = 2;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
+	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
@@ -474,28 +475,6 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
 		}
 		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
-	}
-};
-
-// A classification made against an older visited snapshot (see Engine::prefetch_classify) is
-// brought up to date: BLUNT_END / NOT_SOLID do not depend on the snapshot and "all k-mers
-// visited" is final once true, so only the candidates are tested again.
-template <int NW>
-struct FRefilter {
-	Params p; Batch b; const uint8_t* vis; uint8_t* result;
-	ABG_HDN void operator()(uint64_t r, uint32_t) const
-	{
-		if (result[r] != RES_CANDIDATE) return;
-		const unsigned k = p.k;
-		const uint32_t nk = b.len[r] - k + 1;
-		Vtx<NW> v;
-		v.s = batch_kmer<NW>(b, r, 0, k);
-		vtx_rehash(p, v);
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(p, v))) return;
-		}
-		result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
 	}
 };
 
@@ -1303,12 +1282,14 @@ class Engine {
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
-		if (la_pool2_) be_.free(la_pool2_);
+		if (la_pool_c_) be_.free(la_pool_c_);
 		if (guide_tab_) be_.free(guide_tab_);
 		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
 		free_insert();
-		free_walk();
+		for (int i = 0; i < MAX_CTX; i++) { use_ctx(i); free_walk(); }
+		if (cend_.hmin) free_tab(cend_);
+		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
 	// contigEndKmers -- without giving any memory back (claim tables and time stamps are
@@ -1326,7 +1307,7 @@ class Engine {
 		p2_batch_ = cfg_.p2_first_batch;
 		last_candidates_ = 0;
 		needed_frac_ = 1.0;
-		if (walk_ready_) {
+		if (cend_.hmin) {
 			be_.memset(cend_.hmin, 0xFF, (cend_.mask + 1) * 8);
 			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
 		}
@@ -1365,7 +1346,6 @@ class Engine {
 		// measuring what the partitioned path itself costs
 		const char* f = getenv("ABG_FORCE_DIST");
 		force_dist_ = f && atoi(f) != 0;
-		if (dist()) cfg_.prefetch_classify = false; // every rank classifies its slice of a batch instead
 		if (c.world > 1 && !comm_scaled_) {
 			// R ranks walk a batch's candidates side by side, but a batch still ends with its slowest
 			// walker: fewer, larger batches.  (Measured on one GPU with the 8x schedule: 7 batches
@@ -1486,24 +1466,25 @@ class Engine {
 
 	// ---- PASS 2 on a device-resident packed batch of reads.  results_host (b.n bytes,
 	// may be NULL) receives a ReadResult per read; contigs are delivered in commit order.
+	//
+	// The reads go through in batches (classify -> walk the candidates -> ordered commit), and up
+	// to cfg_.pipeline_depth batches are in flight: a batch's walkers run on a stream of their own
+	// while the batch before it is committed and the batch after it is classified.  A launch of
+	// walkers ends with its slowest walker (a read in a repeat spends tens of milliseconds in
+	// trueBranch searches while the average read needs a few), so with one batch at a time most of
+	// the machine idles through every batch's tail.  The walks are pure functions of the read and
+	// the solid filter; only the commit is ordered, and it settles "visited by now" itself -- a
+	// batch classified against an older snapshot merely walks some candidates in vain.
 	void assemble_packed(const Batch& b, uint8_t* results_host,
 	    const std::function<void(const ContigOut&)>& sink)
 	{
+		use_ctx(0);
 		ensure_walk();
 		gather_counters();
 		build_guide(b);
-		uint64_t done = 0;
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
-		full_b_ = &b; result_base_ = result_d; pre_n_ = 0;
-		while (done < b.n) {
-			uint64_t bs = std::min<uint64_t>(p2_batch_, b.n - done);
-			assemble_range(b, done, bs, result_d, results_host, sink);
-			done += bs;
-			counters_.reads_processed += bs;
-			p2_batch_ = next_batch_size();
-		}
-		be_.sync_side();
-		full_b_ = nullptr; pre_n_ = 0; prefetch_ = nullptr;
+		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
+		use_ctx(0);
 		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);
 	}
@@ -1550,23 +1531,8 @@ class Engine {
 		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * cfg_.p2_starved_growth, 8 * cfg_.p2_max_batch);
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
-	// Classification of the NEXT batch on the side stream, queued right before this batch's walkers
-	// so that it fills the machine while they thin out (a batch ends with its slowest walker).  It
-	// sees an older visited snapshot; FRefilter brings it up to date when its turn comes.
-	template <int NW>
-	void prefetch_classify(uint64_t next_first, uint64_t next_n)
-	{
-		if (!next_n || !cfg_.prefetch_classify) return;
-		if (!la_pool2_) la_pool2_ = (VKey*)be_.alloc((uint64_t)cslots2_ * LA_MAX_VISITED * sizeof(VKey));
-		Batch vn = *full_b_;
-		vn.woff += next_first; vn.len += next_first; vn.koff += next_first; vn.n = next_n;
-		FClassify<NW> f{ p_, vn, 0, cnt_, vis_, result_base_ + next_first, la_pool2_ };
-		be_.launch_slots_side(next_n, f, cslots2_, "classify");
-		pre_first_ = next_first; pre_n_ = next_n;
-	}
-
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
-	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0; };
+	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -1670,7 +1636,7 @@ class Engine {
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
 	bool walk_ready_ = false;
-	WalkTab wtab_{}, cend_{};
+	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
 	uint64_t wtab_per_walker_ = 1536; // planning figure: vertices one walker enters (config 2 averages ~1100)
 	uint32_t* wclaims_ = nullptr;
@@ -1683,10 +1649,7 @@ class Engine {
 	uint64_t cend_count_ = 0;
 	uint8_t* read_flag_ = nullptr;
 	uint64_t last_candidates_ = 0;
-	const Batch* full_b_ = nullptr; uint8_t* result_base_ = nullptr; // the assemble_packed call in progress
-	uint64_t pre_first_ = 0, pre_n_ = 0;      // range classified ahead on the side stream
-	std::function<void()> prefetch_;
-	VKey* la_pool2_ = nullptr; uint32_t cslots2_ = 65536;
+	VKey* la_pool_c_ = nullptr; // lookAhead scratch of the classification (the walkers have their own per context)
 	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	// ---- -g state: the vertices seen by any search so far
@@ -1900,14 +1863,16 @@ class Engine {
 	void ensure_walk()
 	{
 		if (walk_ready_) return;
-		p2_batch_ = cfg_.p2_first_batch;
+		if (!cend_.hmin) { // (shared by all contexts)
+			p2_batch_ = cfg_.p2_first_batch;
+			cslots_ = std::min<uint32_t>(be_.max_slots(), 65536u);
+			alloc_tab(cend_, cfg_.cend_log2);
+		}
 		wslots_ = std::min<uint32_t>(be_.max_slots(), cfg_.walk_slots);
-		cslots_ = std::min<uint32_t>(be_.max_slots(), 65536u);
-		alloc_tab(cend_, cfg_.cend_log2);
 		wtab_log2_ = cfg_.wtab_log2;
 		alloc_tab(wtab_, wtab_log2_);
 		wclaims_ = (uint32_t*)be_.alloc(4ull << cfg_.wclaim_log2);
-		la_pool_ = (VKey*)be_.alloc((uint64_t)std::max(wslots_, cslots_) * LA_MAX_VISITED * sizeof(VKey));
+		la_pool_ = (VKey*)be_.alloc((uint64_t)wslots_ * LA_MAX_VISITED * sizeof(VKey));
 		bulk_pool_ = (BulkScratch*)be_.alloc((uint64_t)wslots_ * sizeof(BulkScratch));
 		if (!wstats_) { wstats_ = (uint64_t*)be_.alloc(WSTAT_N * 8); be_.memset(wstats_, 0, WSTAT_N * 8); }
 		walk_tb_cap_ = cfg_.tb_cap;
@@ -1946,9 +1911,8 @@ class Engine {
 	void free_walk()
 	{
 		if (!walk_ready_) return;
-		free_tab(cend_); free_tab(wtab_);
+		free_tab(wtab_);
 		be_.free(wclaims_); be_.free(la_pool_); be_.free(bulk_pool_);
-		if (wstats_) { be_.free(wstats_); wstats_ = nullptr; }
 		free_walk_scratch();
 		be_.free(pool_); be_.free(kh_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
 		be_.free(order_); be_.free(order_n_);
@@ -2263,171 +2227,338 @@ class Engine {
 		be_.memset(wtab_.meta, 0xFF, (wtab_.mask + 1) * 8);
 	}
 
-	// One batch of reads.  Every candidate is walked once with deferral (a walker that
-	// meets the territory of a lower-numbered read stops: its read is almost always visited
-	// by its turn).  Then, until all candidates are accounted for: predict which deferred
-	// candidates will be needed after all, walk those privately in parallel, and run the
-	// ordered commit as far as the results allow.  Walk results are pure functions of the
-	// read and the solid filter, so they stay valid across iterations.
-	template <int NW>
-	void run_rounds(const Batch& b, std::vector<uint32_t>& cand_h, uint8_t* result_d,
-	    uint64_t read_base, const std::function<void(const ContigOut&)>& sink)
+	// ---- one batch of reads in flight -----------------------------------------------------
+	// Every candidate is walked; then the ordered commit runs as far as the results allow.  (With
+	// the deferral stage -- taken when most candidates of the previous batch turned out not to be
+	// needed -- every candidate first walks until it meets the territory of a lower-numbered read,
+	// a predictor picks the ones that will be needed after all, and those are walked privately.)
+	// Walk results are pure functions of the read and the solid filter, so they stay valid across
+	// iterations and across commits of earlier batches.
+	struct BatchRun {
+		Batch v{};                  // the batch's reads
+		uint64_t first = 0, n = 0;  // ... which are reads [first, first + n) of the call
+		uint8_t* res_d = nullptr;   // their verdicts
+		std::vector<uint32_t> cand_h;
+		uint32_t nc = 0;
+		uint32_t* cand_d = nullptr; uint32_t* status_d = nullptr; uint32_t* first_d = nullptr;
+		uint32_t* list_d = nullptr; uint32_t* need_d = nullptr; uint32_t* need_n = nullptr; uint64_t* rkoff_d = nullptr;
+		uint32_t base = 0;          // candidates [0, base) are accounted for
+		uint32_t prepped = 0, owner_next = 0, committed = 0, force = 0xFFFFFFFFu, nneed = 0, nneed_all = 0;
+		uint64_t batch_rewalked = 0;
+		bool round_started = false; // the prologue of a round (see start_round) ran for `base`
+		bool predicted = false;     // ... including the first prediction
+		bool pending = false;       // ... and its walkers are running (or done) but not yet accounted for
+		bool overflow = false, debug = false;
+	};
+	// what a batch in flight owns besides: vertex table, walker scratch, contig pool and records
+	struct WalkRes {
+		bool ready = false;
+		WalkTab wtab{}; uint32_t wtab_log2 = 0; uint32_t* wclaims = nullptr;
+		void* tb_pool = nullptr; VKey* tbk_pool = nullptr; VKey* la_pool = nullptr; uint8_t* lbuf = nullptr; uint8_t* rbuf = nullptr;
+		BulkScratch* bulk_pool = nullptr;
+		uint8_t* pool = nullptr; uint64_t pool_cap = 0; uint64_t* pool_used = nullptr; uint64_t* kh = nullptr;
+		ContigRec* recs = nullptr; uint32_t rec_cap = 0; uint32_t* rec_used = nullptr; uint32_t* order = nullptr; uint32_t* order_n = nullptr;
+		uint32_t walk_tb_cap = 0, walk_buf_cap = 0, wslots = 0;
+		uint64_t* rkh = nullptr; uint8_t* read_flag = nullptr; uint64_t* dbg = nullptr; uint32_t g_rec = 0; uint64_t g_pool = 0;
+	};
+	static constexpr int MAX_CTX = 4;
+	WalkRes res_[MAX_CTX];
+	BatchRun run_[MAX_CTX];
+	int cur_ctx_ = 0;
+	// the engine's walker members ARE the current context: switching swaps them
+	void use_ctx(int i)
 	{
-		const uint32_t nc = (uint32_t)cand_h.size();
-		const uint32_t cmask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1);
-		uint32_t* cand_d = (uint32_t*)be_.alloc(nc * 4ull);
-		uint32_t* status_d = (uint32_t*)be_.alloc(nc * 4ull);
-		uint32_t* first_d = (uint32_t*)be_.alloc(nc * 4ull);
-		uint32_t* list_d = (uint32_t*)be_.alloc(nc * 4ull);
-		uint32_t* need_d = (uint32_t*)be_.alloc(nc * 4ull);
-		uint32_t* need_n = (uint32_t*)be_.alloc(8);
-		be_.h2d(cand_d, cand_h.data(), nc * 4ull);
-		// hashes of the candidates' read k-mers, used by the predictor and the commit
+		if (i == cur_ctx_) return;
+		WalkRes& o = res_[cur_ctx_];
+		o.ready = walk_ready_; o.wtab = wtab_; o.wtab_log2 = wtab_log2_; o.wclaims = wclaims_;
+		o.tb_pool = tb_pool_; o.tbk_pool = tbk_pool_; o.la_pool = la_pool_; o.lbuf = lbuf_; o.rbuf = rbuf_; o.bulk_pool = bulk_pool_;
+		o.pool = pool_; o.pool_cap = pool_cap_; o.pool_used = pool_used_; o.kh = kh_;
+		o.recs = recs_; o.rec_cap = rec_cap_; o.rec_used = rec_used_; o.order = order_; o.order_n = order_n_;
+		o.walk_tb_cap = walk_tb_cap_; o.walk_buf_cap = walk_buf_cap_; o.wslots = wslots_;
+		o.rkh = rkh_; o.read_flag = read_flag_; o.dbg = dbg_; o.g_rec = g_rec_; o.g_pool = g_pool_;
+		const WalkRes& n = res_[i];
+		walk_ready_ = n.ready; wtab_ = n.wtab; wtab_log2_ = n.wtab_log2; wclaims_ = n.wclaims;
+		tb_pool_ = n.tb_pool; tbk_pool_ = n.tbk_pool; la_pool_ = n.la_pool; lbuf_ = n.lbuf; rbuf_ = n.rbuf; bulk_pool_ = n.bulk_pool;
+		pool_ = n.pool; pool_cap_ = n.pool_cap; pool_used_ = n.pool_used; kh_ = n.kh;
+		recs_ = n.recs; rec_cap_ = n.rec_cap; rec_used_ = n.rec_used; order_ = n.order; order_n_ = n.order_n;
+		walk_tb_cap_ = n.walk_tb_cap; walk_buf_cap_ = n.walk_buf_cap; wslots_ = n.wslots;
+		rkh_ = n.rkh; read_flag_ = n.read_flag; dbg_ = n.dbg; g_rec_ = n.g_rec; g_pool_ = n.g_pool;
+		cur_ctx_ = i;
+	}
+	// how many batches may be in flight right now: the deferral stage and the partitioned run keep
+	// rank-local / cross-batch state and go one batch at a time
+	uint32_t depth_now() const
+	{
+		if (dist() || needed_frac_ < 0.5) return 1;
+		return std::max<uint32_t>(1, std::min<uint32_t>(cfg_.pipeline_depth, MAX_CTX));
+	}
+
+	template <int NW>
+	void assemble_nw(const Batch& b, uint8_t* result_d, uint8_t* results_host,
+	    const std::function<void(const ContigOut&)>& sink)
+	{
+		uint64_t next = 0;          // first read not yet classified
+		std::vector<int> inflight;  // contexts of the batches in flight, oldest first
+		while (next < b.n || !inflight.empty()) {
+			while (next < b.n && inflight.size() < depth_now()) {
+				int ci = 0;
+				while (std::find(inflight.begin(), inflight.end(), ci) != inflight.end()) ci++;
+				use_ctx(ci);
+				ensure_walk();
+				BatchRun& r = run_[ci];
+				classify_batch<NW>(b, next, std::min<uint64_t>(p2_batch_, b.n - next), result_d, r);
+				next += r.n;
+				counters_.reads_processed += r.n;
+				p2_batch_ = next_batch_size();
+				if (r.nc) {
+					setup_batch<NW>(r);
+					// the first round's walkers start right away, on the context's own stream, unless
+					// this batch goes through alone
+					if (depth_now() > 1) start_round<NW>(r, ci, true);
+				}
+				inflight.push_back(ci);
+			}
+			const int ci = inflight.front();
+			inflight.erase(inflight.begin());
+			use_ctx(ci);
+			BatchRun& r = run_[ci];
+			if (r.nc) finish_batch<NW>(r, ci, sink);
+			if (results_host) {
+				be_.d2h(results_host + r.first, r.res_d, r.n);
+				for (uint64_t i = 0; i < r.n; i++)
+					if (results_host[r.first + i] == RES_CANDIDATE) {
+						fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)(r.first + i));
+						abort();
+					}
+			}
+		}
+	}
+
+	// Verdicts of reads [first, first + n) against the current visited snapshot, and the batch they
+	// make: the longest prefix holding at most cfg_.p2_max_candidates candidates (what the walkers'
+	// tables and the commit's positions are sized for); the rest is classified again later.
+	template <int NW>
+	void classify_batch(const Batch& b, uint64_t first, uint64_t n, uint8_t* result_d, BatchRun& r)
+	{
+		Batch v = b;
+		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
+		uint8_t* res_d = result_d + first;
+		if (!la_pool_c_) la_pool_c_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
+		if (dist()) {
+			// every rank classifies a slice of the batch; the verdicts are gathered
+			const uint64_t R = (uint64_t)comm_.world;
+			std::vector<uint64_t> c(R), d(R);
+			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
+			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_c_ };
+			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
+			c_all_gather_v(res_d, c.data(), d.data());
+		} else {
+			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_c_ };
+			be_.launch_slots(n, f, cslots_, "classify");
+		}
+		std::vector<uint8_t> res(n);
+		be_.d2h(res.data(), res_d, n);
+		r = BatchRun();
+		uint64_t used = n;
+		for (uint64_t i = 0; i < n; i++) {
+			if (res[i] == RES_CANDIDATE) {
+				if (r.cand_h.size() >= cfg_.p2_max_candidates) { used = i; break; }
+				r.cand_h.push_back((uint32_t)i);
+			}
+			if (res[i] == RES_CANDIDATE || res[i] == RR_ALL_KMERS_VISITED) counters_.solid_reads++;
+			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
+		}
+		v.n = used;
+		r.v = v; r.first = first; r.n = used; r.res_d = res_d;
+		r.nc = (uint32_t)r.cand_h.size();
+		if (used < n) stats_.batch_cuts++;
+		stats_.candidates += r.nc;
+		last_candidates_ = r.nc;
+	}
+
+	// per-batch arrays and the hashes of the candidates' read k-mers (predictor, commit)
+	template <int NW>
+	void setup_batch(BatchRun& r)
+	{
+		const uint32_t nc = r.nc;
+		const Batch& b = r.v;
+		r.cand_d = (uint32_t*)be_.alloc(nc * 4ull);
+		r.status_d = (uint32_t*)be_.alloc(nc * 4ull);
+		r.first_d = (uint32_t*)be_.alloc(nc * 4ull);
+		r.list_d = (uint32_t*)be_.alloc(nc * 4ull);
+		r.need_d = (uint32_t*)be_.alloc(nc * 4ull);
+		r.need_n = (uint32_t*)be_.alloc(8);
+		be_.h2d(r.cand_d, r.cand_h.data(), nc * 4ull);
 		std::vector<uint32_t> len_h(b.n);
 		be_.d2h(len_h.data(), b.len, b.n * 4ull);
 		std::vector<uint64_t> rkoff(nc + 1, 0);
-		for (uint32_t i = 0; i < nc; i++) rkoff[i + 1] = rkoff[i] + (len_h[cand_h[i]] - p_.k + 1);
-		uint64_t* rkoff_d = (uint64_t*)be_.alloc((nc + 1) * 8ull);
-		be_.h2d(rkoff_d, rkoff.data(), (nc + 1) * 8ull);
+		for (uint32_t i = 0; i < nc; i++) rkoff[i + 1] = rkoff[i] + (len_h[r.cand_h[i]] - p_.k + 1);
+		r.rkoff_d = (uint64_t*)be_.alloc((nc + 1) * 8ull);
+		be_.h2d(r.rkoff_d, rkoff.data(), (nc + 1) * 8ull);
 		rkh_ = (uint64_t*)be_.alloc(std::max<uint64_t>(rkoff[nc], 1) * 8);
 		read_flag_ = (uint8_t*)be_.alloc(nc);
 		{
-			FReadPrep<NW> f{ p_, b, cand_d, rkoff_d, rkh_, 0 };
+			FReadPrep<NW> f{ p_, b, r.cand_d, r.rkoff_d, rkh_, 0 };
 			be_.launch_wave(nc, f, "read_prep");
 		}
-		const bool debug = getenv("ABG_WALK_DEBUG") != nullptr;
-		if (debug) { dbg_ = (uint64_t*)be_.alloc(nc * 128ull); }
-		auto dump = [&](const char* what, uint32_t nwalk) {
-			if (!debug) return;
-			std::vector<uint64_t> d(nc * 16ull);
-			be_.d2h(d.data(), dbg_, nc * 128ull);
-			const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0_).count();
-			uint64_t best = 0, bi = 0, nn = 0, sum[16] = { 0 };
-			for (uint32_t i = 0; i < nc; i++) {
-				const uint64_t* x = &d[i * 16ull];
-				if (!x[0]) continue;
-				nn++;
-				for (int q = 0; q < 16; q++) sum[q] += x[q];
-				if (x[0] > best) { best = x[0]; bi = i; }
-			}
-			auto line = [&](const char* tag, const uint64_t* x) {
-				fprintf(stderr, "[walkdbg]   %s: t=%.2fms (search %.2f [chains %.2f] in %llu calls, %llu tbnodes; linear %.2f of which bulk %.2f in %llu tries / %llu hits / %llu steps; post %.2f) steps=%llu contigs=%llu\n",
-				    tag, x[0] / 1e5, x[2] / 1e5, x[12] / 1e5, (unsigned long long)x[3], (unsigned long long)x[4], x[8] / 1e5, x[5] / 1e5,
-				    (unsigned long long)x[9], (unsigned long long)x[10], (unsigned long long)x[11], x[7] / 1e5,
-				    (unsigned long long)x[1], (unsigned long long)x[6]);
-			};
-			fprintf(stderr, "[walkdbg] %s n=%u ran=%llu launch+copy wall %.1f ms\n", what, nwalk, (unsigned long long)nn, wall_ms);
-			line("sum", sum);
-			line("slowest", &d[bi * 16ull]);
-			be_.memset(dbg_, 0, nc * 128ull);
+		r.debug = getenv("ABG_WALK_DEBUG") != nullptr;
+		if (r.debug) { dbg_ = (uint64_t*)be_.alloc(nc * 128ull); be_.memset(dbg_, 0, nc * 128ull); }
+		r.base = 0; r.round_started = false;
+	}
+	void dump_walkers(BatchRun& r, const char* what, uint32_t nwalk)
+	{
+		if (!r.debug) return;
+		const uint32_t nc = r.nc;
+		std::vector<uint64_t> d(nc * 16ull);
+		be_.d2h(d.data(), dbg_, nc * 128ull);
+		uint64_t best = 0, bi = 0, nn = 0, sum[16] = { 0 };
+		for (uint32_t i = 0; i < nc; i++) {
+			const uint64_t* x = &d[i * 16ull];
+			if (!x[0]) continue;
+			nn++;
+			for (int q = 0; q < 16; q++) sum[q] += x[q];
+			if (x[0] > best) { best = x[0]; bi = i; }
+		}
+		auto line = [&](const char* tag, const uint64_t* x) {
+			fprintf(stderr, "[walkdbg]   %s: t=%.2fms (search %.2f [chains %.2f] in %llu calls, %llu tbnodes; linear %.2f of which bulk %.2f in %llu tries / %llu hits / %llu steps; post %.2f) steps=%llu contigs=%llu\n",
+			    tag, x[0] / 1e5, x[2] / 1e5, x[12] / 1e5, (unsigned long long)x[3], (unsigned long long)x[4], x[8] / 1e5, x[5] / 1e5,
+			    (unsigned long long)x[9], (unsigned long long)x[10], (unsigned long long)x[11], x[7] / 1e5,
+			    (unsigned long long)x[1], (unsigned long long)x[6]);
 		};
-		if (debug) be_.memset(dbg_, 0, nc * 128ull);
-		uint32_t base = 0; // candidates [0, base) are accounted for
-		while (base < nc) {
-			stats_.rounds++;
-			// (re)start for the candidates [base, nc): nothing walked yet
-			be_.memset(status_d + base, 0, (nc - base) * 4ull);
-			be_.memset(first_d + base, 0xFF, (nc - base) * 4ull);
-			be_.memset(pool_used_, 0, 8);
-			be_.memset(rec_used_, 0, 4);
-			be_.memset(order_n_, 0, 4);
-			g_rec_ = 0; g_pool_ = 0;
-			be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
-			uint32_t prepped = 0;
-			uint32_t owner_next = 0;
-			{
-				std::vector<uint32_t> ident(nc - base);
-				for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;
-				be_.h2d(list_d, ident.data(), (nc - base) * 4ull);
-			}
-			// stage 1: everybody walks, deferring to lower-numbered walkers.  It pays when many
-			// candidates share unitigs; when most of them turned out to be needed in the previous
-			// batch they would only be walked twice, so it is skipped and everybody is walked in
-			// full by the first stage-2 launch instead.
-			const bool defer_stage = needed_frac_ < 0.5 && !dist(); // (its claims are rank-local state)
-			if (defer_stage) {
-				ensure_wtab(nc - base);
-				clear_wtab();
-				WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
-				env.claims = wclaims_;
-				env.owner_base = owner_next;
-				owner_next += nc;
-				FWalk<NW> fw{ env, list_d };
-				if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
-				be_.launch_walkers(nc - base, fw, wslots_, "walk");
-				stats_.walked += nc - base;
-				dump("walk", nc - base);
-			}
-			prep_new_records<NW>(prepped);
-			uint32_t committed = base;
-			uint32_t force = 0xFFFFFFFFu;
-			bool overflow = false;
-			uint64_t batch_rewalked = 0;
-			while (committed < nc) {
-				// stage 2: candidates without a result that lower reads will not cover
-				be_.memset(need_n, 0, 8);
-				{
-					FPredict<NW> fp{ p_, b, cand_d, status_d, vis_, rkoff_d, rkh_, wclaims_, cmask,
-						need_d, need_n, committed, force, (uint32_t)comm_.rank, (uint32_t)comm_.world };
-					be_.launch(nc - committed, fp, "predict");
-				}
-				// partitioned run: nneed = what this rank walks (every rank's c % world == rank share of the
-				// needed candidates), nneed_all = what all ranks walk together
-				uint32_t nn2[2] = { 0, 0 };
-				be_.d2h(nn2, need_n, 8);
-				uint32_t nneed = nn2[0];
-				const uint32_t nneed_all = comm_.world > 1 ? nn2[1] : nneed; // (FPredict counts need_n[1] only when it filters)
-				if (nneed_all) {
-					if (owner_next > 0xF0000000u - nc) { overflow = true; break; } // owner ids exhausted: restart
-					ensure_wtab(std::max<uint32_t>(nneed, 1));
-					clear_wtab();
-					WalkEnv<NW> env = make_env<NW>(b, cand_d, status_d, first_d);
-					env.claims = nullptr;
-					env.owner_base = owner_next;
-					owner_next += nc;
-					FWalk<NW> fw{ env, need_d };
-					if (debug) { uint32_t tmp; be_.d2h(&tmp, rec_used_, 4); dbg_t0_ = std::chrono::steady_clock::now(); }
-					if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
-					be_.launch_walkers(nneed, fw, wslots_, "rewalk");
-					stats_.rewalked += nneed_all;
-					batch_rewalked += nneed_all;
-					dump("rewalk", nneed);
-					if (dist()) merge_walk_results(need_d, nneed, status_d, first_d, nc);
-					prep_new_records<NW>(prepped);
+		fprintf(stderr, "[walkdbg] %s n=%u ran=%llu\n", what, nwalk, (unsigned long long)nn);
+		line("sum", sum);
+		line("slowest", &d[bi * 16ull]);
+		be_.memset(dbg_, 0, nc * 128ull);
+	}
+
+	// Prologue of a round over the candidates [r.base, nc) -- nothing of them walked yet -- up to and
+	// including the launch of the round's first walkers.  async: those walkers go to the stream of
+	// context ci and nobody waits for them here (finish_batch does).
+	template <int NW>
+	void start_round(BatchRun& r, int ci, bool async)
+	{
+		const uint32_t nc = r.nc, base = r.base;
+		const Batch& b = r.v;
+		stats_.rounds++;
+		be_.memset(r.status_d + base, 0, (nc - base) * 4ull);
+		be_.memset(r.first_d + base, 0xFF, (nc - base) * 4ull);
+		be_.memset(pool_used_, 0, 8);
+		be_.memset(rec_used_, 0, 4);
+		be_.memset(order_n_, 0, 4);
+		g_rec_ = 0; g_pool_ = 0;
+		be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
+		r.prepped = 0; r.owner_next = 0;
+		// stage 1: everybody walks, deferring to lower-numbered walkers.  It pays when many
+		// candidates share unitigs; when most of them turned out to be needed in the previous
+		// batch they would only be walked twice, so it is skipped and everybody is walked in
+		// full by the first stage-2 launch instead.
+		const bool defer_stage = needed_frac_ < 0.5 && !dist() && !async; // (its claims are rank-local state)
+		if (defer_stage) {
+			std::vector<uint32_t> ident(nc - base);
+			for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;
+			be_.h2d(r.list_d, ident.data(), (nc - base) * 4ull);
+			ensure_wtab(nc - base);
+			clear_wtab();
+			WalkEnv<NW> env = make_env<NW>(b, r.cand_d, r.status_d, r.first_d);
+			env.claims = wclaims_;
+			env.owner_base = r.owner_next;
+			r.owner_next += nc;
+			FWalk<NW> fw{ env, r.list_d };
+			be_.launch_walkers(nc - base, fw, wslots_, "walk", ci, false);
+			stats_.walked += nc - base;
+			dump_walkers(r, "walk", nc - base);
+		}
+		prep_new_records<NW>(r.prepped);
+		r.committed = base; r.force = 0xFFFFFFFFu; r.overflow = false; r.batch_rewalked = 0;
+		r.round_started = true;
+		predict_and_walk<NW>(r, ci, async);
+	}
+	// stage 2: the candidates without a result that lower reads will not cover are walked
+	template <int NW>
+	void predict_and_walk(BatchRun& r, int ci, bool async)
+	{
+		const uint32_t nc = r.nc;
+		const uint32_t cmask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1);
+		be_.memset(r.need_n, 0, 8);
+		{
+			FPredict<NW> fp{ p_, r.v, r.cand_d, r.status_d, vis_, r.rkoff_d, rkh_, wclaims_, cmask,
+				r.need_d, r.need_n, r.committed, r.force, (uint32_t)comm_.rank, (uint32_t)comm_.world };
+			be_.launch(nc - r.committed, fp, "predict");
+		}
+		// partitioned run: nneed = what this rank walks (every rank's c % world == rank share of the
+		// needed candidates), nneed_all = what all ranks walk together
+		uint32_t nn2[2] = { 0, 0 };
+		be_.d2h(nn2, r.need_n, 8);
+		r.nneed = nn2[0];
+		r.nneed_all = comm_.world > 1 ? nn2[1] : r.nneed; // (FPredict counts need_n[1] only when it filters)
+		r.predicted = true; r.pending = false;
+		if (!r.nneed_all) return;
+		if (r.owner_next > 0xF0000000u - nc) { r.overflow = true; return; } // owner ids exhausted: restart
+		ensure_wtab(std::max<uint32_t>(r.nneed, 1));
+		clear_wtab();
+		WalkEnv<NW> env = make_env<NW>(r.v, r.cand_d, r.status_d, r.first_d);
+		env.claims = nullptr;
+		env.owner_base = r.owner_next;
+		r.owner_next += nc;
+		FWalk<NW> fw{ env, r.need_d };
+		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk", ci, async);
+		r.pending = true;
+	}
+
+	template <int NW>
+	void finish_batch(BatchRun& r, int ci, const std::function<void(const ContigOut&)>& sink)
+	{
+		const uint32_t nc = r.nc;
+		while (r.base < nc) {
+			if (!r.round_started) start_round<NW>(r, ci, false);
+			while (r.committed < nc && !r.overflow) {
+				if (!r.predicted) predict_and_walk<NW>(r, ci, false);
+				r.predicted = false;
+				if (r.overflow) break;
+				if (r.pending) {
+					be_.wait_walkers(ci);
+					r.pending = false;
+					stats_.rewalked += r.nneed_all;
+					r.batch_rewalked += r.nneed_all;
+					dump_walkers(r, "rewalk", r.nneed);
+					if (dist()) merge_walk_results(r.need_d, r.nneed, r.status_d, r.first_d, nc);
+					prep_new_records<NW>(r.prepped);
 				}
 				// stage 3: ordered commit as far as the results allow
-				uint32_t next = use_par_commit() ? commit_par<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc)
-				                                 : commit<NW>(b, cand_d, status_d, first_d, result_d, rkoff_d, committed, nc);
+				uint32_t next = use_par_commit() ? commit_par<NW>(r.v, r.cand_d, r.status_d, r.first_d, r.res_d, r.rkoff_d, r.committed, nc)
+				                                 : commit<NW>(r.v, r.cand_d, r.status_d, r.first_d, r.res_d, r.rkoff_d, r.committed, nc);
 				if (next < nc) {
 					stats_.breaks++;
 					uint32_t st = 0;
-					be_.d2h(&st, status_d + next, 4);
-					if (st == WS_OVERFLOW) { committed = next; overflow = true; break; }
-					if (st == WS_COMPLETE || (next == committed && force == next)) {
+					be_.d2h(&st, r.status_d + next, 4);
+					if (st == WS_OVERFLOW) { r.committed = next; r.overflow = true; break; }
+					if (st == WS_COMPLETE || (next == r.committed && r.force == next)) {
 						fprintf(stderr, "abyss_amd: commit made no progress at candidate %u (status %u)\n", next, st);
 						abort();
 					}
-					force = next; // needed after all: walk it in the next iteration
+					r.force = next; // needed after all: walk it in the next iteration
 				}
-				committed = next;
+				r.committed = next;
 			}
-			deliver(cand_h, read_base, sink);
-			if (nc - base >= 64) needed_frac_ = std::min(1.0, (double)batch_rewalked / (double)(nc - base));
-			if (overflow) {
+			deliver(r.cand_h, r.first, sink);
+			if (nc - r.base >= 64) needed_frac_ = std::min(1.0, (double)r.batch_rewalked / (double)(nc - r.base));
+			if (r.overflow) {
 				// the candidate at `committed` ran out of some capacity.  Results not yet committed
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.
-				if (committed == base) grow_walk_resources();
+				stats_.overflows++;
+				if (r.committed == r.base) grow_walk_resources();
 				else wtab_per_walker_ *= 2; // most likely the vertex table: plan for longer walks from now on
 			}
-			base = committed;
+			r.base = r.committed;
+			r.round_started = false; r.predicted = false; r.pending = false;
 		}
 		be_.free(rkh_); rkh_ = nullptr;
 		be_.free(read_flag_); read_flag_ = nullptr;
-		if (debug) { be_.free(dbg_); dbg_ = nullptr; }
-		be_.free(cand_d); be_.free(status_d); be_.free(first_d); be_.free(list_d);
-		be_.free(need_d); be_.free(need_n); be_.free(rkoff_d);
-		cand_h.clear();
+		if (r.debug) { be_.free(dbg_); dbg_ = nullptr; }
+		be_.free(r.cand_d); be_.free(r.status_d); be_.free(r.first_d); be_.free(r.list_d);
+		be_.free(r.need_d); be_.free(r.need_n); be_.free(r.rkoff_d);
+		r.cand_h.clear();
 	}
 
 	void deliver(const std::vector<uint32_t>& cand_h, uint64_t read_base,
@@ -2465,74 +2596,6 @@ class Engine {
 		}
 	}
 
-	template <int NW>
-	void assemble_range_nw(const Batch& v, uint64_t first, uint64_t n, uint8_t* res_d,
-	    uint8_t* results_host, const std::function<void(const ContigOut&)>& sink)
-	{
-		if (pre_n_ == n && pre_first_ == first) {
-			be_.sync_side();
-			FRefilter<NW> f{ p_, v, vis_, res_d };
-			be_.launch(n, f, "reclassify");
-		} else if (dist()) {
-			// every rank classifies a slice of the batch; the verdicts are gathered
-			const uint64_t R = (uint64_t)comm_.world;
-			std::vector<uint64_t> c(R), d(R);
-			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
-			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_ };
-			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
-			c_all_gather_v(res_d, c.data(), d.data());
-		} else {
-			be_.sync_side();
-			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_ };
-			be_.launch_slots(n, f, cslots_, "classify");
-		}
-		pre_n_ = 0;
-		std::vector<uint8_t> res(n);
-		be_.d2h(res.data(), res_d, n);
-		std::vector<uint32_t> cand;
-		for (uint64_t i = 0; i < n; i++) {
-			if (res[i] == RES_CANDIDATE) cand.push_back((uint32_t)i);
-			if (res[i] == RES_CANDIDATE || res[i] == RR_ALL_KMERS_VISITED) counters_.solid_reads++;
-			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
-		}
-		stats_.candidates += cand.size();
-		last_candidates_ = cand.size();
-		if (full_b_ && first + n < full_b_->n) {
-			const uint64_t nf = first + n, nn = std::min<uint64_t>(next_batch_size(), full_b_->n - nf);
-			prefetch_ = [this, nf, nn]() { prefetch_classify<NW>(nf, nn); };
-		}
-		if (!cand.empty()) run_rounds<NW>(v, cand, res_d, first, sink);
-		if (results_host) {
-			be_.d2h(results_host + first, res_d, n);
-			for (uint64_t i = 0; i < n; i++)
-				if (results_host[first + i] == RES_CANDIDATE) {
-					fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)(first + i));
-					abort();
-				}
-		}
-	}
-
-	void assemble_range(const Batch& b, uint64_t first, uint64_t n, uint8_t* result_d,
-	    uint8_t* results_host, const std::function<void(const ContigOut&)>& sink)
-	{
-		// view of reads [first, first + n)
-		Batch v = b;
-		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
-		uint8_t* res_d = result_d + first;
-		// spaced seed: the build that carries the masked-out terms (see NW_MASKED, abg_core.h)
-		switch (p_.mask ? NW_MASKED + p_.nw : p_.nw) {
-		case 1: assemble_range_nw<1>(v, first, n, res_d, results_host, sink); break;
-		case 2: assemble_range_nw<2>(v, first, n, res_d, results_host, sink); break;
-		case 3: assemble_range_nw<3>(v, first, n, res_d, results_host, sink); break;
-		case 4: assemble_range_nw<4>(v, first, n, res_d, results_host, sink); break;
-		case 5: case 6: assemble_range_nw<6>(v, first, n, res_d, results_host, sink); break;
-		case NW_MASKED + 1: assemble_range_nw<NW_MASKED + 1>(v, first, n, res_d, results_host, sink); break;
-		case NW_MASKED + 2: assemble_range_nw<NW_MASKED + 2>(v, first, n, res_d, results_host, sink); break;
-		case NW_MASKED + 3: assemble_range_nw<NW_MASKED + 3>(v, first, n, res_d, results_host, sink); break;
-		case NW_MASKED + 4: assemble_range_nw<NW_MASKED + 4>(v, first, n, res_d, results_host, sink); break;
-		default: assemble_range_nw<NW_MASKED + 6>(v, first, n, res_d, results_host, sink); break;
-		}
-	}
 };
 
 } // namespace abg

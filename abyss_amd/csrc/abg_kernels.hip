@@ -172,6 +172,8 @@ struct HipBackend {
 	~HipBackend()
 	{
 		if (ticket) free(ticket);
+		for (int i = 0; i < MAX_WCTX; i++)
+			if (wstream[i]) { hipStreamSynchronize(wstream[i]); hipFree(wticket[i]); hipEventDestroy(wev0[i]); hipEventDestroy(wev1[i]); hipStreamDestroy(wstream[i]); }
 		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
@@ -368,16 +370,54 @@ struct HipBackend {
 		hipLaunchKernelGGL(k_foreach_wave<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
 		end(name);
 	}
+	// Walkers of context `ctx`.  async: on that context's own stream, after everything queued on the
+	// main stream so far; nobody waits here -- wait_walkers(ctx) does (and books the time).
+	static constexpr int MAX_WCTX = 4;
+	hipStream_t wstream[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t wev0[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr }, wev1[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
+	unsigned long long* wticket[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
+	std::string wname[MAX_WCTX];
+	bool wpending[MAX_WCTX] = { false, false, false, false };
 	template <class F>
-	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name)
+	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name, int ctx, bool async)
 	{
 		if (!n) return;
 		uint64_t blocks = n < slots ? n : slots;
-		if (!ticket) ticket = (unsigned long long*)alloc(8);
-		check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
-		begin(name);
-		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
-		end(name);
+		if (!async) {
+			if (!ticket) ticket = (unsigned long long*)alloc(8);
+			check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
+			begin(name);
+			hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
+			end(name);
+			return;
+		}
+		if (!wstream[ctx]) {
+			check(hipStreamCreateWithFlags(&wstream[ctx], hipStreamNonBlocking), "hipStreamCreate");
+			hipEventCreate(&wev0[ctx]); hipEventCreate(&wev1[ctx]);
+			check(hipMalloc((void**)&wticket[ctx], 8), "hipMalloc");
+		}
+		hipEventRecord(wev0[ctx], stream); // order after the main stream's queue
+		hipStreamWaitEvent(wstream[ctx], wev0[ctx], 0);
+		check(hipMemsetAsync(wticket[ctx], 0, 8, wstream[ctx]), "hipMemsetAsync");
+		hipEventRecord(wev0[ctx], wstream[ctx]);
+		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, wstream[ctx], f, n, wticket[ctx]);
+		check(hipGetLastError(), name);
+		hipEventRecord(wev1[ctx], wstream[ctx]);
+		wname[ctx] = name;
+		wpending[ctx] = true;
+	}
+	void wait_walkers(int ctx)
+	{
+		if (!wpending[ctx]) return;
+		check(hipEventSynchronize(wev1[ctx]), "hipEventSynchronize");
+		if (profiling) {
+			float ms = 0;
+			hipEventElapsedTime(&ms, wev0[ctx], wev1[ctx]);
+			ProfEntry& p = prof[wname[ctx]];
+			p.ms += ms;
+			p.launches++;
+		}
+		wpending[ctx] = false;
 	}
 	void launch_drain(abg::InsertDrainEnv e)
 	{

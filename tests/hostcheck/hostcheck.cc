@@ -54,7 +54,8 @@ struct SerialBackend {
 	alignas(16) unsigned char fastbuf[16384];
 	uint32_t fast_bytes = 2048;
 	SerialBackend() { if (const char* e = getenv("HC_FAST_BYTES")) fast_bytes = (uint32_t)std::min<long>(sizeof fastbuf, std::max<long>(1024, atol(e))); }
-	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false); }
+	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*, int, bool) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false); }
+	void wait_walkers(int) {}
 	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
