@@ -1115,7 +1115,62 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
        CB_TRUE = 1,      // trueBranch answers true
        CB_NOT_CHAIN = 2, // a vertex with no or several neighbours ahead: the general search decides
        CB_NONE = 3 };    // not examined
-enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_N = 8 };
+enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS, WSTAT_N = 8 };
+
+// ------------------------------------------------------- memo of successor()
+// successor(u, dir) with its iterative deepening over trueBranch searches (ExtendPath.h:314-362) is
+// a pure function of the oriented vertex, the direction and the solid filter, and by far the most
+// expensive thing a walker does where the graph is tangled -- a collapsed repeat at several times
+// the coverage carries a thicket of recurring sequencing errors, and every read of it searches the
+// same thicket.  Answers (code and, for a unique successor, its base) are therefore kept in a
+// device-wide table for as long as the solid filter stays as it is: open addressing, entries only
+// ever added, bounded probing; a full neighbourhood just means the answer is not kept.
+struct SuccMemo {
+	uint64_t* k0;   // [cap] u.fh        (MEMO_EMPTY when free)
+	uint64_t* k1;   // [cap] u.rh
+	uint64_t* val;  // [cap] 0 until complete, then 1 << 63 | dir << 8 | code << 4 | base
+	uint64_t mask;  // cap - 1; k0 == NULL: no memo
+};
+constexpr uint64_t MEMO_EMPTY = ~0ULL;
+constexpr unsigned MEMO_PROBES = 8;
+ABG_HD uint64_t memo_slot(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
+{
+	uint64_t x = (fh ^ (rh * 0x9E3779B97F4A7C15ULL)) + (uint64_t)dir;
+	x ^= x >> 31; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29;
+	return x & m.mask;
+}
+// -1: not there; else code << 4 | base
+ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
+{
+	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return -1;
+	uint64_t s = memo_slot(m, fh, rh, dir);
+	for (unsigned i = 0; i < MEMO_PROBES; i++, s = (s + 1) & m.mask) {
+		const uint64_t a = ld_coherent(&m.k0[s]);
+		if (a == MEMO_EMPTY) return -1;
+		if (a != fh) continue;
+		const uint64_t v = ld_coherent(&m.val[s]);
+		if (!(v >> 63) || (int)((v >> 8) & 1u) != dir) continue; // (an entry still being written counts as absent)
+		if (ld_coherent(&m.k1[s]) != rh) continue;
+		return (int)(v & 0xFFu);
+	}
+	return -1;
+}
+ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsigned code, unsigned base, bool coop)
+{
+	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return;
+	uint64_t s = memo_slot(m, fh, rh, dir);
+	for (unsigned i = 0; i < MEMO_PROBES; i++, s = (s + 1) & m.mask) {
+		const uint64_t cur = wu_cas_u64(&m.k0[s], MEMO_EMPTY, fh, coop);
+		if (cur == MEMO_EMPTY) {
+			wu_st_coherent(&m.k1[s], rh, coop);
+			wu_st_coherent(&m.val[s], (1ULL << 63) | ((uint64_t)(dir & 1) << 8) | ((uint64_t)code << 4) | base, coop);
+			return;
+		}
+		if (cur != fh) continue;
+		const uint64_t v = ld_coherent(&m.val[s]);
+		if ((v >> 63) && (int)((v >> 8) & 1u) == dir && ld_coherent(&m.k1[s]) == rh) return; // already there
+	}
+}
 
 // ------------------------------------------------------------ search scratch
 // Explicit stacks for the reference's recursive searches.  One SearchScratch per
@@ -1154,6 +1209,8 @@ struct SearchScratch {
 	uint64_t dbg_search;
 	uint64_t dbg_nodes;    // trueBranch calls entered (frames pushed)
 	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
+	SuccMemo memo;         // answers of successor() shared by all walkers; k0 == NULL: off
+	uint32_t n_memo_hits, n_memo_adds;
 	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
 	BulkScratch* bulk;
 	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
@@ -1727,6 +1784,28 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	uint64_t nfh[4], nrh[4];
 	neighbour_hashes(p, u, sense, nfh, nrh);
 	vout = u;
+	// (the memo holds answers for the walkers' trim only, and not under a spaced seed, whose vertices
+	// are more than their two rolling hashes)
+	const bool use_memo = sc.memo.k0 != nullptr && trim == p.trim && !MASKED_BUILD<NW> && (mask & (mask - 1));
+	if (use_memo) {
+		const int hit = memo_find(sc.memo, u.fh, u.rh, dir);
+		if (hit >= 0) {
+			sc.n_memo_hits++;
+			const int code = hit >> 4;
+			const unsigned b = (unsigned)hit & 3u;
+			if (code == ER_LENGTH_LIMIT || code == ER_AMBI_OUT) vout = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
+			return code;
+		}
+	}
+	auto answer = [&](int code) -> int {
+		if (use_memo) {
+			// the successor's base: the last (SENSE) or first (ANTISENSE) base of vout
+			const unsigned b = (code == ER_LENGTH_LIMIT || code == ER_AMBI_OUT) ? kmer_get(vout.s, sense == SENSE ? p.k - 1 : 0u) : 0u;
+			memo_add(sc.memo, u.fh, u.rh, dir, (unsigned)code, b, sc.coop);
+			sc.n_memo_adds++;
+		}
+		return code;
+	};
 	// Exact by monotonicity of trueBranch in its threshold: every condition that makes
 	// trueBranch(e, i) return true (vertex on the stack, depth >= i, a true child) also holds
 	// for any smaller threshold, while exploration order, direction changes and the visited set
@@ -1757,7 +1836,7 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 			if (((chain_true >> b) & 1u) || true_branch(p, cnt, u, w, dir, trim, sc, &d)) {
 				vout = w;
 				depth_of[b] = trim;
-				if (++tb >= 2) return ER_AMBI_OUT;
+				if (++tb >= 2) return answer(ER_AMBI_OUT);
 			} else {
 				depth_of[b] = d;
 			}
@@ -1774,9 +1853,9 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 				if (++tb >= 2) break;
 			}
 		}
-		if (tb == 0) return ER_DEAD_END;
-		if (tb == 1) return ER_LENGTH_LIMIT;
-		if (i == trim) return ER_AMBI_OUT;
+		if (tb == 0) return answer(ER_DEAD_END);
+		if (tb == 1) return answer(ER_LENGTH_LIMIT);
+		if (i == trim) return answer(ER_AMBI_OUT);
 	}
 }
 template <int NW>

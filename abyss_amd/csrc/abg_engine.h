@@ -45,7 +45,9 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
-	uint32_t pipeline_depth = 2;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
+	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
+	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
+	bool memo = true;
 	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
@@ -431,50 +433,72 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // provisional per-read result of the classify step
 constexpr uint8_t RES_CANDIDATE = 0x80;
 
+// One wave per read (nlanes == 1: a serial caller).  The k-mers of the read are spread over the
+// lanes for the two membership tests -- every lane hashes its k-mers from scratch, the H probes of
+// a k-mer go out together, one ballot folds the verdicts -- and the wave then runs the two
+// blunt-end searches in lock step (look_ahead_t's cooperative form).  `fast` is FCLASSIFY_FAST
+// bytes private to the wave (LDS on the device): the search scratch must not live in per-lane
+// memory.  The verdicts keep the reference's precedence: blunt end, not solid, visited.
+constexpr uint32_t FCLASSIFY_FAST = 1024;
 template <int NW>
-struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
+struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828)
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
 	VKey* la_pool; // [slots][LA_MAX_VISITED]
-	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes, uint32_t slot, void* fast) const
 	{
-		uint64_t r = first + i;
-		uint32_t L = b.len[r];
-		unsigned k = p.k;
-		uint32_t nk = L - k + 1;
-		SearchScratch<NW> sc;
+		static_assert(sizeof(SearchScratch<NW>) <= FCLASSIFY_FAST, "search scratch does not fit the wave's fast memory");
+		const uint64_t r = first + i;
+		const uint32_t L = b.len[r];
+		const unsigned k = p.k;
+		const uint32_t nk = L - k + 1;
+		const uint64_t woff = b.woff[r];
+		// allKmersInBloom(seq, solidKmerSet), allKmersInBloom(seq, assembledKmerSet) (bloom-dbg.h:58-77)
+		bool solid = true, visited = true;
+		for (uint32_t j = lane; j < nk; j += nlanes) {
+			const Kmer<NW> s = window_kmer<NW>(b.words, woff, j, k);
+			uint64_t h;
+			if constexpr (MASKED_BUILD<NW>) {
+				h = scratch_hash(p, [&](unsigned q) { return kmer_get(s, q); });
+			} else {
+				uint64_t fh, rh;
+				kmer_hashes(s, k, fh, rh);
+				h = rh < fh ? rh : fh;
+			}
+			bool so = true, vi = true;
+			for (unsigned q = 0; q < p.nh; q++) {
+				const uint64_t pos = pos_i(p, h, q);
+				so = so & (cnt[pos] >= p.kc);
+				vi = vi & (((vis[pos >> 3] >> (pos & 7)) & 1u) != 0);
+			}
+			solid = solid & so; visited = visited & vi;
+		}
+		solid = wave_all_lanes(solid, nlanes);
+		visited = wave_all_lanes(visited, nlanes);
+		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of the read and
+		// from the first k-mer of its reverse complement
+		SearchScratch<NW>& sc = *(SearchScratch<NW>*)fast;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
-		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
+		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = nlanes > 1;
 		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0;
+		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
-		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
-		// the read and from the first k-mer of its reverse complement
-		Vtx<NW> v;
-		v.s = batch_kmer<NW>(b, r, 0, k);
-		vtx_rehash(p, v);
-		Vtx<NW> first_v = v;
-		if (!look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
-		Vtx<NW> lastv;
-		lastv.s = batch_kmer<NW>(b, r, nk - 1, k);
-		vtx_rehash(p, lastv);
-		vtx_revcomp(p, lastv);
-		if (!look_ahead(p, cnt, lastv, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
-		// allKmersInBloom(seq, solidKmerSet) (bloom-dbg.h:58-77)
-		v = first_v;
-		bool solid = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!solid_contains(p, cnt, vtx_hash(p, v))) { solid = false; break; }
+		bool blunt;
+		{
+			Vtx<NW> v;
+			v.s = window_kmer<NW>(b.words, woff, 0, k);
+			vtx_rehash(p, v);
+			blunt = !look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc);
 		}
-		if (!solid) { result[r] = RR_NOT_SOLID; return; }
-		// allKmersInBloom(seq, assembledKmerSet) against the snapshot
-		v = first_v;
-		bool visited = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
+		if (!blunt) {
+			Vtx<NW> v;
+			v.s = window_kmer<NW>(b.words, woff, nk - 1, k);
+			vtx_rehash(p, v);
+			vtx_revcomp(p, v);
+			blunt = !look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc);
 		}
-		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
+		if (lane == 0)
+			result[r] = blunt ? (uint8_t)RR_BLUNT_END : !solid ? (uint8_t)RR_NOT_SOLID : visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
 	}
 };
 
@@ -1289,6 +1313,7 @@ class Engine {
 		free_insert();
 		for (int i = 0; i < MAX_CTX; i++) { use_ctx(i); free_walk(); }
 		if (cend_.hmin) free_tab(cend_);
+		if (memo_tab_.hmin) free_tab(memo_tab_);
 		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
@@ -1303,6 +1328,7 @@ class Engine {
 		counters_ = Counters();
 		stats_ = Stats();
 		cnt_partial_ = false;
+		memo_valid_ = false;
 		last_rounds_ = 0;
 		p2_batch_ = cfg_.p2_first_batch;
 		last_candidates_ = 0;
@@ -1318,7 +1344,7 @@ class Engine {
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	// (a partitioned run leaves only the rank's own range current until the shards are gathered)
-	uint8_t* counters_dev() { gather_counters(); return cnt_; }
+	uint8_t* counters_dev() { gather_counters(); memo_valid_ = false; /* (the caller may write) */ return cnt_; }
 
 	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
 	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
@@ -1453,6 +1479,7 @@ class Engine {
 	void load_packed(const Batch& b, const uint64_t* koff_h)
 	{
 		ensure_insert();
+		memo_valid_ = false;
 		last_rounds_ = 0;
 		// op ranges of at most insert_batch_kmers along sequence boundaries
 		uint64_t s = 0;
@@ -1482,11 +1509,29 @@ class Engine {
 		ensure_walk();
 		gather_counters();
 		build_guide(b);
+		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
 		use_ctx(0);
 		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);
+	}
+	// The memo of successor() answers (SuccMemo): emptied whenever the solid filter may have changed.
+	void ensure_memo()
+	{
+		if (!cfg_.memo || p_.mask) { memo_.k0 = nullptr; return; }
+		if (!memo_tab_.hmin) {
+			uint32_t log2 = cfg_.memo_log2;
+			if (!log2) { log2 = 16; while (log2 < 26 && (1ull << log2) < m_ / 128) log2++; }
+			alloc_tab(memo_tab_, log2);
+			memo_valid_ = false;
+		}
+		if (!memo_valid_) {
+			be_.memset(memo_tab_.hmin, 0xFF, (memo_tab_.mask + 1) * 8);
+			be_.memset(memo_tab_.meta, 0, (memo_tab_.mask + 1) * 8);
+			memo_valid_ = true;
+		}
+		memo_ = SuccMemo{ memo_tab_.hmin, memo_tab_.hmax, memo_tab_.meta, memo_tab_.mask };
 	}
 	// The guide of the bulk steps for the reads of one assemble_packed call (see FGuideBuild).  Even k
 	// without a spaced seed only (walk_bulk); sized to the sampled reads' k-mers, of which the solid
@@ -1532,7 +1577,7 @@ class Engine {
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
-	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0; };
+	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -1540,6 +1585,7 @@ class Engine {
 			uint64_t v[WSTAT_N];
 			be_.d2h(v, wstats_, sizeof v);
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
+			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
 		}
 		s.guide_slots = guide_slots_;
 		return s;
@@ -1635,6 +1681,7 @@ class Engine {
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
+	SuccMemo memo_{ nullptr, nullptr, nullptr, 0 }; WalkTab memo_tab_{ nullptr, nullptr, nullptr, 0 }; bool memo_valid_ = false; // (valid: filled against the solid filter as it is now)
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
@@ -1956,7 +2003,7 @@ class Engine {
 		e.tb_cap = walk_tb_cap_;
 		e.fast = nullptr; e.fast_bytes = 0; e.dbg = dbg_; e.coop = false;
 		e.la_pool = la_pool_;
-		e.guide = guide_; e.bulk_pool = bulk_pool_; e.wstats = wstats_;
+		e.guide = guide_; e.bulk_pool = bulk_pool_; e.wstats = wstats_; e.memo = memo_;
 		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
 		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
 		e.recs = recs_; e.rec_cap = rec_cap_; e.rec_used = rec_used_;
@@ -2343,18 +2390,18 @@ class Engine {
 		Batch v = b;
 		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
 		uint8_t* res_d = result_d + first;
-		if (!la_pool_c_) la_pool_c_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
+		if (!la_pool_c_) la_pool_c_ = (VKey*)be_.alloc((uint64_t)be_.wave_slots() * LA_MAX_VISITED * sizeof(VKey));
 		if (dist()) {
 			// every rank classifies a slice of the batch; the verdicts are gathered
 			const uint64_t R = (uint64_t)comm_.world;
 			std::vector<uint64_t> c(R), d(R);
 			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
 			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_c_ };
-			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
+			be_.launch_wave_fast(c[comm_.rank], f, "classify");
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_c_ };
-			be_.launch_slots(n, f, cslots_, "classify");
+			be_.launch_wave_fast(n, f, "classify");
 		}
 		std::vector<uint8_t> res(n);
 		be_.d2h(res.data(), res_d, n);

@@ -161,6 +161,7 @@ struct WalkEnv {
 	uint64_t* dbg;             // optional [ncand][16] per-walker work counters (profiling aid)
 	bool coop;                 // the walker is a whole wavefront in lock step
 	Guide guide;               // read-guided bulk steps (tab == NULL: off)
+	SuccMemo memo;             // shared answers of successor() (k0 == NULL: off)
 	BulkScratch* bulk_pool;    // [slots] scratch of the bulk steps when the fast memory has no room for it
 	uint64_t* wstats;          // [WSTAT_N] work counters summed over all walkers
 	// contig output
@@ -774,6 +775,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		else if (e.bulk_pool) w.bulk = e.bulk_pool + slot;
 	}
 	sc.guide = e.guide; sc.bulk = w.bulk;
+	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
 	if (!w.bulk) sc.guide.tab = nullptr;
 	{
 		// trueBranch keys and frames side by side
@@ -970,6 +972,8 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		wu_atomic_add_u64(&e.wstats[WSTAT_BULK_STEPS], w.n_bulk_steps, sc.coop);
 		wu_atomic_add_u64(&e.wstats[WSTAT_LIN_STEPS], w.n_lin_steps, sc.coop);
 		wu_atomic_add_u64(&e.wstats[WSTAT_CHAIN_STEPS], sc.n_chain_steps, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_MEMO_HITS], sc.n_memo_hits, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_MEMO_ADDS], sc.n_memo_adds, sc.coop);
 	}
 	if (e.dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)

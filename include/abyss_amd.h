@@ -265,6 +265,9 @@ typedef struct abg_stats {
 	uint64_t lin_steps;     /* unbranched steps taken one at a time */
 	uint64_t guide_slots;   /* slots of the guide table of the last abg_assemble_* call (0: none) */
 	uint64_t chain_steps;   /* branch-chain vertices settled a read at a time (successor()'s trueBranch chains) */
+	uint64_t batch_cuts;    /* PASS-2 batches cut short at the candidate cap */
+	uint64_t overflows;     /* rounds restarted because a walker ran out of some capacity */
+	uint64_t memo_hits, memo_adds; /* successor() answers taken from / added to the shared memo */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

@@ -46,6 +46,9 @@ struct SerialBackend {
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
+	uint32_t wave_slots() const { return 1; }
+	alignas(16) unsigned char wavebuf[abg::FCLASSIFY_FAST];
+	template <class F> void launch_wave_fast(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1, 0, (void*)wavebuf); }
 	template <class F> void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name) { launch_slots(n, f, slots, name); }
 	void sync_side() {}
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests;
@@ -180,7 +183,8 @@ void hc_get_stats(void* h, abg_stats* out)
 	auto s = ((Sess*)h)->eng->stats();
 	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
 	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
-	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps;
+	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
+	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
 }
 uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)
 {
