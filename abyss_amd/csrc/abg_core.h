@@ -535,14 +535,7 @@ ABG_HD void kmer_hashes(const Kmer<NW>& s, unsigned k, uint64_t& fh_out, uint64_
 template <int NW>
 ABG_HD void vtx_rehash(const Params& p, Vtx<NW>& v)
 {
-	uint64_t fh = 0, rh = 0;
-	unsigned k = p.k;
-	for (unsigned i = 0; i < k; i++) {
-		fh = srol1(fh) ^ seed_of(kmer_get(v.s, i));
-		rh = srol1(rh) ^ seed_of(3u - kmer_get(v.s, k - 1 - i));
-	}
-	v.fh = fh;
-	v.rh = rh;
+	kmer_hashes(v.s, p.k, v.fh, v.rh);
 	if constexpr (MASKED_BUILD<NW>) masked_terms(p, v.s, v.df, v.dr);
 }
 // Vertex::shift (RollingBloomDBG.h:55-63): RollingHash::rollRight / rollLeft
@@ -625,6 +618,46 @@ ABG_HD unsigned lane_id() { return 0; }
 ABG_HD uint64_t wave_ballot(bool v) { return v ? 1 : 0; }
 ABG_HD bool wave_any(bool v) { return v; }
 #endif
+
+// bits 2i, 2i + 1 of the result = bit i of lo, bit i of hi (i < 32)
+ABG_HD uint64_t interleave32(uint64_t lo, uint64_t hi)
+{
+	auto spread = [](uint64_t x) -> uint64_t {
+		x &= 0xFFFFFFFFULL;
+		x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+		x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+		x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+		x = (x | (x << 2)) & 0x3333333333333333ULL;
+		x = (x | (x << 1)) & 0x5555555555555555ULL;
+		return x;
+	};
+	return spread(lo) | (spread(hi) << 1);
+}
+// A k-mer whose bases come one at a time from get(i) (a load each).  A cooperative caller has its
+// lanes fetch 64 bases at once and folds them into the words with two ballots; everybody else
+// loops.  get(i) is only called for i < k.
+template <int NW, class Get>
+ABG_HD Kmer<NW> gather_kmer(unsigned k, bool coop, Get get)
+{
+	Kmer<NW> s;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) s.w[j] = 0;
+	if (coop) {
+		const unsigned lane = lane_id();
+#pragma unroll
+		for (int c = 0; c < (KW<NW> + 1) / 2; c++) {
+			if (64u * c >= k) continue;
+			const unsigned i = 64u * c + lane;
+			const unsigned b = i < k ? get(i) : 0u;
+			const uint64_t lo = wave_ballot((b & 1u) != 0), hi = wave_ballot((b & 2u) != 0);
+			s.w[2 * c] = interleave32(lo, hi);
+			if (2 * c + 1 < KW<NW>) s.w[2 * c + 1] = interleave32(lo >> 32, hi >> 32);
+		}
+		return s;
+	}
+	for (unsigned i = 0; i < k; i++) kmer_set(s, i, get(i));
+	return s;
+}
 
 // A value that is the same in every lane of a cooperative wave, read back through lane 0 so that
 // the compiler knows it (scalar registers, scalar ALU); the identity for other callers.

@@ -45,6 +45,7 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
+	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
 	bool memo = true;
@@ -433,72 +434,78 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // provisional per-read result of the classify step
 constexpr uint8_t RES_CANDIDATE = 0x80;
 
-// One wave per read (nlanes == 1: a serial caller).  The k-mers of the read are spread over the
-// lanes for the two membership tests -- every lane hashes its k-mers from scratch, the H probes of
-// a k-mer go out together, one ballot folds the verdicts -- and the wave then runs the two
-// blunt-end searches in lock step (look_ahead_t's cooperative form).  `fast` is FCLASSIFY_FAST
-// bytes private to the wave (LDS on the device): the search scratch must not live in per-lane
-// memory.  The verdicts keep the reference's precedence: blunt end, not solid, visited.
-constexpr uint32_t FCLASSIFY_FAST = 1024;
+// (A wave-per-read form of this kernel -- k-mers over the lanes, hashed from scratch, the two
+// blunt-end searches in lock step -- was measured at 375 ms per config-1 step against 155 ms for
+// this one: hashing every k-mer from scratch costs more ALU than the probes cost memory time, and
+// the 6 G probes of a step are what bounds the kernel.  One read per lane it stays; the next
+// batch's classification is queued on a side stream ahead of the current batch's walkers.)
 template <int NW>
-struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828)
+struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
 	VKey* la_pool; // [slots][LA_MAX_VISITED]
-	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes, uint32_t slot, void* fast) const
+	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
 	{
-		static_assert(sizeof(SearchScratch<NW>) <= FCLASSIFY_FAST, "search scratch does not fit the wave's fast memory");
-		const uint64_t r = first + i;
-		const uint32_t L = b.len[r];
-		const unsigned k = p.k;
-		const uint32_t nk = L - k + 1;
-		const uint64_t woff = b.woff[r];
-		// allKmersInBloom(seq, solidKmerSet), allKmersInBloom(seq, assembledKmerSet) (bloom-dbg.h:58-77)
-		bool solid = true, visited = true;
-		for (uint32_t j = lane; j < nk; j += nlanes) {
-			const Kmer<NW> s = window_kmer<NW>(b.words, woff, j, k);
-			uint64_t h;
-			if constexpr (MASKED_BUILD<NW>) {
-				h = scratch_hash(p, [&](unsigned q) { return kmer_get(s, q); });
-			} else {
-				uint64_t fh, rh;
-				kmer_hashes(s, k, fh, rh);
-				h = rh < fh ? rh : fh;
-			}
-			bool so = true, vi = true;
-			for (unsigned q = 0; q < p.nh; q++) {
-				const uint64_t pos = pos_i(p, h, q);
-				so = so & (cnt[pos] >= p.kc);
-				vi = vi & (((vis[pos >> 3] >> (pos & 7)) & 1u) != 0);
-			}
-			solid = solid & so; visited = visited & vi;
-		}
-		solid = wave_all_lanes(solid, nlanes);
-		visited = wave_all_lanes(visited, nlanes);
-		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of the read and
-		// from the first k-mer of its reverse complement
-		SearchScratch<NW>& sc = *(SearchScratch<NW>*)fast;
+		uint64_t r = first + i;
+		uint32_t L = b.len[r];
+		unsigned k = p.k;
+		uint32_t nk = L - k + 1;
+		SearchScratch<NW> sc;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
-		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = nlanes > 1;
+		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
 		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0;
 		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
-		bool blunt;
-		{
-			Vtx<NW> v;
-			v.s = window_kmer<NW>(b.words, woff, 0, k);
-			vtx_rehash(p, v);
-			blunt = !look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc);
+		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
+		// the read and from the first k-mer of its reverse complement
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		Vtx<NW> first_v = v;
+		if (!look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		Vtx<NW> lastv;
+		lastv.s = batch_kmer<NW>(b, r, nk - 1, k);
+		vtx_rehash(p, lastv);
+		vtx_revcomp(p, lastv);
+		if (!look_ahead(p, cnt, lastv, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		// allKmersInBloom(seq, solidKmerSet) (bloom-dbg.h:58-77)
+		v = first_v;
+		bool solid = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!solid_contains(p, cnt, vtx_hash(p, v))) { solid = false; break; }
 		}
-		if (!blunt) {
-			Vtx<NW> v;
-			v.s = window_kmer<NW>(b.words, woff, nk - 1, k);
-			vtx_rehash(p, v);
-			vtx_revcomp(p, v);
-			blunt = !look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc);
+		if (!solid) { result[r] = RR_NOT_SOLID; return; }
+		// allKmersInBloom(seq, assembledKmerSet) against the snapshot
+		v = first_v;
+		bool visited = true;
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
 		}
-		if (lane == 0)
-			result[r] = blunt ? (uint8_t)RR_BLUNT_END : !solid ? (uint8_t)RR_NOT_SOLID : visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
+		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
+	}
+};
+
+// A classification made against an older visited snapshot (see Engine::prefetch_classify) is
+// brought up to date: BLUNT_END / NOT_SOLID do not depend on the snapshot and "all k-mers
+// visited" is final once true, so only the candidates are tested again.
+template <int NW>
+struct FRefilter {
+	Params p; Batch b; const uint8_t* vis; uint8_t* result;
+	ABG_HDN void operator()(uint64_t r, uint32_t) const
+	{
+		if (result[r] != RES_CANDIDATE) return;
+		const unsigned k = p.k;
+		const uint32_t nk = b.len[r] - k + 1;
+		Vtx<NW> v;
+		v.s = batch_kmer<NW>(b, r, 0, k);
+		vtx_rehash(p, v);
+		for (uint32_t j = 0; j < nk; j++) {
+			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+			if (!visited_contains(p, vis, vtx_hash(p, v))) return;
+		}
+		result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
 	}
 };
 
@@ -1307,6 +1314,7 @@ class Engine {
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
 		if (la_pool_c_) be_.free(la_pool_c_);
+		if (la_pool_c2_) be_.free(la_pool_c2_);
 		if (guide_tab_) be_.free(guide_tab_);
 		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
@@ -1512,6 +1520,8 @@ class Engine {
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
+		be_.sync_side();
+		pre_n_ = 0; prefetch_ = nullptr;
 		use_ctx(0);
 		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);
@@ -1697,6 +1707,9 @@ class Engine {
 	uint8_t* read_flag_ = nullptr;
 	uint64_t last_candidates_ = 0;
 	VKey* la_pool_c_ = nullptr; // lookAhead scratch of the classification (the walkers have their own per context)
+	VKey* la_pool_c2_ = nullptr; // ... and of the classification running ahead on the side stream
+	uint64_t pre_first_ = 0, pre_n_ = 0;      // range classified ahead on the side stream
+	std::function<void()> prefetch_;          // queues that classification (called right before a launch of walkers)
 	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	// ---- -g state: the vertices seen by any search so far
@@ -2357,6 +2370,21 @@ class Engine {
 				next += r.n;
 				counters_.reads_processed += r.n;
 				p2_batch_ = next_batch_size();
+				prefetch_ = nullptr;
+				if (next < b.n && depth_now() == 1 && !dist() && cfg_.prefetch_classify) {
+					// Classification of the NEXT batch on the side stream, queued right before this batch's
+					// walkers so that it fills the machine while they thin out (a launch ends with its
+					// slowest walker).  It sees an older snapshot; FRefilter brings it up to date.
+					const uint64_t nf = next, nn = std::min<uint64_t>(p2_batch_, b.n - next);
+					prefetch_ = [this, &b, result_d, nf, nn]() {
+						if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
+						Batch vn = b;
+						vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
+						FClassify<NW> f{ p_, vn, 0, cnt_, vis_, result_d + nf, la_pool_c2_ };
+						be_.launch_slots_side(nn, f, cslots_, "classify");
+						pre_first_ = nf; pre_n_ = nn;
+					};
+				}
 				if (r.nc) {
 					setup_batch<NW>(r);
 					// the first round's walkers start right away, on the context's own stream, unless
@@ -2390,19 +2418,28 @@ class Engine {
 		Batch v = b;
 		v.woff = b.woff + first; v.len = b.len + first; v.koff = b.koff + first; v.n = n;
 		uint8_t* res_d = result_d + first;
-		if (!la_pool_c_) la_pool_c_ = (VKey*)be_.alloc((uint64_t)be_.wave_slots() * LA_MAX_VISITED * sizeof(VKey));
-		if (dist()) {
+		if (!la_pool_c_) la_pool_c_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
+		if (pre_n_ == n && pre_first_ == first) {
+			// classified ahead against an older snapshot (prefetch_classify): BLUNT_END / NOT_SOLID do not
+			// depend on the snapshot and "all k-mers visited" is final once true, so only the candidates
+			// are tested again
+			be_.sync_side();
+			FRefilter<NW> f{ p_, v, vis_, res_d };
+			be_.launch(n, f, "reclassify");
+		} else if (dist()) {
 			// every rank classifies a slice of the batch; the verdicts are gathered
 			const uint64_t R = (uint64_t)comm_.world;
 			std::vector<uint64_t> c(R), d(R);
 			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
 			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_c_ };
-			be_.launch_wave_fast(c[comm_.rank], f, "classify");
+			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
+			be_.sync_side();
 			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_c_ };
-			be_.launch_wave_fast(n, f, "classify");
+			be_.launch_slots(n, f, cslots_, "classify");
 		}
+		pre_n_ = 0;
 		std::vector<uint8_t> res(n);
 		be_.d2h(res.data(), res_d, n);
 		r = BatchRun();
@@ -2474,6 +2511,11 @@ class Engine {
 		};
 		fprintf(stderr, "[walkdbg] %s n=%u ran=%llu\n", what, nwalk, (unsigned long long)nn);
 		line("sum", sum);
+		{
+			uint64_t p2 = 0, p3 = 0; // (two 32-bit tick counts share the last slot)
+			for (uint32_t i = 0; i < nc; i++) { p2 += d[i * 16ull + 15] & 0xFFFFFFFFull; p3 += d[i * 16ull + 15] >> 32; }
+			fprintf(stderr, "[walkdbg]   bulk phases: verify %.2f examine %.2f repeats %.2f take %.2f ms\n", sum[13] / 1e5, sum[14] / 1e5, p2 / 1e5, p3 / 1e5);
+		}
 		line("slowest", &d[bi * 16ull]);
 		be_.memset(dbg_, 0, nc * 128ull);
 	}
@@ -2511,6 +2553,7 @@ class Engine {
 			env.owner_base = r.owner_next;
 			r.owner_next += nc;
 			FWalk<NW> fw{ env, r.list_d };
+			if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 			be_.launch_walkers(nc - base, fw, wslots_, "walk", ci, false);
 			stats_.walked += nc - base;
 			dump_walkers(r, "walk", nc - base);
@@ -2548,6 +2591,7 @@ class Engine {
 		env.owner_base = r.owner_next;
 		r.owner_next += nc;
 		FWalk<NW> fw{ env, r.need_d };
+		if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk", ci, async);
 		r.pending = true;
 	}

@@ -81,18 +81,6 @@ __global__ void __launch_bounds__(256) k_foreach_wave(F f, uint64_t n)
 	for (; w < n; w += nw) f(w, lane, 64u);
 }
 
-// the same with abg::FCLASSIFY_FAST bytes of LDS per wave: f(item, lane, 64, wave slot, fast memory)
-template <class F>
-__global__ void __launch_bounds__(256) k_foreach_wave_fast(F f, uint64_t n)
-{
-	__shared__ __attribute__((aligned(16))) unsigned char lds[4][abg::FCLASSIFY_FAST];
-	const uint32_t lane = threadIdx.x & 63;
-	uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-	const uint32_t slot = (uint32_t)w;
-	for (; w < n; w += nw) f(w, lane, 64u, slot, (void*)lds[threadIdx.x >> 6]);
-}
-
 constexpr int COMMIT_THREADS = 256;
 constexpr int SYNC_WORDS = 34; // up to 16 waves (1024 threads) + broadcast slot at [32]
 struct DeviceSync {
@@ -370,18 +358,6 @@ struct HipBackend {
 			p.launches++;
 		}
 		side_pending = false;
-	}
-	uint32_t wave_slots() const { return cus * 8 * 4; } // waves of a launch_wave_fast grid
-	template <class F>
-	void launch_wave_fast(uint64_t n, F f, const char* name)
-	{
-		if (!n) return;
-		uint64_t blocks = (n + 3) / 4;
-		uint64_t cap = (uint64_t)cus * 8;
-		if (blocks > cap) blocks = cap;
-		begin(name);
-		hipLaunchKernelGGL(k_foreach_wave_fast<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
-		end(name);
 	}
 	template <class F>
 	void launch_wave(uint64_t n, F f, const char* name)

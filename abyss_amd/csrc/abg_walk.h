@@ -188,6 +188,7 @@ struct WalkState {
 	uint32_t n_bulk_calls, n_bulk_steps, n_lin_steps; // work counters of this walker
 	uint32_t n_bulk_tries;
 	uint64_t t_bulk, t_lin, t_post; // profiling aid (ABG_WALK_DEBUG): clock ticks in walk_bulk / walk_linear / after the extensions
+	uint64_t t_bp[4];               // ... and inside walk_bulk: verify the hint / examine the vertices / repeats / take the steps
 };
 template <int NW>
 ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
@@ -198,22 +199,18 @@ ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
 	return w.rbuf[j - p.k];
 }
 template <int NW>
-ABG_HDN Vtx<NW> ws_vertex(const Params& p, const WalkState<NW>& w, uint32_t i)
+ABG_HDN Vtx<NW> ws_vertex(const Params& p, const WalkState<NW>& w, uint32_t i, bool coop = false)
 {
 	Vtx<NW> v;
-#pragma unroll
-	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = 0;
-	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, ws_base(p, w, i + j));
+	v.s = gather_kmer<NW>(p.k, coop, [&](unsigned j) { return ws_base(p, w, i + j); });
 	vtx_rehash(p, v);
 	return v;
 }
 template <int NW>
-ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i)
+ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i, bool coop = false)
 {
 	Vtx<NW> v;
-#pragma unroll
-	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = 0;
-	for (unsigned j = 0; j < p.k; j++) kmer_set(v.s, j, seq[i + j]);
+	v.s = gather_kmer<NW>(p.k, coop, [&](unsigned j) { return (unsigned)seq[i + j] & 3u; });
 	vtx_rehash(p, v);
 	return v;
 }
@@ -245,6 +242,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		(void)e; (void)w; (void)dir_in; (void)owner_in; (void)contig_in; (void)hint_in;
 		return 0;
 	} else {
+	const uint64_t tq0 = dbg_clock(e.dbg);
 	const Params p = uniform_params<COOP>(e.p);
 	const unsigned k = p.k;
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(e.cnt);
@@ -312,6 +310,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 	};
 	for (uint32_t l = lane0; l < 2 * BULK_LANES; l += lstep) bs.dup[l] = 0;
 	if (lane0 == 0) { bs.dupstop = n; bs.full = 0; }
+	const uint64_t tq1 = dbg_clock(e.dbg);
 	// ---- every predicted vertex: identity, "new to the walker", "simple", "continues as predicted"
 	Kmer<NW> my_s; uint64_t my_fh = 0, my_rh = 0;
 #pragma unroll
@@ -364,6 +363,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		bs.fbase[l] = (uint8_t)fb;
 	}
 	wave_sync();
+	const uint64_t tq2 = dbg_clock(e.dbg);
 	// ---- a vertex that repeats an earlier one of the chunk (a cycle within the read) stops the prefix
 	for (uint32_t l = lane0; l < n; l += lstep) {
 		const VKey key = bs.key[l];
@@ -389,6 +389,8 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		const uint32_t ds = uni32<COOP>(ld_coherent(&bs.dupstop));
 		if (ds < m) m = ds;
 	}
+	const uint64_t tq3 = dbg_clock(e.dbg);
+	if (e.dbg) { w.t_bp[0] += tq1 - tq0; w.t_bp[1] += tq2 - tq1; w.t_bp[2] += tq3 - tq2; }
 	if (m == 0) return 0;
 	// ---- take the m steps
 	for (uint32_t l = lane0; l < m; l += lstep) {
@@ -420,6 +422,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 	w.bulk_skip = m < n ? 1u : 0u; // the vertex the prefix stopped at goes through the step-by-step code
 	if (uni32<COOP>(ld_coherent(&bs.full))) w.bulk_overflow = 1;
 	w.n_bulk_calls++; w.n_bulk_steps += m;
+	if (e.dbg) w.t_bp[3] += dbg_clock(e.dbg) - tq3;
 	return m;
 	}
 }
@@ -601,9 +604,9 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 	const Params& p = e.p;
 	int other = (dir == FORWARD) ? REVERSE : FORWARD;
 	uint32_t n = w.nl + 1 + w.nr;
-	Vtx<NW> head = (dir == FORWARD) ? ws_vertex(p, w, n - 1) : ws_vertex(p, w, 0);
+	Vtx<NW> head = (dir == FORWARD) ? ws_vertex(p, w, n - 1, sc.coop) : ws_vertex(p, w, 0, sc.coop);
 	VKey prev_key = vtx_ident(p, head); // identity of the vertex before the head (the head itself when n == 1)
-	if (n > 1) prev_key = vtx_ident(p, (dir == FORWARD) ? ws_vertex(p, w, n - 2) : ws_vertex(p, w, 1));
+	if (n > 1) prev_key = vtx_ident(p, (dir == FORWARD) ? ws_vertex(p, w, n - 2, sc.coop) : ws_vertex(p, w, 1, sc.coop));
 	uint32_t ext = 0;
 	bool look_behind = false;
 	bool pending = false; // the head was pushed but not yet entered into `visited`
@@ -785,7 +788,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		sc.tbf_cap = cap - 1;
 	}
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
-	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0;
+	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
 	sc.overflow = 0;
 	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0;
 	sc.coop = e.coop;
@@ -845,7 +848,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			// a tip is not output, so its k-mers stay unvisited: withdraw the claims on them, or
 			// the predictor would count reads lying on the tip as covered by this walker
 			for (uint32_t i = 0; i < n; i++) {
-				Vtx<NW> x = ws_vertex(p, w, i);
+				Vtx<NW> x = ws_vertex(p, w, i, sc.coop);
 				uint64_t hm = vtx_hash(p, x);
 				wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
 			}
@@ -865,7 +868,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			Vtx<NW> popped[2]; bool popped_earlier[2]; int npopped = 0;
 			Vtx<NW> pushed; int pushed_side = 0; // see preprocessCircularContig below
 			if (n > 1) {
-				Vtx<NW> front = pool_vertex<NW>(p, S, 0), back = pool_vertex<NW>(p, S, n - 1);
+				Vtx<NW> front = pool_vertex<NW>(p, S, 0, sc.coop), back = pool_vertex<NW>(p, S, n - 1, sc.coop);
 				// getContigType (bloom-dbg.h:629-645): edge(back, front) via adjacency (RollingBloomDBG.h:558-574)
 				int type = CT_LINEAR;
 				{
@@ -906,8 +909,8 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 					}
 				}
 				int64_t l = hi - lo;
-				Vtx<NW> p0 = pool_vertex<NW>(p, S, lo), p1 = pool_vertex<NW>(p, S, lo + 1);
-				Vtx<NW> q1 = pool_vertex<NW>(p, S, hi - 1), q2 = pool_vertex<NW>(p, S, hi - 2);
+				Vtx<NW> p0 = pool_vertex<NW>(p, S, lo, sc.coop), p1 = pool_vertex<NW>(p, S, lo + 1, sc.coop);
+				Vtx<NW> q1 = pool_vertex<NW>(p, S, hi - 1, sc.coop), q2 = pool_vertex<NW>(p, S, hi - 2, sc.coop);
 				if (pushed_side > 0) q1 = pushed;
 				if (pushed_side < 0) p0 = pushed;
 				(void)l;
@@ -934,7 +937,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			// part of the contig; forget them unless an earlier contig of this read holds them
 			// or the same vertex is still an end of the path (circular / hairpin duplicates)
 			if (npopped) {
-				Vtx<NW> nf = pool_vertex<NW>(p, S, lo), nb = pool_vertex<NW>(p, S, hi - 1);
+				Vtx<NW> nf = pool_vertex<NW>(p, S, lo, sc.coop), nb = pool_vertex<NW>(p, S, hi - 1, sc.coop);
 				if (pushed_side < 0) nf = pushed;
 				if (pushed_side > 0) nb = pushed;
 				for (int q = 0; q < npopped; q++) {
@@ -985,6 +988,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
 		d[4] = sc.dbg_nodes; d[5] = w.t_bulk; d[6] = contig; d[7] = w.t_post;
 		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
+		d[13] = w.t_bp[0]; d[14] = w.t_bp[1]; d[15] = w.t_bp[2] + (w.t_bp[3] << 32);
 	}
 }
 

@@ -46,9 +46,6 @@ struct SerialBackend {
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_slots(uint64_t n, F f, uint32_t, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
-	uint32_t wave_slots() const { return 1; }
-	alignas(16) unsigned char wavebuf[abg::FCLASSIFY_FAST];
-	template <class F> void launch_wave_fast(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1, 0, (void*)wavebuf); }
 	template <class F> void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name) { launch_slots(n, f, slots, name); }
 	void sync_side() {}
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests;
