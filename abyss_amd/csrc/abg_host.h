@@ -77,6 +77,7 @@ class Session {
 		if (const char* e = getenv("ABG_INSERT_BATCH")) cfg.insert_batch_kmers = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_WALK_SLOTS")) cfg.walk_slots = (uint32_t)atoi(e);
 		if (const char* e = getenv("ABG_WTAB_LOG2")) cfg.wtab_log2 = (uint32_t)atoi(e);
+		if (const char* e = getenv("ABG_WTAB_LOG2_MAX")) cfg.wtab_log2_max = (uint32_t)std::max<int>(atoi(e), (int)cfg.wtab_log2); // (tests: forces overflow restarts)
 		if (const char* e = getenv("ABG_P2_FIRST_BATCH")) cfg.p2_first_batch = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_P2_MAX_BATCH")) cfg.p2_max_batch = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_PAR_COMMIT")) cfg.par_commit = atoi(e) != 0;

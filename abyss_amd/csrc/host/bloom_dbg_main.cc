@@ -645,6 +645,17 @@ int main(int argc, char** argv)
 		fprintf(stderr, "Assembled %llu bp in %llu contigs\nAssembly complete\n", (unsigned long long)c.bases_assembled,
 		    (unsigned long long)c.next_contig_id);
 	}
+	if (getenv("ABG_PRINT_STATS")) { // engine work counters (tests assert which code paths a run took)
+		abg_stats st;
+		memset(&st, 0, sizeof st);
+		abg_get_stats(ctx, &st);
+		fprintf(stderr, "abyss_amd stats: insert_rounds=%llu walk_rounds=%llu candidates=%llu rewalked=%llu commit_rounds=%llu "
+		    "batch_cuts=%llu overflows=%llu bulk_steps=%llu lin_steps=%llu chain_steps=%llu memo_hits=%llu memo_adds=%llu\n",
+		    (unsigned long long)st.insert_rounds, (unsigned long long)st.walk_rounds, (unsigned long long)st.candidates,
+		    (unsigned long long)st.rewalked, (unsigned long long)st.commit_rounds, (unsigned long long)st.batch_cuts,
+		    (unsigned long long)st.overflows, (unsigned long long)st.bulk_steps, (unsigned long long)st.lin_steps,
+		    (unsigned long long)st.chain_steps, (unsigned long long)st.memo_hits, (unsigned long long)st.memo_adds);
+	}
 	if (ckpt && !keepCheckpoint) remove_checkpoint(checkpointPrefix, verbose);
 	if (trace) fclose(trace);
 	if (readlog) fclose(readlog);

@@ -40,7 +40,9 @@ def make_genome(length: int, seed: int = 42, repeat_frac: float = 0.01,
     h2 = g.copy()
     if snp_every > 0:
         nsnp = length // snp_every
-        pos = rng.choice(length, size=nsnp, replace=False)
+        # (without replacement needs a permutation of the whole genome: beyond 2^28 bases the positions
+        # are drawn independently instead -- a few coincide, which merely drops those SNPs)
+        pos = rng.choice(length, size=nsnp, replace=False) if length <= (1 << 28) else rng.integers(0, length, size=nsnp)
         h2[pos] = (h2[pos] + rng.integers(1, 4, size=nsnp, dtype=np.uint8)) & 3
     return g, h2
 

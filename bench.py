@@ -145,10 +145,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=5_000_000, help="read pairs per GPU (configs[1]: 5 M)")
-    ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--bloom", type=str, default="2G")
-    ap.add_argument("--K", type=int, default=0, help="spaced seed of two K-mers (-K of abyss-bloom-dbg; configs[3]: --k 96 --K 32)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
+                    help="BASELINE.json configs[N]: 1 = E. coli-scale (5 M pairs, k=64, B=2G; the default and the benchmark), "
+                         "2 = human-chr-scale (200 M pairs, k=64, B=40G), 3 = spaced seed (5 M pairs, -k96 -K32, B=2G)")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (overrides --config)")
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--bloom", type=str, default=None)
+    ap.add_argument("--K", type=int, default=None, help="spaced seed of two K-mers (-K of abyss-bloom-dbg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
                     help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
@@ -158,6 +161,13 @@ def main() -> int:
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
+    preset = {1: (5_000_000, 64, "2G", 0, "E. coli-scale"), 2: (200_000_000, 64, "40G", 0, "human-chr-scale"),
+              3: (5_000_000, 96, "2G", 32, "spaced-seed")}[a.config]
+    a.pairs = preset[0] if a.pairs is None else a.pairs
+    a.k = preset[1] if a.k is None else a.k
+    a.bloom = preset[2] if a.bloom is None else a.bloom
+    a.K = preset[3] if a.K is None else a.K
+    workload_name = preset[4]
 
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # RCCL's banner / logs: not on stdout next to the JSON line
     rank = int(os.environ.get("RANK", "0"))
@@ -354,10 +364,10 @@ def main() -> int:
             "higher_is_better": True, "scaling": a.scaling if (partitioned or (world == 1 and a.mode == "partitioned")) else "weak",
             "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "E. coli-scale synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
-                       % (a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom,
+            "config": {"workload": "%s synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
+                       % (workload_name, a.pairs, read_len, a.k, (" K=%d spaced seed" % a.K) if a.K else "", a.bloom,
                           "one job over %d MI355X" % world if partitioned else "1xMI355X per rank"),
-                       "genome_bp": genome_len, "coverage": cov, "error_rate": err,
+                       "baseline_config": a.config, "genome_bp": genome_len, "coverage": cov, "error_rate": err,
                        "read_kmers": kmers_all if partitioned else kmers,
                        "parallelism": ("filter range-partitioned over %d ranks in PASS 1 (%s), gathered for PASS 2; walks split"
                                        % (world, "RCCL all_gather + all_reduce on the engine's stream" if a.comm == "rccl"
