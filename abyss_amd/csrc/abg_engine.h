@@ -54,7 +54,7 @@ struct Config {
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
-	uint64_t par_commit_max_bytes = 64ull << 30; // ... unless that would take more than this; then the ordered kernel
+	uint64_t par_commit_max_bytes = 16ull << 30; // ... unless that would take more than this: then a stamp per bit the commit touches (hashed)
 	int verbose = 0;
 };
 
@@ -1016,7 +1016,11 @@ struct ParCommit {
 	ContigRec* recs; const uint8_t* pool; uint8_t* result;
 	const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff; const uint8_t* read_flag;
 	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
-	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp
+	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp;
+	                       // or NULL: the stamps live in the hash table below, keyed by bit position
+	uint64_t* Tk;          // [Tmask + 1] bit positions (T_KEY_EMPTY: free)
+	uint32_t* Tv;          // [Tmask + 1] their stamps
+	uint64_t Tmask;
 	uint32_t tag;          // tag of the current pass (smaller = newer, so a newer pass wins every atomicMin)
 	WalkTab cend;          // contigEndKmers (bloom-dbg.h:992), owner 0
 	WalkTab tcend;         // end k-mers of this range's inserted short contigs; meta = earliest position
@@ -1030,13 +1034,44 @@ struct ParCommit {
 	uint32_t* scal;        // [0] changed  [1] break candidate  [2] short_list length  [3] new contigEndKmers entries
 	uint32_t c_begin, c_end, brk;
 };
+// The stamp of a filter bit.  One 4-byte stamp per bit of the filter costs 4 bytes x m (7.6 GB for
+// B=2G, 152 GB for B=40G); beyond par_commit_max_bytes the stamps of the bits a commit actually
+// touches -- the k-mers of its contigs x H -- are kept in an open-addressing table instead.
+constexpr uint64_t T_KEY_EMPTY = ~0ULL;
+ABG_HD uint64_t pc_T_hash(const ParCommit& e, uint64_t pos)
+{
+	uint64_t x = pos * 0x9E3779B97F4A7C15ULL;
+	x ^= x >> 32;
+	return x & e.Tmask;
+}
+ABG_HD uint32_t* pc_T_slot(const ParCommit& e, uint64_t pos) // find or create
+{
+	if (e.T) return &e.T[pos];
+	uint64_t s = pc_T_hash(e, pos);
+	for (;;) {
+		const uint64_t cur = cas_u64(&e.Tk[s], T_KEY_EMPTY, pos);
+		if (cur == T_KEY_EMPTY || cur == pos) return &e.Tv[s];
+		s = (s + 1) & e.Tmask;
+	}
+}
+ABG_HD uint32_t pc_T_get(const ParCommit& e, uint64_t pos) // the raw stamp, or "never"
+{
+	if (e.T) return e.T[pos];
+	uint64_t s = pc_T_hash(e, pos);
+	for (;;) {
+		const uint64_t cur = e.Tk[s];
+		if (cur == pos) return e.Tv[s];
+		if (cur == T_KEY_EMPTY) return T_NEVER;
+		s = (s + 1) & e.Tmask;
+	}
+}
 ABG_HD bool pc_bit_before(const ParCommit& e, uint64_t h, uint32_t time)
 {
 	bool ok = true;
 	for (unsigned q = 0; q < e.p.nh; q++) {
 		uint64_t pos = pos_i(e.p, h, q);
 		bool set = ((e.vis32[pos >> 5] >> (pos & 31)) & 1u) != 0;
-		ok = ok & (set | (t_read(e.T[pos], e.tag) < time));
+		ok = ok & (set | (t_read(pc_T_get(e, pos), e.tag) < time));
 	}
 	return ok;
 }
@@ -1079,7 +1114,7 @@ struct FPcTimeMin { // T: one wave per candidate
 			const uint32_t cnk = rec.len - e.p.k + 1;
 			for (uint32_t j = lane; j < cnk; j += nlanes) {
 				uint64_t h = ch[j];
-				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(&e.T[pos_i(e.p, h, q)], t_stamp(e.tag, rec.time));
+				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(pc_T_slot(e, pos_i(e.p, h, q)), t_stamp(e.tag, rec.time));
 			}
 		}
 	}
@@ -1191,7 +1226,7 @@ struct FPcDecide { // one wave per candidate: re-decide the read and its contigs
 						for (uint32_t j = lane; j < cnk; j += nlanes)
 							for (unsigned q = 0; q < e.p.nh; q++) {
 								uint64_t pos = pos_i(e.p, ch[j], q);
-								mine = mine | (t_read(e.T[pos], e.tag) == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
+								mine = mine | (t_read(pc_T_get(e, pos), e.tag) == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
 							}
 						moves = !wave_all_lanes(!mine, nlanes);
 					}
@@ -1313,6 +1348,7 @@ class Engine {
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
+		if (Tk_) { be_.free(Tk_); be_.free(Tv_); }
 		if (la_pool_c_) be_.free(la_pool_c_);
 		if (la_pool_c2_) be_.free(la_pool_c2_);
 		if (guide_tab_) be_.free(guide_tab_);
@@ -1617,9 +1653,13 @@ class Engine {
 	uint32_t t_tag_ = 0;    // next pass takes tag t_tag_ - 1; 0: clear T first
 	// the parallel commit needs 4 bytes of time stamp per filter bit; without that memory (or when
 	// switched off) the ordered single-workgroup kernel runs
+	uint64_t* Tk_ = nullptr; uint32_t* Tv_ = nullptr; uint32_t Tlog2_ = 0; // ... or per touched bit (see pc_T_slot)
+	uint64_t T_entries_ = 0; // upper bound of the keys in the table
+	bool t_hashed() const { return m_ * 4ull > cfg_.par_commit_max_bytes; }
 	bool use_par_commit()
 	{
-		if (!cfg_.par_commit || m_ * 4ull > cfg_.par_commit_max_bytes || t_failed_) return false;
+		if (!cfg_.par_commit || t_failed_) return false;
+		if (t_hashed()) return true; // (the table is sized by commit_par)
 		if (!T_) {
 			T_ = (uint32_t*)be_.try_alloc(m_ * 4ull);
 			t_tag_ = 0;
@@ -2081,6 +2121,29 @@ class Engine {
 		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
 		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_;
+		e.Tk = nullptr; e.Tv = nullptr; e.Tmask = 0;
+		if (t_hashed()) {
+			// the bits this commit can stamp: (k-mers of the contigs in the pool) x H
+			uint64_t bases = 0;
+			be_.d2h(&bases, pool_used_, 8);
+			const uint64_t need = std::min<uint64_t>(bases, pool_cap_) * p_.nh + 16;
+			if (!Tk_ || (T_entries_ + need) * 2 > (1ull << Tlog2_)) {
+				uint32_t log2 = 20;
+				while ((1ull << log2) < 2 * need) log2++;
+				if (!Tk_ || log2 > Tlog2_) {
+					if (Tk_) { be_.free(Tk_); be_.free(Tv_); }
+					Tlog2_ = log2;
+					Tk_ = (uint64_t*)be_.alloc(8ull << Tlog2_);
+					Tv_ = (uint32_t*)be_.alloc(4ull << Tlog2_);
+				}
+				be_.memset(Tk_, 0xFF, 8ull << Tlog2_);
+				be_.memset(Tv_, 0xFF, 4ull << Tlog2_);
+				T_entries_ = 0;
+				t_tag_ = std::min<uint32_t>(cfg_.t_tags, T_TAGS) - 1;
+			}
+			T_entries_ += need;
+			e.T = nullptr; e.Tk = Tk_; e.Tv = Tv_; e.Tmask = (1ull << Tlog2_) - 1;
+		}
 		e.c_begin = c_begin; e.c_end = c_end; e.brk = c_end;
 		e.off = (uint32_t*)be_.alloc((n + 1ull) * 4); e.cnt = (uint32_t*)be_.alloc(n * 4ull + 4);
 		e.cnt2 = (uint32_t*)be_.alloc(n * 4ull + 4); e.cnt3 = (uint64_t*)be_.alloc(n * 8ull + 8);
@@ -2113,7 +2176,12 @@ class Engine {
 		for (uint32_t round = 0;; round++) {
 			// (tag T_TAGS - 1 is what the cleared array carries: never handed out; cfg_.t_tags < T_TAGS only
 			// makes the clearing more frequent -- the tests use that to exercise it)
-			if (t_tag_ == 0) { be_.memset(e.T, 0xFF, m_ * 4ull); t_tag_ = std::min<uint32_t>(cfg_.t_tags, T_TAGS) - 1; }
+			if (t_tag_ == 0) {
+				// the tags ran out: every stamp back to "never" (a hashed table keeps its keys)
+				if (e.T) be_.memset(e.T, 0xFF, m_ * 4ull);
+				else be_.memset(e.Tv, 0xFF, 4ull << Tlog2_);
+				t_tag_ = std::min<uint32_t>(cfg_.t_tags, T_TAGS) - 1;
+			}
 			e.tag = --t_tag_;
 			if (nshort) {
 				be_.memset(e.tcend.hmin, 0xFF, (e.tcend.mask + 1) * 8);

@@ -393,3 +393,64 @@ def test_host_packing_on_several_threads_is_invisible(name, split, monkeypatch):
     assert api.format_fasta(contigs, g.ids) == g.fasta
     assert api.format_read_log(results, g.ids) == g.readlog
     assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_hashed_time_stamps_stay_exact(monkeypatch):
+    """ABG_PAR_COMMIT_MAX_GB=0: the parallel commit keeps its time stamps in a hash table keyed by bit
+    position (what a filter too large for one stamp per bit gets, e.g. B=40G) instead of one per bit."""
+    monkeypatch.setenv("ABG_PAR_COMMIT_MAX_GB", "0")
+    monkeypatch.setenv("ABG_T_TAGS", "5")
+    for name in ("k64", "k48_K16"):
+        g = GoldenCase(name)
+        kw = g.kwargs()
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=64, mask=mask_of(g))
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        assert hc.stats()["commit_rounds"] >= 6
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+        assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_device_sized_fast_memory_runs_the_chain_searches(monkeypatch):
+    """HC_FAST_BYTES=16384: the walkers get what LDS gives them on the device, so successor()'s chain
+    searches (chain_true_branches, chain_bulk) and the bulk scratch run as they do there."""
+    monkeypatch.setenv("HC_FAST_BYTES", "16384")
+    for name in ("k64", "k96", "k25_h3_kc3_t40"):
+        g = GoldenCase(name)
+        kw = g.kwargs()
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=128, mask=mask_of(g))
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        st = hc.stats()
+        if name != "k25_h3_kc3_t40":  # (odd k: no guide)
+            assert st["bulk_steps"] > 5 * st["lin_steps"] and st["chain_steps"] > 0
+        assert st["memo_hits"] > 0
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+        assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_guide_and_memo_do_not_change_results(monkeypatch):
+    """The guide table and the successor() memo are accelerators: with both off (ABG_GUIDE_STRIDE=0,
+    ABG_MEMO=0), with the densest guide (stride 1) and with two batches in flight (ABG_PIPELINE=2: a
+    batch classified against an older snapshot) the outputs are the reference's."""
+    g = GoldenCase("k64")
+    kw = g.kwargs()
+    for env in ({"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"}, {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PIPELINE": "2"}):
+        for key in ("ABG_GUIDE_STRIDE", "ABG_MEMO", "ABG_PIPELINE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=128)
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        st = hc.stats()
+        if env.get("ABG_GUIDE_STRIDE") == "0":
+            assert st["bulk_steps"] == 0 and st["memo_hits"] == 0
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+        assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
