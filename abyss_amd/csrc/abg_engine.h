@@ -30,6 +30,7 @@ struct Config {
 	uint64_t insert_batch_kmers = 1ull << 24; // k-mer ops per ordered-insert batch (a genome k-mer then recurs ~once per batch at 50x)
 	uint32_t claim_log2 = 30;         // PASS 1 claim slots per table (x2 tables, 8 B each: 16 GiB; false conflicts fall with the load)
 	uint32_t drain_threshold = 1u << 12; // pending ops at or below which the retry tail runs in one workgroup
+	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
 	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
@@ -428,6 +429,195 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 		if (nz) atomic_add_u64(&out[0], nz);
 		if (ge) atomic_add_u64(&out[1], ge);
 	}
+};
+
+// ============================================================ PASS 1, tiled
+// The counter array cut into tiles of TILE_COUNTERS counters that a workgroup holds in LDS.  Per
+// batch of ops the (op, counter) pairs are binned by tile; what happens to a counter is then
+// decided and applied by the one workgroup that has its tile in LDS, reading and writing the
+// filter as a stream of whole tiles instead of one random sector per probe:
+//
+//   hash      h0[t] for every op (rolling ntHash, 8 ops per lane)                            FHashOps
+//   bin       every (op, hash) pair into its tile's bin: [h, t, offset within the tile]      FBinPairs
+//   purity    per tile: sort the bin by offset (LDS); a counter all of whose pairs belong to
+//             ONE k-mer is pure; the earliest op of the k-mer leads its n ops                tile_purity
+//   target    per op: a leader whose k-mer has only pure counters computes what n successive
+//             conservative updates leave behind: every counter max(c, min(m + n, 255))       FOpTarget
+//   apply     per tile: counters into LDS, max() with the leaders' targets, tile back        tile_apply
+//   the rest  ops of k-mers sharing a counter with another k-mer of the batch go through the
+//             reservation rounds (FClaim / FInsertRound / insert_drain) in op order
+//
+// Why that is the sequential result (CountingBloomFilter::incrementMin in read order,
+// CountingBloomFilter.hpp:135-162): the ops of one k-mer touch the same H counters.  If no op of
+// any OTHER k-mer of the batch touches one of them, those n ops commute with every other op of the
+// batch, and n conservative updates in a row turn minimum m into min(m + n, 255) and raise every
+// counter below that to it -- one update raises the counters equal to the minimum by one and
+// leaves the others, which are above it, alone.  All remaining ops touch counters no such k-mer
+// touches, and keep their order among themselves in the reservation rounds.
+constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
+constexpr uint32_t TILE_SORT_MAX = 4096;                            // pairs of one tile per batch, at most
+struct TilePair { uint64_t h; uint32_t t; uint32_t off; };          // (off: offset within the tile | hash index << 16)
+struct TileEnv {
+	Params p; uint8_t* cnt; uint64_t m;
+	const uint64_t* h0;
+	TilePair* bins; uint32_t cap;     // [ntiles][cap]
+	uint32_t* tcur;                   // [ntiles] pairs in each bin
+	uint32_t* lead;                   // [T] ops of the k-mer this op leads (0: not a leader / not settled here)
+	uint8_t* opflag;                  // [T] 1: the op's k-mer shares a counter with another k-mer
+	uint8_t* tgt;                     // [T] leaders: the value their counters are raised to (0: nothing to do)
+	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
+};
+struct FHashOps { // FHashClaim without the claims
+	Params p; Batch b; uint64_t* h0; uint64_t T;
+	ABG_HD void operator()(uint64_t g, uint32_t) const
+	{
+		uint64_t t0 = g * HC_RUN;
+		if (t0 >= T) return;
+		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
+		uint64_t r = find_seq(b.koff, b.n, t0);
+		uint64_t rend = b.koff[r + 1];
+		unsigned k = p.k;
+		uint64_t fh = 0, rh = 0;
+		bool fresh = true;
+		for (uint64_t t = t0; t < t1; t++) {
+			while (t >= rend) { r++; rend = b.koff[r + 1]; fresh = true; }
+			uint32_t j = (uint32_t)(t - b.koff[r]);
+			if (p.mask) { h0[t] = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); }); continue; }
+			if (fresh) {
+				fh = 0; rh = 0;
+				for (unsigned i = 0; i < k; i++) {
+					fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
+					rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
+				}
+				fresh = false;
+			} else {
+				unsigned out = batch_base(b, r, j - 1), in = batch_base(b, r, j + k - 1);
+				fh = srol1(fh) ^ seed_of(in) ^ p.seed_k[out];
+				rh = sror1(rh ^ p.seedrc_k[in] ^ seed_of(3u - out));
+			}
+			h0[t] = rh < fh ? rh : fh;
+		}
+	}
+};
+struct FBinPairs { // one op per item
+	TileEnv e;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		const uint64_t h = e.h0[t];
+		for (unsigned j = 0; j < e.p.nh; j++) {
+			const uint64_t pos = pos_i(e.p, h, j);
+			const uint64_t tile = pos >> TILE_BITS;
+			const uint32_t slot = atomic_add_u32(&e.tcur[tile], 1);
+			if (slot >= e.cap) { e.flags[0] = 1; continue; }
+			TilePair& r = e.bins[tile * e.cap + slot];
+			r.h = h; r.t = (uint32_t)t; r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | (j << 16);
+		}
+	}
+};
+// Sync policy of the tile procedures: tid(), nthreads(), barrier(), sort_u32(keys, n) (ascending,
+// cooperative; n <= TILE_SORT_MAX, keys has room for the next power of two).
+template <class Sync>
+ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, uint32_t* keys, Sync& sy)
+{
+	const uint32_t n = ld_coherent(&e.tcur[tile]) < e.cap ? ld_coherent(&e.tcur[tile]) : e.cap;
+	if (!n) return;
+	const TilePair* bin = e.bins + tile * e.cap;
+	const uint32_t tid = sy.tid(), nt = sy.nthreads();
+	for (uint32_t i = tid; i < n; i += nt) keys[i] = ((bin[i].off & 0xFFFFu) << 12) | i;
+	sy.barrier();
+	sy.sort_u32(keys, n);
+	sy.barrier();
+	// every thread takes the runs (pairs on one counter) that start at its positions
+	for (uint32_t i = tid; i < n; i += nt) {
+		const uint32_t off = keys[i] >> 12;
+		if (i && (keys[i - 1] >> 12) == off) continue;
+		const TilePair& first = bin[keys[i] & 0xFFFu];
+		uint32_t len = 1, tmin = first.t;
+		bool pure = true;
+		for (uint32_t j = i + 1; j < n && (keys[j] >> 12) == off; j++, len++) {
+			const TilePair& r = bin[keys[j] & 0xFFFu];
+			pure = pure & (r.h == first.h);
+			tmin = r.t < tmin ? r.t : tmin;
+		}
+		if (pure) {
+			// the k-mer's ops: the run holds one pair per op and per hash function that lands here
+			uint32_t d = 0;
+			const uint64_t pos = (tile << TILE_BITS) | off;
+			for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, first.h, q) == pos;
+			e.lead[tmin] = len / (d ? d : 1);
+		} else {
+			for (uint32_t j = i; j < i + len; j++) e.opflag[bin[keys[j] & 0xFFFu].t] = 1;
+		}
+	}
+}
+struct FOpTarget { // one op per item: leaders of k-mers with pure counters only compute their target
+	TileEnv e; uint32_t* pend; uint32_t* pend_n;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		const bool conflict = e.opflag[t] != 0;
+		// ops of k-mers that share a counter go to the reservation rounds (one counter bump per wave)
+		const uint32_t slot = wave_append_slot(pend_n, conflict);
+		if (conflict) { pend[slot] = (uint32_t)t; e.tgt[t] = 0; return; }
+		const uint32_t n = e.lead[t];
+		uint8_t tg = 0;
+		if (n) {
+			const uint64_t h = e.h0[t];
+			unsigned mn = 255;
+			for (unsigned j = 0; j < e.p.nh; j++) { unsigned c = e.cnt[pos_i(e.p, h, j)]; mn = c < mn ? c : mn; }
+			if (mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
+		}
+		e.tgt[t] = tg;
+	}
+};
+// `lds`: TILE_COUNTERS bytes
+template <class Sync>
+ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
+{
+	const uint32_t n = ld_coherent(&e.tcur[tile]) < e.cap ? ld_coherent(&e.tcur[tile]) : e.cap;
+	if (!n) return;
+	const TilePair* bin = e.bins + tile * e.cap;
+	const uint32_t tid = sy.tid(), nt = sy.nthreads();
+	const uint64_t base = tile << TILE_BITS;
+	const uint32_t span = (uint32_t)(e.m - base < TILE_COUNTERS ? e.m - base : TILE_COUNTERS); // (m is a multiple of 8)
+	uint64_t* l8 = (uint64_t*)lds;
+	const uint64_t* g8 = (const uint64_t*)(e.cnt + base);
+	for (uint32_t i = tid; i < span / 8; i += nt) l8[i] = g8[i];
+	sy.barrier();
+	bool any = false;
+	for (uint32_t i = tid; i < n; i += nt) {
+		const TilePair& r = bin[i];
+		const uint8_t tg = e.tgt[r.t];
+		if (!tg) continue;
+		// (a pure counter has one writer -- its k-mer's leader, possibly through two hash functions
+		// with the same value -- so plain byte stores do)
+		const uint32_t off = r.off & 0xFFFFu;
+		if (lds[off] < tg) { lds[off] = tg; any = true; }
+	}
+	if (sy.any(any)) {
+		uint64_t* o8 = (uint64_t*)(e.cnt + base);
+		for (uint32_t i = tid; i < span / 8; i += nt) o8[i] = l8[i];
+	}
+}
+struct FClaimList { // FClaim over a list of ops
+	Params p; const uint64_t* h0; const uint32_t* pend; uint64_t* claim; uint64_t cmask; uint32_t epoch;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t t = pend[i];
+		const uint64_t h = h0[t];
+		const uint64_t v = claim_val(epoch, t);
+		for (unsigned j = 0; j < p.nh; j++) atomic_min_u64(&claim[pos_i(p, h, j) & cmask], v);
+	}
+};
+
+struct FTilePurity { // tile procedures as items of Backend::launch_tiles: f(tile, FAST bytes of fast memory, sync)
+	static constexpr uint32_t FAST = TILE_SORT_MAX * 4;
+	TileEnv e;
+	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_purity(e, tile, (uint32_t*)fast, sy); }
+};
+struct FTileApply {
+	static constexpr uint32_t FAST = TILE_COUNTERS;
+	TileEnv e;
+	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_apply(e, tile, (uint8_t*)fast, sy); }
 };
 
 // ============================================================ PASS 2 functors
@@ -1306,6 +1496,7 @@ struct FPcWrite { // commit order of the records and the contig ids (off = recor
 //   template<class F> void launch_wave(uint64_t n, F f, const char* name);   // f(item, lane, nlanes): one item per wave
 //   template<int NW> void launch_commit(CommitEnv<NW>, uint32_t c_begin, uint32_t c_end);
 //   void launch_drain(InsertDrainEnv);          // one workgroup running insert_drain
+//   template<class F> void launch_tiles(uint64_t n, F f, const char* name); // f(tile, fast memory [F::FAST bytes], sync): one workgroup per item
 template <class BE>
 class Engine {
   public:
@@ -1525,11 +1716,11 @@ class Engine {
 		ensure_insert();
 		memo_valid_ = false;
 		last_rounds_ = 0;
-		// op ranges of at most insert_batch_kmers along sequence boundaries
+		// op ranges of at most batch_ops_ along sequence boundaries
 		uint64_t s = 0;
 		while (s < b.n) {
 			uint64_t e = s;
-			while (e < b.n && (e == s || koff_h[e + 1] - koff_h[s] <= cfg_.insert_batch_kmers)) e++;
+			while (e < b.n && (e == s || koff_h[e + 1] - koff_h[s] <= batch_ops_)) e++;
 			insert_range(b, s, e, koff_h);
 			s = e;
 		}
@@ -1623,7 +1814,8 @@ class Engine {
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
-	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0; };
+	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
+	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -1728,6 +1920,9 @@ class Engine {
 	// PASS 1 resources
 	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
+	uint64_t batch_ops_ = 0;   // ops per ordered-insert batch (ensure_insert)
+	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
+	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr;
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
@@ -1823,7 +2018,33 @@ class Engine {
 	void ensure_insert()
 	{
 		if (h0_) return;
-		uint64_t nb = cfg_.insert_batch_kmers;
+		// ops per ordered-insert batch.  Tiled: what keeps a tile's bin within the LDS sort (about
+		// 3000 pairs per tile and batch), and for a large filter enough ops that a tile's 64 KB are
+		// streamed for a few thousand pairs, not for a handful
+		batch_ops_ = cfg_.insert_batch_kmers;
+		tiled_ = false;
+		ntiles_ = (m_ + TILE_COUNTERS - 1) >> TILE_BITS;
+		if (cfg_.tiled_insert && !casc_.bits && !dist() && p_.nh <= 16) {
+			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114));
+			T = std::min<uint64_t>(T, 3000ull * ntiles_ / p_.nh);
+			if (T >= 1024) {
+				tiled_ = true;
+				batch_ops_ = T;
+				const uint64_t mean = (T * p_.nh + ntiles_ - 1) / ntiles_;
+				uint64_t sq = 1;
+				while (sq * sq < mean) sq++;
+				tile_cap_ = (uint32_t)std::min<uint64_t>(TILE_SORT_MAX, mean + 8 * sq + 64);
+				if (const char* e = getenv("ABG_TILE_CAP")) tile_cap_ = (uint32_t)std::max(1, std::min<int>(TILE_SORT_MAX, atoi(e))); // (tests: forces bin overflows)
+			}
+		}
+		uint64_t nb = batch_ops_;
+		if (tiled_) {
+			bins_ = (TilePair*)be_.alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
+			tcur_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
+			lead_ = (uint32_t*)be_.alloc(nb * 4);
+			opflag_ = (uint8_t*)be_.alloc(nb);
+			tgt_ = (uint8_t*)be_.alloc(nb);
+		}
 		h0_ = (uint64_t*)be_.alloc(nb * 8);
 		for (int i = 0; i < 2; i++) {
 			claim_[i] = (uint64_t*)be_.alloc((8ull << cfg_.claim_log2));
@@ -1836,6 +2057,7 @@ class Engine {
 	void free_insert()
 	{
 		if (!h0_) return;
+		if (tiled_) { be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
 		if (dres_) { be_.free(dres_); be_.free(dlost_); dres_ = nullptr; }
 		be_.free(h0_);
 		for (int i = 0; i < 2; i++) { be_.free(claim_[i]); be_.free(pend_[i]); }
@@ -1846,7 +2068,7 @@ class Engine {
 	{
 		uint64_t T = koff_h[e] - koff_h[s];
 		if (T == 0) return;
-		if (T > cfg_.insert_batch_kmers || T >= 0xFFFFFFFFull) {
+		if (T > batch_ops_ || T >= 0xFFFFFFFFull) {
 			fprintf(stderr, "abyss_amd: a single sequence has more k-mers (%llu) than insert_batch_kmers\n",
 			    (unsigned long long)T);
 			abort();
@@ -1871,13 +2093,44 @@ class Engine {
 			be_.free(kv_d);
 			return;
 		}
-		{
-			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_, 0, 0 };
-			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
-		}
 		uint64_t npend = T;
 		const uint32_t* pin = nullptr; // NULL: all ops 0..T-1
 		uint32_t* pout = pend_[0];
+		bool claimed = false;
+		if (tiled_) {
+			// the k-mers that share no counter with another k-mer of the batch are settled tile by
+			// tile; what is left goes through the reservation rounds below
+			TileEnv te{ p_, cnt_, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, (uint32_t*)scal_ };
+			be_.memset(tcur_, 0, ntiles_ * 4);
+			be_.memset(lead_, 0, T * 4);
+			be_.memset(opflag_, 0, T);
+			be_.memset(scal_, 0, 8);
+			{ FHashOps f{ p_, v, h0_, T }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); }
+			{ FBinPairs f{ te }; be_.launch(T, f, "bin_pairs"); }
+			uint32_t over = 0;
+			be_.d2h(&over, scal_, 4);
+			if (over) {
+				stats_.tile_overflows++; // (a bin ran over: the whole batch takes the rounds)
+				FClaim fc{ p_, h0_, ccur, cmask, epoch_ };
+				be_.launch(T, fc, "hash_claim");
+			} else {
+				{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+				be_.memset(pend_n_, 0, 4);
+				{ FOpTarget f{ te, pend_[1], pend_n_ }; be_.launch(T, f, "op_target"); }
+				{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+				uint32_t nn = 0;
+				be_.d2h(&nn, pend_n_, 4);
+				stats_.tiled_ops += T; stats_.tiled_pending += nn;
+				npend = nn;
+				pin = pend_[1];
+				if (npend) { FClaimList fc{ p_, h0_, pin, ccur, cmask, epoch_ }; be_.launch(npend, fc, "claim_list"); }
+			}
+			claimed = true;
+		}
+		if (!claimed) {
+			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_, 0, 0 };
+			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
+		}
 		while (npend) {
 			if (pin && npend <= cfg_.drain_threshold) {
 				// few ops left: finish all remaining rounds inside one workgroup

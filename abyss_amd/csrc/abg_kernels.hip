@@ -102,6 +102,26 @@ struct DeviceSync {
 		__syncthreads();
 		return t;
 	}
+	__device__ bool any(bool v) { return __syncthreads_or(v ? 1 : 0) != 0; }
+	// ascending bitonic sort of keys[0, n) in place (the array has room for the next power of two)
+	__device__ void sort_u32(uint32_t* keys, uint32_t n)
+	{
+		uint32_t P = 1;
+		while (P < n) P <<= 1;
+		for (uint32_t i = n + threadIdx.x; i < P; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
+		__syncthreads();
+		for (uint32_t k = 2; k <= P; k <<= 1)
+			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+					const uint32_t x = i ^ j;
+					if (x > i) {
+						const uint32_t a = keys[i], b = keys[x];
+						if ((a > b) == ((i & k) == 0)) { keys[i] = b; keys[x] = a; }
+					}
+				}
+				__syncthreads();
+			}
+	}
 	__device__ uint32_t bcast(uint32_t v)
 	{
 		__syncthreads();
@@ -119,6 +139,18 @@ __global__ void __launch_bounds__(COMMIT_THREADS) k_commit(abg::CommitEnv<NW> e,
 	__shared__ abg::CommitDesc dsc[abg::COMMIT_CHUNK];
 	DeviceSync sy{ sh, dsc };
 	abg::commit_candidates<NW>(e, c_begin, c_end, sy);
+}
+
+// one workgroup per tile of the counter array (abg::TileEnv): F::FAST bytes of LDS, tiles strided over the grid
+template <class F>
+__global__ void __launch_bounds__(256) k_tiles(F f, uint64_t n)
+{
+	__shared__ __attribute__((aligned(16))) unsigned char lds[F::FAST]; // (all of the 64 KB a workgroup may declare, for tile_apply)
+	DeviceSync sy{ nullptr }; // (the tile procedures use barrier / any / sort_u32 only: no shared words)
+	for (uint64_t tile = blockIdx.x; tile < n; tile += gridDim.x) {
+		f(tile, (void*)lds, sy);
+		__syncthreads();
+	}
 }
 
 __global__ void __launch_bounds__(1024) k_insert_drain(abg::InsertDrainEnv e)
@@ -418,6 +450,17 @@ struct HipBackend {
 			p.launches++;
 		}
 		wpending[ctx] = false;
+	}
+	template <class F>
+	void launch_tiles(uint64_t n, F f, const char* name)
+	{
+		if (!n) return;
+		uint64_t blocks = n;
+		const uint64_t cap = (uint64_t)cus * (F::FAST > 32768 ? 2 : 8);
+		if (blocks > cap) blocks = cap;
+		begin(name);
+		hipLaunchKernelGGL(k_tiles<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
+		end(name);
 	}
 	void launch_drain(abg::InsertDrainEnv e)
 	{
@@ -792,6 +835,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
 	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
 	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
+	out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
 	return ABG_OK;
 }
 

@@ -268,6 +268,9 @@ typedef struct abg_stats {
 	uint64_t batch_cuts;    /* PASS-2 batches cut short at the candidate cap */
 	uint64_t overflows;     /* rounds restarted because a walker ran out of some capacity */
 	uint64_t memo_hits, memo_adds; /* successor() answers taken from / added to the shared memo */
+	uint64_t tiled_ops;     /* PASS 1: k-mer ops of batches that went through the LDS tiles ... */
+	uint64_t tiled_pending; /* ... of which this many shared a counter with another k-mer and took the reservation rounds */
+	uint64_t tile_overflows; /* ... batches whose bins overflowed (handled by the reservation rounds as a whole) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

@@ -18,6 +18,8 @@ struct SerialSync {
 	bool all(bool v) { return v; }
 	uint32_t sum(uint32_t v) { return v; }
 	uint32_t bcast(uint32_t v) { return v; }
+	bool any(bool v) { return v; }
+	void sort_u32(uint32_t* keys, uint32_t n) { std::sort(keys, keys + n); }
 	abg::CommitDesc buf[abg::COMMIT_CHUNK];
 	abg::CommitDesc* descs() { return buf; }
 };
@@ -57,6 +59,13 @@ struct SerialBackend {
 	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*, int, bool) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false); }
 	void wait_walkers(int) {}
 	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
+	std::vector<unsigned char> tilebuf;
+	template <class F> void launch_tiles(uint64_t n, F f, const char*)
+	{
+		tilebuf.resize(F::FAST + 16);
+		SerialSync sy;
+		for (uint64_t i = 0; i < n; i++) f(i, (void*)tilebuf.data(), sy);
+	}
 	template <int NW> void launch_commit(abg::CommitEnv<NW> e, uint32_t b, uint32_t c)
 	{
 		SerialSync sy;
@@ -182,6 +191,7 @@ void hc_get_stats(void* h, abg_stats* out)
 	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
 	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
 	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
+	out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
 }
 uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)
 {

@@ -454,3 +454,40 @@ def test_guide_and_memo_do_not_change_results(monkeypatch):
         assert api.format_fasta(contigs, g.ids) == g.fasta
         assert api.format_read_log(results, g.ids) == g.readlog
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
+    """PASS 1 through LDS-sized tiles (TileEnv, abg_engine.h): k-mers that share no counter with
+    another k-mer of the batch are settled tile by tile, the rest by the reservation rounds.  Same
+    counter array as the oracle's sequential incrementMin -- also when a filter saturates, when the
+    bins are too small (ABG_TILE_CAP: the batch then takes the rounds as a whole) and with the tiles
+    switched off (ABG_TILED=0)."""
+    k = 40
+    m1, m2 = synth.make_read_set(30000, 30.0)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    for counters, env, want in ((1 << 21, {}, "tiled"), (1 << 21, {"ABG_TILE_CAP": "600"}, "overflow"),
+                                (1 << 21, {"ABG_TILED": "0"}, "rounds"), (1 << 16, {}, "tiled")):
+        for key in ("ABG_TILE_CAP", "ABG_TILED"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        o = ob.Oracle(k, counters=counters)
+        hc = HostCheck(k, counters, insert_batch=30000, claim_log2=16)
+        o.load(buf, off)
+        hc.load(buf, off)
+        st = hc.stats()
+        if want == "tiled":
+            assert st["tiled_ops"] > 0 and st["tile_overflows"] == 0 and 0 < st["tiled_pending"] < st["tiled_ops"]
+        elif want == "overflow":
+            assert st["tile_overflows"] > 0
+        else:
+            assert st["tiled_ops"] == 0
+        assert np.array_equal(o.counters(), hc.counters()), (counters, env)
+    # a repeated sequence drives counters to 255 within one batch: n ops of one k-mer in one go
+    rep = np.tile(np.frombuffer(b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAGCTTGGCATTCGGATACCGGTAAGCTAGCTAACGGT", dtype=np.uint8), (400, 1))
+    buf, off = api.matrix_to_seqs(rep)
+    o = ob.Oracle(k, counters=1 << 18)
+    hc = HostCheck(k, 1 << 18, insert_batch=30000, claim_log2=16)
+    o.load(buf, off)
+    hc.load(buf, off)
+    assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
