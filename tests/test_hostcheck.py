@@ -466,7 +466,7 @@ def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
     m1, m2 = synth.make_read_set(30000, 30.0)
     buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
     for counters, env, want in ((1 << 21, {}, "tiled"), (1 << 21, {"ABG_TILE_CAP": "600"}, "overflow"),
-                                (1 << 21, {"ABG_TILED": "0"}, "rounds"), (1 << 16, {}, "tiled")):
+                                (1 << 21, {"ABG_TILED": "0"}, "rounds"), (1 << 19, {}, "tiled")):
         for key in ("ABG_TILE_CAP", "ABG_TILED"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
