@@ -30,6 +30,7 @@ struct Config {
 	uint64_t insert_batch_kmers = 1ull << 24; // k-mer ops per ordered-insert batch (a genome k-mer then recurs ~once per batch at 50x)
 	uint32_t claim_log2 = 30;         // PASS 1 claim slots per table (x2 tables, 8 B each: 16 GiB; false conflicts fall with the load)
 	uint32_t drain_threshold = 1u << 12; // pending ops at or below which the retry tail runs in one workgroup
+	uint64_t compact_threshold = 1u << 20; // rounds with at least this many ops flag their losers and compact them (FInsertRound)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
@@ -241,6 +242,7 @@ struct FInsertRound {
 	Params p; const uint64_t* h0; uint8_t* cnt; Cascade casc;
 	const uint32_t* pend; uint32_t* next; uint32_t* next_n;
 	const uint64_t* claim_cur; uint64_t* claim_next; uint64_t cmask; uint32_t epoch;
+	uint8_t* lost; // non-NULL: losers are flagged here (and compacted by the caller) instead of appended to `next`
 	ABG_HD void operator()(uint64_t i, uint32_t) const
 	{
 		uint32_t t = pend ? pend[i] : (uint32_t)i;
@@ -249,8 +251,11 @@ struct FInsertRound {
 		bool win = true;
 		for (unsigned j = 0; j < p.nh; j++)
 			win = win & (claim_cur[pos_i(p, h, j) & cmask] == v);
-		// losers queue for the next round: one counter bump per wavefront
-		const uint32_t slot = wave_append_slot(next_n, !win);
+		// losers queue for the next round: one counter bump per wavefront -- all on ONE address, which a
+		// round with millions of ops feels; such rounds flag the losers and have them compacted instead
+		uint32_t slot = 0;
+		if (lost) lost[i] = win ? 0 : 1;
+		else slot = wave_append_slot(next_n, !win);
 		if (win && casc.bits) {
 			cascade_insert(p, casc, h, false);
 		} else if (win) {
@@ -262,7 +267,7 @@ struct FInsertRound {
 					if (cnt[q] == mn) cnt[q] = (uint8_t)(mn + 1);
 				}
 		} else {
-			next[slot] = t;
+			if (!lost) next[slot] = t;
 			uint64_t v2 = claim_val(epoch + 1, t);
 			for (unsigned j = 0; j < p.nh; j++)
 				atomic_min_u64(&claim_next[pos_i(p, h, j) & cmask], v2);
@@ -455,7 +460,7 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // leaves the others, which are above it, alone.  All remaining ops touch counters no such k-mer
 // touches, and keep their order among themselves in the reservation rounds.
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
-constexpr uint32_t TILE_SORT_MAX = 4096;                            // pairs of one tile per batch, at most
+constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
 struct TilePair { uint64_t h; uint32_t t; uint32_t off; };          // (off: offset within the tile | hash index << 16)
 struct TileEnv {
 	Params p; uint8_t* cnt; uint64_t m;
@@ -499,65 +504,143 @@ struct FHashOps { // FHashClaim without the claims
 		}
 	}
 };
-struct FBinPairs { // one op per item
-	TileEnv e;
-	ABG_HD void operator()(uint64_t t, uint32_t) const
+// Binning in two passes, each a workgroup-local counting sort, because one global atomic per pair
+// on the bins' cursors is what such a kernel then spends its time on (67 M device-scope atomics
+// on 29 k addresses: 6 ms per batch).  Pass 1: a workgroup takes BIN_CHUNK_OPS ops, counts its
+// pairs per COARSE bin (a run of 2^cshift tiles) in LDS, reserves room in every coarse bin with one
+// global atomic, and writes the pairs there in runs.  Pass 2: a workgroup takes BIN_CHUNK_PAIRS
+// pairs of one coarse bin and does the same over that bin's tiles.
+constexpr uint32_t BIN_CHUNK_OPS = 2048, BIN_CHUNK_PAIRS = 8192, BIN_MAX_COARSE = 2048, BIN_MAX_FINE = 4096;
+struct BinEnv {
+	TileEnv e; uint64_t T;
+	TilePair* coarse; uint32_t ccap; uint32_t* ccur; // [ncoarse][ccap], [ncoarse]
+	uint32_t cshift, ncoarse;
+};
+struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoarse words
+	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 256;
+	BinEnv b;
+	template <class Sync> ABG_HDN void operator()(uint64_t c, void* fast, Sync& sy) const
 	{
-		const uint64_t h = e.h0[t];
-		for (unsigned j = 0; j < e.p.nh; j++) {
-			const uint64_t pos = pos_i(e.p, h, j);
-			const uint64_t tile = pos >> TILE_BITS;
-			const uint32_t slot = atomic_add_u32(&e.tcur[tile], 1);
-			if (slot >= e.cap) { e.flags[0] = 1; continue; }
-			TilePair& r = e.bins[tile * e.cap + slot];
-			r.h = h; r.t = (uint32_t)t; r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | (j << 16);
+		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + b.ncoarse;
+		const uint32_t tid = sy.tid(), nt = sy.nthreads();
+		const uint64_t t0 = c * BIN_CHUNK_OPS, t1 = t0 + BIN_CHUNK_OPS < b.T ? t0 + BIN_CHUNK_OPS : b.T;
+		for (uint32_t i = tid; i < b.ncoarse; i += nt) hist[i] = 0;
+		sy.barrier();
+		for (uint64_t t = t0 + tid; t < t1; t += nt) {
+			const uint64_t h = b.e.h0[t];
+			for (unsigned j = 0; j < b.e.p.nh; j++) atomic_add_u32(&hist[(pos_i(b.e.p, h, j) >> TILE_BITS) >> b.cshift], 1);
+		}
+		sy.barrier();
+		for (uint32_t i = tid; i < b.ncoarse; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.ccur[i], hist[i]) : 0;
+		sy.barrier();
+		for (uint64_t t = t0 + tid; t < t1; t += nt) {
+			const uint64_t h = b.e.h0[t];
+			for (unsigned j = 0; j < b.e.p.nh; j++) {
+				const uint64_t pos = pos_i(b.e.p, h, j);
+				const uint32_t cb = (uint32_t)((pos >> TILE_BITS) >> b.cshift);
+				const uint32_t slot = atomic_add_u32(&cur[cb], 1);
+				if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
+				TilePair& r = b.coarse[(uint64_t)cb * b.ccap + slot];
+				// (off: offset within the tile | tile within the coarse bin << 16)
+				r.h = h; r.t = (uint32_t)t;
+				r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | ((uint32_t)((pos >> TILE_BITS) & ((1u << b.cshift) - 1)) << 16);
+			}
 		}
 	}
 };
-// Sync policy of the tile procedures: tid(), nthreads(), barrier(), sort_u32(keys, n) (ascending,
-// cooperative; n <= TILE_SORT_MAX, keys has room for the next power of two).
+struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin + q); fast memory: 2 x 2^cshift words
+	static constexpr uint32_t FAST = 2 * BIN_MAX_FINE * 4, THREADS = 256;
+	BinEnv b; uint32_t chunks_per_bin;
+	template <class Sync> ABG_HDN void operator()(uint64_t item, void* fast, Sync& sy) const
+	{
+		const uint32_t cb = (uint32_t)(item / chunks_per_bin), q = (uint32_t)(item % chunks_per_bin);
+		const uint32_t filled = ld_coherent(&b.ccur[cb]);
+		const uint32_t total = filled < b.ccap ? filled : b.ccap;
+		const uint32_t i0 = q * BIN_CHUNK_PAIRS;
+		if (i0 >= total) return;
+		const uint32_t i1 = i0 + BIN_CHUNK_PAIRS < total ? i0 + BIN_CHUNK_PAIRS : total;
+		const uint32_t nfine = 1u << b.cshift;
+		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + nfine;
+		const uint32_t tid = sy.tid(), nt = sy.nthreads();
+		const TilePair* src = b.coarse + (uint64_t)cb * b.ccap;
+		for (uint32_t i = tid; i < nfine; i += nt) hist[i] = 0;
+		sy.barrier();
+		for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[src[i].off >> 16], 1);
+		sy.barrier();
+		const uint64_t tile0 = (uint64_t)cb << b.cshift;
+		for (uint32_t i = tid; i < nfine; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.e.tcur[tile0 + i], hist[i]) : 0;
+		sy.barrier();
+		for (uint32_t i = i0 + tid; i < i1; i += nt) {
+			TilePair r = src[i];
+			const uint32_t f = r.off >> 16;
+			const uint32_t slot = atomic_add_u32(&cur[f], 1);
+			if (slot >= b.e.cap) { b.e.flags[0] = 1; continue; }
+			r.off &= 0xFFFFu;
+			b.e.bins[(tile0 + f) * b.e.cap + slot] = r;
+		}
+	}
+};
+// Sync policy of the tile procedures: tid(), nthreads(), barrier(), any(bool).
+// tile_purity: the pairs of one tile are grouped by counter in an open-addressing table in fast
+// memory (TILE_TAB slots: the counter's offset; the earliest pair on it as op id << 12 | pair
+// index; how many pairs).  A counter all of whose pairs carry the hash of its earliest pair's
+// k-mer is pure, and that pair's op leads the k-mer's ops.
+constexpr uint32_t TILE_TAB = 4096; // (TILE_SORT_MAX = 3072 pairs at most: the table is never full)
+constexpr uint32_t PUR_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t TILE_PURITY_FAST = TILE_TAB * (4 + 8 + 4);
 template <class Sync>
-ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, uint32_t* keys, Sync& sy)
+ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 {
-	const uint32_t n = ld_coherent(&e.tcur[tile]) < e.cap ? ld_coherent(&e.tcur[tile]) : e.cap;
+	const uint32_t filled = ld_coherent(&e.tcur[tile]);
+	const uint32_t n = filled < e.cap ? filled : e.cap;
 	if (!n) return;
 	const TilePair* bin = e.bins + tile * e.cap;
 	const uint32_t tid = sy.tid(), nt = sy.nthreads();
-	for (uint32_t i = tid; i < n; i += nt) keys[i] = ((bin[i].off & 0xFFFFu) << 12) | i;
+	uint64_t* first = (uint64_t*)fast;                 // [TILE_TAB]
+	uint32_t* key = (uint32_t*)(first + TILE_TAB);     // [TILE_TAB] offset within the tile, or PUR_EMPTY
+	uint32_t* info = key + TILE_TAB;                   // [TILE_TAB] pairs on the counter | impure << 31
+	for (uint32_t i = tid; i < TILE_TAB; i += nt) { key[i] = PUR_EMPTY; first[i] = ~0ULL; info[i] = 0; }
 	sy.barrier();
-	sy.sort_u32(keys, n);
-	sy.barrier();
-	// every thread takes the runs (pairs on one counter) that start at its positions
+	auto slot_of = [&](uint32_t off) -> uint32_t {
+		uint32_t s = ((off * 0x9E3779B1u) >> 20) & (TILE_TAB - 1);
+		for (;;) {
+			const uint32_t cur = cas_u32(&key[s], PUR_EMPTY, off);
+			if (cur == PUR_EMPTY || cur == off) return s;
+			s = (s + 1) & (TILE_TAB - 1);
+		}
+	};
 	for (uint32_t i = tid; i < n; i += nt) {
-		const uint32_t off = keys[i] >> 12;
-		if (i && (keys[i - 1] >> 12) == off) continue;
-		const TilePair& first = bin[keys[i] & 0xFFFu];
-		uint32_t len = 1, tmin = first.t;
-		bool pure = true;
-		for (uint32_t j = i + 1; j < n && (keys[j] >> 12) == off; j++, len++) {
-			const TilePair& r = bin[keys[j] & 0xFFFu];
-			pure = pure & (r.h == first.h);
-			tmin = r.t < tmin ? r.t : tmin;
-		}
-		if (pure) {
-			// the k-mer's ops: the run holds one pair per op and per hash function that lands here
-			uint32_t d = 0;
-			const uint64_t pos = (tile << TILE_BITS) | off;
-			for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, first.h, q) == pos;
-			e.lead[tmin] = len / (d ? d : 1);
-		} else {
-			for (uint32_t j = i; j < i + len; j++) e.opflag[bin[keys[j] & 0xFFFu].t] = 1;
-		}
+		const uint32_t s = slot_of(bin[i].off & 0xFFFFu);
+		atomic_min_u64(&first[s], ((uint64_t)bin[i].t << 12) | i);
+		atomic_add_u32(&info[s], 1);
+	}
+	sy.barrier();
+	for (uint32_t i = tid; i < n; i += nt) {
+		const uint32_t s = slot_of(bin[i].off & 0xFFFFu);
+		if (bin[i].h != bin[(uint32_t)(first[s] & 0xFFFu)].h) atomic_or_u32(&info[s], 0x80000000u);
+	}
+	sy.barrier();
+	for (uint32_t i = tid; i < n; i += nt) {
+		const TilePair& r = bin[i];
+		const uint32_t off = r.off & 0xFFFFu;
+		const uint32_t s = slot_of(off);
+		const uint32_t inf = info[s];
+		if (inf >> 31) { e.opflag[r.t] = 1; continue; }
+		if ((uint32_t)(first[s] & 0xFFFu) != i) continue;
+		// the earliest op of the counter's one k-mer leads its ops: the counter holds one pair per op and
+		// per hash function of the k-mer that lands here
+		uint32_t d = 0;
+		const uint64_t pos = (tile << TILE_BITS) | off;
+		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, r.h, q) == pos;
+		e.lead[r.t] = (inf & 0x7FFFFFFFu) / (d ? d : 1);
 	}
 }
 struct FOpTarget { // one op per item: leaders of k-mers with pure counters only compute their target
-	TileEnv e; uint32_t* pend; uint32_t* pend_n;
+	TileEnv e;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
-		const bool conflict = e.opflag[t] != 0;
-		// ops of k-mers that share a counter go to the reservation rounds (one counter bump per wave)
-		const uint32_t slot = wave_append_slot(pend_n, conflict);
-		if (conflict) { pend[slot] = (uint32_t)t; e.tgt[t] = 0; return; }
+		// (ops of k-mers that share a counter go to the reservation rounds: the caller compacts opflag)
+		if (e.opflag[t]) { e.tgt[t] = 0; return; }
 		const uint32_t n = e.lead[t];
 		uint8_t tg = 0;
 		if (n) {
@@ -609,13 +692,13 @@ struct FClaimList { // FClaim over a list of ops
 	}
 };
 
-struct FTilePurity { // tile procedures as items of Backend::launch_tiles: f(tile, FAST bytes of fast memory, sync)
-	static constexpr uint32_t FAST = TILE_SORT_MAX * 4;
+struct FTilePurity { // tile procedures as items of Backend::launch_tiles: f(tile, FAST bytes of fast memory, sync), THREADS per item
+	static constexpr uint32_t FAST = TILE_PURITY_FAST, THREADS = 512;
 	TileEnv e;
-	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_purity(e, tile, (uint32_t*)fast, sy); }
+	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_purity(e, tile, fast, sy); }
 };
 struct FTileApply {
-	static constexpr uint32_t FAST = TILE_COUNTERS;
+	static constexpr uint32_t FAST = TILE_COUNTERS, THREADS = 1024;
 	TileEnv e;
 	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_apply(e, tile, (uint8_t*)fast, sy); }
 };
@@ -1922,6 +2005,7 @@ class Engine {
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
 	uint64_t batch_ops_ = 0;   // ops per ordered-insert batch (ensure_insert)
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
+	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr;
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
@@ -2026,7 +2110,7 @@ class Engine {
 		ntiles_ = (m_ + TILE_COUNTERS - 1) >> TILE_BITS;
 		if (cfg_.tiled_insert && !casc_.bits && !dist() && p_.nh <= 16) {
 			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114));
-			T = std::min<uint64_t>(T, 3000ull * ntiles_ / p_.nh);
+			T = std::min<uint64_t>(T, 2048ull * ntiles_ / p_.nh);
 			if (T >= 1024) {
 				tiled_ = true;
 				batch_ops_ = T;
@@ -2039,6 +2123,18 @@ class Engine {
 		}
 		uint64_t nb = batch_ops_;
 		if (tiled_) {
+			// coarse bins of the first binning pass: runs of 2^cshift tiles, at most BIN_MAX_COARSE of them
+			cshift_ = 0;
+			while ((ntiles_ >> cshift_) > 512 && cshift_ < 12) cshift_++;
+			ncoarse_ = (uint32_t)((ntiles_ + (1ull << cshift_) - 1) >> cshift_);
+			{
+				const uint64_t mean = (nb * p_.nh + ncoarse_ - 1) / ncoarse_;
+				uint64_t sq = 1;
+				while (sq * sq < mean) sq++;
+				coarse_cap_ = (uint32_t)(mean + 8 * sq + 256);
+			}
+			coarse_ = (TilePair*)be_.alloc((uint64_t)ncoarse_ * coarse_cap_ * sizeof(TilePair));
+			ccur_ = (uint32_t*)be_.alloc(ncoarse_ * 4 + 64);
 			bins_ = (TilePair*)be_.alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
 			tcur_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
@@ -2052,13 +2148,15 @@ class Engine {
 			pend_[i] = (uint32_t*)be_.alloc(nb * 4);
 		}
 		pend_n_ = (uint32_t*)be_.alloc(8);
-		if (dist()) { dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32)); dlost_ = (uint8_t*)be_.alloc(nb); }
+		if (dist()) dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32));
+		dlost_ = (uint8_t*)be_.alloc(nb);
 	}
 	void free_insert()
 	{
 		if (!h0_) return;
-		if (tiled_) { be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
-		if (dres_) { be_.free(dres_); be_.free(dlost_); dres_ = nullptr; }
+		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
+		if (dres_) { be_.free(dres_); dres_ = nullptr; }
+		be_.free(dlost_);
 		be_.free(h0_);
 		for (int i = 0; i < 2; i++) { be_.free(claim_[i]); be_.free(pend_[i]); }
 		be_.free(pend_n_);
@@ -2106,7 +2204,15 @@ class Engine {
 			be_.memset(opflag_, 0, T);
 			be_.memset(scal_, 0, 8);
 			{ FHashOps f{ p_, v, h0_, T }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); }
-			{ FBinPairs f{ te }; be_.launch(T, f, "bin_pairs"); }
+			{
+				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
+				be_.memset(ccur_, 0, ncoarse_ * 4);
+				FBinCoarse f1{ bn };
+				be_.launch_tiles((T + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f1, "bin_coarse");
+				const uint32_t cpb = (coarse_cap_ + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS;
+				FBinFine f2{ bn, cpb };
+				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
+			}
 			uint32_t over = 0;
 			be_.d2h(&over, scal_, 4);
 			if (over) {
@@ -2115,9 +2221,9 @@ class Engine {
 				be_.launch(T, fc, "hash_claim");
 			} else {
 				{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
-				be_.memset(pend_n_, 0, 4);
-				{ FOpTarget f{ te, pend_[1], pend_n_ }; be_.launch(T, f, "op_target"); }
+				{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
 				{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+				be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
 				uint32_t nn = 0;
 				be_.d2h(&nn, pend_n_, 4);
 				stats_.tiled_ops += T; stats_.tiled_pending += nn;
@@ -2146,8 +2252,10 @@ class Engine {
 				break;
 			}
 			be_.memset(pend_n_, 0, 4);
-			FInsertRound fr{ p_, h0_, cnt_, casc_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_ };
+			const bool flagged = npend >= cfg_.compact_threshold;
+			FInsertRound fr{ p_, h0_, cnt_, casc_, pin, pout, pend_n_, ccur, cnext, cmask, epoch_, flagged ? dlost_ : nullptr };
 			be_.launch(npend, fr, pin ? "insert_retry" : "insert_round");
+			if (flagged) be_.compact_flagged(pin, dlost_, npend, pout, pend_n_);
 			uint32_t nn = 0;
 			be_.d2h(&nn, pend_n_, 4);
 			npend = nn;

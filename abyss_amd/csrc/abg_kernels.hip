@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(COMMIT_THREADS) k_commit(abg::CommitEnv<NW> e,
 
 // one workgroup per tile of the counter array (abg::TileEnv): F::FAST bytes of LDS, tiles strided over the grid
 template <class F>
-__global__ void __launch_bounds__(256) k_tiles(F f, uint64_t n)
+__global__ void __launch_bounds__(F::THREADS) k_tiles(F f, uint64_t n)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[F::FAST]; // (all of the 64 KB a workgroup may declare, for tile_apply)
 	DeviceSync sy{ nullptr }; // (the tile procedures use barrier / any / sort_u32 only: no shared words)
@@ -459,7 +459,7 @@ struct HipBackend {
 		const uint64_t cap = (uint64_t)cus * (F::FAST > 32768 ? 2 : 8);
 		if (blocks > cap) blocks = cap;
 		begin(name);
-		hipLaunchKernelGGL(k_tiles<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
+		hipLaunchKernelGGL(k_tiles<F>, dim3((uint32_t)blocks), dim3(F::THREADS), 0, stream, f, n);
 		end(name);
 	}
 	void launch_drain(abg::InsertDrainEnv e)

@@ -282,7 +282,7 @@ def main() -> int:
     warm_prof = None
     if partitioned and a.warmup and g is not None:
         warm_prof = True
-    names = ["hash_ops", "bin_pairs", "tile_purity", "op_target", "tile_apply", "claim_list", "guide_build",
+    names = ["hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "tile_apply", "claim_list", "guide_build",
              "hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
              "insert_drain", "classify", "read_prep", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
              "share_fix",

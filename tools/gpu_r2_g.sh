@@ -2,13 +2,13 @@
 set -u
 O=gpurun_out/r2g; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest.log; cat $O/pytest.log
 show() { python - $1 $2 <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); k=d["kernel_ms"]; s=d["engine_stats"]
 print(sys.argv[2], "ms/step %.0f" % d["ms_per_step"], "unitigs", d["config"]["unitigs"], d["config"]["unitig_bp"], {a:s[a] for a in ("tiled_ops","tiled_pending","tile_overflows","insert_rounds")})
-print({a:round(b["ms"]) for a,b in k.items() if b["ms"]>3})
+print({a:(round(b["ms"]), b["launches"]) for a,b in k.items() if b["ms"]>3})
 PY
 }
-timeout 600 python bench.py --no-cpu-baseline --steps 2 > $O/bench.json 2> $O/bench.err; show $O/bench.json tiled
-ABG_TILED=0 timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench_rounds.json 2> $O/bench_rounds.err; show $O/bench_rounds.json rounds
+timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench.json 2> $O/bench.err; show $O/bench.json tiled
+ABG_TILED=0 timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench_rounds.json 2> $O/bench_rounds.err; show $O/bench_rounds.json rounds_compact
+ABG_TILED=0 ABG_COMPACT_THRESHOLD=99999999999 timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench_rounds2.json 2> $O/bench_rounds2.err; show $O/bench_rounds2.json rounds_append
