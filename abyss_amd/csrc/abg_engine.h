@@ -472,7 +472,8 @@ struct TileEnv {
 	uint8_t* tgt;                     // [T] leaders: the value their counters are raised to (0: nothing to do)
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
 };
-struct FHashOps { // FHashClaim without the claims
+template <int NW>
+struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's run comes off the read's words at once
 	Params p; Batch b; uint64_t* h0; uint64_t T;
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
@@ -489,11 +490,8 @@ struct FHashOps { // FHashClaim without the claims
 			uint32_t j = (uint32_t)(t - b.koff[r]);
 			if (p.mask) { h0[t] = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); }); continue; }
 			if (fresh) {
-				fh = 0; rh = 0;
-				for (unsigned i = 0; i < k; i++) {
-					fh = srol1(fh) ^ seed_of(batch_base(b, r, j + i));
-					rh = srol1(rh) ^ seed_of(3u - batch_base(b, r, j + k - 1 - i));
-				}
+				const Kmer<NW> s = window_kmer<NW>(b.words, b.woff[r], j, k);
+				kmer_hashes(s, k, fh, rh);
 				fresh = false;
 			} else {
 				unsigned out = batch_base(b, r, j - 1), in = batch_base(b, r, j + k - 1);
@@ -588,6 +586,7 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 constexpr uint32_t TILE_TAB = 4096; // (TILE_SORT_MAX = 3072 pairs at most: the table is never full)
 constexpr uint32_t PUR_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t TILE_PURITY_FAST = TILE_TAB * (4 + 8 + 4);
+constexpr uint32_t TILE_PURITY_THREADS = 512, TILE_PURITY_PER = (TILE_SORT_MAX + TILE_PURITY_THREADS - 1) / TILE_PURITY_THREADS;
 template <class Sync>
 ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 {
@@ -601,6 +600,11 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	uint32_t* info = key + TILE_TAB;                   // [TILE_TAB] pairs on the counter | impure << 31
 	for (uint32_t i = tid; i < TILE_TAB; i += nt) { key[i] = PUR_EMPTY; first[i] = ~0ULL; info[i] = 0; }
 	sy.barrier();
+	// a thread keeps its pairs (and the table slot of each one's counter) in registers through the phases;
+	// a serial caller (one thread, all pairs) looks everything up again instead
+	const bool keep = nt >= TILE_PURITY_THREADS;
+	TilePair mine[TILE_PURITY_PER];
+	uint32_t slot[TILE_PURITY_PER];
 	auto slot_of = [&](uint32_t off) -> uint32_t {
 		uint32_t s = ((off * 0x9E3779B1u) >> 20) & (TILE_TAB - 1);
 		for (;;) {
@@ -609,31 +613,44 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 			s = (s + 1) & (TILE_TAB - 1);
 		}
 	};
-	for (uint32_t i = tid; i < n; i += nt) {
-		const uint32_t s = slot_of(bin[i].off & 0xFFFFu);
-		atomic_min_u64(&first[s], ((uint64_t)bin[i].t << 12) | i);
+	auto pairs = [&](auto&& body) { // body(pair, index in the bin, its slot)
+		if (keep) {
+#pragma unroll
+			for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
+				const uint32_t i = tid + q * nt;
+				if (i < n) body(mine[q], i, slot[q]);
+			}
+		} else {
+			for (uint32_t i = tid; i < n; i += nt) body(bin[i], i, slot_of(bin[i].off & 0xFFFFu));
+		}
+	};
+	if (keep) {
+#pragma unroll
+		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
+			const uint32_t i = tid + q * nt;
+			if (i < n) { mine[q] = bin[i]; slot[q] = slot_of(mine[q].off & 0xFFFFu); }
+		}
+	}
+	pairs([&](const TilePair& r, uint32_t i, uint32_t s) {
+		atomic_min_u64(&first[s], ((uint64_t)r.t << 12) | i);
 		atomic_add_u32(&info[s], 1);
-	}
+	});
 	sy.barrier();
-	for (uint32_t i = tid; i < n; i += nt) {
-		const uint32_t s = slot_of(bin[i].off & 0xFFFFu);
-		if (bin[i].h != bin[(uint32_t)(first[s] & 0xFFFu)].h) atomic_or_u32(&info[s], 0x80000000u);
-	}
+	pairs([&](const TilePair& r, uint32_t, uint32_t s) {
+		if (r.h != bin[(uint32_t)(first[s] & 0xFFFu)].h) atomic_or_u32(&info[s], 0x80000000u);
+	});
 	sy.barrier();
-	for (uint32_t i = tid; i < n; i += nt) {
-		const TilePair& r = bin[i];
-		const uint32_t off = r.off & 0xFFFFu;
-		const uint32_t s = slot_of(off);
+	pairs([&](const TilePair& r, uint32_t i, uint32_t s) {
 		const uint32_t inf = info[s];
-		if (inf >> 31) { e.opflag[r.t] = 1; continue; }
-		if ((uint32_t)(first[s] & 0xFFFu) != i) continue;
+		if (inf >> 31) { e.opflag[r.t] = 1; return; }
+		if ((uint32_t)(first[s] & 0xFFFu) != i) return;
 		// the earliest op of the counter's one k-mer leads its ops: the counter holds one pair per op and
 		// per hash function of the k-mer that lands here
 		uint32_t d = 0;
-		const uint64_t pos = (tile << TILE_BITS) | off;
+		const uint64_t pos = (tile << TILE_BITS) | (r.off & 0xFFFFu);
 		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, r.h, q) == pos;
 		e.lead[r.t] = (inf & 0x7FFFFFFFu) / (d ? d : 1);
-	}
+	});
 }
 struct FOpTarget { // one op per item: leaders of k-mers with pure counters only compute their target
 	TileEnv e;
@@ -693,7 +710,7 @@ struct FClaimList { // FClaim over a list of ops
 };
 
 struct FTilePurity { // tile procedures as items of Backend::launch_tiles: f(tile, FAST bytes of fast memory, sync), THREADS per item
-	static constexpr uint32_t FAST = TILE_PURITY_FAST, THREADS = 512;
+	static constexpr uint32_t FAST = TILE_PURITY_FAST, THREADS = TILE_PURITY_THREADS;
 	TileEnv e;
 	template <class Sync> ABG_HDN void operator()(uint64_t tile, void* fast, Sync& sy) const { tile_purity(e, tile, fast, sy); }
 };
@@ -2203,7 +2220,7 @@ class Engine {
 			be_.memset(lead_, 0, T * 4);
 			be_.memset(opflag_, 0, T);
 			be_.memset(scal_, 0, 8);
-			{ FHashOps f{ p_, v, h0_, T }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); }
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 			{
 				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 				be_.memset(ccur_, 0, ncoarse_ * 4);

@@ -9,6 +9,5 @@ print(sys.argv[2], "ms/step %.0f" % d["ms_per_step"], "unitigs", d["config"]["un
 print({a:(round(b["ms"]), b["launches"]) for a,b in k.items() if b["ms"]>3})
 PY
 }
-timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench.json 2> $O/bench.err; show $O/bench.json tiled
-ABG_TILED=0 timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench_rounds.json 2> $O/bench_rounds.err; show $O/bench_rounds.json rounds_compact
-ABG_TILED=0 ABG_COMPACT_THRESHOLD=99999999999 timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench_rounds2.json 2> $O/bench_rounds2.err; show $O/bench_rounds2.json rounds_append
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+timeout 600 python bench.py --no-cpu-baseline --steps 1 > $O/bench.json 2> $O/bench.err; show $O/bench.json tiled; tail -2 $O/bench.err
