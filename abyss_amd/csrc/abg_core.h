@@ -606,6 +606,13 @@ ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, u
 // state in every lane (one unitig walker per wave).  Probes then spread over the lanes:
 // lane l handles hash function (l & 7) of k-mer (l >> 3), and a ballot gathers the verdict.
 // Non-cooperative callers (one item per lane, or the serial host check) pass coop = false.
+// lanes of one wavefront exchanging data through memory they share (LDS or global): everything
+// written before is visible to the wave's other lanes after
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#else
+ABG_HD void wave_sync() {}
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // AND over the lanes of a wave-per-item kernel (nlanes == 64) / identity for serial callers
 ABG_HD bool wave_all_lanes(bool v, uint32_t nlanes) { return nlanes > 1 ? __ballot(v ? 0 : 1) == 0 : v; }
@@ -961,6 +968,58 @@ ABG_HD unsigned nbr_mask_lean(const Params& p, const SeedTabs& t, const uint8_t*
 	}
 	return ok;
 }
+// Which neighbours of a vertex exist is a pure function of the vertex and the solid filter, and
+// the searches ask it of the same vertices again and again: trueBranch wants a vertex's neighbours
+// ahead when it enters it and the ones behind when it turns around, lookAhead re-explores what the
+// search before it explored, and in a tangle successive successor() calls walk the same few
+// hundred vertices.  A walker therefore keeps the answers for both directions in a small
+// direct-mapped table in fast memory (LDS), filled by ONE probe round per vertex: lanes 0-31 probe
+// the neighbours in SENSE direction, lanes 32-63 the ones in ANTISENSE direction.
+constexpr uint32_t MC_N = 256;
+struct MaskCache {
+	uint64_t fh[MC_N], rh[MC_N]; // the vertex (its oriented strand hashes)
+	uint8_t m[MC_N];             // bits 0-3: neighbours in SENSE direction, bits 4-7: in ANTISENSE direction
+	uint8_t valid[MC_N];
+};
+template <int NW, bool COOP>
+ABG_HD unsigned nbr_mask_cached(const Params& p, const SeedTabs& t, const uint8_t* __restrict__ cnt, const Vtx<NW>& v, int sense,
+    MaskCache* mc)
+{
+	if constexpr (MASKED_BUILD<NW>) { (void)mc; return nbr_mask_lean<NW, COOP>(p, t, cnt, v, sense); }
+	else {
+	if (!mc || p.nh > 8) return nbr_mask_lean<NW, COOP>(p, t, cnt, v, sense);
+	const uint32_t slot = (uint32_t)((v.fh ^ (v.rh >> 17)) * 0x9E3779B97F4A7C15ULL >> 40) & (MC_N - 1);
+	if (mc->valid[slot] && mc->fh[slot] == v.fh && mc->rh[slot] == v.rh) {
+		const unsigned m = mc->m[slot];
+		return sense == SENSE ? (m & 0xFu) : (m >> 4);
+	}
+	unsigned ok = 0xFFu;
+	uint64_t fb_s, rb_s, fb_a, rb_a;
+	nbr_base(t, v, p.k, SENSE, fb_s, rb_s);
+	nbr_base(t, v, p.k, ANTISENSE, fb_a, rb_a);
+	if (COOP) {
+		const unsigned lane = lane_id(), s = lane >> 5, b = (lane >> 3) & 3u, i = lane & 7u;
+		uint64_t fh, rh;
+		nbr_hash(t, s ? ANTISENSE : SENSE, s ? fb_a : fb_s, s ? rb_a : rb_s, b, fh, rh);
+		const uint64_t h = rh < fh ? rh : fh;
+		bool bad = false;
+		if (i < p.nh) bad = cnt[pos_i(p, h, i)] < p.kc;
+		const uint64_t bm = wave_ballot(bad);
+#pragma unroll
+		for (unsigned q = 0; q < 8; q++)
+			if ((bm >> (8 * q)) & 0xFFu) ok &= ~(1u << q);
+	} else {
+		for (unsigned q = 0; q < 8; q++) {
+			uint64_t fh, rh;
+			nbr_hash(t, q < 4 ? SENSE : ANTISENSE, q < 4 ? fb_s : fb_a, q < 4 ? rb_s : rb_a, q & 3u, fh, rh);
+			if (!solid_contains(p, cnt, rh < fh ? rh : fh)) ok &= ~(1u << q);
+		}
+	}
+	mc->fh[slot] = v.fh; mc->rh[slot] = v.rh; mc->m[slot] = (uint8_t)ok; mc->valid[slot] = 1;
+	wave_sync();
+	return sense == SENSE ? (ok & 0xFu) : (ok >> 4);
+	}
+}
 template <int NW>
 ABG_HD Vtx<NW> nbr_vertex_lean(const Params& p, const SeedTabs& t, const Vtx<NW>& v, int sense, unsigned b)
 {
@@ -995,9 +1054,6 @@ ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v)
 {
 	return (uint64_t)atomicMin((unsigned long long*)p, (unsigned long long)v);
 }
-// lanes of one wavefront exchanging data through memory they share (LDS or global): everything
-// written before is visible to the wave's other lanes after
-ABG_HD void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
 {
@@ -1016,7 +1072,6 @@ ABG_HD uint64_t cas_u64(uint64_t* p, uint64_t expect, uint64_t val)
 	return old;
 }
 ABG_HD uint32_t cas_u32(uint32_t* p, uint32_t expect, uint32_t val) { uint32_t o = *p; if (o == expect) *p = val; return o; }
-ABG_HD void wave_sync() {}
 ABG_HD uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
 ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -1242,6 +1297,7 @@ struct SearchScratch {
 	uint64_t dbg_search;
 	uint64_t dbg_nodes;    // trueBranch calls entered (frames pushed)
 	LAFrame<NW> la_local[FP_TRIM + 1]; // used when no fast memory is available
+	MaskCache* mcache;     // neighbour masks of the vertices the searches have looked at (NULL: none)
 	SuccMemo memo;         // answers of successor() shared by all walkers; k0 == NULL: off
 	uint32_t n_memo_hits, n_memo_adds;
 	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
@@ -1275,7 +1331,8 @@ ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in
 	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
 	int depth = 0;
 	la[0].v = start;
-	la[0].mask = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, start, sense);
+	MaskCache* const mcache = uniptr<COOP>(sc.mcache);
+	la[0].mask = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, start, sense, mcache);
 	la[0].next = 0;
 	while (depth >= 0) {
 		LAFrame<NW>& f = la[depth];
@@ -1303,7 +1360,7 @@ ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in
 		if ((unsigned)(depth + 1) >= limit) return true;
 		depth++;
 		la[depth].v = w;
-		la[depth].mask = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, w, sense);
+		la[depth].mask = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, w, sense, mcache);
 		la[depth].next = 0;
 	}
 	return false;
@@ -1338,6 +1395,7 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 	VKey* const tbs_keys = uniptr<COOP>(sc.tb_keys);
 	const uint32_t tbf_cap = uni32<COOP>(sc.tbf_cap);
 	const int cap = (int)(tbf_cap + uni32<COOP>(sc.tb_cap));
+	MaskCache* const mcache = uniptr<COOP>(sc.mcache);
 	auto frame = [&](int i) -> TBFrame<NW>& { return (uint32_t)i < tbf_cap ? tbf[i] : tbs[(uint32_t)i - tbf_cap]; };
 	auto keyat = [&](int i) -> VKey& { return (uint32_t)i < tbf_cap ? tbf_keys[i] : tbs_keys[(uint32_t)i - tbf_cap]; };
 	auto uniform_vtx = [&](const Vtx<NW>& x) {
@@ -1380,7 +1438,7 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 			f.v = cv; f.ufh = cuk.fh; f.urh = cuk.rh;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
-			f.mask_same = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE);
+			f.mask_same = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE, mcache);
 		}
 		// ---- resume frames until one of them makes a new call
 		bool called = false;
@@ -1412,7 +1470,7 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
 				f.next = 0;
-				f.mask_other = (uint8_t)nbr_mask_lean<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE);
+				f.mask_other = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE, mcache);
 				f.have_other = 1;
 			}
 			// stage 1: other-direction children, skipping the vertex we came from

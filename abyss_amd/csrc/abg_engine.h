@@ -743,7 +743,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
 		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0;
-		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
+		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.mcache = nullptr;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
@@ -825,6 +825,7 @@ struct FGuideBuild {
 	}
 };
 
+constexpr uint32_t WALK_FAST_WITH_CACHE = 12288; // fast memory of at least this size ends with a MaskCache
 template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
 	WalkEnv<NW> e; const uint32_t* list;
@@ -838,6 +839,13 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 		WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
 		const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
 		*env = e;
+		// the tail of the fast memory is the walkers' neighbour-mask cache (MaskCache): the launcher
+		// zeroed its valid flags, and it carries over from one walker of this slot to the next
+		env->mcache = nullptr;
+		if (fast_bytes >= WALK_FAST_WITH_CACHE) {
+			fast_bytes -= (uint32_t)sizeof(MaskCache);
+			env->mcache = (MaskCache*)((char*)fast + fast_bytes);
+		}
 		env->fast = (char*)fast + a;
 		env->fast_bytes = fast_bytes - a;
 		env->coop = coop;
@@ -2434,7 +2442,7 @@ class Engine {
 		e.tb_cap = walk_tb_cap_;
 		e.fast = nullptr; e.fast_bytes = 0; e.dbg = dbg_; e.coop = false;
 		e.la_pool = la_pool_;
-		e.guide = guide_; e.bulk_pool = bulk_pool_; e.wstats = wstats_; e.memo = memo_;
+		e.guide = guide_; e.bulk_pool = bulk_pool_; e.wstats = wstats_; e.memo = memo_; e.mcache = nullptr;
 		e.lbuf_pool = lbuf_; e.rbuf_pool = rbuf_; e.buf_cap = walk_buf_cap_;
 		e.pool = pool_; e.pool_cap = pool_cap_; e.pool_used = pool_used_;
 		e.recs = recs_; e.rec_cap = rec_cap_; e.rec_used = rec_used_;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
 // trueBranch on-stack test scans 64 frames at a time; atomics go through lane 0.
 // The walker's trueBranch stack (frames + keys) lives in WALK_LDS bytes of LDS.
 #ifndef ABG_WALK_LDS
-#define ABG_WALK_LDS 16384
+#define ABG_WALK_LDS 20480 // (8 walkers per CU, which the registers allow anyway, share its 160 KB)
 #endif
 #ifndef ABG_WALK_WAVES
 #define ABG_WALK_WAVES 2 // wavefronts per SIMD the walker kernel is compiled for (register budget 512 / waves)
@@ -58,6 +58,12 @@ template <class F>
 __global__ void __launch_bounds__(64, ABG_WALK_WAVES) k_walkers(F f, uint64_t n, unsigned long long* ticket)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[WALK_LDS];
+	{
+		// the walkers' neighbour-mask cache at the end of the block starts out empty (see FWalk)
+		abg::MaskCache* mc = (abg::MaskCache*)(lds + WALK_LDS - sizeof(abg::MaskCache));
+		for (unsigned i = threadIdx.x; i < abg::MC_N; i += 64) mc->valid[i] = 0;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	}
 	// walks differ in length by orders of magnitude: waves draw candidates from a ticket
 	// counter (in candidate order) instead of striding, so no wave is left with a queue of
 	// long walks while others idle
@@ -204,6 +210,7 @@ struct HipBackend {
 	~HipBackend()
 	{
 		if (ticket) free(ticket);
+		if (pin) hipHostFree(pin);
 		for (int i = 0; i < MAX_WCTX; i++)
 			if (wstream[i]) { hipStreamSynchronize(wstream[i]); hipFree(wticket[i]); hipEventDestroy(wev0[i]); hipEventDestroy(wev1[i]); hipStreamDestroy(wstream[i]); }
 		if (cub_tmp) hipFree(cub_tmp);
@@ -283,15 +290,32 @@ struct HipBackend {
 		cache_held = 0;
 	}
 	void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
+	// Small transfers (counters read back after nearly every kernel of a batch, little tables going
+	// up) pass through a pinned staging buffer: a copy to or from pageable memory is staged by the
+	// runtime at several times the cost.
+	static constexpr size_t PIN_BYTES = 1u << 16;
+	void* pin = nullptr;
 	void h2d(void* d, const void* s, size_t n)
 	{
 		if (!n) return;
+		if (n <= PIN_BYTES && (pin || hipHostMalloc(&pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess)) {
+			memcpy(pin, s, n);
+			check(hipMemcpyAsync(d, pin, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
+			check(hipStreamSynchronize(stream), "hipStreamSynchronize"); // (the buffer is reused right away)
+			return;
+		}
 		check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}
 	void d2h(void* d, const void* s, size_t n)
 	{
 		if (!n) return;
+		if (n <= PIN_BYTES && (pin || hipHostMalloc(&pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess)) {
+			check(hipMemcpyAsync(pin, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
+			check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			memcpy(d, pin, n);
+			return;
+		}
 		check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 	}

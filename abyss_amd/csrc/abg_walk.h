@@ -162,6 +162,7 @@ struct WalkEnv {
 	bool coop;                 // the walker is a whole wavefront in lock step
 	Guide guide;               // read-guided bulk steps (tab == NULL: off)
 	SuccMemo memo;             // shared answers of successor() (k0 == NULL: off)
+	MaskCache* mcache;         // neighbour masks kept in the walker's fast memory (NULL: none)
 	BulkScratch* bulk_pool;    // [slots] scratch of the bulk steps when the fast memory has no room for it
 	uint64_t* wstats;          // [WSTAT_N] work counters summed over all walkers
 	// contig output
@@ -779,6 +780,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	}
 	sc.guide = e.guide; sc.bulk = w.bulk;
 	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
+	sc.mcache = e.mcache;
 	if (!w.bulk) sc.guide.tab = nullptr;
 	{
 		// trueBranch keys and frames side by side

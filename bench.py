@@ -153,6 +153,8 @@ def main() -> int:
     ap.add_argument("--bloom", type=str, default=None)
     ap.add_argument("--K", type=int, default=None, help="spaced seed of two K-mers (-K of abyss-bloom-dbg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true",
+                    help="time the steps without HIP events around every launch (no per-kernel numbers: shows what the events cost)")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
                     help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -243,6 +245,7 @@ def main() -> int:
     g = None
     unitigs = bases = 0
     setup_s = 0.0
+    phase_s = [0.0, 0.0]  # wall seconds in PASS 1 / PASS 2 over the timed steps
 
     def step(profile=True):
         nonlocal g, unitigs, bases, setup_s, comm
@@ -266,10 +269,14 @@ def main() -> int:
             rw, ro, rl, rn = g.share_reads(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
         else:
             rw, ro, rl, rn = words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads
+        t_a = time.perf_counter()
         g.load_packed(rw, ro, rl, rn)
+        t_b = time.perf_counter()
         # contigs stay on the device (no per-contig callback into Python): the unitig count and
         # their total length come from the assembly counters (AssemblyCounters.h:15-31)
         g.assemble_packed(rw, ro, rl, rn, want_results=False, want_contigs=False)
+        phase_s[0] += t_b - t_a  # (both calls return with the device idle)
+        phase_s[1] += time.perf_counter() - t_b
         c = g.assembly_counters()
         unitigs, bases = c["next_contig_id"], c["bases_assembled"]
 
@@ -290,9 +297,10 @@ def main() -> int:
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names} if (warm_prof and g is not None) else None
     barrier()
+    phase_s[0] = phase_s[1] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step(profile=timed_profile)
+        step(profile=timed_profile and not a.no_events)
     barrier()
     elapsed = time.perf_counter() - t0
     red_dev = device if (world > 1 and dist.get_backend() == "nccl") else None
@@ -380,6 +388,7 @@ def main() -> int:
             "engine_stats": stats,
             # part of every step: creating the filters (first step) or clearing them (abg_reset)
             "setup_ms_per_step": round(setup_s / max(a.steps + a.warmup, 1) * 1e3, 1),
+            "pass_ms_per_step": {"pass1": round(phase_s[0] / a.steps * 1e3, 1), "pass2": round(phase_s[1] / a.steps * 1e3, 1)},
         }
         if partitioned:
             out["config"]["ranks_agree"] = ranks_agree

@@ -53,10 +53,14 @@ struct SerialBackend {
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests;
 	// HC_FAST_BYTES=16384 gives the walkers what the device gives them (the chain searches and the
 	// bulk scratch then live in it as they do in LDS)
-	alignas(16) unsigned char fastbuf[16384];
+	alignas(16) unsigned char fastbuf[20480];
 	uint32_t fast_bytes = 2048;
 	SerialBackend() { if (const char* e = getenv("HC_FAST_BYTES")) fast_bytes = (uint32_t)std::min<long>(sizeof fastbuf, std::max<long>(1024, atol(e))); }
-	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*, int, bool) { for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false); }
+	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*, int, bool)
+	{
+		if (fast_bytes >= sizeof(abg::MaskCache)) memset(fastbuf + fast_bytes - sizeof(abg::MaskCache), 0, sizeof(abg::MaskCache)); // (as k_walkers does)
+		for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false);
+	}
 	void wait_walkers(int) {}
 	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
 	std::vector<unsigned char> tilebuf;

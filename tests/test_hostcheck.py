@@ -416,7 +416,7 @@ def test_hashed_time_stamps_stay_exact(monkeypatch):
 def test_device_sized_fast_memory_runs_the_chain_searches(monkeypatch):
     """HC_FAST_BYTES=16384: the walkers get what LDS gives them on the device, so successor()'s chain
     searches (chain_true_branches, chain_bulk) and the bulk scratch run as they do there."""
-    monkeypatch.setenv("HC_FAST_BYTES", "16384")
+    monkeypatch.setenv("HC_FAST_BYTES", "20480")
     for name in ("k64", "k96", "k25_h3_kc3_t40"):
         g = GoldenCase(name)
         kw = g.kwargs()
