@@ -1267,7 +1267,8 @@ ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsig
 template <int NW>
 struct TBFrame {        // one active call of trueBranch (ExtendPath.h:174-244)
 	Vtx<NW> v;          // the vertex this call inserted into `visited`
-	uint64_t ufh, urh;  // identity of the vertex we came from (skipped when changing direction)
+	// (the vertex this call came from -- skipped when changing direction -- is the vertex of the call
+	// below it on the stack, i.e. the key one slot down; the root call's comes with the search)
 	uint16_t depth;
 	uint8_t dir;        // direction of this call
 	uint8_t stage;      // 0: same-direction children, 1: other-direction children
@@ -1281,6 +1282,7 @@ struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
 	uint8_t mask, next;
 };
 constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
+constexpr uint32_t LA_FAST = 96;      // ... of which this many live in a walker's fast memory
 // The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on
 // the device), deeper ones in the global pool.
 template <int NW>
@@ -1290,8 +1292,8 @@ struct SearchScratch {
 	uint32_t tb_cap;
 	bool coop;             // the caller is a whole wavefront in lock step (see solid_mask8)
 	TBFrame<NW>* tbf;      // [tbf_cap] fast tier (may be NULL with tbf_cap == 0)
-	VKey* tbf_keys;
-	uint32_t tbf_cap;
+	VKey* tbf_keys;        // [tbk_cap] the on-stack test scans keys only, so more of them than frames are kept in fast memory
+	uint32_t tbf_cap, tbk_cap;
 	uint32_t overflow;     // set when a stack capacity was exceeded
 	uint32_t dbg_calls;    // profiling aid: out-of-line successor() calls and the clock ticks spent in them
 	uint64_t dbg_search;
@@ -1305,9 +1307,12 @@ struct SearchScratch {
 	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
 	uint64_t dbg_chain;    // profiling aid: clock ticks in chain_true_branches (when dbg_on)
 	uint32_t dbg_on;
+	uint64_t dbg_la; uint32_t dbg_la_calls; // ... in the lookAhead calls of trueBranch
 	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
 	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
-	VKey* la_visited;      // [LA_MAX_VISITED]
+	VKey* la_visited;      // [LA_MAX_VISITED] (global memory)
+	VKey* la_fast;         // [la_fast_cap] the first entries of lookAhead's visited set, in fast memory (may be NULL / 0)
+	uint32_t la_fast_cap;
 };
 
 // lookAhead (ExtendPath.h:100-161): is there a path of >= `limit` further vertices
@@ -1324,9 +1329,13 @@ ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in
 	const int sense = ((int)uni32<COOP>((uint32_t)dir) == FORWARD) ? SENSE : ANTISENSE;
 	limit = uni32<COOP>(limit);
 	unsigned nv = 0;
-	VKey* const vis = uniptr<COOP>(sc.la_visited);
+	// the visited set: its first entries in fast memory (a search rarely sees more), the rest in global memory
+	VKey* const vis_fast = uniptr<COOP>(sc.la_fast);
+	const unsigned nfast = vis_fast ? uni32<COOP>(sc.la_fast_cap) : 0u;
+	VKey* const vis_slow = uniptr<COOP>(sc.la_visited);
+	auto vis = [&](unsigned i) -> VKey& { return i < nfast ? vis_fast[i] : vis_slow[i - nfast]; };
 	LAFrame<NW>* const la = uniptr<COOP>(sc.la);
-	vis[nv++] = vtx_ident(p, start);
+	vis(nv++) = vtx_ident(p, start);
 	if (limit == 0) return true;
 	if (limit > FP_TRIM) { sc.overflow = 1; return true; }
 	int depth = 0;
@@ -1351,11 +1360,11 @@ ABG_HDX bool look_ahead_t(const Params& p_in, const uint8_t* __restrict__ cnt_in
 		const VKey wk = vtx_ident(p, w);
 		// visited.find(w): cooperative callers spread the scan over the lanes
 		bool seen = false;
-		for (unsigned i = COOP ? lane_id() : 0u; i < nv; i += (COOP ? 64u : 1u)) seen = seen | key_equal(vis[i], wk);
+		for (unsigned i = COOP ? lane_id() : 0u; i < nv; i += (COOP ? 64u : 1u)) seen = seen | key_equal(vis(i), wk);
 		if (COOP) seen = wave_any(seen);
 		if (seen) continue;
 		// recursive call lookAhead(w, depth + 1)
-		if (nv < (unsigned)LA_MAX_VISITED) vis[nv++] = wk;
+		if (nv < (unsigned)LA_MAX_VISITED) vis(nv++) = wk;
 		else sc.overflow = 1;
 		if ((unsigned)(depth + 1) >= limit) return true;
 		depth++;
@@ -1393,11 +1402,11 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 	TBFrame<NW>* const tbs = uniptr<COOP>(sc.tb);
 	VKey* const tbf_keys = uniptr<COOP>(sc.tbf_keys);
 	VKey* const tbs_keys = uniptr<COOP>(sc.tb_keys);
-	const uint32_t tbf_cap = uni32<COOP>(sc.tbf_cap);
+	const uint32_t tbf_cap = uni32<COOP>(sc.tbf_cap), tbk_cap = uni32<COOP>(sc.tbk_cap);
 	const int cap = (int)(tbf_cap + uni32<COOP>(sc.tb_cap));
 	MaskCache* const mcache = uniptr<COOP>(sc.mcache);
 	auto frame = [&](int i) -> TBFrame<NW>& { return (uint32_t)i < tbf_cap ? tbf[i] : tbs[(uint32_t)i - tbf_cap]; };
-	auto keyat = [&](int i) -> VKey& { return (uint32_t)i < tbf_cap ? tbf_keys[i] : tbs_keys[(uint32_t)i - tbf_cap]; };
+	auto keyat = [&](int i) -> VKey& { return (uint32_t)i < tbk_cap ? tbf_keys[i] : tbs_keys[(uint32_t)i - tbk_cap]; };
 	auto uniform_vtx = [&](const Vtx<NW>& x) {
 		Vtx<NW> r;
 #pragma unroll
@@ -1410,6 +1419,7 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 	// "call" trueBranch(u0 -> v0, depth 0, dir0)
 	Vtx<NW> cv = uniform_vtx(v0);
 	VKey cuk = vtx_ident(p, uniform_vtx(u0)); // identity of the vertex the call comes from
+	const VKey root_uk = cuk;
 	unsigned cdepth = 0;
 	int cdir = (int)uni32<COOP>((uint32_t)dir0);
 	for (;;) {
@@ -1435,7 +1445,7 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 		{
 			keyat(top) = ck;
 			TBFrame<NW>& f = frame(top);
-			f.v = cv; f.ufh = cuk.fh; f.urh = cuk.rh;
+			f.v = cv;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
 			f.mask_same = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE, mcache);
@@ -1466,7 +1476,15 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				// same-direction children exhausted: may we change direction?
 				// (depth >= fpTrim || lookAhead(v, dir, fpTrim), ExtendPath.h:208,230)
 				bool flip = fdepth >= FP_TRIM;
-				if (!flip) flip = look_ahead_t<NW, COOP>(p, cnt, fv, fdir, FP_TRIM, sc);
+				if (!flip) {
+#if defined(__HIP_DEVICE_COMPILE__)
+					const uint64_t tl0 = sc.dbg_on ? wall_clock64() : 0;
+#endif
+					flip = look_ahead_t<NW, COOP>(p, cnt, fv, fdir, FP_TRIM, sc);
+#if defined(__HIP_DEVICE_COMPILE__)
+					if (sc.dbg_on) { sc.dbg_la += wall_clock64() - tl0; sc.dbg_la_calls++; }
+#endif
+				}
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
 				f.next = 0;
@@ -1480,7 +1498,8 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				bool made = false;
 				unsigned nx = uni32<COOP>((uint32_t)f.next);
 				const unsigned mo = uni32<COOP>((uint32_t)f.mask_other);
-				const uint64_t ufh = uni64<COOP>(f.ufh), urh = uni64<COOP>(f.urh);
+				const VKey uk = top > 0 ? keyat(top - 1) : root_uk;
+				const uint64_t ufh = uni64<COOP>(uk.fh), urh = uni64<COOP>(uk.rh);
 				while (nx < 4) {
 					unsigned b = nx++;
 					if (!((mo >> b) & 1u)) continue;

@@ -741,9 +741,9 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		uint32_t nk = L - k + 1;
 		SearchScratch<NW> sc;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
-		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.coop = false;
-		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0;
-		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.mcache = nullptr;
+		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.tbk_cap = 0; sc.coop = false;
+		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
+		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
@@ -2965,10 +2965,10 @@ class Engine {
 		};
 		fprintf(stderr, "[walkdbg] %s n=%u ran=%llu\n", what, nwalk, (unsigned long long)nn);
 		line("sum", sum);
+		fprintf(stderr, "[walkdbg]   lookAhead inside trueBranch: %.2f ms in %llu calls; bulk examine phase %.2f ms\n", sum[13] / 1e5, (unsigned long long)sum[14], sum[15] / 1e5);
 		{
-			uint64_t p2 = 0, p3 = 0; // (two 32-bit tick counts share the last slot)
-			for (uint32_t i = 0; i < nc; i++) { p2 += d[i * 16ull + 15] & 0xFFFFFFFFull; p3 += d[i * 16ull + 15] >> 32; }
-			fprintf(stderr, "[walkdbg]   bulk phases: verify %.2f examine %.2f repeats %.2f take %.2f ms\n", sum[13] / 1e5, sum[14] / 1e5, p2 / 1e5, p3 / 1e5);
+			const uint64_t* x = &d[bi * 16ull];
+			fprintf(stderr, "[walkdbg]   slowest walker's lookAhead: %.2f ms in %llu calls\n", x[13] / 1e5, (unsigned long long)x[14]);
 		}
 		line("slowest", &d[bi * 16ull]);
 		be_.memset(dbg_, 0, nc * 128ull);

@@ -768,7 +768,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_cap = e.tb_cap;
-	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0;
+	sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.tbk_cap = 0;
 	sc.la = sc.la_local;
 	// the scratch of the read-guided bulk steps (walk_bulk, chain_bulk): in fast memory when that
 	// leaves the trueBranch stack a decent fast tier, else in the walker's global scratch
@@ -778,21 +778,29 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (fast_bytes >= bb + 64u * (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey))) { w.bulk = (BulkScratch*)fast; fast += bb; fast_bytes -= bb; }
 		else if (e.bulk_pool) w.bulk = e.bulk_pool + slot;
 	}
+	// lookAhead's visited set starts in fast memory too (LA_FAST entries)
+	sc.la_fast = nullptr; sc.la_fast_cap = 0;
+	if (fast_bytes >= LA_FAST * sizeof(VKey) + 64u * (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey))) {
+		sc.la_fast = (VKey*)fast; sc.la_fast_cap = LA_FAST;
+		fast += LA_FAST * sizeof(VKey); fast_bytes -= LA_FAST * (uint32_t)sizeof(VKey);
+	}
 	sc.guide = e.guide; sc.bulk = w.bulk;
 	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
 	sc.mcache = e.mcache;
 	if (!w.bulk) sc.guide.tab = nullptr;
 	{
-		// trueBranch keys and frames side by side
-		uint32_t cap = fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + sizeof(VKey));
+		// trueBranch keys and frames side by side: three keys per frame (a deep search scans every key of
+		// its stack at every call but touches only the top frame)
+		uint32_t cap = fast_bytes / (uint32_t)(sizeof(TBFrame<NW>) + 3 * sizeof(VKey));
 		sc.tbf_keys = (VKey*)fast;
-		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)cap * sizeof(VKey) + 15) & ~15ull));
+		sc.tbf = (TBFrame<NW>*)(fast + (((uint64_t)3 * cap * sizeof(VKey) + 15) & ~15ull));
 		sc.tbf_cap = cap - 1;
+		sc.tbk_cap = 3 * cap;
 	}
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
 	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
 	sc.overflow = 0;
-	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0;
+	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -990,7 +998,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
 		d[4] = sc.dbg_nodes; d[5] = w.t_bulk; d[6] = contig; d[7] = w.t_post;
 		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
-		d[13] = w.t_bp[0]; d[14] = w.t_bp[1]; d[15] = w.t_bp[2] + (w.t_bp[3] << 32);
+		d[13] = sc.dbg_la; d[14] = sc.dbg_la_calls; d[15] = w.t_bp[1];
 	}
 }
 
