@@ -2490,7 +2490,7 @@ class Engine {
 	uint32_t commit_par(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d,
 	    uint8_t* result_d, uint64_t* rkoff_d, uint32_t c_begin, uint32_t c_end)
 	{
-		const uint32_t n = c_end - c_begin;
+		uint32_t n = c_end - c_begin;
 		uint32_t nrec = 0, nord = 0;
 		be_.d2h(&nrec, rec_used_, 4);
 		be_.d2h(&nord, order_n_, 4);
@@ -2544,6 +2544,14 @@ class Engine {
 		be_.d2h(c1.data(), e.cnt, n * 4ull);
 		off[0] = 0;
 		for (uint32_t i = 0; i < n; i++) off[i + 1] = off[i] + c1[i];
+		// (a stamp holds 2^T_TIME_BITS commit positions: a range with more contig records than that is
+		// committed up to there, and the caller comes back for the rest)
+		if (off[n] > (1u << T_TIME_BITS)) {
+			uint32_t keep = 1;
+			while (keep < n && off[keep + 1] <= (1u << T_TIME_BITS)) keep++;
+			if (off[keep] > (1u << T_TIME_BITS)) { fprintf(stderr, "abyss_amd: one read produced more contigs than a commit can order\n"); abort(); }
+			n = keep; c_end = c_begin + n; e.c_end = c_end; e.brk = c_end;
+		}
 		be_.h2d(e.off, off.data(), (n + 1ull) * 4);
 		{ FPcStamp f{ e }; be_.launch(n, f, "pc_stamp"); }
 		be_.d2h(scal_h, e.scal, sizeof scal_h);
@@ -2558,7 +2566,6 @@ class Engine {
 			be_.launch(nshort, f, "pc_short_keys");
 		}
 		// the fixed point
-		if (off[n] > (1u << T_TIME_BITS)) { fprintf(stderr, "abyss_amd: too many contig records in one commit\n"); abort(); }
 		for (uint32_t round = 0;; round++) {
 			// (tag T_TAGS - 1 is what the cleared array carries: never handed out; cfg_.t_tags < T_TAGS only
 			// makes the clearing more frequent -- the tests use that to exercise it)
@@ -3077,7 +3084,7 @@ class Engine {
 					uint32_t st = 0;
 					be_.d2h(&st, r.status_d + next, 4);
 					if (st == WS_OVERFLOW) { r.committed = next; r.overflow = true; break; }
-					if (st == WS_COMPLETE || (next == r.committed && r.force == next)) {
+					if (next == r.committed && (st == WS_COMPLETE || r.force == next)) {
 						fprintf(stderr, "abyss_amd: commit made no progress at candidate %u (status %u)\n", next, st);
 						abort();
 					}

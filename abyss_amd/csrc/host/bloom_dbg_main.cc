@@ -7,6 +7,7 @@
 // Every option of the reference's table is served, -g (GraphViz dump, abg_output_graph_seqs) included.
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
+#include "si_bytes.h"
 
 #include <csignal>
 #include <sys/wait.h>
@@ -68,15 +69,18 @@ static void on_sigchld(int)
 {
 	int st;
 	pid_t pid;
-	while ((pid = waitpid(-1, &st, WNOHANG)) > 0) {
-		bool mine = false;
-		for (int i = 0; i < g_nchildren; i++) mine = mine || g_children[i] == pid;
-		if (!mine) continue;
+	// (only the ranks are reaped here: the decompressors of compressed inputs are children too, and
+	// their reader waits for them itself)
+	for (int i = 0; i < g_nchildren; i++) {
+		if (g_children[i] <= 0) continue;
+		pid = waitpid(g_children[i], &st, WNOHANG);
+		if (pid <= 0) continue;
+		g_children[i] = -1;
 		g_children_left--;
 		if (WIFEXITED(st) && WEXITSTATUS(st) == 0) continue;
 		static const char msg[] = "abyss-bloom-dbg: a rank of the multi-GPU run failed\n";
 		if (write(2, msg, sizeof msg - 1)) {}
-		for (int i = 0; i < g_nchildren; i++) kill(g_children[i], SIGKILL);
+		for (int j = 0; j < g_nchildren; j++) if (g_children[j] > 0) kill(g_children[j], SIGKILL);
 		_exit(EXIT_FAILURE);
 	}
 }
@@ -101,23 +105,6 @@ static const struct option longopts[] = {
 };
 
 // SIToBytes, Common/StringUtil.h:181-219: k/M/G are powers of 1024
-static bool si_to_bytes(const char* s, uint64_t* out)
-{
-	char* end;
-	double x = strtod(s, &end);
-	if (end == s) return false;
-	switch (*end) {
-	case 'k': case 'K': x *= 1024.0; end++; break;
-	case 'M': x *= 1048576.0; end++; break;
-	case 'G': x *= 1073741824.0; end++; break;
-	case 'T': x *= 1099511627776.0; end++; break;
-	default: break;
-	}
-	if (*end == 'B') end++;
-	if (*end) return false;
-	*out = (uint64_t)x;
-	return true;
-}
 
 struct Chunk { // one batch of sequences for the C ABI
 	std::string seqs;
@@ -384,6 +371,9 @@ int main(int argc, char** argv)
 	memset(&comm, 0, sizeof comm);
 	const bool use_comm = gpus > 1 || (getenv("ABG_FORCE_DIST") && atoi(getenv("ABG_FORCE_DIST")));
 	if (gpus > 1 && readsPerCheckpoint) { fprintf(stderr, PROGRAM ": --checkpoint is not available with --gpus\n"); exit(EXIT_FAILURE); }
+	if (gpus > 1) // every rank reads every input: one shared stdin would be split between them
+		for (int i = optind; i < argc; i++)
+			if (!strcmp(argv[i], "-")) { fprintf(stderr, PROGRAM ": standard input (`-') cannot be read with --gpus\n"); exit(EXIT_FAILURE); }
 	if (use_comm) {
 		std::vector<int> rd(gpus, -1), wr(gpus, -1);
 		for (unsigned r = 1; r < gpus; r++) {

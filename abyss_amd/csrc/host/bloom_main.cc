@@ -7,6 +7,7 @@
 // compare, graph, kmers, trim) and `-t konnector` filters are not part of this path.
 #include "../../../include/abyss_amd.h"
 #include "fasta_reader.h"
+#include "si_bytes.h"
 
 #include <algorithm>
 #include <thread>
@@ -33,22 +34,6 @@ static const struct option longopts[] = {
 	{ NULL, 0, NULL, 0 }
 };
 
-static bool si_to_bytes(const char* s, uint64_t* out) // SIToBytes, Common/StringUtil.h:181-219
-{
-	char* end;
-	double x = strtod(s, &end);
-	if (end == s) return false;
-	switch (*end) {
-	case 'k': case 'K': x *= 1024.0; end++; break;
-	case 'M': x *= 1048576.0; end++; break;
-	case 'G': x *= 1073741824.0; end++; break;
-	default: break;
-	}
-	if (*end == 'B') end++;
-	if (*end) return false;
-	*out = (uint64_t)x;
-	return true;
-}
 static void check(int rc, abg_ctx* ctx, const char* what)
 {
 	if (rc == ABG_OK) return;

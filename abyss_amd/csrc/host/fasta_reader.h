@@ -17,7 +17,11 @@
 #include <thread>
 #include <vector>
 
+#include <csignal>
 #include <sys/stat.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 namespace abghost {
 
@@ -39,8 +43,22 @@ class FastaReader {
 		for (auto& z : zs) {
 			size_t n = strlen(z.ext);
 			if (path.size() > n && path.compare(path.size() - n, n, z.ext) == 0) {
-				std::string cmd = std::string(z.cmd) + " '" + path + "'";
-				m_f = popen(cmd.c_str(), "r");
+				// the decompressor as a child with an argv of its own (no shell: a file name may hold
+				// quotes or spaces), its stdout our stream; its exit status is checked when the stream closes
+				char prog[32], flag[8];
+				if (sscanf(z.cmd, "%31s %7s", prog, flag) != 2) continue;
+				int fd[2];
+				if (pipe(fd)) { perror("pipe"); exit(EXIT_FAILURE); }
+				m_child = fork();
+				if (m_child < 0) { perror("fork"); exit(EXIT_FAILURE); }
+				if (m_child == 0) {
+					dup2(fd[1], 1); close(fd[0]); close(fd[1]);
+					execlp(prog, prog, flag, path.c_str(), (char*)NULL);
+					fprintf(stderr, "error: cannot run `%s': %s\n", prog, strerror(errno));
+					_exit(127);
+				}
+				close(fd[1]);
+				m_f = fdopen(fd[0], "r");
 				m_pipe = true;
 			}
 		}
@@ -64,7 +82,15 @@ class FastaReader {
 	~FastaReader()
 	{
 		if (m_f) funlockfile(m_f);
-		if (m_f && m_f != stdin) { if (m_pipe) pclose(m_f); else fclose(m_f); }
+		if (m_f && m_f != stdin) fclose(m_f);
+		if (m_pipe && m_child > 0) {
+			// (waitpid on this child only; if somebody else reaped it already its status is unknown here)
+			int st = 0;
+			if (waitpid(m_child, &st, 0) == m_child && !(WIFEXITED(st) && WEXITSTATUS(st) == 0) && !(WIFSIGNALED(st) && WTERMSIG(st) == SIGPIPE)) {
+				fprintf(stderr, "error: decompressing `%s' failed\n", m_path.c_str());
+				exit(EXIT_FAILURE);
+			}
+		}
 		free(m_line_buf);
 	}
 	FastaReader(const FastaReader&) = delete;
@@ -237,6 +263,7 @@ class FastaReader {
 	ReaderOptions m_opt;
 	FILE* m_f = nullptr;
 	bool m_pipe = false;
+	pid_t m_child = -1; // the decompressor, when the input is compressed
 	unsigned m_line = 0;
 	char* m_line_buf = nullptr;
 	size_t m_line_cap = 0;

@@ -1,0 +1,85 @@
+"""abyss-pe plumbing (BASELINE.json configs[0]: "through `abyss-pe k=32 B=100M j=1` up to `-1.fa`").
+
+The reference's pipeline driver is a Makefile (bin/abyss-pe); with `B=` set its `%-1.fa` rule is
+`abyss-stack-size 65536 abyss-bloom-dbg $(abyssopt) $(in) $(se) > $@` (bin/abyss-pe:553-555,
+191-235).  Two halves, because the reference tree exists only in the build container and a GPU
+only on the GPU box:
+
+* here (no GPU, reference present): the unmodified abyss-pe is run with OUR binary first on PATH,
+  wrapped by a recorder; the recorded command line is the one the GPU tests feed the binary
+  (tests/test_gpu_cli.py::test_cli_matches_reference_binary_on_fastq), our option parser accepts
+  it (the run ends at "no HIP device", not at an option error), and the one-letter `name=` trap of
+  SURVEY.md 8c (`name=t` injects `-t<files>`) is what it is;
+* on the GPU box (`-m gpu`, no reference tree): a stand-in for that one rule -- the same command
+  through an `abyss-stack-size` wrapper raising the stack limit -- writes the same `asm-1.fa` as
+  the direct invocation.
+"""
+import os
+import stat
+import subprocess
+
+import pytest
+
+from abyss_amd import build, synth
+
+REF_PE = "/root/reference/bin/abyss-pe"
+
+
+def _write_reads(tmp_path, genome=20000, cov=10.0):
+    m1, m2 = synth.make_read_set(genome, cov)
+    synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)
+    synth.write_fastq(str(tmp_path / "r2.fq"), m2, "r", 2)
+
+
+def _shim_dir(tmp_path, real):
+    d = tmp_path / "shim"
+    d.mkdir()
+    rec = tmp_path / "argv.txt"
+    sh = d / "abyss-bloom-dbg"
+    sh.write_text("#!/bin/sh\nprintf '%%s\\n' \"$@\" > %s\nexec %s \"$@\"\n" % (rec, real))
+    sh.chmod(sh.stat().st_mode | stat.S_IXUSR)
+    return d, rec
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PE), reason="the reference tree is not on this machine")
+def test_abyss_pe_issues_the_command_line_our_binary_accepts(tmp_path):
+    cli = build.build_cli()
+    _write_reads(tmp_path)
+    shim, rec = _shim_dir(tmp_path, cli)
+    env = dict(os.environ, PATH="%s:%s" % (shim, os.environ["PATH"]))
+    r = subprocess.run(["make", "-rRf", REF_PE, "name=asm", "k=32", "B=100M", "j=1", "in=r1.fq r2.fq", "asm-1.fa"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    out = (r.stdout + r.stderr).decode()
+    assert "abyss-stack-size 65536 abyss-bloom-dbg -k32 -q3" in out, out
+    assert rec.read_text().split("\n")[:-1] == ["-k32", "-q3", "-b100M", "-j1", "r1.fq", "r2.fq"]
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        assert r.returncode == 0 and (tmp_path / "asm-1.fa").read_bytes().startswith(b">0 ")
+    else:
+        # the options were accepted and the inputs opened; what stops the run is the missing device
+        assert r.returncode != 0 and "no HIP device" in out and "invalid option" not in out and "missing" not in out, out
+    # the one-letter trap: `name=t` makes $(t) the input files, which abyss-pe turns into `-t<files>`
+    r = subprocess.run(["make", "-rRf", REF_PE, "name=t", "k=32", "B=100M", "j=1", "in=r1.fq r2.fq", "t-1.fa"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert any(a.startswith("-t") and "r1.fq" in a for a in rec.read_text().split("\n")), rec.read_text()
+
+
+@pytest.mark.gpu
+def test_pipeline_rule_writes_the_same_file_as_the_direct_call(tmp_path):
+    cli = build.build_cli()
+    _write_reads(tmp_path, genome=200000, cov=40.0)
+    wrap = tmp_path / "abyss-stack-size"  # what bin/abyss-stack-size does: raise the soft stack limit, run the command
+    wrap.write_text("#!/bin/sh\nulimit -s \"$1\" 2>/dev/null\nshift\nexec \"$@\"\n")
+    wrap.chmod(wrap.stat().st_mode | stat.S_IXUSR)
+    argv = ["-k32", "-q3", "-b100M", "-j1", "r1.fq", "r2.fq"]
+    direct = subprocess.run([cli] + argv, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert direct.returncode == 0, direct.stderr.decode()
+    env = dict(os.environ, PATH="%s:%s:%s" % (tmp_path, os.path.dirname(cli), os.environ["PATH"]))
+    rule = "abyss-stack-size 65536 abyss-bloom-dbg %s > asm-1.fa" % " ".join(argv)
+    r = subprocess.run(["sh", "-c", rule], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert (tmp_path / "asm-1.fa").read_bytes() == direct.stdout and direct.stdout.count(b">") > 300

@@ -48,3 +48,43 @@ def test_ranks_sharing_one_gpu_match_oracle(world):
         assert out[key], (key, out)
     assert out["n_contigs"] > 10
     assert out["comm_calls"]["all_reduce"] > 0
+
+
+def _gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: the first real multi-rank run of the RCCL communicator")
+def test_two_real_ranks_over_rccl_agree_with_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (one process per GPU, backend nccl = RCCL): the
+    library's own communicator (in-place ncclAllGather, the ragged broadcast group, all_reduce per
+    round) between two real ranks, against the same job on one GPU; then the host binary's --gpus 2."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ABG_FORCE_DIST", None)
+    args = ["--pairs", "400000", "--bloom", "160M", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    a = json.loads([ln for ln in one.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--scaling", "strong"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    b = json.loads([ln for ln in two.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["config"]["ranks_agree"] is True and "note" not in b["config"], b["config"]
+    assert (b["config"]["unitigs"], b["config"]["unitig_bp"]) == (a["config"]["unitigs"], a["config"]["unitig_bp"])
+    # the drop-in binary with --gpus 2 writes the FASTA of the one-GPU run
+    from abyss_amd import build, synth
+    m1, m2 = synth.make_read_set(200000, 40.0)
+    synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)
+    synth.write_fastq(str(tmp_path / "r2.fq"), m2, "r", 2)
+    cli = build.build_cli()
+    r1 = subprocess.run([cli, "-k32", "-q3", "-b100M", "r1.fq", "r2.fq"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r2 = subprocess.run([cli, "-k32", "-q3", "-b100M", "--gpus=2", "r1.fq", "r2.fq"], cwd=tmp_path, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=600)
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stderr.decode()[-2000:]
+    assert r1.stdout == r2.stdout and len(r1.stdout) > 100000
