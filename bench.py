@@ -326,44 +326,59 @@ def main() -> int:
     # Partitioned: a rank hashes every op of the job but touches only its 1/world of the claim slots
     # and counters, classifies 1/world of the reads and walks 1/world of the candidates.
     share = 1.0 / world if partitioned else 1.0
-    alg_total = {
-        "hash_claim": (per_kmer_bases + 8 + H * 8 * share) * kmers_all,   # 2-bit bases, hash out, H claim slots
-        "insert_round": ((8 + H * 8 * share + H * share + 1) if partitioned  # hash, owned claims + counters, verdict byte
-                         else (8 + H * 8 + 2 * H)) * kmers_all,             # hash, H claims, H counter reads + writes
-        "classify": (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share,
-        "rewalk": 8 * H * unitig_kmers * share,                  # 8 neighbour queries x H per unitig k-mer
-        "walk": 8 * H * unitig_kmers * share,
-        "commit": 3 * H * unitig_kmers,                          # redundancy test + insertion + coverage
-        "pc_timemin": 4 * H * unitig_kmers,                      # one 4-byte time stamp per (k-mer, hash)
-        "pc_decide": 8 * H * unitig_kmers,                       # time stamp + filter word per (k-mer, hash)
-        "pc_apply": 4 * H * unitig_kmers,                        # filter word per (k-mer, hash)
+    # SURVEY.md 8d, per read k-mer: 2-bit bases (one pass), 2H for the insert (H counter reads + H writes), H + H for
+    # the solid / visited membership tests (+ the blunt-end look-ahead); per unitig k-mer: 8 neighbour queries x H
+    # for the walk, 3 commit passes x H + H writes.  The kernels of one family share its bytes: a family's
+    # achieved rate = its algorithmic bytes / the summed duration of its kernels.
+    families = {
+        "pass1": (["hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "tile_apply", "claim_list", "hash_claim",
+                   "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load", "insert_drain"],
+                  (per_kmer_bases + 2 * H * share) * kmers_all),
+        "classify": (["classify", "reclassify"],
+                     (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share),
+        "walk": (["walk", "rewalk"], 8 * H * unitig_kmers * share),
+        "commit": (["contig_prep", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin", "pc_decide",
+                    "pc_break", "pc_apply", "pc_write"], 4 * H * unitig_kmers),
     }
     per_kernel = {}
-    for nm, total in alg_total.items():
-        ms, n = prof[nm]
-        if n:
-            # bytes per launch / average launch duration == total bytes / total duration
+    for fam, (members, total) in families.items():
+        ms = sum(prof[nm][0] for nm in members)
+        n = max([prof[nm][1] for nm in members] + [0])
+        if ms > 0:
             gbs = total / 1e9 / (ms / 1e3)
-            per_kernel[nm] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": ms / n, "launches": n}
+            top = max(members, key=lambda nm: prof[nm][0])
+            per_kernel[fam] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "ms": ms, "algorithmic_GB": total / 1e9,
+                               "longest_kernel": top, "avg_launch_ms": prof[top][0] / max(prof[top][1], 1),
+                               "launches": prof[top][1]}
     if not per_kernel:
         # (partitioned run without a warm-up step: no per-launch events were taken -- see timed_profile)
-        per_kernel = {"walk": {"achieved": None, "frac": None, "avg_launch_ms": None, "launches": 0}}
-    dom = max(per_kernel, key=lambda nm: prof[nm][0])
-    traffic = None
-    tsrc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tsrc) and a.pairs == 5_000_000 and world == 1:
-        # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) of
-        # this same command, committed with the profile; KB units, per launch like `achieved`
-        t = json.load(open(tsrc)).get({"rewalk": "k_walkers", "walk": "k_walkers", "commit": "k_commit",
-                                       "insert_round": "FInsertRound", "hash_claim": "FHashClaim",
-                                       "classify": "FClassify", "pc_timemin": "FPcTimeMin", "pc_decide": "FPcDecide",
-                                       "pc_apply": "FPcApply"}[dom])
+        per_kernel = {"walk": {"achieved": None, "frac": None, "avg_launch_ms": None, "launches": 0, "ms": 0, "longest_kernel": "rewalk"}}
+    dom = max(per_kernel, key=lambda fam: per_kernel[fam]["ms"] if fam != "classify" else 0)  # (classification overlaps the walk)
+    # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this very
+    # command, tools/gpu_r2_prof.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
+    # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
+    traffic = traffic_src = None
+    tsrc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(tsrc) and a.config == 1 and a.pairs == 5_000_000 and world == 1:
+        tj = json.load(open(tsrc))
+        kname = {"rewalk": "k_walkers", "walk": "k_walkers", "tile_apply": "FTileApply", "tile_purity": "FTilePurity",
+                 "bin_coarse": "FBinCoarse", "bin_fine": "FBinFine", "op_target": "FOpTarget", "hash_ops": "FHashOps",
+                 "insert_round": "FInsertRound", "insert_retry": "FInsertRound", "hash_claim": "FHashClaim",
+                 "classify": "FClassify", "pc_timemin": "FPcTimeMin", "pc_decide": "FPcDecide"}.get(per_kernel[dom]["longest_kernel"])
+        t = tj.get(kname)
         if t:
             traffic = (t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024 / max(t["FETCH_SIZE"]["dispatches"], 1)
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
+            traffic_src = "profiles/r02_pmc_traffic.json (%s, taken at commit %s)" % (kname, tj.get("_commit", "?"))
+    step_bytes = (2 * per_kmer_bases + 4 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers + 12 * H * unitig_kmers
+    roofline = {"bound": "hbm", "kernel": per_kernel[dom]["longest_kernel"], "family": dom,
+                "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "launches": per_kernel[dom]["launches"],
-                "note": "dominant kernel by time; it is a latency-bound graph walk, not a stream (DESIGN.md 5)",
+                "note": "dominant kernel family by time (the classification overlaps the walk on a side stream); algorithmic "
+                        "bytes of the family (SURVEY.md 8d) over the summed duration of its kernels; the walk is a "
+                        "latency-bound graph traversal of dependent random probes, not a stream (DESIGN.md)",
+                "whole_step": {"algorithmic_GB": step_bytes / 1e9, "achieved": step_bytes / 1e9 / (elapsed / a.steps),
+                               "frac": step_bytes / 1e9 / (elapsed / a.steps) / HBM_PEAK_GBS},
                 "kernels": per_kernel}
 
     if rank == 0:
@@ -397,6 +412,15 @@ def main() -> int:
             out["config"]["note"] = comm_note
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)
+            # like for like (measured once on the GPU box, committed under profiles/): the unmodified reference on
+            # the FULL configs[1] read set, and the drop-in binary end to end (FASTQ in, FASTA out) on the same files
+            for key, fn in (("reference_full_config", "r02_cpu_reference_config1.json"), ("end_to_end", "r02_end_to_end.json")):
+                src = os.path.join(ROOT, "profiles", fn)
+                if os.path.exists(src) and a.config == 1:
+                    out["cpu_baseline" if key == "reference_full_config" else key] = dict(
+                        out.get("cpu_baseline", {}) if key == "reference_full_config" else {}, **{
+                            (key if key == "reference_full_config" else "measured"): json.load(open(src)),
+                            **({} if key == "reference_full_config" else {"source": "profiles/" + fn})})
         # whatever native libraries buffered on stdout (RCCL's version banner) goes out first: the
         # JSON line stays a line of its own
         import ctypes
