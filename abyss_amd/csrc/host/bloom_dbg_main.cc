@@ -496,6 +496,11 @@ int main(int argc, char** argv)
 		if (prev) fclose(prev);
 	} else if (prebuilt.empty()) {
 		// PASS 1: loadBloomFilter, BloomIO.h:97-118 (a ":" argument separates load and assembly files)
+		if (threads > 1 && !ckpt) { // compressed inputs inflate side by side, ahead of the reader (Prefetch)
+			std::vector<std::string> ins;
+			for (int i = optind; i < argc && strcmp(argv[i], ":"); ++i) ins.push_back(argv[i]);
+			abghost::Prefetch::get().start(ins);
+		}
 		for (int i = optind; i < argc; ++i) {
 			if (!strcmp(argv[i], ":")) { first_asm = i + 1; break; }
 			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);

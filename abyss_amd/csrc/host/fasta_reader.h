@@ -13,6 +13,7 @@
 #include <cstring>
 #include <algorithm>
 #include <future>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -284,6 +285,91 @@ class FastaReader {
 	}
 };
 
+// Compressed inputs decompressed AHEAD: every one by a decompressor child of its own (gunzip -c
+// and the like, as Common/Uncompress.cpp runs them), each drained into memory by a thread of its
+// own, all at once -- the reference and the sequential reader below take the files one after the
+// other at the pace of one gunzip.  Only when the inputs, inflated, fit a quarter of the host's
+// memory (estimated at 8 x the compressed size); otherwise, and for whatever is asked for a
+// second time, the stream is read as it comes.
+class Prefetch {
+  public:
+	static Prefetch& get() { static Prefetch p; return p; }
+	static bool compressed(const std::string& path, const char** prog, const char** flag)
+	{
+		static const struct { const char* ext; const char* prog; const char* flag; } zs[] = {
+			{ ".gz", "gunzip", "-c" }, { ".bz2", "bunzip2", "-c" }, { ".xz", "xzdec", "-c" }, { ".zst", "zstd", "-dc" },
+		};
+		for (auto& z : zs) {
+			const size_t n = strlen(z.ext);
+			if (path.size() > n && path.compare(path.size() - n, n, z.ext) == 0) { *prog = z.prog; *flag = z.flag; return true; }
+		}
+		return false;
+	}
+	void start(const std::vector<std::string>& paths)
+	{
+		uint64_t total = 0;
+		std::vector<std::string> todo;
+		for (auto& p : paths) {
+			const char* prog; const char* flag;
+			struct stat st;
+			if (!compressed(p, &prog, &flag) || stat(p.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+			if (std::find(todo.begin(), todo.end(), p) != todo.end()) continue;
+			total += (uint64_t)st.st_size;
+			todo.push_back(p);
+		}
+		const uint64_t ram = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+		if (todo.empty() || total * 8 > ram / 4) return;
+		for (auto& p : todo) {
+			const char* prog; const char* flag;
+			compressed(p, &prog, &flag);
+			int fd[2];
+			if (pipe(fd)) return;
+			const pid_t pid = fork();
+			if (pid < 0) { close(fd[0]); close(fd[1]); return; }
+			if (pid == 0) {
+				dup2(fd[1], 1); close(fd[0]); close(fd[1]);
+				execlp(prog, prog, flag, p.c_str(), (char*)NULL);
+				_exit(127);
+			}
+			close(fd[1]);
+			Item* it = new Item;
+			it->pid = pid;
+			it->th = std::thread([it, rfd = fd[0]]() {
+				std::string& d = it->data;
+				size_t have = 0;
+				for (;;) {
+					if (d.size() - have < (8u << 20)) d.resize(d.size() + (64u << 20));
+					const ssize_t got = ::read(rfd, &d[have], d.size() - have);
+					if (got <= 0) break;
+					have += (size_t)got;
+				}
+				d.resize(have);
+				close(rfd);
+				int st = 0;
+				it->ok = waitpid(it->pid, &st, 0) == it->pid && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+			});
+			m_items[p] = it;
+		}
+	}
+	// the inflated bytes of `path` if they were fetched ahead (once: the next request reads the stream)
+	bool take(const std::string& path, std::string& data)
+	{
+		auto f = m_items.find(path);
+		if (f == m_items.end()) return false;
+		Item* it = f->second;
+		m_items.erase(f);
+		it->th.join();
+		const bool ok = it->ok;
+		if (ok) data.swap(it->data);
+		delete it;
+		return ok; // (a failed decompressor: the ordinary reader runs it again and reports)
+	}
+	~Prefetch() { for (auto& kv : m_items) { kv.second->th.join(); delete kv.second; } }
+  private:
+	struct Item { std::thread th; std::string data; pid_t pid = -1; bool ok = false; };
+	std::map<std::string, Item*> m_items;
+};
+
 // FASTQ files parsed by several threads.  Parsing is what the host binary spends its time on once
 // the kernels are fast (a single thread reads ~330 MB/s); records are independent, so a window of
 // the file is cut into blocks at record boundaries and every block is parsed by the SAME
@@ -301,6 +387,19 @@ class SequenceReader {
 		for (const char* ext : { ".gz", ".bz2", ".xz", ".zst" }) {
 			size_t n = strlen(ext);
 			if (path.size() > n && path.compare(path.size() - n, n, ext) == 0) plain = false;
+		}
+		if (!plain && Prefetch::get().take(path, m_buf)) {
+			// inflated ahead, in memory: a FASTQ stream is parsed as one window, block-parallel; anything
+			// else by the sequential reader over the buffer
+			const size_t l1 = m_buf.find('\n');
+			const size_t l2 = l1 == std::string::npos ? l1 : m_buf.find('\n', l1 + 1);
+			const bool fastq = threads > 1 && !m_buf.empty() && m_buf[0] == '@' && l2 != std::string::npos && l2 + 1 < m_buf.size() && m_buf[l2 + 1] == '+';
+			if (fastq) { m_eof = true; m_mem = true; m_window = 1; return; }
+			if (m_buf.empty()) fprintf(stderr, "%s:0: warning: file is empty\n", m_path.c_str());
+			FILE* f = m_buf.empty() ? fopen("/dev/null", "r") : fmemopen((void*)m_buf.data(), m_buf.size(), "r");
+			if (!f) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
+			m_seq = new FastaReader(f, path, 0, o);
+			return;
 		}
 		if (plain) {
 			m_f = fopen(path.c_str(), "rb");
@@ -334,6 +433,7 @@ class SequenceReader {
 	bool read(std::string& id, std::string& comment, std::string& s)
 	{
 		if (m_seq) return m_seq->read(id, comment, s);
+		if (m_mem && m_done) return false;
 		for (;;) {
 			while (m_block < m_blocks.size()) {
 				Block& b = m_blocks[m_block];
@@ -349,7 +449,7 @@ class SequenceReader {
 			// the next window was being parsed while the caller worked on this one (GPU calls included)
 			if (!m_next.valid()) m_next = std::async(std::launch::async, [this]() { return parse_window(); });
 			Window w = m_next.get();
-			if (!w.ok) return false;
+			if (!w.ok) { m_done = true; return false; }
 			m_blocks = std::move(w.blocks); m_block = 0; m_rec = 0;
 			m_next = std::async(std::launch::async, [this]() { return parse_window(); });
 		}
@@ -469,7 +569,7 @@ class SequenceReader {
 	FastaReader* m_seq = nullptr;
 	FILE* m_f = nullptr;
 	size_t m_window = 0;
-	bool m_eof = false;
+	bool m_eof = false, m_mem = false, m_done = false; // (m_mem: the whole inflated file is in m_buf)
 	std::string m_buf;
 	unsigned m_lines = 0;
 	std::vector<Block> m_blocks;

@@ -9,7 +9,7 @@ int main(int argc, char** argv)
 	abghost::ReaderOptions o;
 	const char* path = NULL;
 	unsigned threads = 1;
-	bool count_only = false;
+	bool count_only = false, prefetch = false;
 	for (int i = 1; i < argc; i++) {
 		if (!strcmp(argv[i], "-q")) o.qualityThreshold = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-Q")) o.internalQThreshold = atoi(argv[++i]);
@@ -18,8 +18,10 @@ int main(int argc, char** argv)
 		else if (!strcmp(argv[i], "--illumina-quality")) o.qualityOffset = 64;
 		else if (!strcmp(argv[i], "-j")) threads = (unsigned)atoi(argv[++i]); // SequenceReader: blocks parsed in parallel
 		else if (!strcmp(argv[i], "--count")) count_only = true;
+		else if (!strcmp(argv[i], "--prefetch")) prefetch = true; // compressed input inflated ahead (abghost::Prefetch)
 		else path = argv[i];
 	}
+	if (prefetch) abghost::Prefetch::get().start({ path });
 	abghost::SequenceReader in(path, o, threads);
 	std::string id, comment, seq;
 	unsigned long long n = 0, bases = 0, sum = 0;

@@ -144,3 +144,20 @@ def test_parallel_reader_on_quality_lines_starting_with_at_and_plus(tmp_path, mo
             else:
                 monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
             assert run_mine(opts + ["-j", str(j)], str(p)) == want, (opts, window, j)
+
+
+def test_compressed_input_inflated_ahead_yields_the_same_records(tmp_path):
+    """abghost::Prefetch: a compressed input inflated into memory by a thread of its own and then parsed
+    block-parallel (FASTQ) or sequentially (anything else) gives the records of the plain file."""
+    import shutil
+    for name, opts in (("reader_input.fq", ["-q", "3"]), ("reader_input.fq", []), ("reader_input.sam", [])):
+        src = os.path.join(GOLDEN, name)
+        if not os.path.exists(src):
+            continue
+        want = run_mine(opts, src)
+        shutil.copy(src, tmp_path / name)
+        subprocess.run(["gzip", "-kf", str(tmp_path / name)], check=True)
+        gz = str(tmp_path / (name + ".gz"))
+        assert run_mine(opts, gz) == want                       # the stream as it comes (one gunzip, sequential reader)
+        assert run_mine(opts + ["-j", "4", "--prefetch"], gz) == want
+        assert run_mine(opts + ["--prefetch"], gz) == want      # one thread: sequential reader over the inflated buffer
