@@ -8,14 +8,15 @@ conservative-update insert of every read k-mer into the counting Bloom filter), 
 each counted once although both passes touch it.
 
 Workload: BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads, k=64,
-B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors).  With --gpus N (one process per
-GPU) the SAME job is split over the ranks (strong scaling): every rank holds 1/N of the reads,
-the counting filter is range-partitioned by position over the ranks' HBM during PASS 1 (RCCL
-all_gather of the 2-bit reads, one all_reduce(MIN) of a byte per k-mer op and round), gathered
-for PASS 2, whose walks are split over the ranks and merged before the ordered commit
-(DESIGN.md section 7); the unitigs are bit-identical to the 1-GPU run.  --scaling weak makes the
-job N times as big instead (reads, genome and filter: the shape of configs[2]); --mode replicas
-runs N independent copies of the job (no collective on the data path).
+B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors); --config 2 / 3 select configs[2]
+(200 M pairs, B=40G) / configs[3] (-k96 -K32).  With --gpus N (one process per GPU) ONE job N
+times as big (reads, genome and filter: weak scaling, the shape of configs[2]) is split over the
+ranks: every rank holds 1/N of the reads, the counting filter is range-partitioned by position
+over the ranks' HBM during PASS 1 (RCCL all_gather of the 2-bit reads, one all_reduce(MIN) of a
+byte per k-mer op and round), gathered for PASS 2, whose walks are split over the ranks and merged
+before the ordered commit; the unitigs are bit-identical to a 1-GPU run of
+that job.  --scaling strong splits the fixed configs[1] job instead; --mode replicas runs N
+independent copies of the job (no collective on the data path).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -157,9 +158,10 @@ def main() -> int:
                     help="time the steps without HIP events around every launch (no per-kernel numbers: shows what the events cost)")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
                     help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="partitioned mode: the fixed --pairs / --bloom job over N ranks (strong), or a job N times as big "
-                         "(--pairs and --bloom per rank: the shape of BASELINE.json configs[2])")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
+                    help="partitioned mode: a job N times as big (--pairs and --bloom per rank: the shape of BASELINE.json "
+                         "configs[2]; the default -- partitioning exists to hold filters one GPU cannot), or the fixed "
+                         "--pairs / --bloom job over N ranks (strong)")
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
