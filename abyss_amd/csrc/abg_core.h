@@ -1894,9 +1894,10 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	uint64_t nfh[4], nrh[4];
 	neighbour_hashes(p, u, sense, nfh, nrh);
 	vout = u;
-	// (the memo holds answers for the walkers' trim only, and not under a spaced seed, whose vertices
-	// are more than their two rolling hashes)
-	const bool use_memo = sc.memo.k0 != nullptr && trim == p.trim && !MASKED_BUILD<NW> && (mask & (mask - 1));
+	// (the memo holds answers for the walkers' trim only.  Under a spaced seed the key is still the
+	// vertex's two UNMASKED rolling hashes: they stand for the whole oriented k-mer, positions under
+	// a '0' included, which is what the search's later steps depend on.)
+	const bool use_memo = sc.memo.k0 != nullptr && trim == p.trim && (mask & (mask - 1));
 	if (use_memo) {
 		const int hit = memo_find(sc.memo, u.fh, u.rh, dir);
 		if (hit >= 0) {

@@ -1864,7 +1864,7 @@ class Engine {
 	// The memo of successor() answers (SuccMemo): emptied whenever the solid filter may have changed.
 	void ensure_memo()
 	{
-		if (!cfg_.memo || p_.mask) { memo_.k0 = nullptr; return; }
+		if (!cfg_.memo) { memo_.k0 = nullptr; return; }
 		if (!memo_tab_.hmin) {
 			uint32_t log2 = cfg_.memo_log2;
 			if (!log2) { log2 = 16; while (log2 < 26 && (1ull << log2) < m_ / 128) log2++; }
