@@ -148,6 +148,7 @@ template <bool DIST>
 struct FHashClaimT {
 	Params p; Batch b; uint64_t* h0; uint64_t T; uint64_t* claim; uint64_t cmask; uint32_t epoch;
 	uint64_t lo, span;
+	uint64_t kbase; // (see FHashOps)
 	ABG_HD void claim_all(uint64_t h, uint64_t v) const
 	{
 		for (unsigned i = 0; i < p.nh; i++) {
@@ -160,14 +161,14 @@ struct FHashClaimT {
 		uint64_t t0 = g * HC_RUN;
 		if (t0 >= T) return;
 		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
-		uint64_t r = find_seq(b.koff, b.n, t0);
-		uint64_t rend = b.koff[r + 1];
+		uint64_t r = find_seq(b.koff, b.n, t0 + kbase);
+		uint64_t rend = b.koff[r + 1] - kbase;
 		unsigned k = p.k;
 		uint64_t fh = 0, rh = 0;
 		bool fresh = true;
 		for (uint64_t t = t0; t < t1; t++) {
-			while (t >= rend) { r++; rend = b.koff[r + 1]; fresh = true; }
-			uint32_t j = (uint32_t)(t - b.koff[r]);
+			while (t >= rend) { r++; rend = b.koff[r + 1] - kbase; fresh = true; }
+			uint32_t j = (uint32_t)(t + kbase - b.koff[r]);
 			if (p.mask) {
 				// spaced seed: from scratch over the '1' positions (not the headline configuration)
 				uint64_t h = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
@@ -475,19 +476,20 @@ struct TileEnv {
 template <int NW>
 struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's run comes off the read's words at once
 	Params p; Batch b; uint64_t* h0; uint64_t T;
+	uint64_t kbase; // b.koff holds k-mer prefix sums of a longer batch: op t of this one is k-mer kbase + t there
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
 		uint64_t t0 = g * HC_RUN;
 		if (t0 >= T) return;
 		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
-		uint64_t r = find_seq(b.koff, b.n, t0);
-		uint64_t rend = b.koff[r + 1];
+		uint64_t r = find_seq(b.koff, b.n, t0 + kbase);
+		uint64_t rend = b.koff[r + 1] - kbase;
 		unsigned k = p.k;
 		uint64_t fh = 0, rh = 0;
 		bool fresh = true;
 		for (uint64_t t = t0; t < t1; t++) {
-			while (t >= rend) { r++; rend = b.koff[r + 1]; fresh = true; }
-			uint32_t j = (uint32_t)(t - b.koff[r]);
+			while (t >= rend) { r++; rend = b.koff[r + 1] - kbase; fresh = true; }
+			uint32_t j = (uint32_t)(t + kbase - b.koff[r]);
 			if (p.mask) { h0[t] = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); }); continue; }
 			if (fresh) {
 				const Kmer<NW> s = window_kmer<NW>(b.words, b.woff[r], j, k);
@@ -590,6 +592,7 @@ constexpr uint32_t TILE_PURITY_THREADS = 512, TILE_PURITY_PER = (TILE_SORT_MAX +
 template <class Sync>
 ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 {
+	if (ld_coherent(&e.flags[0])) return; // a bin overflowed: the batch takes the reservation rounds as a whole
 	const uint32_t filled = ld_coherent(&e.tcur[tile]);
 	const uint32_t n = filled < e.cap ? filled : e.cap;
 	if (!n) return;
@@ -657,7 +660,7 @@ struct FOpTarget { // one op per item: leaders of k-mers with pure counters only
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
 		// (ops of k-mers that share a counter go to the reservation rounds: the caller compacts opflag)
-		if (e.opflag[t]) { e.tgt[t] = 0; return; }
+		if (e.opflag[t] || e.flags[0]) { e.tgt[t] = 0; return; }
 		const uint32_t n = e.lead[t];
 		uint8_t tg = 0;
 		if (n) {
@@ -673,6 +676,7 @@ struct FOpTarget { // one op per item: leaders of k-mers with pure counters only
 template <class Sync>
 ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 {
+	if (ld_coherent(&e.flags[0])) return;
 	const uint32_t n = ld_coherent(&e.tcur[tile]) < e.cap ? ld_coherent(&e.tcur[tile]) : e.cap;
 	if (!n) return;
 	const TilePair* bin = e.bins + tile * e.cap;
@@ -2199,11 +2203,9 @@ class Engine {
 		// a view of sequences [s, e) whose op ids start at 0
 		Batch v = b;
 		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s;
-		std::vector<uint64_t> kv(e - s + 1);
-		for (uint64_t i = 0; i <= e - s; i++) kv[i] = koff_h[s + i] - koff_h[s];
-		uint64_t* kv_d = (uint64_t*)be_.alloc(kv.size() * 8);
-		be_.h2d(kv_d, kv.data(), kv.size() * 8);
-		v.koff = kv_d;
+		// (the view keeps the whole batch's k-mer prefix sums: the functors subtract kbase)
+		v.koff = b.koff + s;
+		const uint64_t kbase = koff_h[s];
 		uint64_t cmask = (1ull << cfg_.claim_log2) - 1;
 		if (epoch_ > 0xFFFFFF00u) { // claim epochs exhausted: start over
 			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
@@ -2212,8 +2214,7 @@ class Engine {
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
 		if (dist()) {
-			insert_rounds_dist(v, T, cmask);
-			be_.free(kv_d);
+			insert_rounds_dist(v, T, cmask, kbase);
 			return;
 		}
 		uint64_t npend = T;
@@ -2223,12 +2224,12 @@ class Engine {
 		if (tiled_) {
 			// the k-mers that share no counter with another k-mer of the batch are settled tile by
 			// tile; what is left goes through the reservation rounds below
-			TileEnv te{ p_, cnt_, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, (uint32_t*)scal_ };
+			TileEnv te{ p_, cnt_, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
 			be_.memset(tcur_, 0, ntiles_ * 4);
 			be_.memset(lead_, 0, T * 4);
 			be_.memset(opflag_, 0, T);
-			be_.memset(scal_, 0, 8);
-			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+			be_.memset(pend_n_, 0, 8);
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 			{
 				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 				be_.memset(ccur_, 0, ncoarse_ * 4);
@@ -2238,28 +2239,27 @@ class Engine {
 				FBinFine f2{ bn, cpb };
 				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 			}
-			uint32_t over = 0;
-			be_.d2h(&over, scal_, 4);
-			if (over) {
+			// (the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
+			{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
+			{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+			be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
+			uint32_t nn[2] = { 0, 0 };
+			be_.d2h(nn, pend_n_, 8);
+			if (nn[1]) {
 				stats_.tile_overflows++; // (a bin ran over: the whole batch takes the rounds)
 				FClaim fc{ p_, h0_, ccur, cmask, epoch_ };
 				be_.launch(T, fc, "hash_claim");
 			} else {
-				{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
-				{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
-				{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
-				be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
-				uint32_t nn = 0;
-				be_.d2h(&nn, pend_n_, 4);
-				stats_.tiled_ops += T; stats_.tiled_pending += nn;
-				npend = nn;
+				stats_.tiled_ops += T; stats_.tiled_pending += nn[0];
+				npend = nn[0];
 				pin = pend_[1];
 				if (npend) { FClaimList fc{ p_, h0_, pin, ccur, cmask, epoch_ }; be_.launch(npend, fc, "claim_list"); }
 			}
 			claimed = true;
 		}
 		if (!claimed) {
-			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_, 0, 0 };
+			FHashClaim fc{ p_, v, h0_, T, ccur, cmask, epoch_, 0, 0, kbase };
 			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
 		}
 		while (npend) {
@@ -2293,20 +2293,19 @@ class Engine {
 			stats_.insert_rounds++;
 		}
 		epoch_++;
-		be_.free(kv_d);
 	}
 
 	// The reservation rounds of insert_range over a range-partitioned filter: the same rounds,
 	// every rank running every pending op against the counters it owns, one all_reduce(MIN) of a
 	// byte per op between "who holds all claims / what is the minimum" and "apply".  The list of
 	// losers is compacted in op order, so it is the same list on every rank.
-	void insert_rounds_dist(const Batch& v, uint64_t T, uint64_t cmask)
+	void insert_rounds_dist(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase)
 	{
 		cnt_partial_ = true;
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
 		{
-			FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_ };
+			FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_, kbase };
 			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
 		}
 		uint64_t npend = T;
