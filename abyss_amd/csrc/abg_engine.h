@@ -41,8 +41,8 @@ struct Config {
 	uint32_t wtab_log2_max = 31;
 	uint32_t wclaim_log2 = 26;        // walker claim slots
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
-	uint64_t p2_first_batch = 16384;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
-	uint64_t p2_max_batch = 1ull << 21;
+	uint64_t p2_first_batch = 32768;  // PASS 2 read batches grow geometrically from here (smaller ones are bound by their slowest walker)
+	uint64_t p2_max_batch = 1ull << 22;
 	uint32_t p2_growth = 2;           // batch i + 1 holds p2_growth times the reads of batch i
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
@@ -829,7 +829,7 @@ struct FGuideBuild {
 	}
 };
 
-constexpr uint32_t WALK_FAST_WITH_CACHE = 12288; // fast memory of at least this size ends with a MaskCache
+constexpr uint32_t WALK_FAST_WITH_CACHE = 16384; // fast memory of at least this size ends with a MaskCache
 template <int NW>
 struct FWalk { // one walker per item; `list` selects the candidates to walk
 	WalkEnv<NW> e; const uint32_t* list;
