@@ -2033,6 +2033,7 @@ class Engine {
 	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
 	uint64_t batch_ops_ = 0;   // ops per ordered-insert batch (ensure_insert)
+	uint32_t claim_log2_ = 0;  // slots per claim table
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
 	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr;
@@ -2171,9 +2172,25 @@ class Engine {
 			tgt_ = (uint8_t*)be_.alloc(nb);
 		}
 		h0_ = (uint64_t*)be_.alloc(nb * 8);
+		// The claim tables of the reservation rounds: the false-conflict rate falls with the load, so
+		// as many slots as the configuration allows -- but no more than 8 per (op, counter) pair the
+		// rounds can see in one batch (a quarter of the batch's pairs when the tiles settle the rest),
+		// and no more than the device has room for.
+		{
+			const uint64_t pairs = nb * p_.nh / (tiled_ ? 4 : 1);
+			uint32_t log2 = 16;
+			while (log2 < cfg_.claim_log2 && (1ull << log2) < 8 * pairs) log2++;
+			for (;; log2--) {
+				claim_[0] = (uint64_t*)be_.try_alloc(8ull << log2);
+				claim_[1] = claim_[0] ? (uint64_t*)be_.try_alloc(8ull << log2) : nullptr;
+				if (claim_[1] || log2 <= 16) break;
+				if (claim_[0]) be_.free(claim_[0]);
+			}
+			if (!claim_[1]) { fprintf(stderr, "abyss_amd: no device memory for the insert claim tables\n"); abort(); }
+			claim_log2_ = log2;
+		}
 		for (int i = 0; i < 2; i++) {
-			claim_[i] = (uint64_t*)be_.alloc((8ull << cfg_.claim_log2));
-			be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
+			be_.memset(claim_[i], 0xFF, 8ull << claim_log2_);
 			pend_[i] = (uint32_t*)be_.alloc(nb * 4);
 		}
 		pend_n_ = (uint32_t*)be_.alloc(8);
@@ -2206,9 +2223,9 @@ class Engine {
 		// (the view keeps the whole batch's k-mer prefix sums: the functors subtract kbase)
 		v.koff = b.koff + s;
 		const uint64_t kbase = koff_h[s];
-		uint64_t cmask = (1ull << cfg_.claim_log2) - 1;
+		uint64_t cmask = (1ull << claim_log2_) - 1;
 		if (epoch_ > 0xFFFFFF00u) { // claim epochs exhausted: start over
-			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << cfg_.claim_log2);
+			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << claim_log2_);
 			epoch_ = 1;
 		}
 		uint64_t* ccur = claim_[0];

@@ -213,3 +213,35 @@ def test_graphviz_dump_matches_reference(name):
     again, n2, e2 = g.output_graph(g0.buf, g0.off, frame=False)
     assert again == b"" and (n2, e2) == (0, 0)
     g.close()
+
+
+@pytest.mark.parametrize("env", [{"ABG_TILED": "0"}, {"ABG_TILE_CAP": "300"}, {"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"},
+                                 {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"}, {"ABG_PIPELINE": "2"},
+                                 {"ABG_COMPACT_THRESHOLD": "1"}])
+def test_accelerators_and_fallbacks_do_not_change_results(env, monkeypatch):
+    """Every accelerator has an exact slow path behind it and every table a fallback: PASS 1 without the
+    LDS tiles / with bins that overflow, walkers without guide and memo / with the densest guide, the
+    commit with hashed time stamps, two batches in flight, flagged-and-compacted losers in every round.
+    Same bytes as the reference, and the work counters show the path was taken."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    gc = GoldenCase("k64")
+    g = api.BloomDBG(insert_batch_kmers=1 << 17, **gc.kwargs())
+    g.load(gc.buf, gc.off)
+    assert g.counting_stats()[1] == gc.meta["filtered_popcount"]
+    results, contigs = g.assemble(gc.buf, gc.off)
+    st = g.stats()
+    if env.get("ABG_TILED") == "0":
+        assert st["tiled_ops"] == 0
+    elif "ABG_TILE_CAP" in env:
+        assert st["tile_overflows"] > 0
+    else:
+        assert st["tiled_ops"] > 0 and st["tile_overflows"] == 0
+    if env.get("ABG_GUIDE_STRIDE") == "0":
+        assert st["bulk_steps"] == 0 and st["memo_hits"] == 0
+    else:
+        assert st["bulk_steps"] > st["lin_steps"] and st["memo_hits"] > 0
+    assert api.format_fasta(contigs, gc.ids) == gc.fasta
+    assert api.format_read_log(results, gc.ids) == gc.readlog
+    assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace
+    g.close()
