@@ -733,6 +733,7 @@ constexpr uint8_t RES_CANDIDATE = 0x80;
 // this one: hashing every k-mer from scratch costs more ALU than the probes cost memory time, and
 // the 6 G probes of a step are what bounds the kernel.  One read per lane it stays; the next
 // batch's classification is queued on a side stream ahead of the current batch's walkers.)
+constexpr uint32_t CLS_GROUP = 4; // k-mers of a read probed per round of FClassify / FRefilter
 template <int NW>
 struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
@@ -762,21 +763,46 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		vtx_rehash(p, lastv);
 		vtx_revcomp(p, lastv);
 		if (!look_ahead(p, cnt, lastv, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
-		// allKmersInBloom(seq, solidKmerSet) (bloom-dbg.h:58-77)
+		// allKmersInBloom(seq, solidKmerSet), then allKmersInBloom(seq, assembledKmerSet) against the
+		// snapshot (bloom-dbg.h:58-77,816-828).  One sweep over the k-mers, CLS_GROUP of them per
+		// round: their 2 x H probes go out together, so a round costs one memory latency instead of
+		// 2 x CLS_GROUP.  The verdicts are those of the two separate loops: not solid wins over
+		// everything later, "visited" only counts for an entirely solid read.
 		v = first_v;
-		bool solid = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!solid_contains(p, cnt, vtx_hash(p, v))) { solid = false; break; }
+		bool solid = true, visited = true;
+		for (uint32_t j0 = 0; j0 < nk && solid; j0 += CLS_GROUP) {
+			uint64_t h[CLS_GROUP];
+#pragma unroll
+			for (uint32_t q = 0; q < CLS_GROUP; q++) {
+				const uint32_t j = j0 + q;
+				if (j < nk) {
+					if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+					h[q] = vtx_hash(p, v);
+				} else {
+					h[q] = h[0]; // (past the end: the group's first k-mer again)
+				}
+			}
+			bool so = true, vi = true;
+			for (unsigned base = 0; base < p.nh; base += 4) {
+				uint8_t c[CLS_GROUP][4], w[CLS_GROUP][4];
+#pragma unroll
+				for (uint32_t q = 0; q < CLS_GROUP; q++) {
+#pragma unroll
+					for (unsigned t = 0; t < 4; t++) {
+						const uint64_t pos = pos_i(p, h[q], base + t < p.nh ? base + t : 0u);
+						c[q][t] = cnt[pos];
+						w[q][t] = (uint8_t)((vis[pos >> 3] >> (pos & 7)) & 1u);
+					}
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < CLS_GROUP; q++) {
+#pragma unroll
+					for (unsigned t = 0; t < 4; t++) { so = so & (c[q][t] >= p.kc); vi = vi & (w[q][t] != 0); }
+				}
+			}
+			solid = solid & so; visited = visited & vi;
 		}
 		if (!solid) { result[r] = RR_NOT_SOLID; return; }
-		// allKmersInBloom(seq, assembledKmerSet) against the snapshot
-		v = first_v;
-		bool visited = true;
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(p, v))) { visited = false; break; }
-		}
 		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
 	}
 };
@@ -795,9 +821,22 @@ struct FRefilter {
 		Vtx<NW> v;
 		v.s = batch_kmer<NW>(b, r, 0, k);
 		vtx_rehash(p, v);
-		for (uint32_t j = 0; j < nk; j++) {
-			if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
-			if (!visited_contains(p, vis, vtx_hash(p, v))) return;
+		for (uint32_t j0 = 0; j0 < nk; j0 += CLS_GROUP) {
+			uint64_t h[CLS_GROUP];
+#pragma unroll
+			for (uint32_t q = 0; q < CLS_GROUP; q++) {
+				const uint32_t j = j0 + q;
+				if (j < nk) {
+					if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+					h[q] = vtx_hash(p, v);
+				} else {
+					h[q] = h[0];
+				}
+			}
+			bool vi = true;
+#pragma unroll
+			for (uint32_t q = 0; q < CLS_GROUP; q++) vi = vi & visited_contains(p, vis, h[q]);
+			if (!vi) return;
 		}
 		result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
 	}
