@@ -1916,6 +1916,7 @@ class Engine {
 		}
 		if (!memo_valid_) {
 			be_.memset(memo_tab_.hmin, 0xFF, (memo_tab_.mask + 1) * 8);
+			be_.memset(memo_tab_.hmax, 0xFF, (memo_tab_.mask + 1) * 8); // (a reader that sees an entry's value before its second key word sees "no key")
 			be_.memset(memo_tab_.meta, 0, (memo_tab_.mask + 1) * 8);
 			memo_valid_ = true;
 		}
