@@ -479,6 +479,15 @@ ABG_HD VKey vtx_ident(const Params& p, const Vtx<NW>& v)
 	return key;
 }
 ABG_HD bool key_equal(const VKey& a, const VKey& b) { return a.fh == b.fh && a.rh == b.rh; }
+// vtx_ident of a k-mer given with its rolling hashes and (spaced seed) masked-out terms
+template <int NW>
+ABG_HD VKey kmer_ident(const Params& p, const Kmer<NW>& s, uint64_t fh, uint64_t rh, uint64_t df, uint64_t dr)
+{
+	Vtx<NW> t;
+	t.s = s; t.fh = fh; t.rh = rh;
+	vtx_set_d(t, df, dr);
+	return vtx_ident(p, t);
+}
 
 // Canonical hash of one k-mer computed from scratch: RollingHash::reset (RollingHash.h:69-80),
 // i.e. NTF64 / NTR64 base forms (nthash.hpp:220-239), and under a spaced seed what NTMC64 +
@@ -1195,9 +1204,9 @@ struct BulkScratch {
 	uint32_t dup[2 * BULK_LANES]; // open-addressing set of the chunk's identities (lane + 1)
 	uint32_t dupstop;             // first position that repeats an earlier vertex of the chunk
 	uint32_t full;                // the vertex table has no room
-	uint64_t hw[MAX_NW], hfh, hrh; // hand-over of the new head
+	uint64_t hw[MAX_NW], hfh, hrh, hdf, hdr; // hand-over of the new head (hdf, hdr: its masked-out terms, spaced seed)
 	// chain_bulk: where each of the (up to four) branches of a successor() call stands
-	struct Chain { uint64_t w[MAX_NW], fh, rh; uint32_t depth, state; } chain[4];
+	struct Chain { uint64_t w[MAX_NW], fh, rh, df, dr; uint32_t depth, state; } chain[4];
 };
 enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide has nothing more to say
        CB_TRUE = 1,      // trueBranch answers true
@@ -1553,17 +1562,15 @@ ABG_HD int successor_fast(const Params& p, const Vtx<NW>& u, int dir, unsigned m
 // a guide read holds v, its following k-mers predict the next vertices: one lane each computes
 // their identities and their neighbours ahead, and the rule is then applied to all of them in
 // order.  Updates (v, depth, keys[0, depth)); returns CB_TRUE, CB_NOT_CHAIN, or CB_ACTIVE when the
-// guide has no (more) advice for v.  Even k without a mask only (identity = ordered strand hashes).
+// guide has no (more) advice for v.  The guide is keyed by the
+// k-mers' UNMASKED canonical hashes (the walkers' rolling state), whatever the seed.
 template <int NW> struct SearchScratch;
 // (state goes in and out through bs.chain[gi]: vertex, depth, and on return the verdict)
 template <int NW, bool COOP>
 ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_in, SearchScratch<NW>& sc,
     const unsigned gi_in, const int sense_in, const unsigned trim_in, VKey* keys_in)
 {
-	if constexpr (MASKED_BUILD<NW>) {
-		(void)p_in; (void)cnt_in; (void)sc; (void)gi_in; (void)sense_in; (void)trim_in; (void)keys_in;
-		return CB_ACTIVE;
-	} else {
+	{
 	const Params p = uniform_params<COOP>(p_in);
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(cnt_in);
 	Guide g;
@@ -1577,11 +1584,13 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 #pragma unroll
 	for (int j = 0; j < KW<NW>; j++) v.s.w[j] = uni64<COOP>(bs.chain[gi].w[j]);
 	v.fh = uni64<COOP>(bs.chain[gi].fh); v.rh = uni64<COOP>(bs.chain[gi].rh);
+	vtx_set_d(v, uni64<COOP>(bs.chain[gi].df), uni64<COOP>(bs.chain[gi].dr));
 	uint32_t depth_io = uni32<COOP>(bs.chain[gi].depth);
 	auto done = [&](uint32_t d, uint32_t st) -> uint32_t {
 #pragma unroll
 		for (int j = 0; j < KW<NW>; j++) bs.chain[gi].w[j] = v.s.w[j];
-		bs.chain[gi].fh = v.fh; bs.chain[gi].rh = v.rh; bs.chain[gi].depth = d; bs.chain[gi].state = st;
+		bs.chain[gi].fh = v.fh; bs.chain[gi].rh = v.rh; bs.chain[gi].df = vtx_df(v); bs.chain[gi].dr = vtx_dr(v);
+		bs.chain[gi].depth = d; bs.chain[gi].state = st;
 		return st;
 	};
 	const unsigned k = p.k;
@@ -1635,13 +1644,20 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 		for (uint32_t l = lane0; l < 2 * BULK_LANES; l += lstep) bs.dup[l] = 0;
 		if (lane0 == 0) bs.dupstop = n;
 		Kmer<NW> my_s; uint64_t my_fh = 0, my_rh = 0;
+		// spaced seed: the masked-out terms of the lane's vertex and of its four neighbours ahead
+		uint64_t my_df = 0, my_dr = 0, my_ndf = 0, my_ndr = 0;
+		auto terms = [&]() {
+			if constexpr (MASKED_BUILD<NW>) {
+				masked_terms(p, my_s, my_df, my_dr);
+				masked_terms_shifted(p, my_s, my_df, my_dr, sense, my_ndf, my_ndr);
+			}
+		};
 #pragma unroll
 		for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
 		for (uint32_t l = lane0; l < n; l += lstep) {
 			vertex_at(l, my_s, my_fh, my_rh);
-			VKey key;
-			key.fh = my_rh < my_fh ? my_rh : my_fh;
-			key.rh = my_rh < my_fh ? my_fh : my_rh;
+			terms();
+			const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);
 			bs.key[l] = key;
 			unsigned bad = 0; // bit q: the neighbour ahead with base q is not in the solid filter
 			for (unsigned base = 0; base < p.nh; base += 4) {
@@ -1650,6 +1666,7 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 				for (unsigned q = 0; q < 4; q++) {
 					uint64_t nfh, nrh;
 					nbr(my_s, my_fh, my_rh, q, nfh, nrh);
+					nfh ^= my_ndf; nrh ^= my_ndr;
 					const uint64_t h = nrh < nfh ? nrh : nfh;
 #pragma unroll
 					for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
@@ -1715,20 +1732,21 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 		for (uint32_t l = lane0; l <= C; l += lstep) {
 			keys[depth + l] = bs.key[l];
 			if (l == C) {
-				if (!COOP) vertex_at(l, my_s, my_fh, my_rh);
+				if (!COOP) { vertex_at(l, my_s, my_fh, my_rh); terms(); }
 				uint64_t nfh, nrh;
 				const unsigned fb = bs.fbase[l];
 				nbr(my_s, my_fh, my_rh, fb, nfh, nrh);
 				kmer_shift(my_s, k, sense, fb);
 #pragma unroll
 				for (int j = 0; j < KW<NW>; j++) bs.hw[j] = my_s.w[j];
-				bs.hfh = nfh; bs.hrh = nrh;
+				bs.hfh = nfh; bs.hrh = nrh; bs.hdf = my_ndf; bs.hdr = my_ndr;
 			}
 		}
 		wave_sync();
 #pragma unroll
 		for (int j = 0; j < KW<NW>; j++) v.s.w[j] = uni64<COOP>(bs.hw[j]);
 		v.fh = uni64<COOP>(bs.hfh); v.rh = uni64<COOP>(bs.hrh);
+		vtx_set_d(v, uni64<COOP>(bs.hdf), uni64<COOP>(bs.hdr));
 		depth += C + 1;
 	}
 	return done(depth, CB_ACTIVE);
@@ -1764,7 +1782,7 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 	const unsigned lane = COOP ? lane_id() : 0u;
 	const unsigned ngroups = COOP ? 4u : 1u;
 	BulkScratch* const bulk = uniptr<COOP>(sc.bulk);
-	const bool use_guide = !MASKED_BUILD<NW> && uniptr<COOP>(sc.guide.tab) != nullptr && bulk != nullptr && p.ident_fast != 0;
+	const bool use_guide = uniptr<COOP>(sc.guide.tab) != nullptr && bulk != nullptr;
 	unsigned true_mask = 0;
 	// serial callers take the branches one after the other (group 0); cooperative ones all at once
 	for (unsigned first = 0; first < 4; first += ngroups) {
@@ -1804,7 +1822,8 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 					const Vtx<NW> gv = make_neighbour(p, u, sense, gb, fh, rh);
 #pragma unroll
 					for (int j = 0; j < KW<NW>; j++) bs.chain[g].w[j] = gv.s.w[j];
-					bs.chain[g].fh = gv.fh; bs.chain[g].rh = gv.rh; bs.chain[g].depth = 0;
+					bs.chain[g].fh = gv.fh; bs.chain[g].rh = gv.rh; bs.chain[g].df = vtx_df(gv); bs.chain[g].dr = vtx_dr(gv);
+					bs.chain[g].depth = 0;
 				}
 				wave_sync();
 				chain_bulk<NW, COOP>(p_in, cnt_in, sc, g, sense, trim, keys + (uint64_t)g * per_chain);
@@ -1816,7 +1835,7 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 				if (st != CB_NONE) {
 #pragma unroll
 					for (int j = 0; j < KW<NW>; j++) v.s.w[j] = cs.w[j];
-					v.fh = cs.fh; v.rh = cs.rh; depth = cs.depth;
+					v.fh = cs.fh; v.rh = cs.rh; vtx_set_d(v, cs.df, cs.dr); depth = cs.depth;
 					if (st == CB_TRUE) { is_true = true; active = false; }
 					else if (st == CB_NOT_CHAIN) active = false;
 				}

@@ -861,8 +861,11 @@ struct FGuideBuild {
 			const Kmer<NW> s = window_kmer<NW>(b.words, woff, j, p.k);
 			uint64_t fh, rh;
 			kmer_hashes(s, p.k, fh, rh);
-			const uint64_t hm = rh < fh ? rh : fh;
-			if (cnt[pos_i(p, hm, 0)] < p.kc) continue;
+			const uint64_t hm = rh < fh ? rh : fh; // the key: the walkers' rolling state, whatever the seed
+			uint64_t df = 0, dr = 0;
+			if constexpr (MASKED_BUILD<NW>) masked_terms(p, s, df, dr);
+			const uint64_t fs = fh ^ df, rs = rh ^ dr;
+			if (cnt[pos_i(p, rs < fs ? rs : fs, 0)] < p.kc) continue;
 			tab[guide_slot(hm, mask)] = guide_pack(woff, j, nk, guide_tag(hm));
 		}
 	}
@@ -1922,13 +1925,12 @@ class Engine {
 		}
 		memo_ = SuccMemo{ memo_tab_.hmin, memo_tab_.hmax, memo_tab_.meta, memo_tab_.mask };
 	}
-	// The guide of the bulk steps for the reads of one assemble_packed call (see FGuideBuild).  Even k
-	// without a spaced seed only (walk_bulk); sized to the sampled reads' k-mers, of which the solid
-	// ones -- a genome's worth -- stay.
+	// The guide of the bulk steps for the reads of one assemble_packed call (see FGuideBuild):
+	// sized to the sampled reads' k-mers, of which the solid ones -- a genome's worth -- stay.
 	void build_guide(const Batch& b)
 	{
 		guide_.tab = nullptr; guide_slots_ = 0;
-		if (!cfg_.guide_stride || p_.mask || !p_.ident_fast || p_.nh > 8 || !b.n) return;
+		if (!cfg_.guide_stride || p_.nh > 8 || !b.n) return;
 		const uint64_t sampled = (b.n + cfg_.guide_stride - 1) / cfg_.guide_stride;
 		uint64_t nwords = 0;
 		be_.d2h(&nwords, b.woff + b.n, 8);
@@ -1945,10 +1947,8 @@ class Engine {
 		be_.memset(guide_tab_, 0, 8ull << log2);
 		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
 		dispatch_nw([&](auto nw) {
-			if constexpr (!MASKED_BUILD<decltype(nw)::value>) {
-				FGuideBuild<decltype(nw)::value> f{ p_, b, cnt_, guide_tab_, guide_.mask, cfg_.guide_stride };
-				be_.launch_wave(sampled, f, "guide_build");
-			}
+			FGuideBuild<decltype(nw)::value> f{ p_, b, cnt_, guide_tab_, guide_.mask, cfg_.guide_stride };
+			be_.launch_wave(sampled, f, "guide_build");
 		});
 		guide_.tab = guide_tab_;
 		guide_slots_ = guide_.mask + 1;

@@ -239,10 +239,7 @@ template <int NW, bool COOP>
 ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir_in, const uint32_t owner_in,
     const uint32_t contig_in, const uint64_t hint_in)
 {
-	if constexpr (MASKED_BUILD<NW>) {
-		(void)e; (void)w; (void)dir_in; (void)owner_in; (void)contig_in; (void)hint_in;
-		return 0;
-	} else {
+	{
 	const uint64_t tq0 = dbg_clock(e.dbg);
 	const Params p = uniform_params<COOP>(e.p);
 	const unsigned k = p.k;
@@ -314,13 +311,21 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 	const uint64_t tq1 = dbg_clock(e.dbg);
 	// ---- every predicted vertex: identity, "new to the walker", "simple", "continues as predicted"
 	Kmer<NW> my_s; uint64_t my_fh = 0, my_rh = 0;
+	// spaced seed: the masked-out terms of the lane's vertex, of its neighbours behind and of those ahead
+	uint64_t my_df = 0, my_dr = 0, my_bdf = 0, my_bdr = 0, my_fdf = 0, my_fdr = 0;
+	auto terms = [&]() {
+		if constexpr (MASKED_BUILD<NW>) {
+			masked_terms(p, my_s, my_df, my_dr);
+			masked_terms_shifted(p, my_s, my_df, my_dr, bsense, my_bdf, my_bdr);
+			masked_terms_shifted(p, my_s, my_df, my_dr, fsense, my_fdf, my_fdr);
+		}
+	};
 #pragma unroll
 	for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
 	for (uint32_t l = lane0; l < n; l += lstep) {
 		vertex_at(l, my_s, my_fh, my_rh);
-		VKey key; // vtx_ident for even k without a mask: the ordered pair of the strand hashes
-		key.fh = my_rh < my_fh ? my_rh : my_fh;
-		key.rh = my_rh < my_fh ? my_fh : my_rh;
+		terms();
+		const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);
 		bs.key[l] = key;
 		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
 		for (unsigned base = 0; base < p.nh; base += 4) {
@@ -329,6 +334,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 			for (unsigned q = 0; q < 8; q++) {
 				uint64_t nfh, nrh;
 				nbr(my_s, my_fh, my_rh, q < 4 ? bsense : fsense, q & 3u, nfh, nrh);
+				nfh ^= q < 4 ? my_bdf : my_fdf; nrh ^= q < 4 ? my_bdr : my_fdr;
 				const uint64_t h = nrh < nfh ? nrh : nfh;
 #pragma unroll
 				for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
@@ -350,9 +356,9 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 			// positions it is: position l - 1 is a neighbour behind position l and is solid (it passed)
 			uint64_t tfh, trh;
 			nbr(my_s, my_fh, my_rh, bsense, bb, tfh, trh);
-			VKey tk;
-			tk.fh = trh < tfh ? trh : tfh; tk.rh = trh < tfh ? tfh : trh;
-			ok = ok && key_equal(tk, prev_key);
+			Kmer<NW> ts = my_s;
+			kmer_shift(ts, k, bsense, bb);
+			ok = ok && key_equal(kmer_ident(p, ts, tfh, trh, my_bdf, my_bdr), prev_key);
 		}
 		if (l + 1 < n) {
 			// the read's next k-mer adds this base at the walking end
@@ -400,20 +406,21 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		buf[nbuf + l] = bs.fbase[l];
 		if (l == m - 1) {
 			// the new head: the neighbour ahead of the last vertex taken
-			if (!COOP) vertex_at(l, my_s, my_fh, my_rh);
+			if (!COOP) { vertex_at(l, my_s, my_fh, my_rh); terms(); }
 			uint64_t nfh, nrh;
 			const unsigned fb = bs.fbase[l];
 			nbr(my_s, my_fh, my_rh, fsense, fb, nfh, nrh);
 			kmer_shift(my_s, k, fsense, fb);
 #pragma unroll
 			for (int j = 0; j < KW<NW>; j++) bs.hw[j] = my_s.w[j];
-			bs.hfh = nfh; bs.hrh = nrh;
+			bs.hfh = nfh; bs.hrh = nrh; bs.hdf = my_fdf; bs.hdr = my_fdr;
 		}
 	}
 	wave_sync(); // (write-through stores, acknowledged: the table entries are there for whoever looks next)
 #pragma unroll
 	for (int j = 0; j < KW<NW>; j++) w.head.s.w[j] = uni64<COOP>(bs.hw[j]);
 	w.head.fh = uni64<COOP>(bs.hfh); w.head.rh = uni64<COOP>(bs.hrh);
+	vtx_set_d(w.head, uni64<COOP>(bs.hdf), uni64<COOP>(bs.hdr));
 	{
 		const VKey pk = bs.key[m - 1];
 		w.prev_key.fh = uni64<COOP>(pk.fh); w.prev_key.rh = uni64<COOP>(pk.rh);
@@ -480,12 +487,10 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 	const unsigned k = p.k;
 	uint32_t why;
 	int32_t ins = WT_NEW;
-	// read-guided bulk steps (walk_bulk): even k without a mask (the identity of a vertex is then
-	// the ordered pair of its strand hashes), private walks only
+	// read-guided bulk steps (walk_bulk): private walks only
 	const uint64_t* __restrict__ gtab = uniptr<COOP>(e.guide.tab);
 	const uint64_t gmask = uni64<COOP>(e.guide.mask);
-	const bool bulk_on = !MASKED_BUILD<NW> && gtab != nullptr && uniptr<COOP>(w.bulk) != nullptr && claims == nullptr &&
-	                     p.ident_fast != 0 && p.nh <= 8;
+	const bool bulk_on = gtab != nullptr && uniptr<COOP>(w.bulk) != nullptr && claims == nullptr && p.nh <= 8;
 	uint32_t bulk_skip = 0, lin_steps = 0;
 	for (;;) {
 		if (bulk_on) {
@@ -502,6 +507,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 #pragma unroll
 						for (int j = 0; j < KW<NW>; j++) head.s.w[j] = uni64<COOP>(w.head.s.w[j]);
 						head.fh = uni64<COOP>(w.head.fh); head.rh = uni64<COOP>(w.head.rh);
+						vtx_set_d(head, uni64<COOP>(vtx_df(w.head)), uni64<COOP>(vtx_dr(w.head)));
 						prev_key.fh = uni64<COOP>(w.prev_key.fh); prev_key.rh = uni64<COOP>(w.prev_key.rh);
 						ext = uni32<COOP>(w.ext);
 						nbuf = uni32<COOP>(dir == FORWARD ? w.nr : w.nl);
