@@ -464,7 +464,8 @@ constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of 
 constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
 struct TilePair { uint64_t h; uint32_t t; uint32_t off; };          // (off: offset within the tile | hash index << 16)
 struct TileEnv {
-	Params p; uint8_t* cnt; uint64_t m;
+	Params p; uint8_t* cnt;
+	uint64_t lo, m;                   // the counters [lo, m) are tiled (a rank's own range; the whole filter: 0, m)
 	const uint64_t* h0;
 	TilePair* bins; uint32_t cap;     // [ntiles][cap]
 	uint32_t* tcur;                   // [ntiles] pairs in each bin
@@ -477,9 +478,10 @@ template <int NW>
 struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's run comes off the read's words at once
 	Params p; Batch b; uint64_t* h0; uint64_t T;
 	uint64_t kbase; // b.koff holds k-mer prefix sums of a longer batch: op t of this one is k-mer kbase + t there
+	uint64_t tlo;   // the ops [tlo, T) are hashed (partitioned run: each rank hashes a slice of the batch)
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
-		uint64_t t0 = g * HC_RUN;
+		uint64_t t0 = tlo + g * HC_RUN;
 		if (t0 >= T) return;
 		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
 		uint64_t r = find_seq(b.koff, b.n, t0 + kbase);
@@ -524,11 +526,15 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + b.ncoarse;
 		const uint32_t tid = sy.tid(), nt = sy.nthreads();
 		const uint64_t t0 = c * BIN_CHUNK_OPS, t1 = t0 + BIN_CHUNK_OPS < b.T ? t0 + BIN_CHUNK_OPS : b.T;
+		const uint64_t span = b.e.m - b.e.lo;
 		for (uint32_t i = tid; i < b.ncoarse; i += nt) hist[i] = 0;
 		sy.barrier();
 		for (uint64_t t = t0 + tid; t < t1; t += nt) {
 			const uint64_t h = b.e.h0[t];
-			for (unsigned j = 0; j < b.e.p.nh; j++) atomic_add_u32(&hist[(pos_i(b.e.p, h, j) >> TILE_BITS) >> b.cshift], 1);
+			for (unsigned j = 0; j < b.e.p.nh; j++) {
+				const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo; // (a counter outside [lo, m) is another rank's)
+				if (pos < span) atomic_add_u32(&hist[(pos >> TILE_BITS) >> b.cshift], 1);
+			}
 		}
 		sy.barrier();
 		for (uint32_t i = tid; i < b.ncoarse; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.ccur[i], hist[i]) : 0;
@@ -536,7 +542,8 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 		for (uint64_t t = t0 + tid; t < t1; t += nt) {
 			const uint64_t h = b.e.h0[t];
 			for (unsigned j = 0; j < b.e.p.nh; j++) {
-				const uint64_t pos = pos_i(b.e.p, h, j);
+				const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo;
+				if (pos >= span) continue;
 				const uint32_t cb = (uint32_t)((pos >> TILE_BITS) >> b.cshift);
 				const uint32_t slot = atomic_add_u32(&cur[cb], 1);
 				if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
@@ -650,7 +657,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		// the earliest op of the counter's one k-mer leads its ops: the counter holds one pair per op and
 		// per hash function of the k-mer that lands here
 		uint32_t d = 0;
-		const uint64_t pos = (tile << TILE_BITS) | (r.off & 0xFFFFu);
+		const uint64_t pos = e.lo + ((tile << TILE_BITS) | (r.off & 0xFFFFu));
 		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, r.h, q) == pos;
 		e.lead[r.t] = (inf & 0x7FFFFFFFu) / (d ? d : 1);
 	});
@@ -681,8 +688,8 @@ ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 	if (!n) return;
 	const TilePair* bin = e.bins + tile * e.cap;
 	const uint32_t tid = sy.tid(), nt = sy.nthreads();
-	const uint64_t base = tile << TILE_BITS;
-	const uint32_t span = (uint32_t)(e.m - base < TILE_COUNTERS ? e.m - base : TILE_COUNTERS); // (m is a multiple of 8)
+	const uint64_t base = e.lo + (tile << TILE_BITS);
+	const uint32_t span = (uint32_t)(e.m - base < TILE_COUNTERS ? e.m - base : TILE_COUNTERS); // (lo and m are multiples of 8)
 	uint64_t* l8 = (uint64_t*)lds;
 	const uint64_t* g8 = (const uint64_t*)(e.cnt + base);
 	for (uint32_t i = tid; i < span / 8; i += nt) l8[i] = g8[i];
@@ -710,6 +717,63 @@ struct FClaimList { // FClaim over a list of ops
 		const uint64_t h = h0[t];
 		const uint64_t v = claim_val(epoch, t);
 		for (unsigned j = 0; j < p.nh; j++) atomic_min_u64(&claim[pos_i(p, h, j) & cmask], v);
+	}
+};
+
+// ---- the tiles of a partitioned run (Engine::insert_range): every rank bins, judges and applies
+// the pairs on the counters it owns; what an op needs to know from the other ranks travels in
+// three bytes per op through one all_reduce(MAX):
+//   [t]          1: some counter of the op's k-mer is shared with another k-mer (whoever owns it saw that)
+//   [T + t]      n, capped at 255: the op leads the n ops of its k-mer (every owner of a pure counter says the same)
+//   [2T + t]     255 - (minimum of the leader's counters this rank owns); 0 from a rank that owns none
+//   [3T]         1: a bin overflowed somewhere (the whole batch takes the reservation rounds, on every rank)
+struct FDistPack {
+	TileEnv e; uint64_t T; uint8_t* buf;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		const uint32_t n = e.lead[t];
+		buf[t] = e.opflag[t];
+		buf[T + t] = (uint8_t)(n > 255 ? 255u : n);
+		uint8_t v = 0;
+		if (n) {
+			const uint64_t h = e.h0[t];
+			unsigned mn = 255;
+			for (unsigned j = 0; j < e.p.nh; j++) {
+				const uint64_t q = pos_i(e.p, h, j);
+				if (q - e.lo >= e.m - e.lo) continue;
+				const unsigned c = e.cnt[q];
+				mn = c < mn ? c : mn;
+			}
+			v = (uint8_t)(255u - mn);
+		}
+		buf[2 * T + t] = v;
+		if (t == 0) buf[3 * T] = e.flags[0] ? 1 : 0;
+	}
+};
+struct FDistTarget { // FOpTarget from the combined bytes
+	TileEnv e; uint64_t T; const uint8_t* buf;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		if (t == 0 && buf[3 * T]) e.flags[0] = 1;
+		const bool flag = buf[t] != 0;
+		const unsigned n = buf[T + t], mn = 255u - buf[2 * T + t];
+		e.opflag[t] = flag ? 1 : 0;
+		uint8_t tg = 0;
+		if (!flag && !buf[3 * T] && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
+		e.tgt[t] = tg;
+	}
+};
+struct FClaimOwned { // FClaim / FClaimList on the counters of [lo, lo + span) only (pend == NULL: all ops)
+	Params p; const uint64_t* h0; const uint32_t* pend; uint64_t* claim; uint64_t cmask; uint32_t epoch; uint64_t lo, span;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t t = pend ? pend[i] : (uint32_t)i;
+		const uint64_t h = h0[t];
+		const uint64_t v = claim_val(epoch, t);
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint64_t q = pos_i(p, h, j);
+			if (q - lo < span) atomic_min_u64(&claim[q & cmask], v);
+		}
 	}
 };
 
@@ -2016,6 +2080,7 @@ class Engine {
 	Comm comm_;
 	bool force_dist_ = false, comm_scaled_ = false;
 	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
+	uint8_t* tred_ = nullptr; // partitioned tiles: the three bytes per op of FDistPack
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
 	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;
 	std::vector<uint64_t> sh_koff_h_;
@@ -2177,14 +2242,16 @@ class Engine {
 		// streamed for a few thousand pairs, not for a handful
 		batch_ops_ = cfg_.insert_batch_kmers;
 		tiled_ = false;
-		ntiles_ = (m_ + TILE_COUNTERS - 1) >> TILE_BITS;
-		if (cfg_.tiled_insert && !casc_.bits && !dist() && p_.nh <= 16) {
+		// (partitioned run: a rank tiles its own range, and sees 1/R of a batch's pairs)
+		const uint64_t R = dist() ? (uint64_t)comm_.world : 1;
+		ntiles_ = ((dist() ? own_chunk_ : m_) + TILE_COUNTERS - 1) >> TILE_BITS;
+		if (cfg_.tiled_insert && !casc_.bits && p_.nh <= 16) {
 			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114));
-			T = std::min<uint64_t>(T, 2048ull * ntiles_ / p_.nh);
+			T = std::min<uint64_t>(T, 2048ull * ntiles_ * R / p_.nh);
 			if (T >= 1024) {
 				tiled_ = true;
 				batch_ops_ = T;
-				const uint64_t mean = (T * p_.nh + ntiles_ - 1) / ntiles_;
+				const uint64_t mean = (T * p_.nh + ntiles_ * R - 1) / (ntiles_ * R);
 				uint64_t sq = 1;
 				while (sq * sq < mean) sq++;
 				tile_cap_ = (uint32_t)std::min<uint64_t>(TILE_SORT_MAX, mean + 8 * sq + 64);
@@ -2198,7 +2265,7 @@ class Engine {
 			while ((ntiles_ >> cshift_) > 512 && cshift_ < 12) cshift_++;
 			ncoarse_ = (uint32_t)((ntiles_ + (1ull << cshift_) - 1) >> cshift_);
 			{
-				const uint64_t mean = (nb * p_.nh + ncoarse_ - 1) / ncoarse_;
+				const uint64_t mean = (nb * p_.nh + ncoarse_ * R - 1) / (ncoarse_ * R);
 				uint64_t sq = 1;
 				while (sq * sq < mean) sq++;
 				coarse_cap_ = (uint32_t)(mean + 8 * sq + 256);
@@ -2210,6 +2277,7 @@ class Engine {
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
 			opflag_ = (uint8_t*)be_.alloc(nb);
 			tgt_ = (uint8_t*)be_.alloc(nb);
+			if (dist()) tred_ = (uint8_t*)be_.alloc(3 * nb + 64);
 		}
 		h0_ = (uint64_t*)be_.alloc(nb * 8);
 		// The claim tables of the reservation rounds: the false-conflict rate falls with the load, so
@@ -2241,6 +2309,7 @@ class Engine {
 	{
 		if (!h0_) return;
 		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
+		if (tred_) { be_.free(tred_); tred_ = nullptr; }
 		if (dres_) { be_.free(dres_); dres_ = nullptr; }
 		be_.free(dlost_);
 		be_.free(h0_);
@@ -2271,7 +2340,12 @@ class Engine {
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
 		if (dist()) {
-			insert_rounds_dist(v, T, cmask, kbase);
+			if (tiled_) insert_tiles_dist(v, T, cmask, kbase);
+			else {
+				FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_, kbase };
+				be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
+				insert_rounds_dist(T, cmask, nullptr, T);
+			}
 			return;
 		}
 		uint64_t npend = T;
@@ -2281,12 +2355,12 @@ class Engine {
 		if (tiled_) {
 			// the k-mers that share no counter with another k-mer of the batch are settled tile by
 			// tile; what is left goes through the reservation rounds below
-			TileEnv te{ p_, cnt_, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
+			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
 			be_.memset(tcur_, 0, ntiles_ * 4);
 			be_.memset(lead_, 0, T * 4);
 			be_.memset(opflag_, 0, T);
 			be_.memset(pend_n_, 0, 8);
-			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 			{
 				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 				be_.memset(ccur_, 0, ncoarse_ * 4);
@@ -2352,21 +2426,71 @@ class Engine {
 		epoch_++;
 	}
 
+	// The tiles of insert_range over a range-partitioned filter.  Each rank hashes a slice of the
+	// batch's ops and the slices are all-gathered (8 bytes per op instead of every rank hashing
+	// every op); each rank then bins the pairs on the counters it owns into its own tiles and
+	// judges them there; three bytes per op through one all_reduce(MAX) tell every rank which ops
+	// share a counter anywhere, which ops lead their k-mer and what the minimum of a leader's
+	// counters is (FDistPack); every rank applies the leaders' targets to its tiles, and the ops
+	// left over -- the same list on every rank -- go through the partitioned reservation rounds.
+	void insert_tiles_dist(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase)
+	{
+		cnt_partial_ = true;
+		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
+		be_.memset(tcur_, 0, ntiles_ * 4);
+		be_.memset(lead_, 0, T * 4);
+		be_.memset(opflag_, 0, T);
+		be_.memset(pend_n_, 0, 8);
+		{
+			std::vector<uint64_t> c(R), d(R);
+			for (uint64_t q = 0; q < R; q++) {
+				const uint64_t a = (T * q / R) & ~7ull, b = q + 1 == R ? T : (T * (q + 1) / R) & ~7ull;
+				d[q] = a * 8; c[q] = (b - a) * 8;
+			}
+			const uint64_t a = d[me] / 8, b = a + c[me] / 8;
+			if (b > a)
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a }; be_.launch((b - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+			c_all_gather_v(h0_, c.data(), d.data());
+		}
+		{
+			BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
+			be_.memset(ccur_, 0, ncoarse_ * 4);
+			FBinCoarse f1{ bn };
+			be_.launch_tiles((T + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f1, "bin_coarse");
+			const uint32_t cpb = (coarse_cap_ + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS;
+			FBinFine f2{ bn, cpb };
+			be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
+		}
+		{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+		{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
+		c_all_reduce(tred_, 3 * T + 1, DT_U8, OP_MAX);
+		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
+		{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+		be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_);
+		uint32_t nn[2] = { 0, 0 };
+		be_.d2h(nn, pend_n_, 8);
+		const uint32_t* pin = nullptr;
+		uint64_t npend = T;
+		if (nn[1]) stats_.tile_overflows++;
+		else { stats_.tiled_ops += T; stats_.tiled_pending += nn[0]; npend = nn[0]; pin = pend_[1]; }
+		if (npend) {
+			FClaimOwned fc{ p_, h0_, pin, claim_[0], cmask, epoch_, own_lo_, own_span_ };
+			be_.launch(npend, fc, "claim_list");
+		}
+		insert_rounds_dist(T, cmask, pin, npend);
+	}
 	// The reservation rounds of insert_range over a range-partitioned filter: the same rounds,
 	// every rank running every pending op against the counters it owns, one all_reduce(MIN) of a
 	// byte per op between "who holds all claims / what is the minimum" and "apply".  The list of
-	// losers is compacted in op order, so it is the same list on every rank.
-	void insert_rounds_dist(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase)
+	// losers is compacted in op order, so it is the same list on every rank.  The caller has made
+	// the first claims (in claim_[0], under epoch_) for the ops of `pin` (NULL: all T ops).
+	void insert_rounds_dist(uint64_t T, uint64_t cmask, const uint32_t* pin, uint64_t npend)
 	{
+		(void)T;
 		cnt_partial_ = true;
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
-		{
-			FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_, kbase };
-			be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
-		}
-		uint64_t npend = T;
-		const uint32_t* pin = nullptr;
 		uint32_t* pout = pend_[0];
 		while (npend) {
 			if (pin && npend <= cfg_.drain_threshold) {

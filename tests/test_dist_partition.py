@@ -32,6 +32,10 @@ def test_partitioned_run_reproduces_reference_run(name, world):
     for key in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "ranks_agree"):
         assert out[key], (key, out)
     assert out["comm_calls"]["all_reduce"] > 0 and out["comm_calls"]["all_gather_v"] > 0
+    # PASS 1 went through each rank's own tiles (Engine::insert_tiles_dist), the k-mers that share a
+    # counter with another one through the partitioned reservation rounds
+    st = out["stats"]
+    assert st["tile_overflows"] == 0 and 0 < st["tiled_pending"] < st["tiled_ops"], st
 
 
 def test_partitioned_run_on_eight_ranks():
@@ -53,6 +57,22 @@ def test_partitioned_run_matches_oracle_world2():
     for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
         assert out[key], (key, out)
     assert out["n_contigs"] > 10
+
+
+@pytest.mark.parametrize("env,want", [({"ABG_TILE_CAP": "300"}, "overflow"), ({"ABG_TILED": "0"}, "rounds")])
+def test_partitioned_tiles_overflow_and_switched_off_world2(env, want, monkeypatch):
+    """A bin that overflows on one rank sends the whole batch through the reservation rounds on
+    every rank (the overflow travels with the ops' bytes); ABG_TILED=0 is round 1's partitioned run."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    out = run_ranks(2, "oracle")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    st = out["stats"]
+    if want == "overflow":
+        assert st["tile_overflows"] > 0, st
+    else:
+        assert st["tiled_ops"] == 0 and st["tile_overflows"] == 0, st
 
 
 def test_partitioned_tiny_filter_long_chains_and_drain_world3():
