@@ -56,6 +56,7 @@ struct Config {
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
+	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
 	uint64_t par_commit_max_bytes = 16ull << 30; // ... unless that would take more than this: then a stamp per bit the commit touches (hashed)
 	int verbose = 0;
 };
@@ -652,7 +653,9 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	sy.barrier();
 	pairs([&](const TilePair& r, uint32_t i, uint32_t s) {
 		const uint32_t inf = info[s];
-		if (inf >> 31) { e.opflag[r.t] = 1; return; }
+		// (a counter with 254 pairs or more is treated like a shared one: the partitioned run passes
+		// the leaders' op counts between the ranks in a byte)
+		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= 254) { e.opflag[r.t] = 1; return; }
 		if ((uint32_t)(first[s] & 0xFFFu) != i) return;
 		// the earliest op of the counter's one k-mer leads its ops: the counter holds one pair per op and
 		// per hash function of the k-mer that lands here
@@ -722,18 +725,18 @@ struct FClaimList { // FClaim over a list of ops
 
 // ---- the tiles of a partitioned run (Engine::insert_range): every rank bins, judges and applies
 // the pairs on the counters it owns; what an op needs to know from the other ranks travels in
-// three bytes per op through one all_reduce(MAX):
-//   [t]          1: some counter of the op's k-mer is shared with another k-mer (whoever owns it saw that)
-//   [T + t]      n, capped at 255: the op leads the n ops of its k-mer (every owner of a pure counter says the same)
-//   [2T + t]     255 - (minimum of the leader's counters this rank owns); 0 from a rank that owns none
-//   [3T]         1: a bin overflowed somewhere (the whole batch takes the reservation rounds, on every rank)
+// two bytes per op through one all_reduce(MAX):
+//   [t]          255: some counter of the op's k-mer is shared with another k-mer (whoever owns it saw
+//                that); else n < 254: the op leads the n ops of its k-mer (every owner of a pure counter
+//                says the same; tile_purity sends k-mers with more ops to the rounds)
+//   [T + t]      255 - (minimum of the leader's counters this rank owns); 0 from a rank that owns none
+//   [2T]         1: a bin overflowed somewhere (the whole batch takes the reservation rounds, on every rank)
 struct FDistPack {
 	TileEnv e; uint64_t T; uint8_t* buf;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
 		const uint32_t n = e.lead[t];
-		buf[t] = e.opflag[t];
-		buf[T + t] = (uint8_t)(n > 255 ? 255u : n);
+		buf[t] = (uint8_t)(e.opflag[t] ? 255u : n);
 		uint8_t v = 0;
 		if (n) {
 			const uint64_t h = e.h0[t];
@@ -746,20 +749,20 @@ struct FDistPack {
 			}
 			v = (uint8_t)(255u - mn);
 		}
-		buf[2 * T + t] = v;
-		if (t == 0) buf[3 * T] = e.flags[0] ? 1 : 0;
+		buf[T + t] = v;
+		if (t == 0) buf[2 * T] = e.flags[0] ? 1 : 0;
 	}
 };
 struct FDistTarget { // FOpTarget from the combined bytes
 	TileEnv e; uint64_t T; const uint8_t* buf;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
-		if (t == 0 && buf[3 * T]) e.flags[0] = 1;
-		const bool flag = buf[t] != 0;
-		const unsigned n = buf[T + t], mn = 255u - buf[2 * T + t];
+		if (t == 0 && buf[2 * T]) e.flags[0] = 1;
+		const bool flag = buf[t] == 255;
+		const unsigned n = buf[t], mn = 255u - buf[T + t];
 		e.opflag[t] = flag ? 1 : 0;
 		uint8_t tg = 0;
-		if (!flag && !buf[3 * T] && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
+		if (!flag && !buf[2 * T] && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
 		e.tgt[t] = tg;
 	}
 };
@@ -2080,7 +2083,7 @@ class Engine {
 	Comm comm_;
 	bool force_dist_ = false, comm_scaled_ = false;
 	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
-	uint8_t* tred_ = nullptr; // partitioned tiles: the three bytes per op of FDistPack
+	uint8_t* tred_ = nullptr; // partitioned tiles: the two bytes per op of FDistPack
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
 	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;
 	std::vector<uint64_t> sh_koff_h_;
@@ -2277,7 +2280,7 @@ class Engine {
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
 			opflag_ = (uint8_t*)be_.alloc(nb);
 			tgt_ = (uint8_t*)be_.alloc(nb);
-			if (dist()) tred_ = (uint8_t*)be_.alloc(3 * nb + 64);
+			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
 		}
 		h0_ = (uint64_t*)be_.alloc(nb * 8);
 		// The claim tables of the reservation rounds: the false-conflict rate falls with the load, so
@@ -2442,7 +2445,10 @@ class Engine {
 		be_.memset(lead_, 0, T * 4);
 		be_.memset(opflag_, 0, T);
 		be_.memset(pend_n_, 0, 8);
-		{
+		if (R <= cfg_.dist_hash_all_ranks) {
+			// (two ranks share one xGMI link: hashing the other half of the ops costs what receiving it does)
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+		} else {
 			std::vector<uint64_t> c(R), d(R);
 			for (uint64_t q = 0; q < R; q++) {
 				const uint64_t a = (T * q / R) & ~7ull, b = q + 1 == R ? T : (T * (q + 1) / R) & ~7ull;
@@ -2464,7 +2470,7 @@ class Engine {
 		}
 		{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 		{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
-		c_all_reduce(tred_, 3 * T + 1, DT_U8, OP_MAX);
+		c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
 		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
 		{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
 		be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_);

@@ -150,6 +150,17 @@ def main():
         hc.load(buf, off)
         a, b = o.counters(), hc.counters()
         ok = {"counting_filter": bool(np.array_equal(a, b)), "saturated": int(b.max())}
+    elif what == "saturate_tiled":
+        # the same through the ranks' tiles: one k-mer hundreds of times in a batch, counters driven to 255
+        reads = [b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAGCTTGGCATTCGGATACCGGTAAGCTAGCTAACGGT"] * 400 + [b"A" * 150] * 12 + [b"AC" * 75] * 8
+        buf, off = api.concat_seqs(reads)
+        o = ob.Oracle(40, counters=1 << 20)
+        hc = DistHostCheck(40, 1 << 20, insert_batch=30000, claim_log2=16)
+        hc.attach()
+        o.load(buf, off)
+        hc.load(buf, off)
+        a, b = o.counters(), hc.counters()
+        ok = {"counting_filter": bool(np.array_equal(a, b)), "saturated": int(b.max())}
     elif what == "shared":
         ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=True)
     else:

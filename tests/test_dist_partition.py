@@ -86,6 +86,9 @@ def test_partitioned_counters_saturate_like_the_reference_world3():
     out = run_ranks(3, "saturate")
     assert out["counting_filter"] and out["ranks_agree"], out
     assert out["saturated"] == 255
+    out = run_ranks(3, "saturate_tiled")
+    assert out["counting_filter"] and out["ranks_agree"] and out["saturated"] == 255, out
+    assert out["stats"]["tiled_ops"] > 0 and out["stats"]["tiled_pending"] > 254, out["stats"]
 
 
 def test_partitioned_run_on_gathered_read_shares_world3():

@@ -491,3 +491,13 @@ def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
     o.load(buf, off)
     hc.load(buf, off)
     assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
+    # homopolymer runs: one k-mer hundreds of times in a batch (a counter with 254 pairs or more
+    # is left to the reservation rounds, which then see every op of that k-mer)
+    buf, off = api.concat_seqs([b"A" * 150] * 30 + [bytes(r) for r in rep[:50]] + [b"AC" * 75] * 20)
+    o = ob.Oracle(k, counters=1 << 18)
+    hc = HostCheck(k, 1 << 18, insert_batch=30000, claim_log2=16)
+    o.load(buf, off)
+    hc.load(buf, off)
+    st = hc.stats()
+    assert st["tiled_ops"] > 0 and st["tiled_pending"] > 254
+    assert np.array_equal(o.counters(), hc.counters())
