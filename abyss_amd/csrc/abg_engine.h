@@ -1035,29 +1035,65 @@ struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum m
 // redundant" are final for them.  flags: bit 0 of read_flag[c] = read entirely visited;
 // rec.pre_redundant = contig entirely visited (long contigs only: short ones use the exact
 // contigEndKmers rule, bloom-dbg.h:576-584).
+// Partitioned run (part_c != NULL): a rank looks at the bits of its own range [lo, lo + span) only
+// -- every rank holds the whole visited filter, but the tests are random reads and R ranks would
+// each make all of them -- and leaves one byte per candidate (part_c) and per record (part_r,
+// indexed like recs) that an all_reduce(MIN) turns into the verdicts; FPreCommitFin applies them.
+ABG_HD bool visited_contains_owned(const Params& p, const uint8_t* __restrict__ vis, uint64_t h, uint64_t lo, uint64_t span)
+{
+	bool ok = true;
+	for (unsigned i = 0; i < p.nh; i++) {
+		const uint64_t q = pos_i(p, h, i);
+		if (q - lo < span) ok = ok & (((vis[q >> 3] >> (q & 7)) & 1u) != 0);
+	}
+	return ok;
+}
 template <int NW>
 struct FPreCommit {
 	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
 	ContigRec* recs; const uint8_t* vis; const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff;
 	uint8_t* read_flag; uint32_t first;
+	uint64_t lo, span; uint8_t* part_c; uint8_t* part_r; // (whole filter: 0, ~0, NULL, NULL)
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
 		uint32_t c = first + (uint32_t)i;
 		uint64_t r = cand_read[c];
 		uint32_t nk = b.len[r] - p.k + 1;
 		bool all = true;
-		for (uint32_t j = lane; j < nk; j += nlanes) all = all & visited_contains(p, vis, rkh[rkoff[c] + j]);
+		for (uint32_t j = lane; j < nk; j += nlanes) all = all & visited_contains_owned(p, vis, rkh[rkoff[c] + j], lo, span);
 		all = wave_all_lanes(all, nlanes);
-		if (lane == 0) read_flag[c] = all ? 1 : 0;
-		if (all || status[c] != WS_COMPLETE) return;
+		if (part_c) {
+			if (lane == 0) part_c[i] = all ? 1 : 0;
+			if (status[c] != WS_COMPLETE) return;
+		} else {
+			if (lane == 0) read_flag[c] = all ? 1 : 0;
+			if (all || status[c] != WS_COMPLETE) return;
+		}
 		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
 			ContigRec& rec = recs[ri];
 			uint32_t cnk = rec.len - p.k + 1;
 			if (rec.len < p.k + FP_TRIM - 1 || rec.pre_redundant) continue;
 			bool red = true;
-			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains(p, vis, kh[rec.seq_off + j]);
+			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains_owned(p, vis, kh[rec.seq_off + j], lo, span);
 			red = wave_all_lanes(red, nlanes);
-			if (lane == 0 && red) rec.pre_redundant = 1;
+			if (part_r) { if (lane == 0) part_r[ri] = red ? 1 : 0; }
+			else if (lane == 0 && red) rec.pre_redundant = 1;
+		}
+	}
+};
+struct FPreCommitFin { // the combined verdicts of a partitioned FPreCommit, one candidate per item
+	const uint32_t* status; const uint32_t* first_rec; ContigRec* recs; uint8_t* read_flag; uint32_t first;
+	uint32_t k; const uint8_t* part_c; const uint8_t* part_r;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = first + (uint32_t)i;
+		const bool all = part_c[i] != 0;
+		read_flag[c] = all ? 1 : 0;
+		if (all || status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
+			ContigRec& rec = recs[ri];
+			if (rec.len < k + FP_TRIM - 1 || rec.pre_redundant) continue;
+			if (part_r[ri]) rec.pre_redundant = 1;
 		}
 	}
 };
@@ -1444,6 +1480,10 @@ struct ParCommit {
 	VKey* short_keys;      // [2 per entry of short_list] their canonical end k-mers (FPcShortKeys)
 	uint32_t* scal;        // [0] changed  [1] break candidate  [2] short_list length  [3] new contigEndKmers entries
 	uint32_t c_begin, c_end, brk;
+	// partitioned run: the stamps and the bit tests of [own_lo, own_lo + own_span) only (whole filter: 0, ~0),
+	// and a byte per candidate / per record for what the ranks combine (see FPcDecideA)
+	uint64_t own_lo, own_span;
+	uint8_t* part_c; uint8_t* part_r;
 };
 // The stamp of a filter bit.  One 4-byte stamp per bit of the filter costs 4 bytes x m (7.6 GB for
 // B=2G, 152 GB for B=40G); beyond par_commit_max_bytes the stamps of the bits a commit actually
@@ -1481,6 +1521,7 @@ ABG_HD bool pc_bit_before(const ParCommit& e, uint64_t h, uint32_t time)
 	bool ok = true;
 	for (unsigned q = 0; q < e.p.nh; q++) {
 		uint64_t pos = pos_i(e.p, h, q);
+		if (pos - e.own_lo >= e.own_span) continue;
 		bool set = ((e.vis32[pos >> 5] >> (pos & 31)) & 1u) != 0;
 		ok = ok & (set | (t_read(pc_T_get(e, pos), e.tag) < time));
 	}
@@ -1525,7 +1566,10 @@ struct FPcTimeMin { // T: one wave per candidate
 			const uint32_t cnk = rec.len - e.p.k + 1;
 			for (uint32_t j = lane; j < cnk; j += nlanes) {
 				uint64_t h = ch[j];
-				for (unsigned q = 0; q < e.p.nh; q++) atomic_min_u32(pc_T_slot(e, pos_i(e.p, h, q)), t_stamp(e.tag, rec.time));
+				for (unsigned q = 0; q < e.p.nh; q++) {
+					const uint64_t pos = pos_i(e.p, h, q);
+					if (pos - e.own_lo < e.own_span) atomic_min_u32(pc_T_slot(e, pos), t_stamp(e.tag, rec.time));
+				}
 			}
 		}
 	}
@@ -1648,6 +1692,98 @@ struct FPcDecide { // one wave per candidate: re-decide the read and its contigs
 		}
 		if (changed && lane == 0) e.scal[0] = 1;
 	}
+};
+// ---- FPcDecide of a partitioned run, in three steps around two small all_reduces.  A: every rank
+// tests the bits it owns -- "the read is visited at its turn" into part_c[i], "every k-mer of the
+// (long, not pre-redundant) contig was set earlier" into part_r[record]; all_reduce(MIN).  B: the
+// decisions, identical on every rank; where FPcDecide asks whether a change moves T, the rank
+// answers for its own bits into part_c[i]; all_reduce(MAX).  C: a moved T calls for another pass.
+struct FPcDecideA {
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		const unsigned k = e.p.k;
+		bool pv = true;
+		if (!e.read_flag[c]) {
+			const uint32_t nk = e.b.len[e.cand_read[c]] - k + 1;
+			const uint64_t* rh = e.rkh + e.rkoff[c];
+			const uint32_t t0 = e.off[i];
+			bool mine = true;
+			for (uint32_t j = lane; j < nk; j += nlanes) mine = mine & pc_bit_before(e, rh[j], t0);
+			pv = wave_all_lanes(mine, nlanes);
+		}
+		if (lane == 0) e.part_c[i] = pv ? 1 : 0;
+		if (e.status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+			const ContigRec& rec = e.recs[ri];
+			if (rec.len < k + FP_TRIM - 1 || rec.pre_redundant) continue;
+			const uint64_t* ch = e.kh + rec.seq_off;
+			const uint32_t cnk = rec.len - k + 1;
+			bool mine = true;
+			for (uint32_t j = lane; j < cnk; j += nlanes) mine = mine & pc_bit_before(e, ch[j], rec.time);
+			mine = wave_all_lanes(mine, nlanes);
+			if (lane == 0) e.part_r[ri] = mine ? 1 : 0;
+		}
+	}
+};
+struct FPcDecideB {
+	ParCommit e;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		const unsigned k = e.p.k;
+		const bool visited = e.read_flag[c] != 0 || e.part_c[i] != 0;
+		bool moved_here = false; // (this rank's bits)
+		bool changed = false;
+		if (e.status[c] == WS_COMPLETE) {
+			for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+				ContigRec& rec = e.recs[ri];
+				uint32_t ins = 0;
+				if (!visited) {
+					bool red;
+					if (rec.len < k + FP_TRIM - 1) {
+						const uint8_t* seq = e.pool + rec.seq_off;
+						red = pc_end_before(e, canonical_end_key(e.p, seq), rec.time) &&
+						      pc_end_before(e, canonical_end_key(e.p, seq + rec.len - k), rec.time);
+					} else if (rec.pre_redundant) {
+						red = true;
+					} else {
+						red = e.part_r[ri] != 0;
+					}
+					ins = red ? 0u : 1u;
+				}
+				if (ins != rec.ins) {
+					if (rec.ins && rec.len >= k + FP_TRIM - 1) {
+						if (visited) {
+							const uint64_t* ch = e.kh + rec.seq_off;
+							const uint32_t cnk = rec.len - k + 1;
+							bool mine = false;
+							for (uint32_t j = lane; j < cnk; j += nlanes)
+								for (unsigned q = 0; q < e.p.nh; q++) {
+									uint64_t pos = pos_i(e.p, ch[j], q);
+									if (pos - e.own_lo >= e.own_span) continue;
+									mine = mine | (t_read(pc_T_get(e, pos), e.tag) == rec.time && !((e.vis32[pos >> 5] >> (pos & 31)) & 1u));
+								}
+							moved_here = moved_here | !wave_all_lanes(!mine, nlanes);
+						}
+					} else {
+						changed = true;
+					}
+				}
+				if (lane == 0) rec.ins = ins;
+			}
+		}
+		if (lane == 0) {
+			e.active[i] = visited ? 0 : 1;
+			e.part_c[i] = moved_here ? 1 : 0;
+			if (changed) e.scal[0] = 1;
+		}
+	}
+};
+struct FPcDecideC {
+	ParCommit e;
+	ABG_HD void operator()(uint64_t i, uint32_t) const { if (e.part_c[i]) e.scal[0] = 1; }
 };
 struct FPcBreak { // first candidate that is needed but has no result
 	ParCommit e;
@@ -2282,7 +2418,7 @@ class Engine {
 			tgt_ = (uint8_t*)be_.alloc(nb);
 			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
 		}
-		h0_ = (uint64_t*)be_.alloc(nb * 8);
+		h0_ = (uint64_t*)be_.alloc((nb + 8 * R + 8) * 8);
 		// The claim tables of the reservation rounds: the false-conflict rate falls with the load, so
 		// as many slots as the configuration allows -- but no more than 8 per (op, counter) pair the
 		// rounds can see in one batch (a quarter of the batch's pairs when the tiles settle the rest),
@@ -2449,12 +2585,11 @@ class Engine {
 			// (two ranks share one xGMI link: hashing the other half of the ops costs what receiving it does)
 			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 		} else {
-			std::vector<uint64_t> c(R), d(R);
-			for (uint64_t q = 0; q < R; q++) {
-				const uint64_t a = (T * q / R) & ~7ull, b = q + 1 == R ? T : (T * (q + 1) / R) & ~7ull;
-				d[q] = a * 8; c[q] = (b - a) * 8;
-			}
-			const uint64_t a = d[me] / 8, b = a + c[me] / 8;
+			// equal slices (one ring all-gather); the last one may run into the slack behind the T hashes
+			const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
+			std::vector<uint64_t> c(R, chunk * 8), d(R);
+			for (uint64_t q = 0; q < R; q++) d[q] = q * chunk * 8;
+			const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk);
 			if (b > a)
 				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a }; be_.launch((b - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 			c_all_gather_v(h0_, c.data(), d.data());
@@ -2652,7 +2787,7 @@ class Engine {
 		cs.break_at = c_begin; cs.pad_ = 0; cs.cend_count = cend_count_;
 		be_.h2d(cstate_, &cs, sizeof cs);
 		{
-			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr };
 			be_.launch_wave(c_end - c_begin, f, "precommit");
 		}
 		CommitEnv<NW> e;
@@ -2677,6 +2812,7 @@ class Engine {
 	    uint8_t* result_d, uint64_t* rkoff_d, uint32_t c_begin, uint32_t c_end)
 	{
 		uint32_t n = c_end - c_begin;
+		const uint32_t n0 = n; // (n may shrink below: a commit holds 2^T_TIME_BITS records)
 		uint32_t nrec = 0, nord = 0;
 		be_.d2h(&nrec, rec_used_, 4);
 		be_.d2h(&nord, order_n_, 4);
@@ -2685,11 +2821,24 @@ class Engine {
 			uint64_t need = cend_count_ + 2ull * (nrec - std::min(nord, rec_cap_));
 			while (need * 2 > cend_.mask + 1) grow_cend();
 		}
+		// partitioned run: every rank holds the visited filter and every contig, but tests and stamps
+		// the bits of its own range only; a byte per candidate and per record goes through all_reduce
+		const bool part = dist();
+		uint8_t* part_buf = part ? (uint8_t*)be_.alloc((uint64_t)n + nrec + 64) : nullptr;
+		uint8_t* part_c = part_buf; uint8_t* part_r = part ? part_buf + n : nullptr;
 		{
-			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin };
+			if (part) be_.memset(part_buf, 1, (uint64_t)n + nrec);
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin,
+				part ? own_lo_ : 0, part ? own_span_ : ~0ULL, part_c, part_r };
 			be_.launch_wave(n, f, "precommit");
+			if (part) {
+				c_all_reduce(part_buf, (uint64_t)n + nrec, DT_U8, OP_MIN);
+				FPreCommitFin ff{ status_d, first_d, recs_, read_flag_, c_begin, p_.k, part_c, part_r };
+				be_.launch(n, ff, "precommit");
+			}
 		}
 		ParCommit e;
+		e.own_lo = part ? own_lo_ : 0; e.own_span = part ? own_span_ : ~0ULL; e.part_c = part_c; e.part_r = part_r;
 		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
 		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_;
@@ -2769,7 +2918,14 @@ class Engine {
 			}
 			be_.memset(e.scal, 0, 4);
 			{ FPcTimeMin f{ e }; be_.launch_wave(n, f, "pc_timemin"); }
-			{ FPcDecide f{ e }; be_.launch_wave(n, f, "pc_decide"); }
+			if (part) {
+				be_.memset(part_buf, 1, (uint64_t)n0 + nrec);
+				{ FPcDecideA f{ e }; be_.launch_wave(n, f, "pc_decide"); }
+				c_all_reduce(part_buf, (uint64_t)n0 + nrec, DT_U8, OP_MIN);
+				{ FPcDecideB f{ e }; be_.launch_wave(n, f, "pc_decide"); }
+				c_all_reduce(part_c, n, DT_U8, OP_MAX);
+				{ FPcDecideC f{ e }; be_.launch(n, f, "pc_decide"); }
+			} else { FPcDecide f{ e }; be_.launch_wave(n, f, "pc_decide"); }
 			be_.d2h(scal_h, e.scal, 4);
 			stats_.commit_rounds++;
 			if (!scal_h[0]) break;
@@ -2809,6 +2965,7 @@ class Engine {
 		if (nshort) { free_tab(e.tcend); be_.free(e.short_keys); }
 		be_.free(e.off); be_.free(e.cnt); be_.free(e.cnt2); be_.free(e.cnt3); be_.free(e.active);
 		be_.free(e.short_list); be_.free(e.scal);
+		if (part_buf) be_.free(part_buf);
 		return brk;
 	}
 
@@ -2855,9 +3012,11 @@ class Engine {
 			be_.free(tmp);
 		}
 		if (me && cnt[2 * me + 1]) {
-			void* tmp = be_.alloc(cnt[2 * me + 1]);
+			void* tmp = be_.alloc(cnt[2 * me + 1] * 8);
 			be_.d2d(tmp, pool_ + g_pool_, cnt[2 * me + 1]);
 			be_.d2d(pool_ + g_pool_ + fx.pbase[me], tmp, cnt[2 * me + 1]);
+			be_.d2d(tmp, kh_ + g_pool_, cnt[2 * me + 1] * 8); // (the k-mer hashes of prep_local_records, one per base)
+			be_.d2d(kh_ + g_pool_ + fx.pbase[me], tmp, cnt[2 * me + 1] * 8);
 			be_.free(tmp);
 		}
 		std::vector<uint64_t> c(R), d(R);
@@ -2865,6 +3024,8 @@ class Engine {
 		if (tot_rec) c_all_gather_v(recs_, c.data(), d.data());
 		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q + 1]; d[q] = g_pool_ + fx.pbase[q]; }
 		if (tot_pool) c_all_gather_v(pool_, c.data(), d.data());
+		for (uint32_t q = 0; q < R; q++) { c[q] *= 8; d[q] *= 8; }
+		if (tot_pool) c_all_gather_v(kh_, c.data(), d.data());
 		if (tot_rec) {
 			fx.recs = recs_; fx.g_rec = g_rec_; fx.world = R;
 			be_.launch(tot_rec, fx, "merge_fix");
@@ -2895,6 +3056,18 @@ class Engine {
 			FContigPrep<NW> f{ p_, cnt_, recs_, prepped, pool_, kh_ };
 			be_.launch_wave(nrec - prepped, f, "contig_prep");
 			prepped = nrec;
+		}
+	}
+	// partitioned run: the records this rank's walkers appended after the merged ones
+	template <int NW>
+	void prep_local_records()
+	{
+		uint32_t lr = 0;
+		be_.d2h(&lr, rec_used_, 4);
+		lr = std::min(lr, rec_cap_);
+		if (lr > g_rec_) {
+			FContigPrep<NW> f{ p_, cnt_, recs_, g_rec_, pool_, kh_ };
+			be_.launch_wave(lr - g_rec_, f, "contig_prep");
 		}
 	}
 	void grow_cend()
@@ -3259,8 +3432,12 @@ class Engine {
 					stats_.rewalked += r.nneed_all;
 					r.batch_rewalked += r.nneed_all;
 					dump_walkers(r, "rewalk", r.nneed);
-					if (dist()) merge_walk_results(r.need_d, r.nneed, r.status_d, r.first_d, nc);
-					prep_new_records<NW>(r.prepped);
+					if (dist()) {
+						// (a rank prepares the records it walked; their hashes travel with the sequences)
+						prep_local_records<NW>();
+						merge_walk_results(r.need_d, r.nneed, r.status_d, r.first_d, nc);
+						r.prepped = g_rec_;
+					} else prep_new_records<NW>(r.prepped);
 				}
 				// stage 3: ordered commit as far as the results allow
 				uint32_t next = use_par_commit() ? commit_par<NW>(r.v, r.cand_d, r.status_d, r.first_d, r.res_d, r.rkoff_d, r.committed, nc)

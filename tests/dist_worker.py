@@ -86,13 +86,13 @@ def case_golden(name, rank, world):
     return ok, hc
 
 
-def case_oracle(k, G, counters, cov, err, insert_batch, rank, world, shared):
+def case_oracle(k, G, counters, cov, err, insert_batch, rank, world, shared, p2_first=64):
     """Synthetic reads against the oracle.  shared: each rank holds a slice of the packed reads and
     the ranks all-gather them (abg_share_reads) instead of every rank passing the whole set."""
     m1, m2 = synth.make_read_set(G, cov, err=err, genome_seed=k, read_seed=k + 3)
     codes = np.concatenate([m1, m2])
     buf, off = api.matrix_to_seqs(synth.codes_to_ascii(codes))
-    hc = DistHostCheck(k, counters, insert_batch=insert_batch, claim_log2=12, p2_first=64)
+    hc = DistHostCheck(k, counters, insert_batch=insert_batch, claim_log2=12, p2_first=p2_first)
     hc.attach()
     if shared:
         n = codes.shape[0]
@@ -134,6 +134,10 @@ def main():
         ok, hc = case_golden(sys.argv[2], rank, world)
     elif what == "oracle":
         ok, hc = case_oracle(33, 12000, 1 << 20, 25.0, 0.005, 20000, rank, world, shared=False)
+    elif what == "bigbatch":
+        # every read in ONE batch of PASS 2: the commit has to order thousands of candidates whose
+        # contigs overlap, over several passes of its fixed point (the ranks combine their bits' verdicts)
+        ok, hc = case_oracle(31, 20000, 1 << 21, 30.0, 0.01, 20000, rank, world, shared=False, p2_first=1 << 20)
     elif what == "tiny_filter":
         # a filter so small that counters saturate and every op conflicts with many others: long
         # reservation chains, several rounds per batch, the distributed hand-over to the drain kernel

@@ -75,6 +75,21 @@ def test_partitioned_tiles_overflow_and_switched_off_world2(env, want, monkeypat
         assert st["tiled_ops"] == 0 and st["tile_overflows"] == 0, st
 
 
+@pytest.mark.parametrize("env", [{}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "5"}])
+def test_partitioned_commit_orders_one_big_batch_world3(env, monkeypatch):
+    """The commit of a partitioned run (FPcDecideA/B/C, abg_engine.h): each rank stamps and tests the
+    bits of its own range, a byte per candidate and per record goes through all_reduce.  One batch
+    holding every read makes the fixed point take several passes; with ABG_PAR_COMMIT_MAX_GB=0 the
+    stamps live in the hashed table."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    out = run_ranks(3, "bigbatch")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["stats"]["commit_rounds"] > out["stats"]["walk_rounds"], out["stats"]
+    assert out["n_contigs"] > 20
+
+
 def test_partitioned_tiny_filter_long_chains_and_drain_world3():
     out = run_ranks(3, "tiny_filter")
     for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
