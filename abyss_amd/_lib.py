@@ -50,7 +50,7 @@ def symbols():
     return [
         "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_reset", "abg_filter_size",
         "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
-        "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs",
+        "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs", "abg_assemble_seqs_v",
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
         "abg_contains_seq",
         "abg_attach_comm", "abg_share_reads", "abg_rccl_unique_id", "abg_rccl_comm_create", "abg_rccl_comm_destroy",
@@ -88,6 +88,7 @@ def load(path: str | None = None):
     lib.abg_visited_export.argtypes = [vp, u8p]
     lib.abg_visited_import.argtypes = [vp, u8p]
     lib.abg_assemble_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64, vp, CONTIG_CB, vp]
+    lib.abg_assemble_seqs_v.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, CONTIG_CB, vp]
     lib.abg_assemble_packed.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, CONTIG_CB, vp]
     lib.abg_cascade_export.argtypes = [vp, C.c_uint32, u8p]
     lib.abg_get_counters.argtypes = [vp, C.POINTER(Counters)]

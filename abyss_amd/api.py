@@ -213,6 +213,22 @@ class BloomDBG:
                     "abg_assemble_seqs")
         return results, contigs
 
+    def assemble_chunks(self, chunks) -> Tuple[np.ndarray, List[ContigRecord]]:
+        """PASS 2 over a read set held in several (buf, offsets) chunks, as ONE pass (abg_assemble_seqs_v);
+        read indices count through the chunks in order."""
+        bufs = [C.c_char_p(b) for b, _ in chunks]
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for _, o in chunks]
+        nc = len(chunks)
+        seqs_v = (C.c_char_p * nc)(*bufs)
+        off_v = (C.c_void_p * nc)(*[o.ctypes.data for o in offs])
+        n_v = (C.c_uint64 * nc)(*[len(o) - 1 for o in offs])
+        results = np.zeros(sum(len(o) - 1 for o in offs), dtype=np.uint8)
+        contigs: List[ContigRecord] = []
+        cb = self._collector(contigs)
+        self._check(self._lib.abg_assemble_seqs_v(self._ctx, nc, C.cast(seqs_v, C.c_void_p), C.cast(off_v, C.c_void_p),
+                                                  C.cast(n_v, C.c_void_p), results.ctypes.data, cb, None), "abg_assemble_seqs_v")
+        return results, contigs
+
     def assemble_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int, want_results: bool = True,
                         want_contigs: bool = True) -> Tuple[Optional[np.ndarray], List[ContigRecord]]:
         results = np.zeros(n, dtype=np.uint8) if want_results else None

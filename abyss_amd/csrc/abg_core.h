@@ -1212,7 +1212,9 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
        CB_TRUE = 1,      // trueBranch answers true
        CB_NOT_CHAIN = 2, // a vertex with no or several neighbours ahead: the general search decides
        CB_NONE = 3 };    // not examined
-enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS, WSTAT_N = 8 };
+enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
+       WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
+       WSTAT_N = 8 };
 
 // ------------------------------------------------------- memo of successor()
 // successor(u, dir) with its iterative deepening over trueBranch searches (ExtendPath.h:314-362) is

@@ -57,6 +57,7 @@ struct Config {
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
+	uint64_t keep_insert_scratch_bytes = 16ull << 30; // PASS 1's scratch is given back before PASS 2 when larger than this
 	uint64_t par_commit_max_bytes = 16ull << 30; // ... unless that would take more than this: then a stamp per bit the commit touches (hashed)
 	int verbose = 0;
 };
@@ -475,6 +476,57 @@ struct TileEnv {
 	uint8_t* tgt;                     // [T] leaders: the value their counters are raised to (0: nothing to do)
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
 };
+// canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
+// rolled (NTC64, nthash.hpp:242-257,275-279).  Under a spaced seed the rolled state is the UNMASKED
+// pair plus the XOR of the masked positions' terms (what maskHash takes out again,
+// nthash.hpp:537-547): rolling moves every run of masked positions by one base, so those terms
+// are updated per run (masked_terms_shifted, abg_core.h), not per position.  A code outside 0..3
+// (the 'N' of a contig column no '1' covers) only ever sits under a '0', where its term cancels.
+template <class Get, class Put>
+ABG_HD void kmer_hash_run(const Params& p, Get get, uint32_t j0, uint32_t j1, Put put)
+{
+	if (j0 >= j1) return;
+	const unsigned k = p.k;
+	if (p.mask) {
+		const MaskTab& m = *p.mask;
+		uint64_t fh = 0, rh = 0, df = 0, dr = 0;
+		for (unsigned i = 0; i < k; i++) {
+			fh = srol1(fh) ^ seed_of(get(j0 + i));
+			rh = srol1(rh) ^ seed_of(3u - get(j0 + k - 1 - i));
+		}
+		for (unsigned q = 0; q < m.nmasked; q++) {
+			const unsigned pos = m.pos[q], c = get(j0 + pos);
+			df ^= srol_n(seed_of(c), k - 1 - pos);
+			dr ^= srol_n(seed_of(3u - c), pos);
+		}
+		for (uint32_t j = j0;; j++) {
+			const uint64_t fs = fh ^ df, rs = rh ^ dr;
+			put(j, rs < fs ? rs : fs);
+			if (j + 1 >= j1) break;
+			// to k-mer j + 1: position a of every run [a, b) leaves it, position b enters
+			for (unsigned r = 0; r < m.nruns; r++) {
+				const unsigned ia = m.run_a[r], ib = m.run_b[r];
+				const unsigned xa = get(j + ia), xb = get(j + ib);
+				df ^= srol_n(seed_of(xa), k - 1 - ia) ^ srol_n(seed_of(xb), k - 1 - ib);
+				dr ^= srol_n(seed_of(3u - xa), ia) ^ srol_n(seed_of(3u - xb), ib);
+			}
+			df = srol1(df); dr = sror1(dr);
+			const unsigned out = get(j), in = get(j + k);
+			fh = srol1(fh) ^ seed_of(in) ^ srol_n(seed_of(out), k);
+			rh = sror1(rh ^ srol_n(seed_of(3u - in), k) ^ seed_of(3u - out));
+		}
+		return;
+	}
+	uint64_t fh, rh;
+	scratch_hashes(p, [&](unsigned i) { return get(j0 + i); }, fh, rh);
+	put(j0, rh < fh ? rh : fh);
+	for (uint32_t j = j0 + 1; j < j1; j++) {
+		const unsigned out = get(j - 1), in = get(j + k - 1);
+		fh = srol1(fh) ^ seed_of(in) ^ sel4(p.seed_k, out);
+		rh = sror1(rh ^ sel4(p.seedrc_k, in) ^ seed_of(3u - out));
+		put(j, rh < fh ? rh : fh);
+	}
+}
 template <int NW>
 struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's run comes off the read's words at once
 	Params p; Batch b; uint64_t* h0; uint64_t T;
@@ -493,7 +545,14 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 		for (uint64_t t = t0; t < t1; t++) {
 			while (t >= rend) { r++; rend = b.koff[r + 1] - kbase; fresh = true; }
 			uint32_t j = (uint32_t)(t + kbase - b.koff[r]);
-			if (p.mask) { h0[t] = scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); }); continue; }
+			if (p.mask) {
+				// spaced seed: the k-mers of this read among the lane's ops in one rolled run
+				const uint64_t tend = t1 < rend ? t1 : rend;
+				kmer_hash_run(p, [&](unsigned i) { return batch_base(b, r, i); }, j, j + (uint32_t)(tend - t),
+				    [&](uint32_t jj, uint64_t h) { h0[t + (jj - j)] = h; });
+				t = tend - 1;
+				continue;
+			}
 			if (fresh) {
 				const Kmer<NW> s = window_kmer<NW>(b.words, b.woff[r], j, k);
 				kmer_hashes(s, k, fh, rh);
@@ -976,27 +1035,6 @@ template <int NW>
 ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uint32_t j)
 {
 	return scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
-}
-// canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
-// rolled (NTC64, nthash.hpp:242-257,275-279); from scratch throughout under a spaced seed
-template <class Get, class Put>
-ABG_HD void kmer_hash_run(const Params& p, Get get, uint32_t j0, uint32_t j1, Put put)
-{
-	if (j0 >= j1) return;
-	const unsigned k = p.k;
-	if (p.mask) {
-		for (uint32_t j = j0; j < j1; j++) put(j, scratch_hash(p, [&](unsigned i) { return get(j + i); }));
-		return;
-	}
-	uint64_t fh, rh;
-	scratch_hashes(p, [&](unsigned i) { return get(j0 + i); }, fh, rh);
-	put(j0, rh < fh ? rh : fh);
-	for (uint32_t j = j0 + 1; j < j1; j++) {
-		const unsigned out = get(j - 1), in = get(j + k - 1);
-		fh = srol1(fh) ^ seed_of(in) ^ sel4(p.seed_k, out);
-		rh = sror1(rh ^ sel4(p.seedrc_k, in) ^ seed_of(3u - out));
-		put(j, rh < fh ? rh : fh);
-	}
 }
 constexpr uint32_t PREP_RUN = 8; // consecutive k-mers per lane
 template <int NW>
@@ -1931,6 +1969,7 @@ class Engine {
 		}
 		cend_count_ = 0;
 		if (wstats_) be_.memset(wstats_, 0, WSTAT_N * 8);
+		ovf_seen_[0] = ovf_seen_[1] = 0;
 		if (gtab_.hmin) { free_tab(gtab_); gtab_ = WalkTab{ nullptr, nullptr, nullptr, 0 }; gtab_used_ = 0; }
 	}
 	const Params& params() const { return p_; }
@@ -2098,8 +2137,10 @@ class Engine {
 	    const std::function<void(const ContigOut&)>& sink)
 	{
 		use_ctx(0);
-		ensure_walk();
 		gather_counters();
+		// (PASS 1's bins and claim tables grow with the filter -- 60 GB at B=40G: PASS 2 gets that memory)
+		if (insert_scratch_bytes_ > cfg_.keep_insert_scratch_bytes) free_insert();
+		ensure_walk();
 		build_guide(b);
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
@@ -2277,6 +2318,7 @@ class Engine {
 	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
 	uint64_t batch_ops_ = 0;   // ops per ordered-insert batch (ensure_insert)
+	uint64_t insert_scratch_bytes_ = 0; // what ensure_insert holds
 	uint32_t claim_log2_ = 0;  // slots per claim table
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
 	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
@@ -2288,6 +2330,7 @@ class Engine {
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
+	uint64_t ovf_seen_[2] = { 0, 0 }; // the walkers' pool / record overflow counters as last read
 	uint64_t wtab_per_walker_ = 1536; // planning figure: vertices one walker enters (config 2 averages ~1100)
 	uint32_t* wclaims_ = nullptr;
 	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
@@ -2443,6 +2486,8 @@ class Engine {
 		pend_n_ = (uint32_t*)be_.alloc(8);
 		if (dist()) dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32));
 		dlost_ = (uint8_t*)be_.alloc(nb);
+		insert_scratch_bytes_ = nb * (8 + 4 + 4 + 1) + (16ull << claim_log2_);
+		if (tiled_) insert_scratch_bytes_ += ((uint64_t)ncoarse_ * coarse_cap_ + ntiles_ * tile_cap_) * sizeof(TilePair) + nb * 6;
 	}
 	void free_insert()
 	{
@@ -2455,6 +2500,7 @@ class Engine {
 		for (int i = 0; i < 2; i++) { be_.free(claim_[i]); be_.free(pend_[i]); }
 		be_.free(pend_n_);
 		h0_ = nullptr;
+		insert_scratch_bytes_ = 0;
 	}
 	void insert_range(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h)
 	{
@@ -3094,12 +3140,20 @@ class Engine {
 	{
 		const uint64_t want = 2 * nwalk * wtab_per_walker_;
 		uint32_t log2 = wtab_log2_;
-		while ((1ull << log2) < want && log2 < cfg_.wtab_log2_max) log2++;
+		while ((1ull << log2) < want && log2 < wtab_log2_cap()) log2++;
 		if (log2 == wtab_log2_) return;
 		free_tab(wtab_);
 		wtab_log2_ = log2;
 		alloc_tab(wtab_, wtab_log2_);
 		if (cfg_.verbose) fprintf(stderr, "abyss_amd: walker vertex table grown to 2^%u entries\n", wtab_log2_);
+	}
+	// the vertex table takes 24 bytes per entry: at most an eighth of the device's memory
+	uint32_t wtab_log2_cap()
+	{
+		uint32_t cap = cfg_.wtab_log2_max;
+		const uint64_t mem = be_.device_mem_bytes();
+		while (mem && cap > cfg_.wtab_log2 && (24ull << cap) > mem / 8) cap--;
+		return cap;
 	}
 	void clear_wtab()
 	{
@@ -3264,9 +3318,12 @@ class Engine {
 		be_.d2h(res.data(), res_d, n);
 		r = BatchRun();
 		uint64_t used = n;
+		// (no more candidates in a batch than the vertex table at its largest plans room for)
+		const uint64_t max_cand = std::min<uint64_t>(cfg_.p2_max_candidates,
+		    std::max<uint64_t>(1024, (1ull << wtab_log2_cap()) / (2 * wtab_per_walker_)));
 		for (uint64_t i = 0; i < n; i++) {
 			if (res[i] == RES_CANDIDATE) {
-				if (r.cand_h.size() >= cfg_.p2_max_candidates) { used = i; break; }
+				if (r.cand_h.size() >= max_cand) { used = i; break; }
 				r.cand_h.push_back((uint32_t)i);
 			}
 			if (res[i] == RES_CANDIDATE || res[i] == RR_ALL_KMERS_VISITED) counters_.solid_reads++;
@@ -3462,8 +3519,31 @@ class Engine {
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.
 				stats_.overflows++;
-				if (r.committed == r.base) grow_walk_resources();
-				else wtab_per_walker_ *= 2; // most likely the vertex table: plan for longer walks from now on
+				// what ran out?  The walkers count pool and record overflows; anything else is the vertex
+				// table (plan for longer walks from now on) or, when not even the first candidate got
+				// through, a walker's own stack or path buffer.
+				uint64_t ovf[2] = { 0, 0 };
+				be_.d2h(ovf, wstats_ + WSTAT_OVF_POOL, 16);
+				const bool pool_out = ovf[0] != ovf_seen_[0], recs_out = ovf[1] != ovf_seen_[1];
+				ovf_seen_[0] = ovf[0]; ovf_seen_[1] = ovf[1];
+				if (pool_out) {
+					be_.free(pool_); be_.free(kh_);
+					pool_cap_ *= 2;
+					pool_ = (uint8_t*)be_.alloc(pool_cap_);
+					kh_ = (uint64_t*)be_.alloc(pool_cap_ * 8);
+					if (cfg_.verbose) fprintf(stderr, "abyss_amd: contig pool grown to %llu bases\n", (unsigned long long)pool_cap_);
+				}
+				if (recs_out) {
+					be_.free(recs_); be_.free(order_);
+					rec_cap_ *= 2;
+					recs_ = (ContigRec*)be_.alloc((uint64_t)rec_cap_ * sizeof(ContigRec));
+					order_ = (uint32_t*)be_.alloc((uint64_t)rec_cap_ * 4);
+					if (cfg_.verbose) fprintf(stderr, "abyss_amd: contig records grown to %u\n", rec_cap_);
+				}
+				if (!pool_out && !recs_out) {
+					if (r.committed == r.base) grow_walk_resources();
+					else wtab_per_walker_ *= 2;
+				}
 			}
 			r.base = r.committed;
 			r.round_started = false; r.predicted = false; r.pending = false;

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <map>
 #include <string>
+#include <atomic>
 #include <thread>
 
 namespace abg {
@@ -78,6 +79,8 @@ class Session {
 		if (const char* e = getenv("ABG_WALK_SLOTS")) cfg.walk_slots = (uint32_t)atoi(e);
 		if (const char* e = getenv("ABG_WTAB_LOG2")) cfg.wtab_log2 = (uint32_t)atoi(e);
 		if (const char* e = getenv("ABG_WTAB_LOG2_MAX")) cfg.wtab_log2_max = (uint32_t)std::max<int>(atoi(e), (int)cfg.wtab_log2); // (tests: forces overflow restarts)
+		if (const char* e = getenv("ABG_POOL_CAP")) cfg.pool_cap = std::max<uint64_t>(1024, strtoull(e, 0, 10)); // (tests: the walkers run out of contig pool ...
+		if (const char* e = getenv("ABG_REC_CAP")) cfg.rec_cap = (uint32_t)std::max(16, atoi(e));                  //  ... or of contig records, and the engine grows them)
 		if (const char* e = getenv("ABG_P2_FIRST_BATCH")) cfg.p2_first_batch = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_P2_MAX_BATCH")) cfg.p2_max_batch = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_PAR_COMMIT")) cfg.par_commit = atoi(e) != 0;
@@ -186,27 +189,51 @@ class Session {
 	int assemble_seqs(const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
 	    abg_contig_cb cb, void* user)
 	{
+		return assemble_seqs_v(1, &seqs, &off, &n, results, cb, user);
+	}
+	// The same over a read set held in several buffers (the host binary keeps the records of PASS 1 in
+	// the chunks it parsed them into): ONE assemble call, so one guide and one batch schedule for all
+	// of them.  Read indices (results, abg_contig.read_index) count through the chunks in order.
+	int assemble_seqs_v(uint32_t nchunks, const char* const* seqs_v, const uint64_t* const* off_v, const uint64_t* n_v,
+	    uint8_t* results, abg_contig_cb cb, void* user)
+	{
 		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
 		const uint32_t k = cfg.k;
+		uint64_t n = 0;
+		std::vector<uint64_t> base(nchunks + 1, 0);
+		for (uint32_t c = 0; c < nchunks; c++) { base[c + 1] = base[c] + n_v[c]; }
+		n = base[nchunks];
 		std::vector<uint64_t> orig; // packed index -> caller index
 		std::vector<uint8_t> res(n, (uint8_t)RR_UNINITIALIZED);
-		const std::vector<uint64_t> cut = split_reads(off, n);
-		std::vector<HostBatch> parts(cut.size() - 1);
+		// parts: (chunk, [first, last)) in read order
+		struct Part { uint32_t c; uint64_t a, b; };
+		std::vector<Part> plan;
+		for (uint32_t c = 0; c < nchunks; c++) {
+			if (!n_v[c]) continue;
+			const std::vector<uint64_t> cut = split_reads(off_v[c], n_v[c]);
+			for (size_t t = 0; t + 1 < cut.size(); t++) plan.push_back(Part{ c, cut[t], cut[t + 1] });
+		}
+		std::vector<HostBatch> parts(plan.size());
 		std::vector<std::vector<uint64_t>> origs(parts.size());
 		run_parts(parts.size(), [&](size_t t) {
-			for (uint64_t i = cut[t]; i < cut[t + 1]; i++) {
+			const Part& pt = plan[t];
+			const char* seqs = seqs_v[pt.c];
+			const uint64_t* off = off_v[pt.c];
+			for (uint64_t i = pt.a; i < pt.b; i++) {
 				const char* s = seqs + off[i];
 				uint64_t L = off[i + 1] - off[i];
-				if (L < k) { res[i] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
+				const uint64_t gi = base[pt.c] + i;
+				if (L < k) { res[gi] = RR_SHORTER_THAN_K; continue; }  // bloom-dbg.h:804
 				uint8_t bad = 0;
 				for (uint64_t q = 0; q < L; q++) bad |= codes_.t[(unsigned char)s[q]];
-				if (bad & 0x80) { res[i] = RR_NON_ACGT; continue; }     // allACGT, bloom-dbg.h:808 (either case: the reader folds it)
+				if (bad & 0x80) { res[gi] = RR_NON_ACGT; continue; }     // allACGT, bloom-dbg.h:808 (either case: the reader folds it)
 				parts[t].add_ascii(s, (uint32_t)L, k);
-				origs[t].push_back(i);
+				origs[t].push_back(gi);
 			}
 		});
 		HostBatch joined;
-		const HostBatch& hb = join_parts(parts, joined);
+		HostBatch empty;
+		const HostBatch& hb = parts.empty() ? empty : join_parts(parts, joined);
 		for (auto& o : origs) orig.insert(orig.end(), o.begin(), o.end());
 		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
 		// ones rejected above; the engine counts the ones it sees
@@ -515,8 +542,12 @@ class Session {
 	static void run_parts(size_t nparts, F f)
 	{
 		if (nparts <= 1) { if (nparts) f(0); return; }
+		// (at most host_threads() workers, whatever the number of parts)
+		const size_t T = std::min<size_t>(nparts, std::max(1u, host_threads()));
+		std::atomic<size_t> next{ 0 };
 		std::vector<std::thread> pool;
-		for (size_t t = 0; t < nparts; t++) pool.emplace_back([&f, t]() { f(t); });
+		for (size_t w = 0; w < T; w++)
+			pool.emplace_back([&f, &next, nparts]() { for (size_t t; (t = next.fetch_add(1)) < nparts;) f(t); });
 		for (auto& th : pool) th.join();
 	}
 	// the parts' batches one after the other (a single part is used as it is)

@@ -246,6 +246,7 @@ struct HipBackend {
 		void* p = nullptr;
 		hipSetDevice(device);
 		if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		if (getenv("ABG_MEM_DEBUG")) fprintf(stderr, "[mem] +%.2f GB (optional)\n", n / 1e9);
 		return p;
 	}
 	void* alloc(size_t n)
@@ -253,7 +254,25 @@ struct HipBackend {
 		void* p = nullptr;
 		hipSetDevice(device);
 		if (n > CACHE_MAX_BLOCK) {
-			check(hipMalloc(&p, n), "hipMalloc");
+			hipError_t e = hipMalloc(&p, n);
+			if (e != hipSuccess) {
+				// (give back what the block cache holds and try once more before giving up)
+				(void)hipGetLastError();
+				drop_cache();
+				e = hipMalloc(&p, n);
+			}
+			if (e != hipSuccess) {
+				size_t fr = 0, tot = 0;
+				(void)hipMemGetInfo(&fr, &tot);
+				fprintf(stderr, "abyss_amd: no device memory for a block of %.2f GB (%.2f of %.2f GB free)\n", n / 1e9, fr / 1e9, tot / 1e9);
+			}
+			check(e, "hipMalloc");
+			static const bool mem_debug = getenv("ABG_MEM_DEBUG") != nullptr;
+			if (mem_debug) {
+				size_t fr = 0, tot = 0;
+				(void)hipMemGetInfo(&fr, &tot);
+				fprintf(stderr, "[mem] +%.2f GB, %.2f GB free\n", n / 1e9, fr / 1e9);
+			}
 			return p;
 		}
 		size_t sz = 256;
@@ -348,6 +367,7 @@ struct HipBackend {
 		end("compact");
 	}
 	uint32_t max_slots() const { return cus * 8 * 256; }
+	uint64_t device_mem_bytes() const { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (uint64_t)tot : 0; }
 
 	void begin(const char*) { if (profiling) hipEventRecord(ev0, stream); }
 	void end(const char* name)
@@ -656,6 +676,7 @@ int abg_filter_size(const abg_ctx* ctx, uint64_t* counters)
 int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n)
 {
 	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
+	(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
 	return ctx->s.load_seqs(seqs, offsets, n);
 }
 int abg_load_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
@@ -701,6 +722,14 @@ int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, u
 {
 	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
 	return ctx->s.assemble_seqs(seqs, offsets, n, results, cb, user);
+}
+int abg_assemble_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, const uint64_t* const* offsets,
+    const uint64_t* n, uint8_t* results, abg_contig_cb cb, void* user)
+{
+	if (!ctx || (nchunks && (!seqs || !offsets || !n))) return ABG_EINVAL;
+	for (uint32_t c = 0; c < nchunks; c++) if (n[c] && (!seqs[c] || !offsets[c])) return ABG_EINVAL;
+	(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
+	return ctx->s.assemble_seqs_v(nchunks, seqs, offsets, n, results, cb, user);
 }
 int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
     const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user)

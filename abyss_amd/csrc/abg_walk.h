@@ -873,7 +873,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			// materialise the path: S = reverse(lbuf) + seed + rbuf, one slack base each side
 			uint64_t need = (uint64_t)n + k - 1 + 2;
 			uint64_t off = wu_atomic_add_u64(e.pool_used, need, sc.coop);
-			if (off + need > e.pool_cap) { abort_status = WS_OVERFLOW; break; }
+			if (off + need > e.pool_cap) {
+				wu_atomic_add_u64(&e.wstats[WSTAT_OVF_POOL], 1, sc.coop); // (never NULL for a walker: Engine::ensure_walk)
+				abort_status = WS_OVERFLOW; break;
+			}
 			uint8_t* S = e.pool + off + 1;
 			uint64_t slen = (uint64_t)n + k - 1;
 			// (a cooperative caller's lanes copy 64 bases at a time)
@@ -939,7 +942,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			if (sc.overflow) { abort_status = WS_OVERFLOW; break; }
 			// ---- record for outputContig
 			uint32_t ri = wu_atomic_add_u32(e.rec_used, 1, sc.coop);
-			if (ri >= e.rec_cap) { abort_status = WS_OVERFLOW; break; }
+			if (ri >= e.rec_cap) {
+				wu_atomic_add_u64(&e.wstats[WSTAT_OVF_RECS], 1, sc.coop);
+				abort_status = WS_OVERFLOW; break;
+			}
 			ContigRec& rec = e.recs[ri];
 			rec.seq_off = off + 1 + (uint64_t)lo;
 			rec.len = (uint32_t)(hi - lo) + k - 1;

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <getopt.h>
 #include <unistd.h>
 #include <string>
@@ -118,6 +119,15 @@ struct Chunk { // one batch of sequences for the C ABI
 struct Output {
 	FILE* out; FILE* trace; const Chunk* chunk; unsigned k;
 	FILE* checkpoint = NULL; // duplicate FASTA output for checkpoints (bloom-dbg.h:607-609,919-926)
+	// one assemble call over several chunks (abg_assemble_seqs_v): read index -> (chunk, index in it)
+	const std::vector<Chunk>* chunks = NULL;
+	std::vector<uint64_t> first; // [chunks + 1] index of each chunk's first read
+	void locate(uint64_t read_index, const Chunk*& c, uint64_t& i) const
+	{
+		if (!chunks) { c = chunk; i = read_index; return; }
+		const size_t q = (size_t)(std::upper_bound(first.begin(), first.end(), read_index) - first.begin()) - 1;
+		c = &(*chunks)[q]; i = read_index - first[q];
+	}
 };
 static const char* ext_str(int c)
 {
@@ -127,7 +137,9 @@ static const char* ext_str(int c)
 static void on_contig(void* user, const abg_contig* c)
 {
 	Output* o = (Output*)user;
-	const std::string& rid = o->chunk->ids[c->read_index];
+	const Chunk* ch; uint64_t ri;
+	o->locate(c->read_index, ch, ri);
+	const std::string& rid = ch->ids[ri];
 	if (!c->redundant) // printContig, bloom-dbg.h:455-487
 	{
 		fprintf(o->out, ">%llu %u %u read:%s\n%s\n", (unsigned long long)c->contig_id, c->length, c->coverage, rid.c_str(), c->seq);
@@ -139,8 +151,8 @@ static void on_contig(void* user, const abg_contig* c)
 		fprintf(o->trace, "%u\t%d\t%s\t", c->length, c->redundant, rid.c_str());
 		if (c->left_ext > 0) fprintf(o->trace, "%s\t%u\t", ext_str(c->left_code), c->left_ext); else fputs("NA\tNA\t", o->trace);
 		if (c->right_ext > 0) fprintf(o->trace, "%s\t%u\t", ext_str(c->right_code), c->right_ext); else fputs("NA\tNA\t", o->trace);
-		uint64_t a = o->chunk->off[c->read_index];
-		fprintf(o->trace, "READ\t%u\t%.*s\n", o->k, (int)o->k, o->chunk->seqs.c_str() + a + c->seed_pos);
+		uint64_t a = ch->off[ri];
+		fprintf(o->trace, "READ\t%u\t%.*s\n", o->k, (int)o->k, ch->seqs.c_str() + a + c->seed_pos);
 	}
 }
 static void check(int rc, abg_ctx* ctx, const char* what)
@@ -242,6 +254,15 @@ static bool checkpoint_exists(const std::string& prefix) // Checkpoint.h:130-144
 {
 	return file_readable(prefix + CK_FASTA) && file_readable(prefix + CK_DBG) && file_readable(prefix + CK_VISITED) &&
 	       file_readable(prefix + CK_COUNTERS);
+}
+// ABG_HOST_TIMING=1: wall time of the process so far at every phase boundary, on stderr
+static double host_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static const double g_t0 = host_now();
+static double g_in_load = 0, g_in_asm = 0;
+static void host_mark(const char* what)
+{
+	static const bool on = getenv("ABG_HOST_TIMING") != NULL;
+	if (on) fprintf(stderr, "[host %.3f s] %s (in abg_load_seqs %.3f s, in abg_assemble_seqs %.3f s)\n", host_now() - g_t0, what, g_in_load, g_in_asm);
 }
 static void do_rename(const std::string& a, const std::string& b, int verbose)
 {
@@ -422,6 +443,7 @@ int main(int argc, char** argv)
 	p.verbose = verbose;
 	abg_ctx* ctx = NULL;
 	if (abg_create(&p, &ctx) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
+	host_mark("context created");
 	if (use_comm) check(abg_attach_comm(ctx, &comm), ctx, "communicator");
 	const uint32_t trim = p.trim == 0xFFFFFFFFu ? p.k : p.trim;
 	if (verbose) {
@@ -447,14 +469,30 @@ int main(int argc, char** argv)
 	for (int i = optind; i < argc; ++i) if (!strcmp(argv[i], ":") || !strcmp(argv[i], "-")) keep = false;
 	size_t kept_bytes = 0;
 	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE);
-	auto loaded = [&]() {
-		check(abg_load_seqs(ctx, chunk.seqs.data(), chunk.off.data(), chunk.n()), ctx, "load");
+	// PASS 1 of a chunk runs on a thread of its own while the reader parses the next chunk (one chunk
+	// in flight: the chunks go in in order)
+	std::thread loader;
+	Chunk loading;
+	auto load_done = [&]() {
+		if (!loader.joinable()) return;
+		loader.join();
+		host_mark("chunk loaded");
 		if (keep) {
-			kept_bytes += chunk.seqs.size() + 48 * chunk.n();
+			kept_bytes += loading.seqs.size() + 48 * loading.n();
 			if (kept_bytes > keep_limit) { keep = false; kept.clear(); kept.shrink_to_fit(); }
-			else { kept.push_back(std::move(chunk)); chunk = Chunk(); return; }
+			else { kept.push_back(std::move(loading)); loading = Chunk(); return; }
 		}
-		chunk.clear();
+		loading = Chunk();
+	};
+	auto loaded = [&]() {
+		load_done();
+		loading = std::move(chunk);
+		chunk = Chunk();
+		loader = std::thread([&]() {
+			const double tl = host_now();
+			check(abg_load_seqs(ctx, loading.seqs.data(), loading.off.data(), loading.n()), ctx, "load");
+			g_in_load += host_now() - tl;
+		});
 	};
 	// --checkpoint=N (bloom-dbg.h:1012-1077, Checkpoint.h): the state is saved every N reads, and a
 	// run that finds a complete set of checkpoint files picks up from it (bloom-dbg.cc:546-547).
@@ -513,6 +551,7 @@ int main(int argc, char** argv)
 			if (chunk.n()) loaded();
 			if (verbose) fprintf(stderr, "Loaded %llu reads from `%s` into Bloom filter\n", (unsigned long long)n, argv[i]);
 		}
+		load_done();
 	} else {
 		if (prebuilt.size() != counters) { fprintf(stderr, PROGRAM ": Bloom file size does not match its header\n"); exit(EXIT_FAILURE); }
 		check(abg_counters_import(ctx, prebuilt.data()), ctx, "import");
@@ -605,12 +644,28 @@ int main(int argc, char** argv)
 		if (!c.n()) return;
 		o.chunk = &c;
 		results.assign(c.n(), 0);
+		const double ta = host_now();
 		check(abg_assemble_seqs(ctx, c.seqs.data(), c.off.data(), c.n(), results.data(), on_contig, &o), ctx, "assemble");
+		g_in_asm += host_now() - ta;
+		host_mark("chunk assembled");
 		if (readlog) for (size_t i = 0; i < c.n(); i++) fprintf(readlog, "%s\t%s\n", c.ids[i].c_str(), rr[results[i]]);
 	};
 	auto flush = [&]() { assemble(chunk); chunk.clear(); };
 	if (keep && !kept.empty()) {
-		for (Chunk& c : kept) { assemble(c); c = Chunk(); }
+		// the records kept from PASS 1, all of them in one pass (one guide, one walk schedule)
+		std::vector<const char*> sv; std::vector<const uint64_t*> ov; std::vector<uint64_t> nv;
+		o.chunks = &kept; o.first.assign(1, 0);
+		for (const Chunk& c : kept) { sv.push_back(c.seqs.data()); ov.push_back(c.off.data()); nv.push_back(c.n()); o.first.push_back(o.first.back() + c.n()); }
+		results.assign(o.first.back(), 0);
+		const double ta = host_now();
+		check(abg_assemble_seqs_v(ctx, (uint32_t)kept.size(), sv.data(), ov.data(), nv.data(), results.data(), on_contig, &o), ctx, "assemble");
+		g_in_asm += host_now() - ta;
+		host_mark("kept chunks assembled");
+		if (readlog)
+			for (size_t q = 0; q < kept.size(); q++)
+				for (size_t i = 0; i < kept[q].n(); i++) fprintf(readlog, "%s\t%s\n", kept[q].ids[i].c_str(), rr[results[o.first[q] + i]]);
+		o.chunks = NULL;
+		kept.clear();
 		first_asm = argc; // nothing left to read
 	}
 	for (int i = first_asm; i < argc; ++i) {
@@ -640,6 +695,7 @@ int main(int argc, char** argv)
 		fprintf(stderr, "Assembled %llu bp in %llu contigs\nAssembly complete\n", (unsigned long long)c.bases_assembled,
 		    (unsigned long long)c.next_contig_id);
 	}
+	host_mark("assembly complete");
 	if (getenv("ABG_PRINT_STATS")) { // engine work counters (tests assert which code paths a run took)
 		abg_stats st;
 		memset(&st, 0, sizeof st);

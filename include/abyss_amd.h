@@ -152,6 +152,12 @@ int abg_visited_import(abg_ctx* ctx, const uint8_t* host_in);
  * counters) carries over between calls, so a read stream may be fed in chunks. */
 int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
     uint8_t* results, abg_contig_cb cb, void* user);
+/* the same over a read set held in `nchunks` buffers (seqs[c], offsets[c], n[c] as above): ONE pass
+ * over all of them -- the reference's assemble() reads its files as one stream (bloom-dbg.h:1012-1066),
+ * and one call keeps one walk schedule instead of starting a new one per chunk.  Read indices
+ * (results, abg_contig.read_index) count through the chunks in order; results holds sum(n) bytes. */
+int abg_assemble_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, const uint64_t* const* offsets,
+    const uint64_t* n, uint8_t* results, abg_contig_cb cb, void* user);
 /* the same on device-resident packed reads (pure ACGT, len >= k) */
 int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
     const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user);

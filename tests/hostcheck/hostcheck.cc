@@ -34,6 +34,7 @@ struct SerialBackend {
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	uint32_t max_slots() const { return 1; }
+	uint64_t device_mem_bytes() const { return 0; } // (unknown: no cap)
 	void d2d(void* d, const void* s, size_t n) { memmove(d, s, n); }
 	void sync() {}
 	void begin(const char*) {}
@@ -151,6 +152,11 @@ int hc_assemble_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n,
     abg_contig_cb cb, void* user)
 {
 	return ((Sess*)h)->assemble_seqs(seqs, off, n, results, cb, user);
+}
+int hc_assemble_seqs_v(void* h, uint32_t nchunks, const char* const* seqs, const uint64_t* const* off, const uint64_t* n,
+    uint8_t* results, abg_contig_cb cb, void* user)
+{
+	return ((Sess*)h)->assemble_seqs_v(nchunks, seqs, off, n, results, cb, user);
 }
 int hc_contains_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint8_t* val, uint64_t cap, uint64_t* n)
 {

@@ -167,6 +167,19 @@ def test_chunked_calls_equal_single_call():
     assert api.format_read_log(np.concatenate(results_all), gc.ids) == gc.readlog
 
 
+def test_read_set_in_several_buffers_is_one_pass():
+    """abg_assemble_seqs_v: the reads in four buffers, one pass -- read indices count through them."""
+    gc = GoldenCase("k40_mixed")
+    g = api.BloomDBG(**gc.kwargs())
+    g.load(gc.buf, gc.off)
+    cut = [0, 1, 777, 2000, gc.n]
+    chunks = [(bytes(gc.buf[int(gc.off[a]):int(gc.off[b])]), gc.off[a:b + 1] - gc.off[a]) for a, b in zip(cut, cut[1:])]
+    results, contigs = g.assemble_chunks(chunks)
+    assert api.format_fasta(contigs, gc.ids) == gc.fasta
+    assert api.format_read_log(results, gc.ids) == gc.readlog
+    assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace
+
+
 def test_export_import_roundtrip_and_idempotence():
     # size-independent properties on a larger set: (1) filters survive export/import into a
     # fresh context and give the same assembly (the -i prebuilt path, bloom-dbg.cc:302-343);

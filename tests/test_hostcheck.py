@@ -75,6 +75,26 @@ class HostCheck:
         assert self.l.hc_assemble_seqs(self.h, buf, off.ctypes.data, n, res.ctypes.data, _lib.CONTIG_CB(cb), None) == 0
         return res, out
 
+    def assemble_chunks(self, chunks):
+        """abg_assemble_seqs_v: several (buf, off) chunks, one pass; read indices count through them."""
+        import ctypes as C
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for _, o in chunks]
+        nc = len(chunks)
+        seqs_v = (C.c_char_p * nc)(*[b for b, _ in chunks])
+        off_v = (C.c_void_p * nc)(*[o.ctypes.data for o in offs])
+        n_v = (C.c_uint64 * nc)(*[len(o) - 1 for o in offs])
+        res = np.zeros(sum(len(o) - 1 for o in offs), dtype=np.uint8)
+        out = []
+
+        def cb(_u, c):
+            c = c.contents
+            out.append(api.ContigRecord(c.contig_id, c.read_index, c.seq, c.coverage, bool(c.redundant), c.left_ext,
+                                        c.right_ext, c.left_code, c.right_code, c.seed_pos))
+        self.l.hc_assemble_seqs_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _lib.CONTIG_CB, C.c_void_p]
+        assert self.l.hc_assemble_seqs_v(self.h, nc, C.cast(seqs_v, C.c_void_p), C.cast(off_v, C.c_void_p), C.cast(n_v, C.c_void_p),
+                                         res.ctypes.data, _lib.CONTIG_CB(cb), None) == 0
+        return res, out
+
     def hash_seq(self, seq):
         cap = max(len(seq), 1)
         pos = np.zeros(cap, dtype=np.uint32)
@@ -451,6 +471,48 @@ def test_guide_and_memo_do_not_change_results(monkeypatch):
         st = hc.stats()
         if env.get("ABG_GUIDE_STRIDE") == "0":
             assert st["bulk_steps"] == 0 and st["memo_hits"] == 0
+        assert api.format_fasta(contigs, g.ids) == g.fasta
+        assert api.format_read_log(results, g.ids) == g.readlog
+        assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_read_set_in_several_chunks_is_one_pass():
+    """abg_assemble_seqs_v: the reads of a golden run handed over in three buffers (the second one
+    holding reads that are too short or not ACGT as well) give the reference's outputs, with read
+    indices counting through the chunks."""
+    g = GoldenCase("k40_mixed")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                   claim_log2=16, p2_first=128)
+    hc.load(g.buf, g.off)
+    n = len(g.off) - 1
+    cuts = [0, n // 5, n // 2, n]
+    chunks = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(g.off[a]), int(g.off[b])
+        chunks.append((bytes(g.buf[lo:hi]), np.asarray(g.off[a:b + 1], dtype=np.uint64) - np.uint64(lo)))
+    results, contigs = hc.assemble_chunks(chunks)
+    assert api.format_fasta(contigs, g.ids) == g.fasta
+    assert api.format_read_log(results, g.ids) == g.readlog
+    assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
+
+
+def test_walkers_running_out_of_pool_or_records_get_more(monkeypatch):
+    """A launch whose walkers run out of contig pool or contig records is restarted with twice as
+    much of what ran out (the walkers say which: WSTAT_OVF_POOL / WSTAT_OVF_RECS) -- not with a
+    larger vertex table, which is the remedy for every other overflow."""
+    g = GoldenCase("k64")
+    kw = g.kwargs()
+    for env in ({"ABG_POOL_CAP": "3000"}, {"ABG_REC_CAP": "16"}):
+        for key in ("ABG_POOL_CAP", "ABG_REC_CAP"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=512)
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        assert hc.stats()["overflows"] >= 2, hc.stats()
         assert api.format_fasta(contigs, g.ids) == g.fasta
         assert api.format_read_log(results, g.ids) == g.readlog
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace

@@ -10,3 +10,4 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 > 
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-700 $O/bench.json; echo
 bash tools/gpu_r2_e2e.sh 5000000 noref 2>&1 | grep -E "amd_|written" 
 bash tools/gpu_r2_prof.sh final all 2>&1 | grep -E "k_walkers|FTileApply|FClassify|busy|GB$" | cut -c1-160
+ABG_PRINT_STATS=1 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; cut -c1-300 $O/bench_config3.json; echo
