@@ -107,13 +107,29 @@ static const struct option longopts[] = {
 
 // SIToBytes, Common/StringUtil.h:181-219: k/M/G are powers of 1024
 
-struct Chunk { // one batch of sequences for the C ABI
+struct Chunk { // one batch of sequences for the C ABI; the ids likewise as one string and their ends
 	std::string seqs;
 	std::vector<uint64_t> off{ 0 };
-	std::vector<std::string> ids;
-	void add(const std::string& id, const std::string& s) { seqs += s; off.push_back(seqs.size()); ids.push_back(id); }
-	size_t n() const { return ids.size(); }
-	void clear() { seqs.clear(); off.assign(1, 0); ids.clear(); }
+	std::string idbuf;
+	std::vector<uint64_t> id_end;
+	void add(const std::string& id, const std::string& s)
+	{
+		seqs += s; off.push_back(seqs.size());
+		idbuf += id; id_end.push_back(idbuf.size());
+	}
+	// a parser thread's block of records in one go (SequenceReader::next_block)
+	void add_block(const abghost::SequenceReader::Block& b)
+	{
+		const uint64_t sb = seqs.size(), ib = idbuf.size();
+		seqs += b.seqs; idbuf += b.ids;
+		off.reserve(off.size() + b.seq_end.size()); id_end.reserve(id_end.size() + b.id_end.size());
+		for (size_t e : b.seq_end) off.push_back(sb + e);
+		for (size_t e : b.id_end) id_end.push_back(ib + e);
+	}
+	size_t n() const { return id_end.size(); }
+	std::string id(size_t i) const { const uint64_t a = i ? id_end[i - 1] : 0; return idbuf.substr(a, id_end[i] - a); }
+	size_t bytes() const { return seqs.size() + idbuf.size() + 16 * n(); }
+	void clear() { seqs.clear(); off.assign(1, 0); idbuf.clear(); id_end.clear(); }
 };
 
 struct Output {
@@ -139,7 +155,7 @@ static void on_contig(void* user, const abg_contig* c)
 	Output* o = (Output*)user;
 	const Chunk* ch; uint64_t ri;
 	o->locate(c->read_index, ch, ri);
-	const std::string& rid = ch->ids[ri];
+	const std::string rid = ch->id(ri);
 	if (!c->redundant) // printContig, bloom-dbg.h:455-487
 	{
 		fprintf(o->out, ">%llu %u %u read:%s\n%s\n", (unsigned long long)c->contig_id, c->length, c->coverage, rid.c_str(), c->seq);
@@ -478,7 +494,7 @@ int main(int argc, char** argv)
 		loader.join();
 		host_mark("chunk loaded");
 		if (keep) {
-			kept_bytes += loading.seqs.size() + 48 * loading.n();
+			kept_bytes += loading.bytes();
 			if (kept_bytes > keep_limit) { keep = false; kept.clear(); kept.shrink_to_fit(); }
 			else { kept.push_back(std::move(loading)); loading = Chunk(); return; }
 		}
@@ -544,9 +560,17 @@ int main(int argc, char** argv)
 			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
 			abghost::SequenceReader in(argv[i], ropt, threads);
 			uint64_t n = 0;
-			while (in.read(id, comment, seq)) {
-				chunk.add(id, seq); n++;
-				if (chunk.seqs.size() >= CHUNK_BASES) loaded();
+			if (in.has_blocks()) { // the parser threads' records wholesale
+				abghost::SequenceReader::Block blk;
+				while (in.next_block(blk)) {
+					chunk.add_block(blk); n += blk.seq_end.size();
+					if (chunk.seqs.size() >= CHUNK_BASES) loaded();
+				}
+			} else {
+				while (in.read(id, comment, seq)) {
+					chunk.add(id, seq); n++;
+					if (chunk.seqs.size() >= CHUNK_BASES) loaded();
+				}
 			}
 			if (chunk.n()) loaded();
 			if (verbose) fprintf(stderr, "Loaded %llu reads from `%s` into Bloom filter\n", (unsigned long long)n, argv[i]);
@@ -648,7 +672,7 @@ int main(int argc, char** argv)
 		check(abg_assemble_seqs(ctx, c.seqs.data(), c.off.data(), c.n(), results.data(), on_contig, &o), ctx, "assemble");
 		g_in_asm += host_now() - ta;
 		host_mark("chunk assembled");
-		if (readlog) for (size_t i = 0; i < c.n(); i++) fprintf(readlog, "%s\t%s\n", c.ids[i].c_str(), rr[results[i]]);
+		if (readlog) for (size_t i = 0; i < c.n(); i++) fprintf(readlog, "%s\t%s\n", c.id(i).c_str(), rr[results[i]]);
 	};
 	auto flush = [&]() { assemble(chunk); chunk.clear(); };
 	if (keep && !kept.empty()) {
@@ -663,7 +687,7 @@ int main(int argc, char** argv)
 		host_mark("kept chunks assembled");
 		if (readlog)
 			for (size_t q = 0; q < kept.size(); q++)
-				for (size_t i = 0; i < kept[q].n(); i++) fprintf(readlog, "%s\t%s\n", kept[q].ids[i].c_str(), rr[results[o.first[q] + i]]);
+				for (size_t i = 0; i < kept[q].n(); i++) fprintf(readlog, "%s\t%s\n", kept[q].id(i).c_str(), rr[results[o.first[q] + i]]);
 		o.chunks = NULL;
 		kept.clear();
 		first_asm = argc; // nothing left to read

@@ -8,6 +8,7 @@
 // the matching decompressor the way Common/Uncompress.cpp does.
 #pragma once
 #include <cctype>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -415,11 +416,13 @@ class SequenceReader {
 					const size_t l2 = l1 == std::string::npos ? l1 : m_buf.find('\n', l1 + 1);
 					fastq = !m_buf.empty() && m_buf[0] == '@' && l2 != std::string::npos && l2 + 1 < m_buf.size() && m_buf[l2 + 1] == '+';
 				}
-				if (!fastq) { fclose(m_f); m_f = nullptr; m_buf.clear(); }
+				if (!fastq) { fclose(m_f); m_f = nullptr; }
+				else { m_raw.grow(m_buf.size()); memcpy(m_raw.p, m_buf.data(), m_buf.size()); m_raw.n = m_buf.size(); m_pos = m_buf.size(); }
+				m_buf.clear();
 			}
 		}
 		if (!m_f) m_seq = new FastaReader(path, o); // (also reports a missing file the reference's way)
-		else m_window = std::min<size_t>((size_t)threads * (32u << 20), (size_t)1 << 30);
+		else m_window = std::min<size_t>((size_t)threads * (32u << 20), (size_t)256 << 20);
 		if (const char* e = getenv("ABG_READER_WINDOW")) m_window = std::max<size_t>(64, strtoull(e, nullptr, 10)); // tests: many small windows
 	}
 	~SequenceReader()
@@ -455,11 +458,28 @@ class SequenceReader {
 		}
 	}
 
-  private:
+	// The records a parser thread produced, as they lie: concatenated strings and their end offsets.
 	struct Block {
 		std::string ids, comments, seqs;
 		std::vector<size_t> id_end, com_end, seq_end;
 	};
+	// A caller that takes records wholesale asks for the parser threads' blocks instead of single
+	// records (false: no block mode for this input, or no more blocks; do not mix with read()).
+	bool has_blocks() const { return m_seq == nullptr; }
+	bool next_block(Block& out)
+	{
+		if (m_seq || (m_mem && m_done)) return false;
+		for (;;) {
+			if (m_block < m_blocks.size()) { out = std::move(m_blocks[m_block++]); m_rec = 0; return true; }
+			if (!m_next.valid()) m_next = std::async(std::launch::async, [this]() { return parse_window(); });
+			Window w = m_next.get();
+			if (!w.ok) { m_done = true; return false; }
+			m_blocks = std::move(w.blocks); m_block = 0; m_rec = 0;
+			m_next = std::async(std::launch::async, [this]() { return parse_window(); });
+		}
+	}
+
+  private:
 	// start of the first record at or after `from` (a line start), or `end` if there is none
 	static size_t next_record(const char* p, size_t from, size_t end)
 	{
@@ -503,21 +523,21 @@ class SequenceReader {
 		size_t end = 0;
 		for (;;) {
 			if (!m_eof) { // the unparsed tail of the previous window, then fresh bytes
-				const size_t have = m_buf.size();
-				m_buf.resize(have + m_window);
-				const size_t got = fread(&m_buf[have], 1, m_window, m_f);
-				m_buf.resize(have + got);
+				const size_t have = m_raw.n;
+				m_raw.grow(have + m_window);
+				const size_t got = read_parallel(m_raw.p + have, m_window);
+				m_raw.n = have + got;
 				if (got < m_window) m_eof = true;
 			}
-			if (m_buf.empty()) return w;
-			end = m_buf.size();
+			if (buf_size() == 0) return w;
+			end = buf_size();
 			if (m_eof) break; // everything that is left is parsed
 			// the last record that starts in the buffer may be cut short: it waits for the next window
-			const size_t cut = last_record(m_buf.data(), end);
+			const size_t cut = last_record(buf_data(), end);
 			if (cut > 0) { end = cut; break; }
 			// (no second record start in sight yet: read on)
 		}
-		const char* p = m_buf.data();
+		const char* p = buf_data();
 		std::vector<size_t> start{ 0 };
 		for (unsigned t = 1; t < m_threads; t++) {
 			const size_t r = next_record(p, end / m_threads * t, end);
@@ -559,7 +579,9 @@ class SequenceReader {
 			});
 		for (auto& t : pool) t.join();
 		m_lines = line0[nb - 1] + (unsigned)nlines[nb - 1];
-		m_buf.erase(0, end); // what was not parsed stays for the next window
+		// what was not parsed stays for the next window
+		if (m_mem) m_buf.erase(0, end);
+		else { memmove(m_raw.p, m_raw.p + end, m_raw.n - end); m_raw.n -= end; }
 		w.ok = true;
 		return w;
 	}
@@ -571,6 +593,54 @@ class SequenceReader {
 	size_t m_window = 0;
 	bool m_eof = false, m_mem = false, m_done = false; // (m_mem: the whole inflated file is in m_buf)
 	std::string m_buf;
+	// The windows of a plain file: a buffer that is never zero-filled (a std::string's resize would
+	// write the whole window once before fread writes it again), filled by several threads with
+	// pread -- one thread copying out of the page cache is what the reader used to wait for.
+	struct RawBuf {
+		char* p = nullptr; size_t n = 0, cap = 0;
+		~RawBuf() { free(p); }
+		void grow(size_t want)
+		{
+			if (want <= cap) return;
+			const size_t c = std::max(want, cap + cap / 2);
+			char* q = (char*)realloc(p, c);
+			if (!q) { fprintf(stderr, "error: out of memory reading sequences\n"); exit(EXIT_FAILURE); }
+			p = q; cap = c;
+		}
+	} m_raw;
+	size_t m_pos = 0; // file offset of the next byte to read into m_raw
+	const char* buf_data() const { return m_mem ? m_buf.data() : m_raw.p; }
+	size_t buf_size() const { return m_mem ? m_buf.size() : m_raw.n; }
+	size_t read_parallel(char* dst, size_t want)
+	{
+		const int fd = fileno(m_f);
+		const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(m_threads, 16u), want >> 22));
+		std::vector<size_t> got(T, 0);
+		std::vector<std::thread> pool;
+		const size_t slice = (want + T - 1) / T;
+		for (unsigned t = 0; t < T; t++)
+			pool.emplace_back([&, t]() {
+				const size_t a = std::min(want, t * slice), b = std::min(want, a + slice);
+				size_t done = 0;
+				while (a + done < b) {
+					const ssize_t r = pread(fd, dst + a + done, b - a - done, (off_t)(m_pos + a + done));
+					if (r < 0 && errno == EINTR) continue;
+					if (r <= 0) break; // end of file (or an error: the parser then sees a truncated record)
+					done += (size_t)r;
+				}
+				got[t] = done;
+			});
+		for (auto& th : pool) th.join();
+		// the bytes read form a prefix: a slice that came up short ends the file
+		size_t total = 0;
+		for (unsigned t = 0; t < T; t++) {
+			total += got[t];
+			const size_t a = std::min(want, t * slice), b = std::min(want, a + slice);
+			if (got[t] < b - a) break;
+		}
+		m_pos += total;
+		return total;
+	}
 	unsigned m_lines = 0;
 	std::vector<Block> m_blocks;
 	size_t m_block = 0, m_rec = 0;

@@ -9,7 +9,7 @@ int main(int argc, char** argv)
 	abghost::ReaderOptions o;
 	const char* path = NULL;
 	unsigned threads = 1;
-	bool count_only = false, prefetch = false;
+	bool count_only = false, prefetch = false, blocks = false;
 	for (int i = 1; i < argc; i++) {
 		if (!strcmp(argv[i], "-q")) o.qualityThreshold = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-Q")) o.internalQThreshold = atoi(argv[++i]);
@@ -18,6 +18,7 @@ int main(int argc, char** argv)
 		else if (!strcmp(argv[i], "--illumina-quality")) o.qualityOffset = 64;
 		else if (!strcmp(argv[i], "-j")) threads = (unsigned)atoi(argv[++i]); // SequenceReader: blocks parsed in parallel
 		else if (!strcmp(argv[i], "--count")) count_only = true;
+		else if (!strcmp(argv[i], "--blocks")) blocks = true;     // the records wholesale (SequenceReader::next_block), as the host binary's PASS 1 takes them
 		else if (!strcmp(argv[i], "--prefetch")) prefetch = true; // compressed input inflated ahead (abghost::Prefetch)
 		else path = argv[i];
 	}
@@ -25,6 +26,15 @@ int main(int argc, char** argv)
 	abghost::SequenceReader in(path, o, threads);
 	std::string id, comment, seq;
 	unsigned long long n = 0, bases = 0, sum = 0;
+	if (blocks && in.has_blocks()) {
+		abghost::SequenceReader::Block b;
+		while (in.next_block(b))
+			for (size_t i = 0; i < b.seq_end.size(); i++) {
+				const size_t ia = i ? b.id_end[i - 1] : 0, sa = i ? b.seq_end[i - 1] : 0;
+				printf("%s\t%s\n", b.ids.substr(ia, b.id_end[i] - ia).c_str(), b.seqs.substr(sa, b.seq_end[i] - sa).c_str());
+			}
+		return 0;
+	}
 	while (in.read(id, comment, seq)) {
 		if (!count_only) { printf("%s\t%s\n", id.c_str(), seq.c_str()); continue; }
 		n++; bases += seq.size();

@@ -113,6 +113,11 @@ def test_parallel_reader_matches_golden(i, monkeypatch):
     assert run_mine(OPTS[i] + ["-j", "3"], inp) == want
     monkeypatch.setenv("ABG_READER_WINDOW", "64")  # smaller than a record: the reader reads on
     assert run_mine(OPTS[i] + ["-j", "8"], inp) == want
+    # the records wholesale, a parser thread's block at a time (what the host binary's PASS 1 takes)
+    assert run_mine(OPTS[i] + ["-j", "8", "--blocks"], inp) == want
+    monkeypatch.setenv("ABG_READER_WINDOW", "600")
+    assert run_mine(OPTS[i] + ["-j", "3", "--blocks"], inp) == want
+    assert run_mine(OPTS[i] + ["--blocks"], inp) == want  # (one thread: no block mode, the records one by one)
 
 
 def test_parallel_reader_on_quality_lines_starting_with_at_and_plus(tmp_path, monkeypatch):
