@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 namespace abg {
@@ -215,6 +216,9 @@ class Session {
 		}
 		std::vector<HostBatch> parts(plan.size());
 		std::vector<std::vector<uint64_t>> origs(parts.size());
+		const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
+		const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = tnow();
 		run_parts(parts.size(), [&](size_t t) {
 			const Part& pt = plan[t];
 			const char* seqs = seqs_v[pt.c];
@@ -233,8 +237,10 @@ class Session {
 		});
 		HostBatch joined;
 		HostBatch empty;
+		const double t1 = tnow();
 		const HostBatch& hb = parts.empty() ? empty : join_parts(parts, joined);
 		for (auto& o : origs) orig.insert(orig.end(), o.begin(), o.end());
+		const double t2 = tnow();
 		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
 		// ones rejected above; the engine counts the ones it sees
 		Counters c0 = eng->counters();
@@ -242,6 +248,7 @@ class Session {
 		eng->set_counters(c0);
 		if (hb.n()) {
 			DevBatch d = upload(hb);
+			const double t3 = tnow();
 			std::vector<uint8_t> pres(hb.n());
 			std::function<void(const ContigOut&)> sink;
 			if (cb) sink = [&](const ContigOut& o) {
@@ -253,8 +260,11 @@ class Session {
 				cb(user, &c);
 			};
 			eng->assemble_packed(d.b, pres.data(), sink);
+			const double t4 = tnow();
 			release(d);
 			for (uint64_t j = 0; j < hb.n(); j++) res[orig[j]] = pres[j];
+			if (timing) fprintf(stderr, "[host] assemble: pack %.3f s, join %.3f s, upload %.3f s, device passes + callbacks %.3f s, results %.3f s\n",
+			    t1 - t0, t2 - t1, t3 - t2, t4 - t3, tnow() - t4);
 		}
 		if (results) memcpy(results, res.data(), n);
 		return ABG_OK;
