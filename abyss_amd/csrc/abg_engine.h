@@ -56,6 +56,7 @@ struct Config {
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
+	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
 	uint64_t keep_insert_scratch_bytes = 16ull << 30; // PASS 1's scratch is given back before PASS 2 when larger than this
 	uint64_t par_commit_max_bytes = 16ull << 30; // ... unless that would take more than this: then a stamp per bit the commit touches (hashed)
@@ -2113,14 +2114,63 @@ class Engine {
 		memo_valid_ = false;
 		last_rounds_ = 0;
 		// op ranges of at most batch_ops_ along sequence boundaries
-		uint64_t s = 0;
-		while (s < b.n) {
+		std::vector<std::pair<uint64_t, uint64_t>> ranges;
+		for (uint64_t s = 0; s < b.n;) {
 			uint64_t e = s;
 			while (e < b.n && (e == s || koff_h[e + 1] - koff_h[s] <= batch_ops_)) e++;
-			insert_range(b, s, e, koff_h);
+			ranges.push_back({ s, e });
 			s = e;
 		}
+		// Tiled: hashing and binning a batch reads nothing but the reads, so the NEXT batch is hashed
+		// and binned on the side stream while this one's tiles are judged and applied and its left-over
+		// ops go through the reservation rounds (small kernels and host round trips that leave the
+		// machine idle).  Two sets of hashes and bins take turns.
+		const bool pipe = tiled_ && !dist() && bins_alt_ != nullptr;
+		for (size_t i = 0; i < ranges.size(); i++) {
+			if (!pipe) { insert_range(b, ranges[i].first, ranges[i].second, koff_h, false); continue; }
+			if (i == 0) stage_bins(b, ranges[0].first, ranges[0].second, koff_h);
+			be_.wait_side_scope();
+			// (what was staged is now current; the other set takes the next batch)
+			std::swap(h0_, h0_alt_); std::swap(bins_, bins_alt_); std::swap(tcur_, tcur_alt_); stage_flag_ ^= 1u;
+			const bool staged = staged_ok_;
+			const uint32_t cur_flag = stage_flag_ ^ 1u; // the flag word the batch just staged wrote
+			// (queued behind this batch's tile kernels -- see insert_range -- so that it runs beside the rounds, not beside them)
+			stage_next_ = nullptr;
+			if (i + 1 < ranges.size()) stage_next_ = [this, &b, &ranges, i, koff_h]() { stage_bins(b, ranges[i + 1].first, ranges[i + 1].second, koff_h); };
+			insert_range(b, ranges[i].first, ranges[i].second, koff_h, staged, 2 + cur_flag);
+			if (stage_next_) { stage_next_(); stage_next_ = nullptr; }
+		}
 	}
+	// hash_ops, bin_coarse and bin_fine of the op range [s, e) into the alternate set, on the side stream
+	void stage_bins(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h)
+	{
+		const uint64_t T = koff_h[e] - koff_h[s];
+		staged_ok_ = false;
+		if (T == 0 || T > batch_ops_ || T >= 0xFFFFFFFFull) return; // (insert_range deals with those)
+		Batch v = b;
+		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s; v.koff = b.koff + s;
+		const uint64_t kbase = koff_h[s];
+		uint32_t* flag = pend_n_ + 2 + stage_flag_;
+		TileEnv te{ p_, cnt_, 0, m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, flag };
+		be_.side_scope_begin("hash_bin_staged");
+		be_.memset(tcur_alt_, 0, ntiles_ * 4);
+		be_.memset(flag, 0, 4);
+		be_.memset(ccur_, 0, ncoarse_ * 4);
+		uint64_t* h0 = h0_alt_;
+		dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+		BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
+		FBinCoarse f1{ bn };
+		be_.launch_tiles((T + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f1, "bin_coarse");
+		const uint32_t cpb = (coarse_cap_ + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS;
+		FBinFine f2{ bn, cpb };
+		be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
+		// (tile_purity, which reads nothing but the bins either, stays with the batch: staged as well it made
+		// the side stream the longer branch -- 461 vs 452 ms per configs[1] step)
+		be_.side_scope_end();
+		staged_ok_ = true;
+	}
+	bool staged_ok_ = false; uint32_t stage_flag_ = 0;
+	std::function<void()> stage_next_; // stages the next batch; insert_range calls it once its tile kernels are queued
 
 	// ---- PASS 2 on a device-resident packed batch of reads.  results_host (b.n bytes,
 	// may be NULL) receives a ReadResult per read; contigs are delivered in commit order.
@@ -2323,6 +2373,8 @@ class Engine {
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
 	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr;
+	// a second set of hashes, bins and bin cursors: the batch being staged on the side stream (stage_bins)
+	uint64_t* h0_alt_ = nullptr; TilePair* bins_alt_ = nullptr; uint32_t* tcur_alt_ = nullptr;
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
@@ -2456,6 +2508,13 @@ class Engine {
 			ccur_ = (uint32_t*)be_.alloc(ncoarse_ * 4 + 64);
 			bins_ = (TilePair*)be_.alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
 			tcur_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
+			if (cfg_.overlap_bins && !dist()) {
+				bins_alt_ = (TilePair*)be_.try_alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
+				if (bins_alt_) {
+					tcur_alt_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
+					h0_alt_ = (uint64_t*)be_.alloc((nb + 8 * R + 8) * 8);
+				}
+			}
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
 			opflag_ = (uint8_t*)be_.alloc(nb);
 			tgt_ = (uint8_t*)be_.alloc(nb);
@@ -2483,17 +2542,19 @@ class Engine {
 			be_.memset(claim_[i], 0xFF, 8ull << claim_log2_);
 			pend_[i] = (uint32_t*)be_.alloc(nb * 4);
 		}
-		pend_n_ = (uint32_t*)be_.alloc(8);
+		pend_n_ = (uint32_t*)be_.alloc(16); // [0] pending ops, [1] rounds / bin overflow, [2], [3] bin overflow of a staged batch (by buffer)
+		be_.memset(pend_n_, 0, 16);
 		if (dist()) dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32));
 		dlost_ = (uint8_t*)be_.alloc(nb);
 		insert_scratch_bytes_ = nb * (8 + 4 + 4 + 1) + (16ull << claim_log2_);
-		if (tiled_) insert_scratch_bytes_ += ((uint64_t)ncoarse_ * coarse_cap_ + ntiles_ * tile_cap_) * sizeof(TilePair) + nb * 6;
+		if (tiled_) insert_scratch_bytes_ += ((uint64_t)ncoarse_ * coarse_cap_ + ntiles_ * tile_cap_ * (bins_alt_ ? 2 : 1)) * sizeof(TilePair) + nb * (bins_alt_ ? 14 : 6);
 	}
 	void free_insert()
 	{
 		if (!h0_) return;
 		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
 		if (tred_) { be_.free(tred_); tred_ = nullptr; }
+		if (bins_alt_) { be_.free(bins_alt_); be_.free(tcur_alt_); be_.free(h0_alt_); bins_alt_ = nullptr; tcur_alt_ = nullptr; h0_alt_ = nullptr; }
 		if (dres_) { be_.free(dres_); dres_ = nullptr; }
 		be_.free(dlost_);
 		be_.free(h0_);
@@ -2502,7 +2563,8 @@ class Engine {
 		h0_ = nullptr;
 		insert_scratch_bytes_ = 0;
 	}
-	void insert_range(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h)
+	// staged: the range's hashes and bins are in place (stage_bins), the bin-overflow flag in pend_n_[flag_word]
+	void insert_range(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h, bool staged, uint32_t flag_word = 1)
 	{
 		uint64_t T = koff_h[e] - koff_h[s];
 		if (T == 0) return;
@@ -2540,13 +2602,14 @@ class Engine {
 		if (tiled_) {
 			// the k-mers that share no counter with another k-mer of the batch are settled tile by
 			// tile; what is left goes through the reservation rounds below
-			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
-			be_.memset(tcur_, 0, ntiles_ * 4);
+			if (!staged) flag_word = 1;
+			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + flag_word };
 			be_.memset(lead_, 0, T * 4);
 			be_.memset(opflag_, 0, T);
 			be_.memset(pend_n_, 0, 8);
-			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
-			{
+			if (!staged) {
+				be_.memset(tcur_, 0, ntiles_ * 4);
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 				be_.memset(ccur_, 0, ncoarse_ * 4);
 				FBinCoarse f1{ bn };
@@ -2560,9 +2623,12 @@ class Engine {
 			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
 			{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
 			be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
-			uint32_t nn[2] = { 0, 0 };
-			be_.d2h(nn, pend_n_, 8);
-			if (nn[1]) {
+			// the next batch's hashing and binning starts here, beside the rounds (queued before tile_apply it
+			// slows that down by as much as it gains: 453-463 vs 446-452 ms per configs[1] step)
+			if (stage_next_) { stage_next_(); stage_next_ = nullptr; }
+			uint32_t nn[4] = { 0, 0, 0, 0 };
+			be_.d2h(nn, pend_n_, 16);
+			if (nn[flag_word]) {
 				stats_.tile_overflows++; // (a bin ran over: the whole batch takes the rounds)
 				FClaim fc{ p_, h0_, ccur, cmask, epoch_ };
 				be_.launch(T, fc, "hash_claim");

@@ -423,6 +423,42 @@ struct HipBackend {
 		side_name = name;
 		side_pending = true;
 	}
+	// A stretch of ordinary launches (launch, launch_tiles, memset) goes to the side stream instead:
+	// everything between side_scope_begin() and side_scope_end() is queued there, unprofiled per
+	// kernel; wait_side_scope() blocks until it is done and books the whole stretch under `name`.
+	hipEvent_t evs0 = nullptr, evs1 = nullptr;
+	bool scope_pending = false, scope_saved_prof = false;
+	std::string scope_name;
+	void side_scope_begin(const char* name)
+	{
+		if (!evs0) { hipEventCreate(&evs0); hipEventCreate(&evs1); }
+		scope_name = name;
+		hipEventRecord(evs0, stream);          // (after what the main stream holds so far)
+		hipStreamWaitEvent(stream2, evs0, 0);
+		std::swap(stream, stream2);
+		scope_saved_prof = profiling; profiling = false;
+		hipEventRecord(evs0, stream);
+	}
+	void side_scope_end()
+	{
+		hipEventRecord(evs1, stream);
+		std::swap(stream, stream2);
+		profiling = scope_saved_prof;
+		scope_pending = true;
+	}
+	void wait_side_scope()
+	{
+		if (!scope_pending) return;
+		check(hipEventSynchronize(evs1), "hipEventSynchronize");
+		if (profiling) {
+			float ms = 0;
+			hipEventElapsedTime(&ms, evs0, evs1);
+			ProfEntry& p = prof[scope_name];
+			p.ms += ms;
+			p.launches++;
+		}
+		scope_pending = false;
+	}
 	void sync_side()
 	{
 		if (!side_pending) return;

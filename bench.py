@@ -291,7 +291,7 @@ def main() -> int:
     warm_prof = None
     if partitioned and a.warmup and g is not None:
         warm_prof = True
-    names = ["hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "guide_build",
+    names = ["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "guide_build",
              "hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
              "insert_drain", "classify", "read_prep", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
              "share_fix",
@@ -333,7 +333,7 @@ def main() -> int:
     # for the walk, 3 commit passes x H + H writes.  The kernels of one family share its bytes: a family's
     # achieved rate = its algorithmic bytes / the summed duration of its kernels.
     families = {
-        "pass1": (["hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "hash_claim",
+        "pass1": (["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "hash_claim",
                    "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load", "insert_drain"],
                   (per_kmer_bases + 2 * H * share) * kmers_all),
         "classify": (["classify", "reclassify"],

@@ -31,6 +31,9 @@ struct SerialBackend {
 	void* try_alloc(size_t n) { return malloc(n ? n : 1); }
 	void free(void* p) { ::free(p); }
 	void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
+	void side_scope_begin(const char*) {} // (serial: everything runs at once, in call order)
+	void side_scope_end() {}
+	void wait_side_scope() {}
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	uint32_t max_slots() const { return 1; }
