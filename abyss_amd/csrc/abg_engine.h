@@ -2125,7 +2125,7 @@ class Engine {
 		// and binned on the side stream while this one's tiles are judged and applied and its left-over
 		// ops go through the reservation rounds (small kernels and host round trips that leave the
 		// machine idle).  Two sets of hashes and bins take turns.
-		const bool pipe = tiled_ && !dist() && bins_alt_ != nullptr;
+		const bool pipe = tiled_ && bins_alt_ != nullptr;
 		for (size_t i = 0; i < ranges.size(); i++) {
 			if (!pipe) { insert_range(b, ranges[i].first, ranges[i].second, koff_h, false); continue; }
 			if (i == 0) stage_bins(b, ranges[0].first, ranges[0].second, koff_h);
@@ -2151,13 +2151,32 @@ class Engine {
 		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s; v.koff = b.koff + s;
 		const uint64_t kbase = koff_h[s];
 		uint32_t* flag = pend_n_ + 2 + stage_flag_;
-		TileEnv te{ p_, cnt_, 0, m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, flag };
+		uint64_t* h0 = h0_alt_;
+		const bool part = dist();
+		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, flag };
+		const uint64_t R = part ? (uint64_t)comm_.world : 1, me = part ? (uint64_t)comm_.rank : 0;
+		if (part && R > cfg_.dist_hash_all_ranks) {
+			// partitioned run: this rank's slice of the hashes on the side stream, the all-gather on the main
+			// stream (every collective of the run stays on that one stream, in program order), the bins of
+			// the rank's own range on the side stream again
+			const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
+			std::vector<uint64_t> c(R, chunk * 8), d(R);
+			for (uint64_t q = 0; q < R; q++) d[q] = q * chunk * 8;
+			const uint64_t a = std::min(T, me * chunk), bnd = std::min(T, a + chunk);
+			if (bnd > a) {
+				be_.side_scope_begin("hash_staged");
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, bnd, kbase, a }; be_.launch((bnd - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+				be_.side_scope_end();
+				be_.wait_side_scope();
+			}
+			c_all_gather_v(h0, c.data(), d.data());
+		}
 		be_.side_scope_begin("hash_bin_staged");
 		be_.memset(tcur_alt_, 0, ntiles_ * 4);
 		be_.memset(flag, 0, 4);
 		be_.memset(ccur_, 0, ncoarse_ * 4);
-		uint64_t* h0 = h0_alt_;
-		dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+		if (!part || R <= cfg_.dist_hash_all_ranks)
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 		BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 		FBinCoarse f1{ bn };
 		be_.launch_tiles((T + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f1, "bin_coarse");
@@ -2508,7 +2527,7 @@ class Engine {
 			ccur_ = (uint32_t*)be_.alloc(ncoarse_ * 4 + 64);
 			bins_ = (TilePair*)be_.alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
 			tcur_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
-			if (cfg_.overlap_bins && !dist()) {
+			if (cfg_.overlap_bins) {
 				bins_alt_ = (TilePair*)be_.try_alloc(ntiles_ * tile_cap_ * sizeof(TilePair));
 				if (bins_alt_) {
 					tcur_alt_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
@@ -2587,7 +2606,7 @@ class Engine {
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
 		if (dist()) {
-			if (tiled_) insert_tiles_dist(v, T, cmask, kbase);
+			if (tiled_) insert_tiles_dist(v, T, cmask, kbase, staged, staged ? flag_word : 1);
 			else {
 				FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_, kbase };
 				be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
@@ -2684,16 +2703,18 @@ class Engine {
 	// share a counter anywhere, which ops lead their k-mer and what the minimum of a leader's
 	// counters is (FDistPack); every rank applies the leaders' targets to its tiles, and the ops
 	// left over -- the same list on every rank -- go through the partitioned reservation rounds.
-	void insert_tiles_dist(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase)
+	void insert_tiles_dist(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase, bool staged, uint32_t flag_word)
 	{
 		cnt_partial_ = true;
 		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + 1 };
-		be_.memset(tcur_, 0, ntiles_ * 4);
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + flag_word };
 		be_.memset(lead_, 0, T * 4);
 		be_.memset(opflag_, 0, T);
 		be_.memset(pend_n_, 0, 8);
-		if (R <= cfg_.dist_hash_all_ranks) {
+		if (staged) {
+			// (hashes gathered and the own range's pairs binned while the batch before went through its rounds: stage_bins)
+		} else if (R <= cfg_.dist_hash_all_ranks) {
+			be_.memset(tcur_, 0, ntiles_ * 4);
 			// (two ranks share one xGMI link: hashing the other half of the ops costs what receiving it does)
 			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 		} else {
@@ -2702,11 +2723,12 @@ class Engine {
 			std::vector<uint64_t> c(R, chunk * 8), d(R);
 			for (uint64_t q = 0; q < R; q++) d[q] = q * chunk * 8;
 			const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk);
+			be_.memset(tcur_, 0, ntiles_ * 4);
 			if (b > a)
 				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a }; be_.launch((b - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
 			c_all_gather_v(h0_, c.data(), d.data());
 		}
-		{
+		if (!staged) {
 			BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 			be_.memset(ccur_, 0, ncoarse_ * 4);
 			FBinCoarse f1{ bn };
@@ -2721,11 +2743,12 @@ class Engine {
 		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
 		{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
 		be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_);
-		uint32_t nn[2] = { 0, 0 };
-		be_.d2h(nn, pend_n_, 8);
+		if (stage_next_) { stage_next_(); stage_next_ = nullptr; } // (the next batch, beside this one's rounds)
+		uint32_t nn[4] = { 0, 0, 0, 0 };
+		be_.d2h(nn, pend_n_, 16);
 		const uint32_t* pin = nullptr;
 		uint64_t npend = T;
-		if (nn[1]) stats_.tile_overflows++;
+		if (nn[flag_word]) stats_.tile_overflows++;
 		else { stats_.tiled_ops += T; stats_.tiled_pending += nn[0]; npend = nn[0]; pin = pend_[1]; }
 		if (npend) {
 			FClaimOwned fc{ p_, h0_, pin, claim_[0], cmask, epoch_, own_lo_, own_span_ };
