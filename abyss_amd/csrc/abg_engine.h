@@ -146,7 +146,8 @@ struct FHash { // one item per k-mer op: canonical ntHash computed from scratch
 #endif
 constexpr uint32_t HC_RUN = ABG_HC_RUN;
 // DIST: the filter is range-partitioned over the ranks of a communicator (see Engine::Comm);
-// every rank hashes every op but claims only the counters in its own range [lo, lo + span).
+// every rank hashes every op but claims only the counters in its own range [lo, lo + span)
+// (the partitioned run WITHOUT tiles, ABG_TILED=0; with tiles see Engine::insert_tiles_dist).
 template <bool DIST>
 struct FHashClaimT {
 	Params p; Batch b; uint64_t* h0; uint64_t T; uint64_t* claim; uint64_t cmask; uint32_t epoch;
@@ -1980,8 +1981,9 @@ class Engine {
 
 	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
 	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
-	// positions [q * chunk, (q + 1) * chunk) -- and all-gathered for PASS 2; every rank sees every
-	// read (share_reads), so the op stream is replicated and only the state is partitioned.
+	// positions [q * chunk, (q + 1) * chunk) -- and all-gathered for PASS 2.  Every rank holds every
+	// read (share_reads); the ops are hashed once and every rank settles the ones on its own counters
+	// (insert_tiles_dist), the commit of PASS 2 tests and stamps the bits of its own range (commit_par).
 	struct Comm {
 		int rank = 0, world = 1;
 		bool stream_ordered = false;

@@ -317,7 +317,7 @@ def main() -> int:
         box = [None] * world
         dist.all_gather_object(box, (unitigs, bases, stats["insert_rounds"], stats["candidates"]))
         ranks_agree = all(b == box[0] for b in box)
-    kmers_all = kmers  # k-mer ops one rank runs per step (all of the job's when partitioned: the op stream is replicated)
+    kmers_all = kmers  # k-mer ops whose pairs a rank scans per step (all of the job's when partitioned: every rank picks its own counters' pairs out of all ops)
     if partitioned:
         kmers_all = 2 * a.pairs * (read_len - a.k + 1)
     H = 4

@@ -187,11 +187,15 @@ int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_
  * its filter windows (`abyss-bloom build -w M/N`, Bloom/BloomFilterWindow.h:30-40: a filter
  * split by position).  With a communicator attached, PASS 1 keeps the counting filter
  * range-partitioned by position -- rank q owns counters [q*chunk, (q+1)*chunk), chunk =
- * roundUp64(ceil(size / world)) -- every rank runs every k-mer op against the counters it owns
- * and one all_reduce(MIN) of a byte per op per round decides winners and minima; the shards
- * are all-gathered before PASS 2, whose walks are split over the ranks and whose results are
- * merged before the (replicated) ordered commit.  Results are bit-identical to a single-GPU
- * run over the concatenated read set.
+ * roundUp64(ceil(size / world)).  The ops of a batch are hashed once (each rank a slice, the
+ * slices all-gathered), every rank bins the (op, counter) pairs on the counters it owns into the
+ * LDS-sized tiles of its own range and settles them there, two bytes per op through one
+ * all_reduce(MAX) carry what an op needs to know from the other ranks, and the few ops left
+ * go through reservation rounds with one all_reduce(MIN) of a byte per op and round.  The
+ * shards are all-gathered before PASS 2, whose classification and walks are split over the
+ * ranks, whose contigs are gathered, and whose ordered commit tests and stamps each rank's own
+ * bits (a byte per candidate and per contig through all_reduce).  Results are bit-identical to
+ * a single-GPU run over the concatenated read set.
  *
  * The communicator is a table of two collectives over buffers in the library's memory space
  * (device memory): abg_rccl_comm_create() fills it with RCCL (stream-ordered, over xGMI);
