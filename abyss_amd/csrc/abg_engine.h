@@ -3412,14 +3412,16 @@ class Engine {
 		// (no more candidates in a batch than the vertex table at its largest plans room for)
 		const uint64_t max_cand = std::min<uint64_t>(cfg_.p2_max_candidates,
 		    std::max<uint64_t>(1024, (1ull << wtab_log2_cap()) / (2 * wtab_per_walker_)));
-		for (uint64_t i = 0; i < n; i++) {
-			if (res[i] == RES_CANDIDATE) {
-				if (r.cand_h.size() >= max_cand) { used = i; break; }
-				r.cand_h.push_back((uint32_t)i);
-			}
-			if (res[i] == RES_CANDIDATE || res[i] == RR_ALL_KMERS_VISITED) counters_.solid_reads++;
-			if (res[i] == RR_ALL_KMERS_VISITED) counters_.visited_reads++;
+		// (the candidates are few among millions of verdicts late in a read set: found with memchr, the
+		// other verdicts counted in a loop the compiler vectorises)
+		for (const uint8_t* q = res.data(), *end = q + n; (q = (const uint8_t*)memchr(q, RES_CANDIDATE, (size_t)(end - q))) != nullptr; q++) {
+			if (r.cand_h.size() >= max_cand) { used = (uint64_t)(q - res.data()); break; }
+			r.cand_h.push_back((uint32_t)(q - res.data()));
 		}
+		uint64_t n_visited = 0;
+		for (uint64_t i = 0; i < used; i++) n_visited += res[i] == RR_ALL_KMERS_VISITED;
+		counters_.solid_reads += n_visited + r.cand_h.size();
+		counters_.visited_reads += n_visited;
 		v.n = used;
 		r.v = v; r.first = first; r.n = used; r.res_d = res_d;
 		r.nc = (uint32_t)r.cand_h.size();
