@@ -429,6 +429,45 @@ ABG_HDN void insert_drain(InsertDrainEnv e, Sync& sy)
 	if (tid == 0) e.counter[1] = rounds;
 	sy.barrier();
 }
+struct FGatherU32 { // out[i] = in[idx[i]]
+	const uint32_t* in; const uint32_t* idx; uint32_t* out;
+	ABG_HD void operator()(uint64_t i, uint32_t) const { out[i] = in[idx[i]]; }
+};
+// k-mers per sequence (0 for one shorter than k, which is flagged), ahead of the prefix sum that makes koff
+struct FKmerCounts {
+	const uint32_t* len; uint32_t k; uint64_t* out; uint32_t* short_flag;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t L = len[i];
+		out[i] = L >= k ? (uint64_t)(L - k + 1) : 0;
+		if (L < k) *short_flag = 1;
+	}
+};
+// The op ranges of PASS 1's batches, cut on the device (one thread: a greedy walk of binary searches
+// over the prefix sums): range r holds the sequences [s, e) -- as many as fit in batch_ops ops, at
+// least one -- and their ops [k0, k1).
+struct OpRange { uint64_t s, e, k0, k1; };
+struct FCutRanges {
+	const uint64_t* koff; uint64_t n, batch_ops; OpRange* out; uint32_t cap; uint32_t* count;
+	ABG_HD void operator()(uint64_t, uint32_t) const
+	{
+		uint32_t r = 0;
+		for (uint64_t s = 0; s < n;) {
+			// largest e in (s, n] with koff[e] - koff[s] <= batch_ops; at least s + 1
+			uint64_t lo = s + 1, hi = n;
+			const uint64_t lim = koff[s] + batch_ops;
+			while (lo < hi) {
+				const uint64_t mid = lo + (hi - lo + 1) / 2;
+				if (koff[mid] <= lim) lo = mid; else hi = mid - 1;
+			}
+			const uint64_t e = lo;
+			if (r < cap) out[r] = OpRange{ s, e, koff[s], koff[e] };
+			r++;
+			s = e;
+		}
+		*count = r;
+	}
+};
 struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219-242), 8 counters per item
 	const uint64_t* cnt8; uint32_t kc; uint64_t* out; // out[0] non-zero, out[1] >= kc
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -2052,12 +2091,8 @@ class Engine {
 		for (uint32_t q = 0; q < R; q++) { c[q] = cnt[2 * q] * 8; d[q] = nb[q] * 8; }
 		c_all_gather_v(sh_woff_, c.data(), d.data());
 		be_.h2d(sh_woff_ + nb[R], &wb[R], 8);
-		// k-mer prefix sums (PASS 1 wants them on both sides)
-		sh_koff_h_.assign(nb[R] + 1, 0);
-		std::vector<uint32_t> len(nb[R]);
-		be_.d2h(len.data(), sh_len_, nb[R] * 4);
-		for (uint64_t i = 0; i < nb[R]; i++) sh_koff_h_[i + 1] = sh_koff_h_[i] + (len[i] >= p_.k ? len[i] - p_.k + 1 : 0);
-		be_.h2d(sh_koff_, sh_koff_h_.data(), (nb[R] + 1) * 8);
+		// k-mer prefix sums, on the device (PASS 1 cuts its batches there too: cut_ranges)
+		device_koff(sh_len_, nb[R], sh_koff_);
 		return Batch{ sh_words_, sh_woff_, sh_len_, sh_koff_, nb[R] };
 	}
 	bool cascade_mode() const { return casc_.bits != nullptr; }
@@ -2109,28 +2144,71 @@ class Engine {
 	}
 
 	// ---- PASS 1 on a device-resident packed batch (ops are inserted in batch order).
-	// koff_h is the host copy of b.koff.
-	void load_packed(const Batch& b, const uint64_t* koff_h)
+	// koff[i + 1] = koff[i] + k-mers of sequence i, computed on the device; returns whether a sequence is shorter than k
+	bool device_koff(const uint32_t* len_d, uint64_t n, uint64_t* koff_d)
+	{
+		be_.memset(koff_d, 0, 8);
+		if (!n) return false;
+		uint32_t* flag = (uint32_t*)be_.alloc(4);
+		be_.memset(flag, 0, 4);
+		FKmerCounts f{ len_d, p_.k, koff_d + 1, flag };
+		be_.launch(n, f, "kmer_counts");
+		be_.inclusive_sum_u64(koff_d + 1, n);
+		uint32_t any = 0;
+		be_.d2h(&any, flag, 4);
+		be_.free(flag);
+		return any != 0;
+	}
+	// op ranges of at most batch_ops_ ops along sequence boundaries, from the device's prefix sums
+	std::vector<OpRange> cut_ranges(const uint64_t* koff_d, uint64_t n)
+	{
+		ensure_insert();
+		std::vector<OpRange> out;
+		if (!n) return out;
+		uint64_t total = 0;
+		be_.d2h(&total, koff_d + n, 8);
+		uint32_t cap = (uint32_t)std::min<uint64_t>(n, 2 * (total / std::max<uint64_t>(batch_ops_, 1)) + 16);
+		for (;;) {
+			OpRange* d = (OpRange*)be_.alloc((uint64_t)cap * sizeof(OpRange));
+			uint32_t* cnt = (uint32_t*)be_.alloc(4);
+			FCutRanges f{ koff_d, n, batch_ops_, d, cap, cnt };
+			be_.launch(1, f, "cut_ranges");
+			uint32_t r = 0;
+			be_.d2h(&r, cnt, 4);
+			if (r <= cap) { out.resize(r); be_.d2h(out.data(), d, (uint64_t)r * sizeof(OpRange)); }
+			be_.free(d); be_.free(cnt);
+			if (r <= cap) return out;
+			cap = r; // (sequences longer than a batch make more ranges than planned for)
+		}
+	}
+	// the same from a host copy of the prefix sums
+	std::vector<OpRange> cut_ranges_host(const uint64_t* koff_h, uint64_t n)
+	{
+		ensure_insert();
+		std::vector<OpRange> out;
+		for (uint64_t s = 0; s < n;) {
+			uint64_t e = (uint64_t)(std::upper_bound(koff_h + s + 1, koff_h + n + 1, koff_h[s] + batch_ops_) - koff_h) - 1;
+			if (e <= s) e = s + 1;
+			out.push_back(OpRange{ s, e, koff_h[s], koff_h[e] });
+			s = e;
+		}
+		return out;
+	}
+	void load_packed(const Batch& b, const uint64_t* koff_h) { load_packed(b, cut_ranges_host(koff_h, b.n)); }
+	void load_packed(const Batch& b) { load_packed(b, cut_ranges(b.koff, b.n)); } // (b.koff: device_koff)
+	void load_packed(const Batch& b, const std::vector<OpRange>& ranges)
 	{
 		ensure_insert();
 		memo_valid_ = false;
 		last_rounds_ = 0;
-		// op ranges of at most batch_ops_ along sequence boundaries
-		std::vector<std::pair<uint64_t, uint64_t>> ranges;
-		for (uint64_t s = 0; s < b.n;) {
-			uint64_t e = s;
-			while (e < b.n && (e == s || koff_h[e + 1] - koff_h[s] <= batch_ops_)) e++;
-			ranges.push_back({ s, e });
-			s = e;
-		}
 		// Tiled: hashing and binning a batch reads nothing but the reads, so the NEXT batch is hashed
 		// and binned on the side stream while this one's tiles are judged and applied and its left-over
 		// ops go through the reservation rounds (small kernels and host round trips that leave the
 		// machine idle).  Two sets of hashes and bins take turns.
 		const bool pipe = tiled_ && bins_alt_ != nullptr;
 		for (size_t i = 0; i < ranges.size(); i++) {
-			if (!pipe) { insert_range(b, ranges[i].first, ranges[i].second, koff_h, false); continue; }
-			if (i == 0) stage_bins(b, ranges[0].first, ranges[0].second, koff_h);
+			if (!pipe) { insert_range(b, ranges[i], false); continue; }
+			if (i == 0) stage_bins(b, ranges[0]);
 			be_.wait_side_scope();
 			// (what was staged is now current; the other set takes the next batch)
 			std::swap(h0_, h0_alt_); std::swap(bins_, bins_alt_); std::swap(tcur_, tcur_alt_); stage_flag_ ^= 1u;
@@ -2138,20 +2216,21 @@ class Engine {
 			const uint32_t cur_flag = stage_flag_ ^ 1u; // the flag word the batch just staged wrote
 			// (queued behind this batch's tile kernels -- see insert_range -- so that it runs beside the rounds, not beside them)
 			stage_next_ = nullptr;
-			if (i + 1 < ranges.size()) stage_next_ = [this, &b, &ranges, i, koff_h]() { stage_bins(b, ranges[i + 1].first, ranges[i + 1].second, koff_h); };
-			insert_range(b, ranges[i].first, ranges[i].second, koff_h, staged, 2 + cur_flag);
+			if (i + 1 < ranges.size()) stage_next_ = [this, &b, &ranges, i]() { stage_bins(b, ranges[i + 1]); };
+			insert_range(b, ranges[i], staged, 2 + cur_flag);
 			if (stage_next_) { stage_next_(); stage_next_ = nullptr; }
 		}
 	}
 	// hash_ops, bin_coarse and bin_fine of the op range [s, e) into the alternate set, on the side stream
-	void stage_bins(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h)
+	void stage_bins(const Batch& b, const OpRange& rg)
 	{
-		const uint64_t T = koff_h[e] - koff_h[s];
+		const uint64_t s = rg.s, e = rg.e;
+		const uint64_t T = rg.k1 - rg.k0;
 		staged_ok_ = false;
 		if (T == 0 || T > batch_ops_ || T >= 0xFFFFFFFFull) return; // (insert_range deals with those)
 		Batch v = b;
 		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s; v.koff = b.koff + s;
-		const uint64_t kbase = koff_h[s];
+		const uint64_t kbase = rg.k0;
 		uint32_t* flag = pend_n_ + 2 + stage_flag_;
 		uint64_t* h0 = h0_alt_;
 		const bool part = dist();
@@ -2334,11 +2413,9 @@ class Engine {
 	uint8_t* tred_ = nullptr; // partitioned tiles: the two bytes per op of FDistPack
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
 	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;
-	std::vector<uint64_t> sh_koff_h_;
 	uint8_t* dres_ = nullptr; uint8_t* dlost_ = nullptr; // PASS 1: one byte per pending op
 	uint32_t g_rec_ = 0; uint64_t g_pool_ = 0;           // PASS 2: records / pool bytes every rank holds
   public:
-	const uint64_t* shared_koff_host() const { return sh_koff_h_.data(); }
   private:
 	void free_shared()
 	{
@@ -2585,9 +2662,10 @@ class Engine {
 		insert_scratch_bytes_ = 0;
 	}
 	// staged: the range's hashes and bins are in place (stage_bins), the bin-overflow flag in pend_n_[flag_word]
-	void insert_range(const Batch& b, uint64_t s, uint64_t e, const uint64_t* koff_h, bool staged, uint32_t flag_word = 1)
+	void insert_range(const Batch& b, const OpRange& rg, bool staged, uint32_t flag_word = 1)
 	{
-		uint64_t T = koff_h[e] - koff_h[s];
+		const uint64_t s = rg.s, e = rg.e;
+		uint64_t T = rg.k1 - rg.k0;
 		if (T == 0) return;
 		if (T > batch_ops_ || T >= 0xFFFFFFFFull) {
 			fprintf(stderr, "abyss_amd: a single sequence has more k-mers (%llu) than insert_batch_kmers\n",
@@ -2599,7 +2677,7 @@ class Engine {
 		v.woff = b.woff + s; v.len = b.len + s; v.n = e - s;
 		// (the view keeps the whole batch's k-mer prefix sums: the functors subtract kbase)
 		v.koff = b.koff + s;
-		const uint64_t kbase = koff_h[s];
+		const uint64_t kbase = rg.k0;
 		uint64_t cmask = (1ull << claim_log2_) - 1;
 		if (epoch_ > 0xFFFFFF00u) { // claim epochs exhausted: start over
 			for (int i = 0; i < 2; i++) be_.memset(claim_[i], 0xFF, 8ull << claim_log2_);
@@ -3365,11 +3443,10 @@ class Engine {
 			if (r.nc) finish_batch<NW>(r, ci, sink);
 			if (results_host) {
 				be_.d2h(results_host + r.first, r.res_d, r.n);
-				for (uint64_t i = 0; i < r.n; i++)
-					if (results_host[r.first + i] == RES_CANDIDATE) {
-						fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)(r.first + i));
-						abort();
-					}
+				if (const void* left = memchr(results_host + r.first, RES_CANDIDATE, r.n)) {
+					fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)((const uint8_t*)left - results_host));
+					abort();
+				}
 			}
 		}
 	}
@@ -3443,10 +3520,17 @@ class Engine {
 		r.need_d = (uint32_t*)be_.alloc(nc * 4ull);
 		r.need_n = (uint32_t*)be_.alloc(8);
 		be_.h2d(r.cand_d, r.cand_h.data(), nc * 4ull);
-		std::vector<uint32_t> len_h(b.n);
-		be_.d2h(len_h.data(), b.len, b.n * 4ull);
+		// (the candidates' lengths only: the batch may hold millions of reads)
+		std::vector<uint32_t> len_h(nc);
+		{
+			uint32_t* cl = (uint32_t*)be_.alloc(nc * 4ull + 4);
+			FGatherU32 f{ b.len, r.cand_d, cl };
+			be_.launch(nc, f, "gather_len");
+			be_.d2h(len_h.data(), cl, nc * 4ull);
+			be_.free(cl);
+		}
 		std::vector<uint64_t> rkoff(nc + 1, 0);
-		for (uint32_t i = 0; i < nc; i++) rkoff[i + 1] = rkoff[i] + (len_h[r.cand_h[i]] - p_.k + 1);
+		for (uint32_t i = 0; i < nc; i++) rkoff[i + 1] = rkoff[i] + (len_h[i] - p_.k + 1);
 		r.rkoff_d = (uint64_t*)be_.alloc((nc + 1) * 8ull);
 		be_.h2d(r.rkoff_d, rkoff.data(), (nc + 1) * 8ull);
 		rkh_ = (uint64_t*)be_.alloc(std::max<uint64_t>(rkoff[nc], 1) * 8);

@@ -153,17 +153,13 @@ class Session {
 	int load_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
 	{
 		if (!n) return ABG_OK;
-		std::vector<uint32_t> len(n);
-		be.d2h(len.data(), d_len, n * 4);
-		std::vector<uint64_t> koff(n + 1, 0);
-		for (uint64_t i = 0; i < n; i++) {
-			if (len[i] < cfg.k) return fail(ABG_EINVAL, "packed sequence shorter than k");
-			koff[i + 1] = koff[i] + (len[i] - cfg.k + 1);
-		}
+		// (the k-mer prefix sums and the batches' op ranges are made on the device: the reads are there,
+		// and a host loop over tens of millions of lengths per call is time the device would idle)
 		uint64_t* koff_d = (uint64_t*)be.alloc((n + 1) * 8);
-		be.h2d(koff_d, koff.data(), (n + 1) * 8);
+		const bool any_short = eng->device_koff(d_len, n, koff_d);
+		if (any_short) { be.free(koff_d); return fail(ABG_EINVAL, "packed sequence shorter than k"); }
 		Batch b{ d_words, d_woff, d_len, koff_d, n };
-		eng->load_packed(b, koff.data());
+		eng->load_packed(b);
 		be.free(koff_d);
 		return ABG_OK;
 	}

@@ -366,6 +366,22 @@ struct HipBackend {
 		else check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, iota, flags, out, count_dev, (int)n, stream), "DeviceSelect");
 		end("compact");
 	}
+	// in-place inclusive prefix sum over n 64-bit values
+	void inclusive_sum_u64(uint64_t* data, uint64_t n)
+	{
+		if (!n) return;
+		begin("scan");
+		size_t need = 0;
+		check(hipcub::DeviceScan::InclusiveSum(nullptr, need, data, data, (int)n, stream), "DeviceScan");
+		if (need > cub_tmp_bytes) {
+			if (cub_tmp) { hipStreamSynchronize(stream); hipFree(cub_tmp); }
+			cub_tmp_bytes = need * 2;
+			check(hipMalloc(&cub_tmp, cub_tmp_bytes), "hipMalloc");
+		}
+		size_t bytes = cub_tmp_bytes;
+		check(hipcub::DeviceScan::InclusiveSum(cub_tmp, bytes, data, data, (int)n, stream), "DeviceScan");
+		end("scan");
+	}
 	uint32_t max_slots() const { return cus * 8 * 256; }
 	uint64_t device_mem_bytes() const { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (uint64_t)tot : 0; }
 

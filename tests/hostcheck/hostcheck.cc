@@ -36,6 +36,7 @@ struct SerialBackend {
 	void wait_side_scope() {}
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+	void inclusive_sum_u64(uint64_t* d, uint64_t n) { for (uint64_t i = 1; i < n; i++) d[i] += d[i - 1]; }
 	uint32_t max_slots() const { return 1; }
 	uint64_t device_mem_bytes() const { return 0; } // (unknown: no cap)
 	void d2d(void* d, const void* s, size_t n) { memmove(d, s, n); }
