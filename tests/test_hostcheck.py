@@ -476,6 +476,37 @@ def test_guide_and_memo_do_not_change_results(monkeypatch):
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
 
 
+def test_packed_reads_get_their_prefix_sums_and_batches_on_the_device():
+    """abg_load_packed: the k-mer prefix sums (FKmerCounts + scan) and the batches' op ranges
+    (FCutRanges) are made where the reads are.  Ragged lengths, batches of a few hundred ops (many
+    ranges, one of them a single sequence longer than a batch would be refused: not here), the counters
+    of the oracle; a sequence shorter than k is an error."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    k = 31
+    reads = [bytes(rng.choice(list(b"ACGT"), size=int(L)).astype(np.uint8)) for L in rng.integers(k, 140, size=700)]
+    buf, off = api.concat_seqs(reads)
+    o = ob.Oracle(k, counters=1 << 16)
+    o.load(buf, off)
+    hc = HostCheck(k, 1 << 16, insert_batch=400, claim_log2=12)
+    # pack: 16 bases per word, every sequence on a word boundary
+    words, woff, lens = [], [0], []
+    for r in reads:
+        codes = np.array([b"ACGT".index(bytes([c])) for c in r], dtype=np.uint64)
+        pad = np.zeros((len(r) + 15) // 16 * 16, dtype=np.uint64)
+        pad[:len(r)] = codes
+        words.append((pad.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32))
+        woff.append(woff[-1] + len(words[-1]))
+        lens.append(len(r))
+    words = np.ascontiguousarray(np.concatenate(words)); woff = np.array(woff, dtype=np.uint64); lens = np.array(lens, dtype=np.uint32)
+    vp = C.c_void_p
+    hc.l.hc_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    assert hc.l.hc_load_packed(hc.h, words.ctypes.data, woff.ctypes.data, lens.ctypes.data, len(reads)) == 0
+    assert np.array_equal(o.counters(), hc.counters())
+    lens[5] = k - 1
+    assert hc.l.hc_load_packed(hc.h, words.ctypes.data, woff.ctypes.data, lens.ctypes.data, len(reads)) != 0
+
+
 def test_read_set_in_several_chunks_is_one_pass():
     """abg_assemble_seqs_v: the reads of a golden run handed over in three buffers (the second one
     holding reads that are too short or not ACGT as well) give the reference's outputs, with read
