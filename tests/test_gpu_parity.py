@@ -50,6 +50,9 @@ def test_reproduces_reference_run(name):
     c = g.assembly_counters()
     assert (c["reads_processed"], c["solid_reads"], c["visited_reads"]) == (
         gc.meta["reads"], gc.meta["solid_reads"], gc.meta["visited_reads"])
+    # the accelerators ran, whatever the seed and the parity of k: read-guided bulk steps and chains, the memo
+    st = g.stats()
+    assert st["bulk_steps"] > st["lin_steps"] and st["chain_steps"] > 0 and st["memo_hits"] > 0, (name, st)
 
 
 @pytest.mark.parametrize("k,G,cov", [(21, 40000, 30.0), (64, 200000, 40.0), (33, 60000, 30.0), (97, 50000, 40.0),
