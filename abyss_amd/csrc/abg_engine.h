@@ -79,8 +79,17 @@ struct BaseCodes {
 	}
 };
 // Host-side staging of pure-ACGT sequences in the device layout (see Batch).
+// (a vector whose resize() leaves new elements uninitialised: the packed words are written right after)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+	template <class U> struct rebind { using other = NoInitAlloc<U>; };
+	template <class U, class... A> void construct(U* p, A&&... a)
+	{
+		if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+	}
+};
 struct HostBatch {
-	std::vector<uint32_t> words;
+	std::vector<uint32_t, NoInitAlloc<uint32_t>> words;
 	std::vector<uint64_t> woff{ 0 };
 	std::vector<uint32_t> len;
 	std::vector<uint64_t> koff{ 0 };

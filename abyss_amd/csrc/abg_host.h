@@ -236,7 +236,12 @@ class Session {
 		HostBatch empty;
 		const double t1 = tnow();
 		const HostBatch& hb = parts.empty() ? empty : join_parts(parts, joined);
-		for (auto& o : origs) orig.insert(orig.end(), o.begin(), o.end());
+		{
+			size_t total = 0;
+			for (auto& o : origs) total += o.size();
+			orig.reserve(total);
+			for (auto& o : origs) { orig.insert(orig.end(), o.begin(), o.end()); std::vector<uint64_t>().swap(o); }
+		}
 		const double t2 = tnow();
 		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
 		// ones rejected above; the engine counts the ones it sees
@@ -561,17 +566,25 @@ class Session {
 	static const HostBatch& join_parts(std::vector<HostBatch>& parts, HostBatch& joined)
 	{
 		if (parts.size() == 1) return parts[0];
-		size_t words = 0, reads = 0;
-		for (auto& p : parts) { words += p.words.size(); reads += p.n(); }
-		joined.words.reserve(words); joined.woff.reserve(reads + 1); joined.len.reserve(reads); joined.koff.reserve(reads + 1);
-		for (auto& p : parts) {
-			const uint64_t wbase = joined.words.size(), kbase = joined.koff.back();
-			joined.words.insert(joined.words.end(), p.words.begin(), p.words.end());
-			joined.len.insert(joined.len.end(), p.len.begin(), p.len.end());
-			for (size_t i = 1; i < p.woff.size(); i++) joined.woff.push_back(p.woff[i] + wbase);
-			for (size_t i = 1; i < p.koff.size(); i++) joined.koff.push_back(p.koff[i] + kbase);
-			p = HostBatch(); // give the memory back as we go
+		// where each part goes, then every part copied by a thread of its own
+		std::vector<uint64_t> wbase(parts.size() + 1, 0), rbase(parts.size() + 1, 0), kbase(parts.size() + 1, 0);
+		for (size_t t = 0; t < parts.size(); t++) {
+			wbase[t + 1] = wbase[t] + parts[t].words.size();
+			rbase[t + 1] = rbase[t] + parts[t].n();
+			kbase[t + 1] = kbase[t] + parts[t].koff.back();
 		}
+		const uint64_t reads = rbase[parts.size()];
+		joined.words.resize(wbase[parts.size()]);
+		joined.woff.resize(reads + 1); joined.len.resize(reads); joined.koff.resize(reads + 1);
+		joined.woff[0] = 0; joined.koff[0] = 0;
+		run_parts(parts.size(), [&](size_t t) {
+			HostBatch& p = parts[t];
+			if (!p.words.empty()) memcpy(joined.words.data() + wbase[t], p.words.data(), p.words.size() * 4);
+			if (p.n()) memcpy(joined.len.data() + rbase[t], p.len.data(), p.n() * 4);
+			for (size_t i = 1; i < p.woff.size(); i++) joined.woff[rbase[t] + i] = p.woff[i] + wbase[t];
+			for (size_t i = 1; i < p.koff.size(); i++) joined.koff[rbase[t] + i] = p.koff[i] + kbase[t];
+			p = HostBatch(); // give the memory back as we go
+		});
 		return joined;
 	}
 	struct DevBatch { Batch b; void* words; void* woff; void* len; void* koff; };

@@ -504,6 +504,8 @@ int main(int argc, char** argv)
 		load_done();
 		loading = std::move(chunk);
 		chunk = Chunk();
+		chunk.seqs.reserve(loading.seqs.size() + (64u << 20)); // (the next one grows to about the same size: no copies on the way)
+		chunk.off.reserve(loading.off.size() + 1024); chunk.id_end.reserve(loading.id_end.size() + 1024); chunk.idbuf.reserve(loading.idbuf.size() + (1u << 20));
 		loader = std::thread([&]() {
 			const double tl = host_now();
 			check(abg_load_seqs(ctx, loading.seqs.data(), loading.off.data(), loading.n()), ctx, "load");
@@ -555,6 +557,7 @@ int main(int argc, char** argv)
 			for (int i = optind; i < argc && strcmp(argv[i], ":"); ++i) ins.push_back(argv[i]);
 			abghost::Prefetch::get().start(ins);
 		}
+		chunk.seqs.reserve(CHUNK_BASES + (64u << 20));
 		for (int i = optind; i < argc; ++i) {
 			if (!strcmp(argv[i], ":")) { first_asm = i + 1; break; }
 			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
