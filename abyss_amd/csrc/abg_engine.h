@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -2304,6 +2305,7 @@ class Engine {
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
+		deliveries_wait(); // (the last batch's contigs are with the caller)
 		be_.sync_side();
 		pre_n_ = 0; prefetch_ = nullptr;
 		use_ctx(0);
@@ -3761,21 +3763,31 @@ class Engine {
 		used = std::min<uint64_t>(used, pool_cap_);
 		std::vector<uint8_t> pool(used);
 		be_.d2h(pool.data(), pool_, used);
-		for (uint32_t i = 0; i < n; i++) {
-			const ContigRec& r = recs[order[i]];
+		// The copies are off the device; turning them into strings and handing them to the caller goes on
+		// beside the next batch's device work, on a thread of its own -- one delivery at a time, in order;
+		// assemble_packed waits for the last one before it returns.
+		deliveries_wait();
+		const std::function<void(const ContigOut&)>* sk = &sink;
+		delivery_ = std::async(std::launch::async,
+		    [sk, read_base, n, order = std::move(order), recs = std::move(recs), pool = std::move(pool), cand = cand_h]() {
 			ContigOut o;
-			o.contig_id = r.redundant ? ~0ULL : r.contig_id;
-			o.read_index = read_base + cand_h[r.cand];
-			o.seq.resize(r.len);
-			for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGTN"[pool[r.seq_off + j] <= 4 ? pool[r.seq_off + j] : 4];
-			o.coverage = r.redundant ? 0 : r.coverage;
-			o.redundant = r.redundant != 0;
-			o.left_ext = r.left_ext; o.right_ext = r.right_ext;
-			o.left_code = r.left_code; o.right_code = r.right_code;
-			o.seed_pos = r.seed_pos;
-			sink(o);
-		}
+			for (uint32_t i = 0; i < n; i++) {
+				const ContigRec& r = recs[order[i]];
+				o.contig_id = r.redundant ? ~0ULL : r.contig_id;
+				o.read_index = read_base + cand[r.cand];
+				o.seq.resize(r.len);
+				for (uint32_t j = 0; j < r.len; j++) o.seq[j] = "ACGTN"[pool[r.seq_off + j] <= 4 ? pool[r.seq_off + j] : 4];
+				o.coverage = r.redundant ? 0 : r.coverage;
+				o.redundant = r.redundant != 0;
+				o.left_ext = r.left_ext; o.right_ext = r.right_ext;
+				o.left_code = r.left_code; o.right_code = r.right_code;
+				o.seed_pos = r.seed_pos;
+				(*sk)(o);
+			}
+		});
 	}
+	std::future<void> delivery_;
+	void deliveries_wait() { if (delivery_.valid()) delivery_.get(); }
 
 };
 

@@ -118,6 +118,10 @@ class Session {
 		std::vector<HostBatch> parts(cut.size() - 1);
 		run_parts(parts.size(), [&](size_t t) {
 			HostBatch& hb = parts[t];
+			{
+				const uint64_t nr = cut[t + 1] - cut[t], bases = off[cut[t + 1]] - off[cut[t]];
+				hb.words.reserve(bases / 16 + nr + 1); hb.woff.reserve(nr + 1); hb.len.reserve(nr); hb.koff.reserve(nr + 1);
+			}
 			std::string up;
 			std::vector<std::pair<uint64_t, uint64_t>> runs;
 			std::vector<uint8_t> bad;
@@ -220,6 +224,11 @@ class Session {
 			const Part& pt = plan[t];
 			const char* seqs = seqs_v[pt.c];
 			const uint64_t* off = off_v[pt.c];
+			{
+				const uint64_t nr = pt.b - pt.a, bases = off[pt.b] - off[pt.a];
+				parts[t].words.reserve(bases / 16 + nr + 1); parts[t].woff.reserve(nr + 1); parts[t].len.reserve(nr); parts[t].koff.reserve(nr + 1);
+				origs[t].reserve(nr);
+			}
 			for (uint64_t i = pt.a; i < pt.b; i++) {
 				const char* s = seqs + off[i];
 				uint64_t L = off[i + 1] - off[i];

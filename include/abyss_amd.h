@@ -149,7 +149,9 @@ int abg_visited_import(abg_ctx* ctx, const uint8_t* host_in);
  * assemble() :1012-1066 at -j1).  results (may be NULL) receives one abg_read_result per
  * read; cb is invoked once per outputContig call, in the reference's order, redundant
  * contigs included (they appear in the -T trace).  State (visited filter, contigEndKmers,
- * counters) carries over between calls, so a read stream may be fed in chunks. */
+ * counters) carries over between calls, so a read stream may be fed in chunks.  cb may run on a
+ * thread the library made (a batch's contigs are handed over while the device works on the next
+ * batch): one call at a time, in order, and none after the assemble call has returned. */
 int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
     uint8_t* results, abg_contig_cb cb, void* user);
 /* the same over a read set held in `nchunks` buffers (seqs[c], offsets[c], n[c] as above): ONE pass
