@@ -528,6 +528,36 @@ def test_read_set_in_several_chunks_is_one_pass():
     assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
 
 
+def test_chunks_that_are_empty_or_hold_only_rejected_reads():
+    """abg_assemble_seqs_v with an empty buffer, a buffer of reads that are all too short or not ACGT, and
+    real reads in between: the verdicts and contigs of the one-buffer call, indices counting through."""
+    g = GoldenCase("k32")
+    kw = g.kwargs()
+    n = len(g.off) - 1
+    junk = [b"ACGT", b"ACGTNNNNNNACGTACGTACGTACGTACGTACGTACGTACGT", b"", b"acgtn"]
+    jbuf, joff = api.concat_seqs(junk)
+
+    def cut(a, b):
+        lo, hi = int(g.off[a]), int(g.off[b])
+        return bytes(g.buf[lo:hi]), np.asarray(g.off[a:b + 1], dtype=np.uint64) - np.uint64(lo)
+    chunks = [(b"", np.zeros(1, dtype=np.uint64)), cut(0, n // 3), (jbuf, joff), cut(n // 3, n), (b"", np.zeros(1, dtype=np.uint64))]
+    # the same reads in one buffer
+    one_buf = cut(0, n // 3)[0] + jbuf + cut(n // 3, n)[0]
+    lens = np.concatenate([np.diff(cut(0, n // 3)[1]), np.diff(joff), np.diff(cut(n // 3, n)[1])])
+    one_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    outs = []
+    for mode in ("chunks", "one"):
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
+                       claim_log2=16, p2_first=256)
+        hc.load(g.buf, g.off)
+        res, contigs = hc.assemble_chunks(chunks) if mode == "chunks" else hc.assemble(one_buf, one_off)
+        outs.append((res.tolist(), [(c.contig_id, c.read_index, c.seq, c.coverage, c.redundant) for c in contigs]))
+    assert outs[0] == outs[1]
+    res = outs[0][0]
+    j0 = n // 3
+    assert res[j0:j0 + 4] == [1, 2, 1, 1]  # SHORTER_THAN_K, NON_ACGT, SHORTER_THAN_K, SHORTER_THAN_K
+
+
 def test_walkers_running_out_of_pool_or_records_get_more(monkeypatch):
     """A launch whose walkers run out of contig pool or contig records is restarted with twice as
     much of what ran out (the walkers say which: WSTAT_OVF_POOL / WSTAT_OVF_RECS) -- not with a
