@@ -1069,6 +1069,10 @@ ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v)
 	return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
 }
 ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+ABG_HD uint64_t atomic_exch_u64(uint64_t* p, uint64_t v)
+{
+	return (uint64_t)atomicExch((unsigned long long*)p, (unsigned long long)v);
+}
 #else
 // serial execution (tests/hostcheck): one item at a time, plain memory
 ABG_HD uint64_t ld_coherent(const uint64_t* p) { return *p; }
@@ -1086,6 +1090,7 @@ ABG_HD uint64_t atomic_min_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; if (v
 ABG_HD uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 ABG_HD uint64_t atomic_add_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = o + v; return o; }
 ABG_HD uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+ABG_HD uint64_t atomic_exch_u64(uint64_t* p, uint64_t v) { uint64_t o = *p; *p = v; return o; }
 #endif
 
 // Append slots for a one-item-per-lane kernel: every lane of the wave that `want`s a slot
@@ -1214,7 +1219,9 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
        CB_NONE = 3 };    // not examined
 enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
        WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
-       WSTAT_N = 8 };
+       WSTAT_PRE_REQS, WSTAT_PRE_ADDS, // pre-search: requests made / answers it added to the memo
+       WSTAT_VERIFY, WSTAT_MEMO_BAD, WSTAT_BAD0, WSTAT_BAD1, WSTAT_BAD2, // ABG_MEMO_VERIFY: every memo hit is recomputed and compared (diagnosis)
+       WSTAT_N = 16 };
 
 // ------------------------------------------------------- memo of successor()
 // successor(u, dir) with its iterative deepening over trueBranch searches (ExtendPath.h:314-362) is
@@ -1238,8 +1245,8 @@ ABG_HD uint64_t memo_slot(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
 	x ^= x >> 31; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29;
 	return x & m.mask;
 }
-// -1: not there; else code << 4 | base
-ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
+// -1: not there; else code << 4 | base (| origin << 16 when raw)
+ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, bool raw = false)
 {
 	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return -1;
 	uint64_t s = memo_slot(m, fh, rh, dir);
@@ -1250,11 +1257,11 @@ ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
 		const uint64_t v = ld_coherent(&m.val[s]);
 		if (!(v >> 63) || (int)((v >> 8) & 1u) != dir) continue; // (an entry still being written counts as absent)
 		if (ld_coherent(&m.k1[s]) != rh) continue;
-		return (int)(v & 0xFFu);
+		return (int)(v & (raw ? 0x100FFu : 0xFFu));
 	}
 	return -1;
 }
-ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsigned code, unsigned base, bool coop)
+ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsigned code, unsigned base, bool coop, unsigned origin = 0)
 {
 	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return;
 	uint64_t s = memo_slot(m, fh, rh, dir);
@@ -1262,7 +1269,7 @@ ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsig
 		const uint64_t cur = wu_cas_u64(&m.k0[s], MEMO_EMPTY, fh, coop);
 		if (cur == MEMO_EMPTY) {
 			wu_st_coherent(&m.k1[s], rh, coop);
-			wu_st_coherent(&m.val[s], (1ULL << 63) | ((uint64_t)(dir & 1) << 8) | ((uint64_t)code << 4) | base, coop);
+			wu_st_coherent(&m.val[s], (1ULL << 63) | ((uint64_t)(origin & 1) << 16) | ((uint64_t)(dir & 1) << 8) | ((uint64_t)code << 4) | base, coop);
 			return;
 		}
 		if (cur != fh) continue;
@@ -1313,6 +1320,8 @@ struct SearchScratch {
 	MaskCache* mcache;     // neighbour masks of the vertices the searches have looked at (NULL: none)
 	SuccMemo memo;         // answers of successor() shared by all walkers; k0 == NULL: off
 	uint32_t n_memo_hits, n_memo_adds;
+	uint64_t* wstats;      // the engine's work counters (WSTAT_VERIFY: diagnosis mode of the memo); may be NULL
+	uint32_t origin;       // 1: the pre-search (diagnosis: who wrote a memo entry)
 	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
 	BulkScratch* bulk;
 	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
@@ -1919,9 +1928,12 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	// vertex's two UNMASKED rolling hashes: they stand for the whole oriented k-mer, positions under
 	// a '0' included, which is what the search's later steps depend on.)
 	const bool use_memo = sc.memo.k0 != nullptr && trim == p.trim && (mask & (mask - 1));
+	int verify_hit = -1;
 	if (use_memo) {
 		const int hit = memo_find(sc.memo, u.fh, u.rh, dir);
-		if (hit >= 0) {
+		const uint64_t vmode = (hit >= 0 && sc.wstats) ? ld_coherent(&sc.wstats[WSTAT_VERIFY]) : 0; // 1: walkers recompute and compare, 2: the pre-search does
+		if (vmode && vmode == 1 + sc.origin) verify_hit = memo_find(sc.memo, u.fh, u.rh, dir, true);
+		else if (hit >= 0) {
 			sc.n_memo_hits++;
 			const int code = hit >> 4;
 			const unsigned b = (unsigned)hit & 3u;
@@ -1930,11 +1942,20 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 		}
 	}
 	auto answer = [&](int code) -> int {
-		if (use_memo) {
+		if (use_memo && !sc.overflow) { // (a search that ran out of stack answers anything: its walker is restarted)
 			// the successor's base: the last (SENSE) or first (ANTISENSE) base of vout
 			const unsigned b = (code == ER_LENGTH_LIMIT || code == ER_AMBI_OUT) ? kmer_get(vout.s, sense == SENSE ? p.k - 1 : 0u) : 0u;
-			memo_add(sc.memo, u.fh, u.rh, dir, (unsigned)code, b, sc.coop);
-			sc.n_memo_adds++;
+			if (verify_hit >= 0) {
+				sc.n_memo_hits++;
+				if (((unsigned)verify_hit & 0xFFu) != (((unsigned)code << 4) | b)) {
+					wu_atomic_add_u64(&sc.wstats[WSTAT_MEMO_BAD], 1, sc.coop);
+					wu_st_coherent(&sc.wstats[WSTAT_BAD0], u.fh, sc.coop); wu_st_coherent(&sc.wstats[WSTAT_BAD1], u.rh, sc.coop);
+					wu_st_coherent(&sc.wstats[WSTAT_BAD2], ((uint64_t)dir << 60) | ((uint64_t)mask << 52) | ((uint64_t)sc.origin << 48) | ((uint64_t)verify_hit << 20) | ((unsigned)code << 4) | b, sc.coop);
+				}
+			} else {
+				memo_add(sc.memo, u.fh, u.rh, dir, (unsigned)code, b, sc.coop, sc.origin);
+				sc.n_memo_adds++;
+			}
 		}
 		return code;
 	};

@@ -48,6 +48,8 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
+	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
+	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
@@ -925,7 +927,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.tbk_cap = 0; sc.coop = false;
 		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
-		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
+		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = nullptr; sc.origin = 0; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
@@ -1073,6 +1075,75 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 		env->fast_bytes = fast_bytes - a;
 		env->coop = coop;
 		walk_read<NW>(*env, list[i], slot);
+	}
+};
+
+// ---- pre-search (presearch_one, abg_walk.h).  Scan: one wave per candidate about to be walked, one
+// k-mer of its read per lane: the solid masks of the vertex's neighbours behind and ahead, and for
+// every side with two or more of them -- where successor() has to search (ExtendPath.h:314-362) --
+// a request, unless the memo has the answer or another lane asked first (a lossy set of tags: a
+// lost tag costs a duplicate search, nothing else).  The vertices are taken in the READ's
+// orientation, which is the orientation its own walker meets them in.
+template <int NW>
+struct FPresearchScan {
+	Params p; Batch b; const uint8_t* cnt; const uint32_t* cand_read; const uint32_t* list;
+	SuccMemo memo; uint64_t* tags; uint64_t tag_mask, gen; // (gen: which filling of the memo the tags refer to)
+	PreReq<NW>* req; uint32_t* req_n; uint32_t req_cap;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint64_t r = cand_read[list[i]];
+		const uint32_t L = b.len[r];
+		if (L < p.k) return;
+		const uint32_t nk = L - p.k + 1;
+		const uint64_t woff = b.woff[r];
+		const SeedTabs tabs = seed_tabs(p);
+		for (uint32_t j0 = 0; j0 < nk; j0 += nlanes) {
+			const uint32_t j = j0 + lane;
+			Vtx<NW> u;
+			unsigned want[2] = { 0, 0 };
+			if (j < nk) {
+				u.s = window_kmer<NW>(b.words, woff, j, p.k);
+				kmer_hashes(u.s, p.k, u.fh, u.rh);
+				vtx_set_d(u, 0, 0);
+				for (int dir = 0; dir < 2; dir++) {
+					const unsigned mask = nbr_mask_lean<NW, false>(p, tabs, cnt, u, dir == FORWARD ? SENSE : ANTISENSE);
+					if (!(mask & (mask - 1))) continue;
+					if (memo_find(memo, u.fh, u.rh, dir) >= 0) continue;
+					uint64_t tag = (u.fh ^ (u.rh * 0x9E3779B97F4A7C15ULL)) + (uint64_t)dir + gen * 0xD1B54A32D192ED03ULL;
+					tag ^= tag >> 31; tag *= 0xD6E8FEB86659FD93ULL; tag ^= tag >> 29;
+					if (atomic_exch_u64(&tags[tag & tag_mask], tag) == tag) continue;
+					want[dir] = mask;
+				}
+			}
+			for (int dir = 0; dir < 2; dir++) {
+				const uint32_t slot = wave_append_slot(req_n, want[dir] != 0);
+				if (want[dir] && slot < req_cap) {
+					PreReq<NW>& q = req[slot];
+#pragma unroll
+					for (int w = 0; w < KW<NW>; w++) q.w[w] = u.s.w[w];
+					q.fh = u.fh; q.rh = u.rh; q.dir = (uint32_t)dir; q.mask = want[dir];
+				}
+			}
+		}
+	}
+};
+template <int NW>
+struct FPresearch { // one request per item, launched like the walkers (FWalk): a wave and its fast memory each
+	WalkEnv<NW> e; const PreReq<NW>* req;
+	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes, bool coop)
+	{
+		WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
+		const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
+		*env = e;
+		env->mcache = nullptr;
+		if (fast_bytes >= WALK_FAST_WITH_CACHE) {
+			fast_bytes -= (uint32_t)sizeof(MaskCache);
+			env->mcache = (MaskCache*)((char*)fast + fast_bytes);
+		}
+		env->fast = (char*)fast + a;
+		env->fast_bytes = fast_bytes - a;
+		env->coop = coop;
+		presearch_one<NW>(*env, req[i], slot);
 	}
 };
 
@@ -1995,6 +2066,7 @@ class Engine {
 		for (int i = 0; i < MAX_CTX; i++) { use_ctx(i); free_walk(); }
 		if (cend_.hmin) free_tab(cend_);
 		if (memo_tab_.hmin) free_tab(memo_tab_);
+		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); be_.free(pre_tags_); }
 		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
@@ -2019,7 +2091,7 @@ class Engine {
 			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
 		}
 		cend_count_ = 0;
-		if (wstats_) be_.memset(wstats_, 0, WSTAT_N * 8);
+		if (wstats_) clear_wstats();
 		ovf_seen_[0] = ovf_seen_[1] = 0;
 		if (gtab_.hmin) { free_tab(gtab_); gtab_ = WalkTab{ nullptr, nullptr, nullptr, 0 }; gtab_used_ = 0; }
 	}
@@ -2327,6 +2399,7 @@ class Engine {
 			be_.memset(memo_tab_.hmax, 0xFF, (memo_tab_.mask + 1) * 8); // (a reader that sees an entry's value before its second key word sees "no key")
 			be_.memset(memo_tab_.meta, 0, (memo_tab_.mask + 1) * 8);
 			memo_valid_ = true;
+			memo_gen_++;
 		}
 		memo_ = SuccMemo{ memo_tab_.hmin, memo_tab_.hmax, memo_tab_.meta, memo_tab_.mask };
 	}
@@ -2370,9 +2443,14 @@ class Engine {
 		if (last_candidates_ < cfg_.p2_starved) return std::min<uint64_t>(p2_batch_ * cfg_.p2_starved_growth, 8 * cfg_.p2_max_batch);
 		return std::min<uint64_t>(p2_batch_ * cfg_.p2_growth, cfg_.p2_max_batch);
 	}
+	void clear_wstats()
+	{
+		be_.memset(wstats_, 0, WSTAT_N * 8);
+		if (const char* e = getenv("ABG_MEMO_VERIFY")) { const uint64_t mode = strtoull(e, 0, 10); be_.h2d(wstats_ + WSTAT_VERIFY, &mode, 8); } // diagnosis: memo hits are recomputed
+	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
 	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
-	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0; };
+	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, pre_requests = 0, pre_adds = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -2381,6 +2459,12 @@ class Engine {
 			be_.d2h(v, wstats_, sizeof v);
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
+			s.pre_requests = pre_requests_; s.pre_adds = v[WSTAT_PRE_ADDS];
+			if (v[WSTAT_MEMO_BAD])
+				fprintf(stderr, "abyss_amd: ABG_MEMO_VERIFY: %llu memo hits differ from the recomputed answer; last: fh %016llx rh %016llx dir %llu mask %llx checked-by %s memo %03llx (written by %s) computed %03llx\n",
+				    (unsigned long long)v[WSTAT_MEMO_BAD], (unsigned long long)v[WSTAT_BAD0], (unsigned long long)v[WSTAT_BAD1], (unsigned long long)(v[WSTAT_BAD2] >> 60),
+				    (unsigned long long)((v[WSTAT_BAD2] >> 52) & 0xF), ((v[WSTAT_BAD2] >> 48) & 1) ? "pre-search" : "walker",
+				    (unsigned long long)((v[WSTAT_BAD2] >> 20) & 0xFF), ((v[WSTAT_BAD2] >> 36) & 1) ? "pre-search" : "walker", (unsigned long long)(v[WSTAT_BAD2] & 0xFFF));
 		}
 		s.guide_slots = guide_slots_;
 		return s;
@@ -2487,7 +2571,7 @@ class Engine {
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
-	SuccMemo memo_{ nullptr, nullptr, nullptr, 0 }; WalkTab memo_tab_{ nullptr, nullptr, nullptr, 0 }; bool memo_valid_ = false; // (valid: filled against the solid filter as it is now)
+	SuccMemo memo_{ nullptr, nullptr, nullptr, 0 }; WalkTab memo_tab_{ nullptr, nullptr, nullptr, 0 }; bool memo_valid_ = false; uint64_t memo_gen_ = 0; // (valid: filled against the solid filter as it is now)
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
@@ -2907,7 +2991,7 @@ class Engine {
 		wclaims_ = (uint32_t*)be_.alloc(4ull << cfg_.wclaim_log2);
 		la_pool_ = (VKey*)be_.alloc((uint64_t)wslots_ * LA_MAX_VISITED * sizeof(VKey));
 		bulk_pool_ = (BulkScratch*)be_.alloc((uint64_t)wslots_ * sizeof(BulkScratch));
-		if (!wstats_) { wstats_ = (uint64_t*)be_.alloc(WSTAT_N * 8); be_.memset(wstats_, 0, WSTAT_N * 8); }
+		if (!wstats_) { wstats_ = (uint64_t*)be_.alloc(WSTAT_N * 8); clear_wstats(); }
 		walk_tb_cap_ = cfg_.tb_cap;
 		walk_buf_cap_ = cfg_.buf_cap;
 		alloc_walk_scratch();
@@ -3628,6 +3712,37 @@ class Engine {
 		r.round_started = true;
 		predict_and_walk<NW>(r, ci, async);
 	}
+	// The successor() searches the walkers of `list` are about to ask for at the k-mers of their own
+	// reads, answered ahead of them, one search per wave (FPresearchScan, presearch_one).
+	template <int NW>
+	void presearch(const WalkEnv<NW>& env, const uint32_t* list_d, uint32_t n)
+	{
+		if constexpr (MASKED_BUILD<NW>) return;
+		if (!cfg_.presearch || !memo_.k0 || !n || p_.trim < 2) return;
+		const uint32_t cap = cfg_.presearch_cap;
+		if (!pre_req_) {
+			pre_req_ = be_.alloc((uint64_t)cap * (8ull * MAX_NW + 24)); // (PreReq of the widest k-mer)
+			pre_n_d_ = (uint32_t*)be_.alloc(8);
+			pre_tags_ = (uint64_t*)be_.alloc(8ull << PRE_TAG_LOG2);
+			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
+		}
+		be_.memset(pre_n_d_, 0, 8);
+		FPresearchScan<NW> fs{ p_, env.batch, cnt_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
+			(PreReq<NW>*)pre_req_, pre_n_d_, cap };
+		be_.launch_wave(n, fs, "presearch_scan");
+		uint32_t nreq = 0;
+		be_.d2h(&nreq, pre_n_d_, 4);
+		nreq = std::min(nreq, cap);
+		if (!nreq) return;
+		pre_requests_ += nreq;
+		FPresearch<NW> fp{ env, (const PreReq<NW>*)pre_req_ };
+		uint32_t slots = wslots_;
+		if (const char* e = getenv("ABG_PRESEARCH_SLOTS")) slots = std::max(1, std::min<int>(atoi(e), (int)wslots_)); // (diagnosis)
+		be_.launch_walkers(nreq, fp, slots, "presearch", 0, false);
+	}
+	void* pre_req_ = nullptr; uint32_t* pre_n_d_ = nullptr; uint64_t* pre_tags_ = nullptr; uint64_t pre_requests_ = 0;
+	static constexpr uint32_t PRE_TAG_LOG2 = 22;
+
 	// stage 2: the candidates without a result that lower reads will not cover are walked
 	template <int NW>
 	void predict_and_walk(BatchRun& r, int ci, bool async)
@@ -3656,6 +3771,7 @@ class Engine {
 		env.owner_base = r.owner_next;
 		r.owner_next += nc;
 		FWalk<NW> fw{ env, r.need_d };
+		if (!async) presearch<NW>(env, r.need_d, r.nneed);
 		if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk", ci, async);
 		r.pending = true;

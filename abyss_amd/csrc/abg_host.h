@@ -91,6 +91,7 @@ class Session {
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
+		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
 		if (const char* e = getenv("ABG_MEMO")) cfg.memo = atoi(e) != 0; // shared answers of successor()
 		if (const char* e = getenv("ABG_PIPELINE")) cfg.pipeline_depth = (uint32_t)std::max(1, atoi(e)); // batches of PASS 2 in flight
 		if (const char* e = getenv("ABG_P2_MAX_CANDIDATES")) cfg.p2_max_candidates = (uint32_t)std::max(1, atoi(e));

@@ -753,23 +753,21 @@ ABG_HDN bool ambiguous2(const Params& p, const uint8_t* cnt, const Vtx<NW>& u, c
 	return r == ER_AMBI_OUT || (r == ER_LENGTH_LIMIT && !vtx_equal(p, v, expected));
 }
 
-// One candidate read: the loop of processRead (bloom-dbg.h:839-879).
+// A walker's scratch.  The search scratch and the path state are handed by reference to out-of-line
+// functions, so they live in memory.  As locals that is per-lane scratch: 64 copies per cooperative
+// wave and a 256-byte transaction per dword touched.  They are carved out of the walker's fast
+// memory (LDS on the device) instead: one copy per wave, read by broadcast; the rest of it is the
+// fast tier of the trueBranch stack.  Shared by walk_read and presearch_one.
 template <int NW>
-ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
+ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& scp, WalkState<NW>*& wp)
 {
-	const Params& p = e.p;
-	const unsigned k = p.k;
-	// The search scratch and the path state are handed by reference to out-of-line functions, so
-	// they live in memory.  As locals that is per-lane scratch: 64 copies per cooperative wave
-	// and a 256-byte transaction per dword touched.  They are carved out of the walker's fast
-	// memory (LDS on the device) instead: one copy per wave, read by broadcast; the rest of it
-	// is the fast tier of the trueBranch stack.
 	char* fast = (char*)e.fast;
 	uint32_t fast_bytes = e.fast_bytes;
 	const uint32_t sc_bytes = (uint32_t)((sizeof(SearchScratch<NW>) + 15) & ~15ull);
 	const uint32_t ws_bytes = (uint32_t)((sizeof(WalkState<NW>) + 15) & ~15ull);
 	SearchScratch<NW>& sc = *(SearchScratch<NW>*)fast;
 	WalkState<NW>& w = *(WalkState<NW>*)(fast + sc_bytes);
+	scp = &sc; wp = &w;
 	fast += sc_bytes + ws_bytes; fast_bytes -= sc_bytes + ws_bytes;
 	sc.tb = e.tb_pool + (uint64_t)slot * e.tb_cap;
 	sc.tb_keys = e.tbk_pool + (uint64_t)slot * e.tb_cap;
@@ -791,7 +789,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		fast += LA_FAST * sizeof(VKey); fast_bytes -= LA_FAST * (uint32_t)sizeof(VKey);
 	}
 	sc.guide = e.guide; sc.bulk = w.bulk;
-	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0;
+	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = e.wstats; sc.origin = 0;
 	sc.mcache = e.mcache;
 	if (!w.bulk) sc.guide.tab = nullptr;
 	{
@@ -809,6 +807,48 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
+}
+
+// One request of the pre-search (FPresearchScan, abg_engine.h): successor(u, dir) of a vertex a
+// walker of the coming launch will most likely ask for, computed ahead and left in the memo.  The
+// walkers of a read in a tangle run dozens of these searches one after the other, and a launch lasts
+// as long as its slowest walker; run ahead, one search per wave, they take as long as ONE search.
+// successor() is a pure function of (u, dir) and the solid filter (SuccMemo), so whoever computes an
+// answer computes the same one: the pre-search changes when an answer is computed, never what it is.
+template <int NW>
+struct PreReq { uint64_t w[KW<NW>]; uint64_t fh, rh; uint32_t dir, mask; };
+template <int NW>
+ABG_HDN void presearch_one(WalkEnv<NW>& e, const PreReq<NW>& q, uint32_t slot)
+{
+	SearchScratch<NW>* scp; WalkState<NW>* wp;
+	walker_scratch(e, slot, scp, wp);
+	SearchScratch<NW>& sc = *scp;
+	Vtx<NW> u;
+#pragma unroll
+	for (int j = 0; j < KW<NW>; j++) u.s.w[j] = q.w[j];
+	u.fh = q.fh; u.rh = q.rh;
+	vtx_set_d(u, 0, 0); // (requests are only made without a spaced seed)
+	if (memo_find(e.memo, u.fh, u.rh, (int)q.dir) >= 0) return; // somebody was faster
+	sc.origin = 1;
+	Vtx<NW> vout;
+	successor_m(e.p, e.cnt, u, (int)q.dir, e.p.trim, q.mask, vout, sc);
+	if (e.wstats && ld_coherent(&e.wstats[WSTAT_VERIFY]) == 2) successor_m(e.p, e.cnt, u, (int)q.dir, e.p.trim, q.mask, vout, sc); // (diagnosis: the same search again)
+	if (e.wstats) {
+		wu_atomic_add_u64(&e.wstats[WSTAT_PRE_ADDS], sc.n_memo_adds, sc.coop);
+		wu_atomic_add_u64(&e.wstats[WSTAT_CHAIN_STEPS], sc.n_chain_steps, sc.coop);
+	}
+}
+
+// One candidate read: the loop of processRead (bloom-dbg.h:839-879).
+template <int NW>
+ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
+{
+	const Params& p = e.p;
+	const unsigned k = p.k;
+	SearchScratch<NW>* scp; WalkState<NW>* wp;
+	walker_scratch(e, slot, scp, wp);
+	SearchScratch<NW>& sc = *scp;
+	WalkState<NW>& w = *wp;
 #if defined(__HIP_DEVICE_COMPILE__)
 	const uint64_t t_start = wall_clock64();
 #else

@@ -293,7 +293,7 @@ def main() -> int:
         warm_prof = True
     names = ["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "guide_build",
              "hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
-             "insert_drain", "classify", "read_prep", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
+             "insert_drain", "classify", "read_prep", "presearch_scan", "presearch", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
              "share_fix",
              "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
@@ -338,7 +338,7 @@ def main() -> int:
                   (per_kmer_bases + 2 * H * share) * kmers_all),
         "classify": (["classify", "reclassify"],
                      (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share),
-        "walk": (["walk", "rewalk"], 8 * H * unitig_kmers * share),
+        "walk": (["presearch_scan", "presearch", "walk", "rewalk"], 8 * H * unitig_kmers * share),
         "commit": (["contig_prep", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin", "pc_decide",
                     "pc_break", "pc_apply", "pc_write"], 4 * H * unitig_kmers),
     }
