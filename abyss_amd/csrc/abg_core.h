@@ -160,7 +160,7 @@ struct Params {
 	uint32_t kc;       // minimum count threshold (--kc)
 	uint32_t trim;     // max branch length to trim (-t)
 	uint32_t nw;       // ceil(k / 32)
-	uint32_t pad_;
+	uint32_t solid_bits; // PASS 2: the `cnt` handed to the solid-filter probes is the bit plane "counter >= kc" (probe_c)
 	Mod64 mod;         // counters == visited bits (bloom-dbg.h:910)
 	uint64_t kmul;     // k * multiSeed, for NTE64 (nthash.hpp:337-342)
 	uint64_t seed_k[4];     // srol^k(seed[b])
@@ -174,7 +174,7 @@ struct Params {
 inline Params make_params(uint32_t k, uint32_t nh, uint32_t kc, uint32_t trim, uint64_t m)
 {
 	Params p;
-	p.k = k; p.nh = nh; p.kc = kc; p.trim = trim; p.nw = (k + 31) / 32; p.pad_ = 0;
+	p.k = k; p.nh = nh; p.kc = kc; p.trim = trim; p.nw = (k + 31) / 32; p.solid_bits = 0;
 	p.mod = make_mod64(m);
 	p.kmul = (uint64_t)k * MULTISEED;
 	for (unsigned b = 0; b < 4; b++) {
@@ -230,6 +230,18 @@ ABG_HD uint64_t hash_i(const Params& p, uint64_t h, unsigned i)
 ABG_HD uint64_t pos_i(const Params& p, uint64_t h, unsigned i)
 {
 	return mod64(p.mod, hash_i(p, h, i));
+}
+// One probe of the solid filter as PASS 2 makes them: every caller only ever compares the counter
+// with kc (CountingBloomFilter::contains with a threshold, CountingBloomFilter.hpp:169-184).  Once
+// PASS 1 is over that is ONE BIT per counter, so the engine hands PASS 2 the bit plane
+// "counter >= kc" (Engine::solid_plane) in place of the counters: an eighth of the bytes, i.e. a working
+// set of m/8 bytes for the walkers' and the classification's random probes (238 MB for B=2G: inside the
+// 256 MB Infinity Cache) instead of m.  Returns a value to compare with kc: the counter itself, or
+// 255 / 0 from the plane.  (Coverage sums -- solid_min_count -- keep reading the counters.)
+ABG_HD unsigned probe_c(const Params& p, const uint8_t* __restrict__ cnt, uint64_t pos)
+{
+	if (p.solid_bits) return ((cnt[pos >> 3] >> (pos & 7)) & 1u) ? 255u : 0u;
+	return cnt[pos];
 }
 
 // ------------------------------------------------------------ 2-bit k-mers
@@ -586,7 +598,7 @@ ABG_HD bool solid_contains(const Params& p, const uint8_t* __restrict__ cnt, uin
 {
 	bool ok = true;
 	for (unsigned i = 0; i < p.nh; i++)
-		ok = ok & (cnt[pos_i(p, h, i)] >= p.kc);
+		ok = ok & (probe_c(p, cnt, pos_i(p, h, i)) >= p.kc);
 	return ok;
 }
 // CountingBloomFilter::minCount (CountingBloomFilter.hpp:53-64)
@@ -694,7 +706,7 @@ template <bool COOP> ABG_HD Params uniform_params(const Params& p)
 {
 	Params u;
 	u.k = uni32<COOP>(p.k); u.nh = uni32<COOP>(p.nh); u.kc = uni32<COOP>(p.kc);
-	u.trim = uni32<COOP>(p.trim); u.nw = uni32<COOP>(p.nw);
+	u.trim = uni32<COOP>(p.trim); u.nw = uni32<COOP>(p.nw); u.solid_bits = uni32<COOP>(p.solid_bits);
 	u.mod.m = uni64<COOP>(p.mod.m); u.mod.magic = uni64<COOP>(p.mod.magic);
 	u.mod.shift = uni32<COOP>(p.mod.shift); u.mod.pow2 = uni32<COOP>(p.mod.pow2);
 	u.kmul = uni64<COOP>(p.kmul);
@@ -738,7 +750,7 @@ ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, co
 		for (unsigned q = 1; q < 8; q++) hb = (b == q) ? h[q] : hb;
 		for (unsigned base = 0; base < p.nh; base += 8) {
 			bool bad = false;
-			if (base + i < p.nh) bad = cnt[pos_i(p, hb, base + i)] < p.kc;
+			if (base + i < p.nh) bad = probe_c(p, cnt, pos_i(p, hb, base + i)) < p.kc;
 			uint64_t m = wave_ballot(bad);
 #pragma unroll
 			for (unsigned q = 0; q < 8; q++)
@@ -753,7 +765,7 @@ ABG_HD unsigned solid_mask8(const Params& p, const uint8_t* __restrict__ cnt, co
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++) {
 				unsigned ii = base + i < p.nh ? base + i : 0; // surplus slots re-probe hash 0
-				c[b][i] = cnt[pos_i(p, h[b], ii)];
+				c[b][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h[b], ii));
 			}
 		}
 #pragma unroll
@@ -779,7 +791,7 @@ ABG_HD Probe8 probe8_issue(const Params& p, const uint8_t* __restrict__ cnt, con
 	Probe8 r;
 	r.active = i < p.nh;
 	r.c = 255;
-	if (r.active) r.c = cnt[pos_i(p, hb, i)];
+	if (r.active) r.c = (uint8_t)probe_c(p, cnt, pos_i(p, hb, i));
 	return r;
 }
 ABG_HD unsigned probe8_collect(const Params& p, const Probe8& r)
@@ -809,7 +821,7 @@ ABG_HD unsigned solid_mask4(const Params& p, const uint8_t* __restrict__ cnt, co
 #pragma unroll
 			for (unsigned i = 0; i < 4; i++) {
 				unsigned ii = base + i < p.nh ? base + i : 0;
-				c[b][i] = cnt[pos_i(p, h[b], ii)];
+				c[b][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h[b], ii));
 			}
 		}
 #pragma unroll
@@ -961,7 +973,7 @@ ABG_HD unsigned nbr_mask_lean(const Params& p, const SeedTabs& t, const uint8_t*
 		const uint64_t h = rh < fh ? rh : fh;
 		for (unsigned base = 0; base < p.nh; base += 8) {
 			bool bad = false;
-			if (lane < 32 && base + i < p.nh) bad = cnt[pos_i(p, h, base + i)] < p.kc;
+			if (lane < 32 && base + i < p.nh) bad = probe_c(p, cnt, pos_i(p, h, base + i)) < p.kc;
 			const uint64_t m = wave_ballot(bad);
 #pragma unroll
 			for (unsigned q = 0; q < 4; q++)
@@ -1012,7 +1024,7 @@ ABG_HD unsigned nbr_mask_cached(const Params& p, const SeedTabs& t, const uint8_
 		nbr_hash(t, s ? ANTISENSE : SENSE, s ? fb_a : fb_s, s ? rb_a : rb_s, b, fh, rh);
 		const uint64_t h = rh < fh ? rh : fh;
 		bool bad = false;
-		if (i < p.nh) bad = cnt[pos_i(p, h, i)] < p.kc;
+		if (i < p.nh) bad = probe_c(p, cnt, pos_i(p, h, i)) < p.kc;
 		const uint64_t bm = wave_ballot(bad);
 #pragma unroll
 		for (unsigned q = 0; q < 8; q++)
@@ -1680,7 +1692,7 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 					nfh ^= my_ndf; nrh ^= my_ndr;
 					const uint64_t h = nrh < nfh ? nrh : nfh;
 #pragma unroll
-					for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
+					for (unsigned i = 0; i < 4; i++) c[q][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h, base + i < p.nh ? base + i : 0u));
 				}
 #pragma unroll
 				for (unsigned q = 0; q < 4; q++) {
@@ -1874,7 +1886,7 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 						nbr_hash(tabs, sense, fb, rb, b, fh, rh);
 						fh ^= ndf; rh ^= ndr;
 						bool bad = false;
-						if (i < p.nh) bad = cnt[pos_i(p, rh < fh ? rh : fh, i)] < p.kc;
+						if (i < p.nh) bad = probe_c(p, cnt, pos_i(p, rh < fh ? rh : fh, i)) < p.kc;
 						const unsigned gb = (unsigned)((wave_ballot(bad) >> (16 * grp)) & 0xFFFFull);
 #pragma unroll
 						for (unsigned q = 0; q < 4; q++) if (((gb >> (4 * q)) & 0xFu) == 0) cm |= 1u << q;

@@ -22,6 +22,22 @@
 
 namespace abg {
 
+// A failure inside the engine or its backend -- out of device memory, a capacity the data exceeds,
+// a collective that failed, an invariant that does not hold -- is thrown as a Failure and turned
+// into the C ABI's return code and abg_last_error() text at the boundary (abg_kernels.hip: guarded):
+// the library never exits the host process (the reference's binaries print and exit,
+// Common/IOUtil.h:14-22; that is the host binary's decision here too).  After ABG_ENOMEM /
+// ABG_EINTERNAL a context is only good for abg_destroy.
+struct Failure { int code; std::string msg; };
+constexpr int FAIL_NOMEM = -3, FAIL_INTERNAL = -4; // == ABG_ENOMEM, ABG_EINTERNAL (checked in abg_host.h)
+[[noreturn]] inline void fail_now(int code, const std::string& msg) { throw Failure{ code, msg }; }
+inline std::string strf(const char* fmt, unsigned long long a = 0, unsigned long long b = 0)
+{
+	char buf[256];
+	snprintf(buf, sizeof buf, fmt, a, b);
+	return buf;
+}
+
 struct Config {
 	uint32_t k = 0, nh = 4, kc = 2, trim = 0;
 	uint64_t counters = 0;            // number of uint8 counters == visited bits (cascade mode: bits per level)
@@ -48,6 +64,7 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
+	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
 	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
 	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
@@ -478,6 +495,18 @@ struct FCutRanges {
 			s = e;
 		}
 		*count = r;
+	}
+};
+struct FSolidPlane { // bit i of the plane = counter i >= kc; one item per 64 counters (m is a multiple of 64)
+	const uint64_t* cnt8; uint32_t kc; uint64_t* plane;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		uint64_t bits = 0;
+		for (unsigned w = 0; w < 8; w++) {
+			const uint64_t x = cnt8[i * 8 + w];
+			for (unsigned b = 0; b < 8; b++) bits |= (uint64_t)(((x >> (8 * b)) & 0xFFu) >= kc ? 1u : 0u) << (8 * w + b);
+		}
+		plane[i] = bits;
 	}
 };
 struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219-242), 8 counters per item
@@ -969,7 +998,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 #pragma unroll
 					for (unsigned t = 0; t < 4; t++) {
 						const uint64_t pos = pos_i(p, h[q], base + t < p.nh ? base + t : 0u);
-						c[q][t] = cnt[pos];
+						c[q][t] = (uint8_t)probe_c(p, cnt, pos);
 						w[q][t] = (uint8_t)((vis[pos >> 3] >> (pos & 7)) & 1u);
 					}
 				}
@@ -1044,7 +1073,7 @@ struct FGuideBuild {
 			uint64_t df = 0, dr = 0;
 			if constexpr (MASKED_BUILD<NW>) masked_terms(p, s, df, dr);
 			const uint64_t fs = fh ^ df, rs = rh ^ dr;
-			if (cnt[pos_i(p, rs < fs ? rs : fs, 0)] < p.kc) continue;
+			if (probe_c(p, cnt, pos_i(p, rs < fs ? rs : fs, 0)) < p.kc) continue;
 			tab[guide_slot(hm, mask)] = guide_pack(woff, j, nk, guide_tag(hm));
 		}
 	}
@@ -2066,6 +2095,7 @@ class Engine {
 		for (int i = 0; i < MAX_CTX; i++) { use_ctx(i); free_walk(); }
 		if (cend_.hmin) free_tab(cend_);
 		if (memo_tab_.hmin) free_tab(memo_tab_);
+		if (plane_) be_.free(plane_);
 		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); be_.free(pre_tags_); }
 		if (wstats_) be_.free(wstats_);
 	}
@@ -2081,7 +2111,7 @@ class Engine {
 		counters_ = Counters();
 		stats_ = Stats();
 		cnt_partial_ = false;
-		memo_valid_ = false;
+		memo_valid_ = false; plane_valid_ = false;
 		last_rounds_ = 0;
 		p2_batch_ = cfg_.p2_first_batch;
 		last_candidates_ = 0;
@@ -2098,7 +2128,7 @@ class Engine {
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	// (a partitioned run leaves only the rank's own range current until the shards are gathered)
-	uint8_t* counters_dev() { gather_counters(); memo_valid_ = false; /* (the caller may write) */ return cnt_; }
+	uint8_t* counters_dev() { gather_counters(); memo_valid_ = false; plane_valid_ = false; /* (the caller may write) */ return cnt_; }
 
 	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
 	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
@@ -2281,7 +2311,7 @@ class Engine {
 	void load_packed(const Batch& b, const std::vector<OpRange>& ranges)
 	{
 		ensure_insert();
-		memo_valid_ = false;
+		memo_valid_ = false; plane_valid_ = false;
 		last_rounds_ = 0;
 		// Tiled: hashing and binning a batch reads nothing but the reads, so the NEXT batch is hashed
 		// and binned on the side stream while this one's tiles are judged and applied and its left-over
@@ -2373,6 +2403,7 @@ class Engine {
 		// (PASS 1's bins and claim tables grow with the filter -- 60 GB at B=40G: PASS 2 gets that memory)
 		if (insert_scratch_bytes_ > cfg_.keep_insert_scratch_bytes) free_insert();
 		ensure_walk();
+		ensure_plane();
 		build_guide(b);
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
@@ -2392,7 +2423,7 @@ class Engine {
 			uint32_t log2 = cfg_.memo_log2;
 			if (!log2) { log2 = 16; while (log2 < 26 && (1ull << log2) < m_ / 128) log2++; }
 			alloc_tab(memo_tab_, log2);
-			memo_valid_ = false;
+			memo_valid_ = false; plane_valid_ = false;
 		}
 		if (!memo_valid_) {
 			be_.memset(memo_tab_.hmin, 0xFF, (memo_tab_.mask + 1) * 8);
@@ -2403,6 +2434,23 @@ class Engine {
 		}
 		memo_ = SuccMemo{ memo_tab_.hmin, memo_tab_.hmax, memo_tab_.meta, memo_tab_.mask };
 	}
+	// The solid filter as PASS 2 probes it (probe_c, abg_core.h): the bit plane "counter >= kc", built once
+	// the counters are final and kept until they change (the same events that empty the memo).
+	void ensure_plane()
+	{
+		p2_ = p_; cnt2_ = cnt_;
+		if (!cfg_.solid_plane || casc_.bits || (m_ & 63)) return;
+		if (!plane_) plane_ = (uint8_t*)be_.alloc(m_ / 8 + 64);
+		if (!plane_valid_) {
+			FSolidPlane f{ (const uint64_t*)cnt_, p_.kc, (uint64_t*)plane_ };
+			be_.launch(m_ / 64, f, "solid_plane");
+			plane_valid_ = true;
+		}
+		p2_.solid_bits = 1; cnt2_ = plane_;
+	}
+	uint8_t* plane_ = nullptr; bool plane_valid_ = false;
+	Params p2_; const uint8_t* cnt2_ = nullptr; // what the probing kernels of PASS 2 get: p_ / cnt_, or the plane
+
 	// The guide of the bulk steps for the reads of one assemble_packed call (see FGuideBuild):
 	// sized to the sampled reads' k-mers, of which the solid ones -- a genome's worth -- stay.
 	void build_guide(const Batch& b)
@@ -2425,7 +2473,7 @@ class Engine {
 		be_.memset(guide_tab_, 0, 8ull << log2);
 		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
 		dispatch_nw([&](auto nw) {
-			FGuideBuild<decltype(nw)::value> f{ p_, b, cnt_, guide_tab_, guide_.mask, cfg_.guide_stride };
+			FGuideBuild<decltype(nw)::value> f{ p2_, b, cnt2_, guide_tab_, guide_.mask, cfg_.guide_stride };
 			be_.launch_wave(sampled, f, "guide_build");
 		});
 		guide_.tab = guide_tab_;
@@ -2518,7 +2566,7 @@ class Engine {
 		be_.free(sh_words_); be_.free(sh_woff_); be_.free(sh_len_); be_.free(sh_koff_);
 		sh_words_ = nullptr;
 	}
-	void c_fail(const char* what) { fprintf(stderr, "abyss_amd: collective %s failed on rank %d\n", what, comm_.rank); abort(); }
+	void c_fail(const char* what) { fail_now(FAIL_INTERNAL, std::string("collective ") + what + " failed on rank " + std::to_string(comm_.rank)); }
 	// in place: rank q's part lives at buf + displs[q] (bytes); on return every rank holds all parts
 	void c_all_gather_v(void* buf, const uint64_t* counts, const uint64_t* displs)
 	{
@@ -2646,7 +2694,7 @@ class Engine {
 				uint32_t bad = 0;
 				be_.d2h(&bad, failed, 4);
 				be_.free(failed);
-				if (bad) { fprintf(stderr, "abyss_amd: graph table rehash failed\n"); abort(); }
+				if (bad) fail_now(FAIL_INTERNAL, "graph table rehash failed");
 				free_tab(gtab_);
 				gtab_ = bigger;
 			} else {
@@ -2728,7 +2776,7 @@ class Engine {
 				if (claim_[1] || log2 <= 16) break;
 				if (claim_[0]) be_.free(claim_[0]);
 			}
-			if (!claim_[1]) { fprintf(stderr, "abyss_amd: no device memory for the insert claim tables\n"); abort(); }
+			if (!claim_[1]) fail_now(FAIL_NOMEM, "no device memory for the insert claim tables");
 			claim_log2_ = log2;
 		}
 		for (int i = 0; i < 2; i++) {
@@ -2763,9 +2811,7 @@ class Engine {
 		uint64_t T = rg.k1 - rg.k0;
 		if (T == 0) return;
 		if (T > batch_ops_ || T >= 0xFFFFFFFFull) {
-			fprintf(stderr, "abyss_amd: a single sequence has more k-mers (%llu) than insert_batch_kmers\n",
-			    (unsigned long long)T);
-			abort();
+			fail_now(FAIL_INTERNAL, strf("a single sequence has more k-mers (%llu) than insert_batch_kmers", T));
 		}
 		// a view of sequences [s, e) whose op ids start at 0
 		Batch v = b;
@@ -3043,8 +3089,7 @@ class Engine {
 		walk_tb_cap_ *= 4;
 		walk_buf_cap_ *= 8;
 		if (walk_buf_cap_ > (1u << 28) || wtab_log2_ > 31) {
-			fprintf(stderr, "abyss_amd: a unitig exceeds the walker limits\n");
-			abort();
+			fail_now(FAIL_INTERNAL, "a unitig exceeds the walker limits");
 		}
 		// fewer walkers when each needs a lot of scratch
 		while ((uint64_t)wslots_ * walk_buf_cap_ > (8ull << 30) && wslots_ > 64) wslots_ /= 2;
@@ -3065,7 +3110,7 @@ class Engine {
 	WalkEnv<NW> make_env(const Batch& b, uint32_t* cand_d, uint32_t* status_d, uint32_t* first_d)
 	{
 		WalkEnv<NW> e;
-		e.p = p_; e.cnt = cnt_; e.batch = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
+		e.p = p2_; e.cnt = cnt2_; e.batch = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.tab = wtab_; e.claims = nullptr; e.claim_mask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1); e.owner_base = 0;
 		// scratch strides are sized for the largest TBFrame; a smaller NW fits more frames in them
 		e.tb_pool = (TBFrame<NW>*)tb_pool_;
@@ -3112,7 +3157,7 @@ class Engine {
 		be_.d2h(&cs, cstate_, sizeof cs);
 		counters_ = cs.counters;
 		cend_count_ = cs.cend_count;
-		if (cs.pad_) { fprintf(stderr, "abyss_amd: contigEndKmers table overflowed\n"); abort(); }
+		if (cs.pad_) fail_now(FAIL_INTERNAL, "contigEndKmers table overflowed");
 		return cs.break_at;
 	}
 
@@ -3194,7 +3239,7 @@ class Engine {
 		if (off[n] > (1u << T_TIME_BITS)) {
 			uint32_t keep = 1;
 			while (keep < n && off[keep + 1] <= (1u << T_TIME_BITS)) keep++;
-			if (off[keep] > (1u << T_TIME_BITS)) { fprintf(stderr, "abyss_amd: one read produced more contigs than a commit can order\n"); abort(); }
+			if (off[keep] > (1u << T_TIME_BITS)) fail_now(FAIL_INTERNAL, "one read produced more contigs than a commit can order");
 			n = keep; c_end = c_begin + n; e.c_end = c_end; e.brk = c_end;
 		}
 		be_.h2d(e.off, off.data(), (n + 1ull) * 4);
@@ -3254,7 +3299,7 @@ class Engine {
 		be_.d2h(c3.data(), e.cnt3, n * 8ull);
 		be_.d2h(act.data(), e.active, n);
 		be_.d2h(scal_h, e.scal, sizeof scal_h);
-		if (scal_h[4]) { fprintf(stderr, "abyss_amd: contigEndKmers table overflowed\n"); abort(); }
+		if (scal_h[4]) fail_now(FAIL_INTERNAL, "contigEndKmers table overflowed");
 		uint32_t orec = 0; uint64_t oid = 0, bases = 0, visited = 0;
 		for (uint32_t i = 0; i < n && c_begin + i < brk; i++) {
 			uint32_t r = c1[i], q = c2[i];
@@ -3393,7 +3438,7 @@ class Engine {
 		uint32_t bad = 0;
 		be_.d2h(&bad, failed, 4);
 		be_.free(failed);
-		if (bad) { fprintf(stderr, "abyss_amd: contigEndKmers rehash failed\n"); abort(); }
+		if (bad) fail_now(FAIL_INTERNAL, "contigEndKmers rehash failed");
 		free_tab(cend_);
 		cend_ = bigger;
 	}
@@ -3518,7 +3563,7 @@ class Engine {
 						if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
 						Batch vn = b;
 						vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
-						FClassify<NW> f{ p_, vn, 0, cnt_, vis_, result_d + nf, la_pool_c2_ };
+						FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_ };
 						be_.launch_slots_side(nn, f, cslots_, "classify");
 						pre_first_ = nf; pre_n_ = nn;
 					};
@@ -3539,8 +3584,7 @@ class Engine {
 			if (results_host) {
 				be_.d2h(results_host + r.first, r.res_d, r.n);
 				if (const void* left = memchr(results_host + r.first, RES_CANDIDATE, r.n)) {
-					fprintf(stderr, "abyss_amd: read %llu left unprocessed\n", (unsigned long long)((const uint8_t*)left - results_host));
-					abort();
+					fail_now(FAIL_INTERNAL, strf("read %llu left unprocessed", (unsigned long long)((const uint8_t*)left - results_host)));
 				}
 			}
 		}
@@ -3568,12 +3612,12 @@ class Engine {
 			const uint64_t R = (uint64_t)comm_.world;
 			std::vector<uint64_t> c(R), d(R);
 			for (uint64_t q = 0; q < R; q++) { d[q] = n * q / R; c[q] = n * (q + 1) / R - d[q]; }
-			FClassify<NW> f{ p_, v, d[comm_.rank], cnt_, vis_, res_d, la_pool_c_ };
+			FClassify<NW> f{ p2_, v, d[comm_.rank], cnt2_, vis_, res_d, la_pool_c_ };
 			be_.launch_slots(c[comm_.rank], f, cslots_, "classify");
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			be_.sync_side();
-			FClassify<NW> f{ p_, v, 0, cnt_, vis_, res_d, la_pool_c_ };
+			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_ };
 			be_.launch_slots(n, f, cslots_, "classify");
 		}
 		pre_n_ = 0;
@@ -3727,7 +3771,7 @@ class Engine {
 			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
 		}
 		be_.memset(pre_n_d_, 0, 8);
-		FPresearchScan<NW> fs{ p_, env.batch, cnt_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
+		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
 			(PreReq<NW>*)pre_req_, pre_n_d_, cap };
 		be_.launch_wave(n, fs, "presearch_scan");
 		uint32_t nreq = 0;
@@ -3809,8 +3853,7 @@ class Engine {
 					be_.d2h(&st, r.status_d + next, 4);
 					if (st == WS_OVERFLOW) { r.committed = next; r.overflow = true; break; }
 					if (next == r.committed && (st == WS_COMPLETE || r.force == next)) {
-						fprintf(stderr, "abyss_amd: commit made no progress at candidate %u (status %u)\n", next, st);
-						abort();
+						fail_now(FAIL_INTERNAL, strf("commit made no progress at candidate %llu (status %llu)", next, st));
 					}
 					r.force = next; // needed after all: walk it in the next iteration
 				}

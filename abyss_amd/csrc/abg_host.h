@@ -15,6 +15,8 @@
 #include <thread>
 
 namespace abg {
+static_assert(FAIL_NOMEM == ABG_ENOMEM && FAIL_INTERNAL == ABG_EINTERNAL, "Failure codes are the C ABI's");
+
 
 struct FContainsSolid { // CountingBloomFilter::contains (CountingBloomFilter.hpp:190-196) for every op
 	Params p; const uint64_t* h0; const uint8_t* cnt; uint8_t* out;
@@ -92,6 +94,7 @@ class Session {
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
+		if (const char* e = getenv("ABG_SOLID_PLANE")) cfg.solid_plane = atoi(e) != 0;
 		if (const char* e = getenv("ABG_MEMO")) cfg.memo = atoi(e) != 0; // shared answers of successor()
 		if (const char* e = getenv("ABG_PIPELINE")) cfg.pipeline_depth = (uint32_t)std::max(1, atoi(e)); // batches of PASS 2 in flight
 		if (const char* e = getenv("ABG_P2_MAX_CANDIDATES")) cfg.p2_max_candidates = (uint32_t)std::max(1, atoi(e));

@@ -194,6 +194,7 @@ struct HipBackend {
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint32_t)prop.multiProcessorCount;
 		if (hipStreamCreate(&stream) != hipSuccess) { reason = "hipStreamCreate failed"; return; }
+		if (const char* e = getenv("ABG_MEM_LIMIT_MB")) mem_limit = (size_t)strtoull(e, 0, 10) << 20;
 		{
 			// the side stream only fills gaps: lowest priority (ABG_SIDE_PRIORITY=0 turns that off)
 			int lo = 0, hi = 0;
@@ -228,8 +229,8 @@ struct HipBackend {
 	static void check(hipError_t e, const char* what)
 	{
 		if (e != hipSuccess) {
-			fprintf(stderr, "abyss_amd: %s failed: %s\n", what, hipGetErrorString(e));
-			abort();
+			(void)hipGetLastError();
+			abg::fail_now(e == hipErrorOutOfMemory ? abg::FAIL_NOMEM : abg::FAIL_INTERNAL, std::string(what) + " failed: " + hipGetErrorString(e));
 		}
 	}
 	// Scratch buffers come and go with every batch; hipMalloc / hipFree cost far more than the
@@ -241,11 +242,27 @@ struct HipBackend {
 	std::map<void*, size_t> cache_size;
 	size_t cache_held = 0;
 	// for optional big buffers: NULL instead of aborting when the device has no room
+	// ABG_MEM_LIMIT_MB: a device memory budget for this context (tests: "the device is too small" without
+	// filling a 288 GB device); a request that would exceed it fails like a hipMalloc that found no room
+	size_t mem_limit = 0, mem_used = 0;
+	std::map<void*, size_t> mem_size;
+	hipError_t dev_malloc(void** p, size_t n)
+	{
+		if (mem_limit && mem_used + n > mem_limit) return hipErrorOutOfMemory;
+		const hipError_t e = hipMalloc(p, n);
+		if (e == hipSuccess && mem_limit) { mem_used += n; mem_size[*p] = n; }
+		return e;
+	}
+	void dev_free(void* p)
+	{
+		if (mem_limit) { auto it = mem_size.find(p); if (it != mem_size.end()) { mem_used -= it->second; mem_size.erase(it); } }
+		hipFree(p);
+	}
 	void* try_alloc(size_t n)
 	{
 		void* p = nullptr;
 		hipSetDevice(device);
-		if (hipMalloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		if (dev_malloc(&p, n ? n : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 		if (getenv("ABG_MEM_DEBUG")) fprintf(stderr, "[mem] +%.2f GB (optional)\n", n / 1e9);
 		return p;
 	}
@@ -254,19 +271,22 @@ struct HipBackend {
 		void* p = nullptr;
 		hipSetDevice(device);
 		if (n > CACHE_MAX_BLOCK) {
-			hipError_t e = hipMalloc(&p, n);
+			hipError_t e = dev_malloc(&p, n);
 			if (e != hipSuccess) {
 				// (give back what the block cache holds and try once more before giving up)
 				(void)hipGetLastError();
 				drop_cache();
-				e = hipMalloc(&p, n);
+				e = dev_malloc(&p, n);
 			}
 			if (e != hipSuccess) {
 				size_t fr = 0, tot = 0;
 				(void)hipMemGetInfo(&fr, &tot);
-				fprintf(stderr, "abyss_amd: no device memory for a block of %.2f GB (%.2f of %.2f GB free)\n", n / 1e9, fr / 1e9, tot / 1e9);
+				char msg[200];
+				snprintf(msg, sizeof msg, "no device memory for a block of %.2f GB (%.2f of %.2f GB free%s)", n / 1e9, fr / 1e9, tot / 1e9,
+				    mem_limit ? ", ABG_MEM_LIMIT_MB in force" : "");
+				(void)hipGetLastError();
+				abg::fail_now(abg::FAIL_NOMEM, msg);
 			}
-			check(e, "hipMalloc");
 			static const bool mem_debug = getenv("ABG_MEM_DEBUG") != nullptr;
 			if (mem_debug) {
 				size_t fr = 0, tot = 0;
@@ -284,7 +304,7 @@ struct HipBackend {
 			cache_held -= sz;
 			return p;
 		}
-		check(hipMalloc(&p, sz), "hipMalloc");
+		check(dev_malloc(&p, sz), "hipMalloc");
 		cache_size[p] = sz;
 		return p;
 	}
@@ -299,13 +319,13 @@ struct HipBackend {
 		}
 		if (it != cache_size.end()) cache_size.erase(it);
 		hipStreamSynchronize(stream);
-		hipFree(p);
+		dev_free(p);
 	}
 	void drop_cache()
 	{
 		hipStreamSynchronize(stream);
 		for (auto& kv : cache_free)
-			for (void* q : kv.second) { cache_size.erase(q); hipFree(q); }
+			for (void* q : kv.second) { cache_size.erase(q); dev_free(q); }
 		cache_free.clear();
 		cache_held = 0;
 	}
@@ -673,6 +693,27 @@ struct abg_ctx {
 	explicit abg_ctx(int dev) : s(dev) {}
 };
 
+namespace {
+// The C ABI's promise -- a return code and abg_last_error(), never an exit: whatever the engine or the
+// backend throws on its way (abg::Failure, std::bad_alloc) ends here.
+template <class F>
+int guarded(abg_ctx* ctx, F&& body)
+{
+	try {
+		return body();
+	} catch (const abg::Failure& f) {
+		if (ctx) ctx->s.error = f.msg;
+		return f.code;
+	} catch (const std::bad_alloc&) {
+		if (ctx) ctx->s.error = "host memory exhausted";
+		return ABG_ENOMEM;
+	} catch (const std::exception& e) {
+		if (ctx) ctx->s.error = e.what();
+		return ABG_EINTERNAL;
+	}
+}
+} // namespace
+
 extern "C" {
 
 void abg_params_init(abg_params* p)
@@ -687,8 +728,10 @@ int abg_create(const abg_params* p, abg_ctx** out)
 {
 	if (!p || !out) return ABG_EINVAL;
 	*out = nullptr;
-	abg_ctx* c = new abg_ctx(p->device);
-	int rc = c->s.create(*p);
+	abg_ctx* c = nullptr;
+	int rc = guarded(nullptr, [&]() { c = new abg_ctx(p->device); return ABG_OK; });
+	if (rc != ABG_OK || !c) { std::lock_guard<std::mutex> g(g_err_mutex); g_create_error = "context construction failed"; return rc != ABG_OK ? rc : ABG_EINTERNAL; }
+	rc = guarded(c, [&]() { return c->s.create(*p); });
 	if (rc != ABG_OK) {
 		std::lock_guard<std::mutex> g(g_err_mutex);
 		g_create_error = c->s.error;
@@ -708,132 +751,170 @@ int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_
     uint64_t cap, uint64_t* n_out)
 {
 	if (!ctx || !seq || !n_out) return ABG_EINVAL;
-	return ctx->s.contains_seq(seq, len, pos_out, contains_out, cap, n_out);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.contains_seq(seq, len, pos_out, contains_out, cap, n_out);
+	});
 }
 
 int abg_reset(abg_ctx* ctx)
 {
 	if (!ctx) return ABG_EINVAL;
-	ctx->s.eng->reset();
-	ctx->s.be.sync();
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.eng->reset();
+		ctx->s.be.sync();
+		return ABG_OK;
+	});
 }
 
 int abg_filter_size(const abg_ctx* ctx, uint64_t* counters)
 {
 	if (!ctx || !counters) return ABG_EINVAL;
-	*counters = ctx->s.eng->size();
-	return ABG_OK;
+	return guarded((abg_ctx*)ctx, [&]() -> int {
+		*counters = ctx->s.eng->size();
+		return ABG_OK;
+	});
 }
 int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n)
 {
 	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
-	(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
-	return ctx->s.load_seqs(seqs, offsets, n);
+	return guarded(ctx, [&]() -> int {
+		(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
+		return ctx->s.load_seqs(seqs, offsets, n);
+	});
 }
 int abg_load_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
 {
 	if (!ctx || (n && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
-	return ctx->s.load_packed(d_words, d_woff, d_len, n);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.load_packed(d_words, d_woff, d_len, n);
+	});
 }
 int abg_counting_stats(abg_ctx* ctx, uint64_t* popcount, uint64_t* filtered_popcount)
 {
 	if (!ctx) return ABG_EINVAL;
-	uint64_t a = 0, b = 0;
-	ctx->s.eng->popcounts(&a, &b);
-	if (popcount) *popcount = a;
-	if (filtered_popcount) *filtered_popcount = b;
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		uint64_t a = 0, b = 0;
+		ctx->s.eng->popcounts(&a, &b);
+		if (popcount) *popcount = a;
+		if (filtered_popcount) *filtered_popcount = b;
+		return ABG_OK;
+	});
 }
 int abg_counters_export(abg_ctx* ctx, uint8_t* host_out)
 {
 	if (!ctx || !host_out || ctx->s.eng->cascade_mode()) return ABG_EINVAL;
-	ctx->s.be.d2h(host_out, ctx->s.eng->counters_dev(), ctx->s.eng->size());
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.d2h(host_out, ctx->s.eng->counters_dev(), ctx->s.eng->size());
+		return ABG_OK;
+	});
 }
 int abg_counters_import(abg_ctx* ctx, const uint8_t* host_in)
 {
 	if (!ctx || !host_in) return ABG_EINVAL;
-	ctx->s.be.h2d(ctx->s.eng->counters_dev(), host_in, ctx->s.eng->size());
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.h2d(ctx->s.eng->counters_dev(), host_in, ctx->s.eng->size());
+		return ABG_OK;
+	});
 }
 int abg_visited_export(abg_ctx* ctx, uint8_t* host_out)
 {
 	if (!ctx || !host_out) return ABG_EINVAL;
-	ctx->s.be.d2h(host_out, ctx->s.eng->visited_dev(), ctx->s.eng->visited_bytes());
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.d2h(host_out, ctx->s.eng->visited_dev(), ctx->s.eng->visited_bytes());
+		return ABG_OK;
+	});
 }
 int abg_visited_import(abg_ctx* ctx, const uint8_t* host_in)
 {
 	if (!ctx || !host_in) return ABG_EINVAL;
-	ctx->s.be.h2d(ctx->s.eng->visited_dev(), host_in, ctx->s.eng->visited_bytes());
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.h2d(ctx->s.eng->visited_dev(), host_in, ctx->s.eng->visited_bytes());
+		return ABG_OK;
+	});
 }
 int abg_assemble_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
     uint8_t* results, abg_contig_cb cb, void* user)
 {
 	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
-	return ctx->s.assemble_seqs(seqs, offsets, n, results, cb, user);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.assemble_seqs(seqs, offsets, n, results, cb, user);
+	});
 }
 int abg_assemble_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, const uint64_t* const* offsets,
     const uint64_t* n, uint8_t* results, abg_contig_cb cb, void* user)
 {
 	if (!ctx || (nchunks && (!seqs || !offsets || !n))) return ABG_EINVAL;
-	for (uint32_t c = 0; c < nchunks; c++) if (n[c] && (!seqs[c] || !offsets[c])) return ABG_EINVAL;
-	(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
-	return ctx->s.assemble_seqs_v(nchunks, seqs, offsets, n, results, cb, user);
+	return guarded(ctx, [&]() -> int {
+		for (uint32_t c = 0; c < nchunks; c++) if (n[c] && (!seqs[c] || !offsets[c])) return ABG_EINVAL;
+		(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
+		return ctx->s.assemble_seqs_v(nchunks, seqs, offsets, n, results, cb, user);
+	});
 }
 int abg_assemble_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff,
     const uint32_t* d_len, uint64_t n, uint8_t* results, abg_contig_cb cb, void* user)
 {
 	if (!ctx || (n && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
-	return ctx->s.assemble_packed(d_words, d_woff, d_len, n, results, cb, user);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.assemble_packed(d_words, d_woff, d_len, n, results, cb, user);
+	});
 }
 int abg_cascade_export(abg_ctx* ctx, uint32_t level, uint8_t* host_out)
 {
 	if (!ctx || !host_out || !ctx->s.eng->cascade_mode() || level >= ctx->s.eng->cascade_levels()) return ABG_EINVAL;
-	ctx->s.be.d2h(host_out, ctx->s.eng->cascade_level_dev(level), ctx->s.eng->size() / 8);
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.d2h(host_out, ctx->s.eng->cascade_level_dev(level), ctx->s.eng->size() / 8);
+		return ABG_OK;
+	});
 }
 int abg_get_counters(const abg_ctx* ctx, abg_counters* out)
 {
 	if (!ctx || !out) return ABG_EINVAL;
-	abg::Counters c = ctx->s.eng->counters();
-	out->solid_reads = c.solid_reads;
-	out->visited_reads = c.visited_reads;
-	out->reads_processed = c.reads_processed;
-	out->bases_assembled = c.bases_assembled;
-	out->next_contig_id = c.contig_id;
-	return ABG_OK;
+	return guarded((abg_ctx*)ctx, [&]() -> int {
+		abg::Counters c = ctx->s.eng->counters();
+		out->solid_reads = c.solid_reads;
+		out->visited_reads = c.visited_reads;
+		out->reads_processed = c.reads_processed;
+		out->bases_assembled = c.bases_assembled;
+		out->next_contig_id = c.contig_id;
+		return ABG_OK;
+	});
 }
 int abg_set_counters(abg_ctx* ctx, const abg_counters* in)
 {
 	if (!ctx || !in) return ABG_EINVAL;
-	abg::Counters c;
-	c.solid_reads = in->solid_reads;
-	c.visited_reads = in->visited_reads;
-	c.reads_processed = in->reads_processed;
-	c.bases_assembled = in->bases_assembled;
-	c.contig_id = in->next_contig_id;
-	ctx->s.eng->set_counters(c);
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		abg::Counters c;
+		c.solid_reads = in->solid_reads;
+		c.visited_reads = in->visited_reads;
+		c.reads_processed = in->reads_processed;
+		c.bases_assembled = in->bases_assembled;
+		c.contig_id = in->next_contig_id;
+		ctx->s.eng->set_counters(c);
+		return ABG_OK;
+	});
 }
 int abg_hash_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_out, uint64_t* hashes_out,
     uint64_t cap, uint64_t* n_out)
 {
 	if (!ctx || !seq || !n_out) return ABG_EINVAL;
-	return ctx->s.hash_seq(seq, len, pos_out, hashes_out, cap, n_out);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.hash_seq(seq, len, pos_out, hashes_out, cap, n_out);
+	});
 }
 int abg_attach_comm(abg_ctx* ctx, const abg_comm* comm)
 {
 	if (!ctx || !comm) return ABG_EINVAL;
-	return ctx->s.attach_comm(*comm);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.attach_comm(*comm);
+	});
 }
 int abg_share_reads(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len,
     uint64_t n_local, const uint32_t** g_words, const uint64_t** g_woff, const uint32_t** g_len, uint64_t* n_total)
 {
 	if (!ctx || !g_words || !g_woff || !g_len || !n_total || (n_local && (!d_words || !d_woff || !d_len))) return ABG_EINVAL;
-	return ctx->s.share_reads(d_words, d_woff, d_len, n_local, g_words, g_woff, g_len, n_total);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.share_reads(d_words, d_woff, d_len, n_local, g_words, g_woff, g_len, n_total);
+	});
 }
 int abg_rccl_unique_id(uint8_t id[128])
 {
@@ -882,68 +963,84 @@ int abg_rccl_comm_destroy(abg_comm* comm)
 int abg_dev_alloc(abg_ctx* ctx, uint64_t bytes, void** out)
 {
 	if (!ctx || !out) return ABG_EINVAL;
-	*out = ctx->s.be.try_alloc(bytes);
-	if (!*out) { ctx->s.error = "device allocation failed"; return ABG_ENOMEM; }
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		*out = ctx->s.be.try_alloc(bytes);
+		if (!*out) { ctx->s.error = "device allocation failed"; return ABG_ENOMEM; }
+		return ABG_OK;
+	});
 }
 int abg_dev_free(abg_ctx* ctx, void* ptr)
 {
 	if (!ctx) return ABG_EINVAL;
-	if (ptr) { ctx->s.be.sync(); hipFree(ptr); }
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		if (ptr) { ctx->s.be.sync(); hipFree(ptr); }
+		return ABG_OK;
+	});
 }
 int abg_dev_copy(abg_ctx* ctx, void* dst, const void* src, uint64_t n, int32_t kind)
 {
 	if (!ctx || (n && (!dst || !src)) || kind < 0 || kind > 2) return ABG_EINVAL;
-	if (kind == 0) ctx->s.be.h2d(dst, src, n);
-	else if (kind == 1) ctx->s.be.d2h(dst, src, n);
-	else { ctx->s.be.d2d(dst, src, n); ctx->s.be.sync(); }
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		if (kind == 0) ctx->s.be.h2d(dst, src, n);
+		else if (kind == 1) ctx->s.be.d2h(dst, src, n);
+		else { ctx->s.be.d2d(dst, src, n); ctx->s.be.sync(); }
+		return ABG_OK;
+	});
 }
 int abg_output_graph_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n,
     abg_text_cb cb, void* user, uint64_t* nodes, uint64_t* edges)
 {
 	if (!ctx || (n && (!seqs || !offsets))) return ABG_EINVAL;
-	return ctx->s.output_graph_seqs(seqs, offsets, n, cb, user, nodes, edges);
+	return guarded(ctx, [&]() -> int {
+		return ctx->s.output_graph_seqs(seqs, offsets, n, cb, user, nodes, edges);
+	});
 }
 int abg_profile_enable(abg_ctx* ctx, int on)
 {
 	if (!ctx) return ABG_EINVAL;
-	ctx->s.be.profiling = on != 0;
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.profiling = on != 0;
+		return ABG_OK;
+	});
 }
 int abg_profile_reset(abg_ctx* ctx)
 {
 	if (!ctx) return ABG_EINVAL;
-	ctx->s.be.prof.clear();
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		ctx->s.be.prof.clear();
+		return ABG_OK;
+	});
 }
 int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* launches)
 {
 	if (!ctx || !name) return ABG_EINVAL;
-	auto it = ctx->s.be.prof.find(name);
-	double ms = 0;
-	uint64_t n = 0;
-	if (it != ctx->s.be.prof.end()) { ms = it->second.ms; n = it->second.launches; }
-	if (total_ms) *total_ms = ms;
-	if (launches) *launches = n;
-	return ABG_OK;
+	return guarded(ctx, [&]() -> int {
+		auto it = ctx->s.be.prof.find(name);
+		double ms = 0;
+		uint64_t n = 0;
+		if (it != ctx->s.be.prof.end()) { ms = it->second.ms; n = it->second.launches; }
+		if (total_ms) *total_ms = ms;
+		if (launches) *launches = n;
+		return ABG_OK;
+	});
 }
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 {
 	if (!ctx || !out) return ABG_EINVAL;
-	auto s = ctx->s.eng->stats();
-	out->insert_rounds = s.insert_rounds;
-	out->walk_rounds = s.rounds;
-	out->candidates = s.candidates;
-	out->walked = s.walked;
-	out->rewalked = s.rewalked;
-	out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
-	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
-	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
-	out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
-	out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds;
-	return ABG_OK;
+	return guarded((abg_ctx*)ctx, [&]() -> int {
+		auto s = ctx->s.eng->stats();
+		out->insert_rounds = s.insert_rounds;
+		out->walk_rounds = s.rounds;
+		out->candidates = s.candidates;
+		out->walked = s.walked;
+		out->rewalked = s.rewalked;
+		out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
+		out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
+		out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
+		out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
+		out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds;
+		return ABG_OK;
+	});
 }
 
 } // extern "C"

@@ -337,7 +337,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 				nfh ^= q < 4 ? my_bdf : my_fdf; nrh ^= q < 4 ? my_bdr : my_fdr;
 				const uint64_t h = nrh < nfh ? nrh : nfh;
 #pragma unroll
-				for (unsigned i = 0; i < 4; i++) c[q][i] = cnt[pos_i(p, h, base + i < p.nh ? base + i : 0u)];
+				for (unsigned i = 0; i < 4; i++) c[q][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h, base + i < p.nh ? base + i : 0u));
 			}
 #pragma unroll
 			for (unsigned q = 0; q < 8; q++) {
@@ -553,7 +553,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 			const unsigned lane = lane_id(), q = lane >> 3, i = lane & 7;
 			const uint64_t h = nbr_hash_c(q < 4 ? bsense : fsense, q & 3u);
 			my_active = i < p.nh;
-			if (my_active) my_c = cnt[pos_i(p, h, i)];
+			if (my_active) my_c = (uint8_t)probe_c(p, cnt, pos_i(p, h, i));
 		}
 		const VKey hkey = vtx_ident(p, head);
 		ins = (int32_t)uni32<COOP>((uint32_t)wt_insert(tab, wt_key(hkey), owner, contig, COOP));

@@ -484,14 +484,16 @@ int main(int argc, char** argv)
 	bool keep = prebuilt.empty();
 	for (int i = optind; i < argc; ++i) if (!strcmp(argv[i], ":") || !strcmp(argv[i], "-")) keep = false;
 	size_t kept_bytes = 0;
-	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE);
+	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE) / gpus; // (every rank keeps its own copy)
 	// PASS 1 of a chunk runs on a thread of its own while the reader parses the next chunk (one chunk
 	// in flight: the chunks go in in order)
 	std::thread loader;
 	Chunk loading;
+	int load_rc = ABG_OK; // what the loader thread's call returned: looked at on THIS thread once it is joined
 	auto load_done = [&]() {
 		if (!loader.joinable()) return;
 		loader.join();
+		check(load_rc, ctx, "load"); // (exit() from the loader thread would run the static destructors beside live threads)
 		host_mark("chunk loaded");
 		if (keep) {
 			kept_bytes += loading.bytes();
@@ -508,7 +510,7 @@ int main(int argc, char** argv)
 		chunk.off.reserve(loading.off.size() + 1024); chunk.id_end.reserve(loading.id_end.size() + 1024); chunk.idbuf.reserve(loading.idbuf.size() + (1u << 20));
 		loader = std::thread([&]() {
 			const double tl = host_now();
-			check(abg_load_seqs(ctx, loading.seqs.data(), loading.off.data(), loading.n()), ctx, "load");
+			load_rc = abg_load_seqs(ctx, loading.seqs.data(), loading.off.data(), loading.n());
 			g_in_load += host_now() - tl;
 		});
 	};
@@ -555,7 +557,7 @@ int main(int argc, char** argv)
 		if (threads > 1 && !ckpt) { // compressed inputs inflate side by side, ahead of the reader (Prefetch)
 			std::vector<std::string> ins;
 			for (int i = optind; i < argc && strcmp(argv[i], ":"); ++i) ins.push_back(argv[i]);
-			abghost::Prefetch::get().start(ins);
+			abghost::Prefetch::get().start(ins, gpus);
 		}
 		chunk.seqs.reserve(CHUNK_BASES + (64u << 20));
 		for (int i = optind; i < argc; ++i) {

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <future>
 #include <map>
 #include <string>
@@ -289,9 +290,11 @@ class FastaReader {
 // Compressed inputs decompressed AHEAD: every one by a decompressor child of its own (gunzip -c
 // and the like, as Common/Uncompress.cpp runs them), each drained into memory by a thread of its
 // own, all at once -- the reference and the sequential reader below take the files one after the
-// other at the pace of one gunzip.  Only when the inputs, inflated, fit a quarter of the host's
-// memory (estimated at 8 x the compressed size); otherwise, and for whatever is asked for a
-// second time, the stream is read as it comes.
+// other at the pace of one gunzip.  Only when the inputs, inflated, fit this process's share of a
+// quarter of the host's memory (estimated at 8 x the compressed size; `share` = the ranks of a
+// --gpus run, every one of which reads every input); the estimate is backed by a hard cap on the
+// bytes actually inflated -- a file that inflates past the budget is dropped from the prefetch
+// and read as a stream like anything asked for a second time.
 class Prefetch {
   public:
 	static Prefetch& get() { static Prefetch p; return p; }
@@ -306,7 +309,7 @@ class Prefetch {
 		}
 		return false;
 	}
-	void start(const std::vector<std::string>& paths)
+	void start(const std::vector<std::string>& paths, unsigned share = 1)
 	{
 		uint64_t total = 0;
 		std::vector<std::string> todo;
@@ -319,7 +322,9 @@ class Prefetch {
 			todo.push_back(p);
 		}
 		const uint64_t ram = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
-		if (todo.empty() || total * 8 > ram / 4) return;
+		m_budget = ram / 4 / (share ? share : 1);
+		if (const char* e = getenv("ABG_PREFETCH_BUDGET_MB")) m_budget = strtoull(e, nullptr, 10) << 20; // (tests)
+		if (todo.empty() || total * 8 > m_budget) return;
 		for (auto& p : todo) {
 			const char* prog; const char* flag;
 			compressed(p, &prog, &flag);
@@ -335,19 +340,25 @@ class Prefetch {
 			close(fd[1]);
 			Item* it = new Item;
 			it->pid = pid;
-			it->th = std::thread([it, rfd = fd[0]]() {
+			it->th = std::thread([this, it, rfd = fd[0]]() {
 				std::string& d = it->data;
 				size_t have = 0;
+				bool over = false;
 				for (;;) {
 					if (d.size() - have < (8u << 20)) d.resize(d.size() + (64u << 20));
 					const ssize_t got = ::read(rfd, &d[have], d.size() - have);
 					if (got <= 0) break;
 					have += (size_t)got;
+					if (m_inflated.fetch_add((uint64_t)got) + (uint64_t)got > m_budget) { over = true; break; } // the estimate was wrong: give this one up
 				}
-				d.resize(have);
+				if (over) {
+					kill(it->pid, SIGTERM);
+					m_inflated.fetch_sub(have);
+					std::string().swap(d);
+				} else d.resize(have);
 				close(rfd);
 				int st = 0;
-				it->ok = waitpid(it->pid, &st, 0) == it->pid && WIFEXITED(st) && WEXITSTATUS(st) == 0;
+				it->ok = waitpid(it->pid, &st, 0) == it->pid && WIFEXITED(st) && WEXITSTATUS(st) == 0 && !over;
 			});
 			m_items[p] = it;
 		}
@@ -361,7 +372,7 @@ class Prefetch {
 		m_items.erase(f);
 		it->th.join();
 		const bool ok = it->ok;
-		if (ok) data.swap(it->data);
+		if (ok) { m_inflated.fetch_sub(it->data.size()); data.swap(it->data); } // (the reader owns the bytes now)
 		delete it;
 		return ok; // (a failed decompressor: the ordinary reader runs it again and reports)
 	}
@@ -369,6 +380,8 @@ class Prefetch {
   private:
 	struct Item { std::thread th; std::string data; pid_t pid = -1; bool ok = false; };
 	std::map<std::string, Item*> m_items;
+	std::atomic<uint64_t> m_inflated{ 0 }; // bytes held by the drain threads
+	uint64_t m_budget = 0;
 };
 
 // FASTQ files parsed by several threads.  Parsing is what the host binary spends its time on once

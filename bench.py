@@ -44,47 +44,59 @@ METRIC = "Mk-mers/s inserted+extended (abyss-bloom-dbg, k=64); unitig bit-exact"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, seed: int, device, read_seed=None):
-    """Synthetic read set generated on the GPU in the packed layout of include/abyss_amd.h:
-    2 bits per base, 16 bases per uint32 word, each read on a word boundary.  File order of
-    the reference: all mate-1 reads, then all mate-2 reads (BloomIO.h:102-115)."""
+def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, seed: int, device, read_seed: int = 7,
+                     first: int = 0, total_pairs: int = None):
+    """The synthetic read set, generated on the GPU in the packed layout of include/abyss_amd.h (2 bits
+    per base, 16 bases per uint32 word, each read on a word boundary; all mate-1 reads, then all mate-2
+    reads: the file order of the reference, BloomIO.h:102-115).  synth.packed_reads_torch is the
+    torch twin of synth.make_read_set_cb, whose FASTQ files the reference binary was run on at -j1 for
+    the digests under tests/golden/full_size.json: the reads timed here are THAT read set."""
     h1, h2 = synth.make_genome(genome_len, seed=seed)
-    g1 = torch.from_numpy(h1).to(device)
-    g2 = torch.from_numpy(h2).to(device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed((seed if read_seed is None else read_seed) * 1000003 + 7)
-    wpr = (read_len + 15) // 16
-    words = torch.empty((2 * n_pairs, wpr), dtype=torch.int32, device=device)
-    shifts = (2 * torch.arange(16, device=device, dtype=torch.int64))
-    ar = torch.arange(read_len, device=device, dtype=torch.int64)
-    chunk = 1 << 19
-    for a in range(0, n_pairs, chunk):
-        b = min(n_pairs, a + chunk)
-        m = b - a
-        frag = torch.randint(350, 451, (m,), generator=gen, device=device)
-        start = torch.randint(0, genome_len - 450, (m,), generator=gen, device=device)
-        hap = torch.randint(0, 2, (m, 1), generator=gen, device=device).bool()
-        strand = torch.randint(0, 2, (m, 1), generator=gen, device=device).bool()
-        idx1 = start[:, None] + ar[None, :]
-        idx2 = (start + frag - 1)[:, None] - ar[None, :]
-        m1 = torch.where(hap, g2[idx1], g1[idx1])
-        m2 = 3 - torch.where(hap, g2[idx2], g1[idx2])
-        ra = torch.where(strand, m2, m1)
-        rb = torch.where(strand, m1, m2)
-        for dst, r in ((a, ra), (n_pairs + a, rb)):
-            e = torch.rand(r.shape, generator=gen, device=device) < err
-            r = torch.where(e, (r + torch.randint(1, 4, r.shape, generator=gen, device=device).to(r.dtype)) & 3, r)
-            pad = wpr * 16 - read_len
-            r64 = torch.nn.functional.pad(r.to(torch.int64), (0, pad)).view(m, wpr, 16)
-            w = (r64 << shifts).sum(dim=2)
-            words[dst:dst + m] = w.to(torch.int32)  # wraps modulo 2^32: same bits as uint32
-    n = 2 * n_pairs
-    woff = torch.arange(n + 1, device=device, dtype=torch.int64) * wpr
-    lens = torch.full((n,), read_len, dtype=torch.int32, device=device)
-    return words.view(-1), woff, lens
+    return synth.packed_reads_torch(h1, h2, n_pairs, read_len, err, read_seed, device, first=first, total_pairs=total_pairs)
 
 
-def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
+def golden_for(config: int, pairs: int, k: int, K: int, bloom: str):
+    """The reference's -j1 result on this very read set (tests/golden/full_size.json), or None."""
+    src = os.path.join(ROOT, "tests", "golden", "full_size.json")
+    if not os.path.exists(src):
+        return None
+    for g in json.load(open(src)).get("runs", []):
+        if g.get("generator") == "make_read_set_cb" and (g["pairs"], g["k"], g.get("K", 0), g["bloom"]) == (pairs, k, K, bloom):
+            return g
+    return None
+
+
+def end_to_end(a, genome_len, read_len, err, device, golden):
+    """The drop-in binary on the full read set as FASTQ files: process start to last unitig written
+    (parse, pack, upload, both passes, FASTA out), and the FASTA's sha256 against the reference's."""
+    import hashlib
+    from abyss_amd import build
+    h1, h2 = synth.make_genome(genome_len, seed=42)
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.time()
+        m1, m2 = synth.sample_pairs_cb(h1, h2, a.pairs, read_len=read_len, err=err, seed=7)
+        synth.write_fastq(os.path.join(td, "r1.fq"), m1, "r", 1)
+        synth.write_fastq(os.path.join(td, "r2.fq"), m2, "r", 2)
+        prep = time.time() - t0
+        del m1, m2
+        args = [build.build_cli(), "-k%d" % a.k, "-b%s" % a.bloom, "-H4", "-q3", "-j%d" % (os.cpu_count() or 1)]
+        if a.K:
+            args.append("-K%d" % a.K)
+        t0 = time.time()
+        r = subprocess.run(args + ["r1.fq", "r2.fq"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.time() - t0
+    kmers = 2 * a.pairs * (read_len - a.k + 1)
+    out = {"what": "abyss_amd/bin/abyss-bloom-dbg on the FASTQ files of this read set (two %.2f GB files, page cache warm), process "
+                   "start to last unitig written" % (a.pairs * (2 * read_len + 12) / 1e9),
+           "rc": r.returncode, "wall_ms": round(wall * 1e3), "value": kmers / wall / 1e6, "unit": "Mk-mers/s",
+           "threads": os.cpu_count() or 1, "unitigs": r.stdout.count(b">"), "fasta_sha256": hashlib.sha256(r.stdout).hexdigest(),
+           "files_written_in_s": round(prep, 1), "measured": "in this run"}
+    if golden:
+        out["matches_reference_fasta"] = bool(out["fasta_sha256"] == golden["fasta_sha256"])
+    return out
+
+
+def cpu_baseline(k: int, cores: int, K: int = 0, target_s: float = 20.0):
     """The unmodified reference binary (oracle/_ref, kind "reference") -- or the oracle's C port
     when it is not built -- timed on the host cores on a bounded sample of the same workload
     (same read length, coverage, error rate, k, H; genome and B scaled down together)."""
@@ -93,7 +105,8 @@ def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
     m1, m2 = synth.make_read_set(genome, cov, read_len=L)
     n_reads = 2 * m1.shape[0]
     kmers = n_reads * (L - k + 1)
-    sample = "%d x 2x%d bp reads of a %d bp genome (50x, 0.5%% err), k=%d, B=160M, H=4" % (m1.shape[0], L, genome, k)
+    kopt = ["-k%d" % k] + (["-K%d" % K] if K else [])
+    sample = "%d x 2x%d bp reads of a %d bp genome (50x, 0.5%% err), k=%d%s, B=160M, H=4" % (m1.shape[0], L, genome, k, " -K%d" % K if K else "")
     if ob.have_ref():
         with tempfile.TemporaryDirectory() as td:
             synth.write_fastq(os.path.join(td, "r1.fq"), m1, "r", 1)
@@ -101,17 +114,17 @@ def cpu_baseline(k: int, cores: int, target_s: float = 20.0):
             # fixed start-up cost of the reference (contigEndKmers.rehash(2^28), bloom-dbg.h:993)
             open(os.path.join(td, "one.fq"), "w").write("@x\n%s\n+\n%s\n" % ("A" * L, "I" * L))
             t0 = time.time()
-            ob.run_ref(["-k%d" % k, "-b1M", "one.fq"], cwd=td, threads=1)
+            ob.run_ref(kopt + ["-b1M", "one.fq"], cwd=td, threads=1)
             startup = time.time() - t0
             t0 = time.time()
-            out, _ = ob.run_ref(["-k%d" % k, "-b160M", "-H4", "r1.fq", "r2.fq"], cwd=td, threads=cores)
+            out, _ = ob.run_ref(kopt + ["-b160M", "-H4", "r1.fq", "r2.fq"], cwd=td, threads=cores)
             wall = time.time() - t0
             # one thread (the deterministic order the GPU path reproduces) on an eighth of the sample
             n8 = m1.shape[0] // 8
             synth.write_fastq(os.path.join(td, "s1.fq"), m1[:n8], "r", 1)
             synth.write_fastq(os.path.join(td, "s2.fq"), m2[:n8], "r", 2)
             t0 = time.time()
-            ob.run_ref(["-k%d" % k, "-b160M", "-H4", "s1.fq", "s2.fq"], cwd=td, threads=1)
+            ob.run_ref(kopt + ["-b160M", "-H4", "s1.fq", "s2.fq"], cwd=td, threads=1)
             wall1 = time.time() - t0
             kmers1 = 2 * n8 * (L - k + 1)
         return {"value": kmers / wall / 1e6, "unit": "Mk-mers/s", "cores": cores, "kind": "reference",
@@ -154,6 +167,8 @@ def main() -> int:
     ap.add_argument("--bloom", type=str, default=None)
     ap.add_argument("--K", type=int, default=None, help="spaced seed of two K-mers (-K of abyss-bloom-dbg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
+                    help="skip the drop-in binary's FASTQ-in / FASTA-out run on this read set (about 20 s: writes the two FASTQ files)")
     ap.add_argument("--no-events", action="store_true",
                     help="time the steps without HIP events around every launch (no per-kernel numbers: shows what the events cost)")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
@@ -229,12 +244,15 @@ def main() -> int:
     if partitioned:
         # one job: rank r holds the r-th block of the read set (same genome on every rank)
         pairs_local = a.pairs // world + (1 if rank < a.pairs % world else 0)
+        first_pair = rank * (a.pairs // world) + min(rank, a.pairs % world)
         words, woff, lens = gen_packed_reads(genome_len, pairs_local, read_len, err, seed=42, device=device,
-                                             read_seed=42 + 7919 * rank)
+                                             first=first_pair, total_pairs=a.pairs)
         n_reads = 2 * pairs_local
     else:
-        words, woff, lens = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42 + rank, device=device)
+        # (replicas: every rank its own read set; rank 0's is the pinned one)
+        words, woff, lens = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42, device=device, read_seed=7 + rank)
         n_reads = 2 * a.pairs
+    golden = golden_for(a.config, a.pairs, a.k, a.K, a.bloom) if (world == 1 or (partitioned and a.scaling == "strong")) else None
     kmers = n_reads * (read_len - a.k + 1)
     torch.cuda.synchronize()
 
@@ -305,12 +323,36 @@ def main() -> int:
         step(profile=timed_profile and not a.no_events)
     barrier()
     elapsed = time.perf_counter() - t0
-    red_dev = device if (world > 1 and dist.get_backend() == "nccl") else None
-    elapsed, total_kmers = aggregate(elapsed, kmers, a.steps, world, red_dev)
-
-    # per-kernel HIP-event timings of the last step (events are recorded on the library's stream)
+    # per-kernel HIP-event timings of the last timed step (events are recorded on the library's stream)
     if prof is None:
         prof = {nm: g.profile_get(nm) for nm in names}
+    red_dev = device if (world > 1 and dist.get_backend() == "nccl") else None
+    elapsed, total_kmers = aggregate(elapsed, kmers, a.steps, world, red_dev)
+    timed_pass_s = list(phase_s)
+    # Parity of the timed workload: its unitig count and total length against the reference's -j1 run on
+    # this very read set (tests/golden/full_size.json; the FASTA's bytes are compared by
+    # tests/test_gpu_fullsize.py and by the end-to-end leg below).  A fast wrong answer is no result.
+    parity = None
+    if golden is not None:
+        parity = {"reference": "oracle/_ref/abyss-bloom-dbg -j1 on the FASTQ files of this read set (tests/golden/full_size.json)",
+                  "unitigs": [unitigs, golden["unitigs"]], "unitig_bp": [bases, golden["unitig_bp"]],
+                  "ok": bool(unitigs == golden["unitigs"] and bases == golden["unitig_bp"])}
+        if not parity["ok"] and rank == 0:
+            sys.stderr.write("bench.py: PARITY FAILURE: %r\n" % (parity,))
+    # the same steps without a HIP event pair (and its host synchronisation) around every launch: what the
+    # library achieves when nobody is measuring its kernels
+    no_events = None
+    if timed_profile and not a.no_events and world == 1:
+        k2 = max(1, min(a.steps, 3))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step(profile=False)
+        barrier()
+        e2 = time.perf_counter() - t1
+        no_events = {"value": kmers * k2 / e2 / 1e6, "ms_per_step": e2 / k2 * 1e3, "steps": k2}
+    phase_s[0], phase_s[1] = timed_pass_s
+
     stats = g.stats()
     ranks_agree = None
     if partitioned and world > 1:
@@ -412,22 +454,26 @@ def main() -> int:
             "setup_ms_per_step": round(setup_s / max(a.steps + a.warmup, 1) * 1e3, 1),
             "pass_ms_per_step": {"pass1": round(phase_s[0] / a.steps * 1e3, 1), "pass2": round(phase_s[1] / a.steps * 1e3, 1)},
         }
+        if parity is not None:
+            out["parity"] = parity
+        if no_events is not None:
+            out["no_events"] = no_events
         if partitioned:
             out["config"]["ranks_agree"] = ranks_agree
             out["kernel_ms_note"] = "rank 0, last warm-up step (the timed steps run without per-launch events)"
         if comm_note:
             out["config"]["note"] = comm_note
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1)
-            # like for like (measured once on the GPU box, committed under profiles/): the unmodified reference on
-            # the FULL configs[1] read set, and the drop-in binary end to end (FASTQ in, FASTA out) on the same files
-            for key, fn in (("reference_full_config", "r02_cpu_reference_config1.json"), ("end_to_end", "r02_end_to_end.json")):
-                src = os.path.join(ROOT, "profiles", fn)
-                if os.path.exists(src) and a.config == 1:
-                    out["cpu_baseline" if key == "reference_full_config" else key] = dict(
-                        out.get("cpu_baseline", {}) if key == "reference_full_config" else {}, **{
-                            (key if key == "reference_full_config" else "measured"): json.load(open(src)),
-                            **({} if key == "reference_full_config" else {"source": "profiles/" + fn})})
+            out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1, K=a.K)
+            # like for like on the FULL read set: the unmodified reference at -j<all cores> is a 4-minute run, measured
+            # once on the GPU box and REPLAYED here from the committed file (not measured in this run)
+            src = os.path.join(ROOT, "profiles", "r02_cpu_reference_config1.json")
+            if os.path.exists(src) and a.config == 1 and a.pairs == 5_000_000:
+                out["cpu_baseline"]["reference_full_config"] = dict(json.load(open(src)), replayed=True, source="profiles/r02_cpu_reference_config1.json",
+                                                                    note="measured at commit 27c3426 on the read set of synth.make_read_set (the sequential generator); "
+                                                                         "same recipe and size as the one timed here")
+        if world == 1 and a.end_to_end and a.config in (1, 3):
+            out["end_to_end"] = end_to_end(a, genome_len, read_len, err, device, golden)
         # whatever native libraries buffered on stdout (RCCL's version banner) goes out first: the
         # JSON line stays a line of its own
         import ctypes
@@ -440,7 +486,7 @@ def main() -> int:
     if world > 1:
         dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 0 if (parity is None or parity["ok"]) else 1
 
 
 if __name__ == "__main__":

@@ -21,4 +21,13 @@ def _built():
     build.build_lib()
     build.build_oracle()
     build.build_hostcheck()
+    # On a GPU box torch brings its own HIP runtime: it must open the device BEFORE libabyss_amd.so's
+    # runtime does (the other order leaves torch without a GPU: "No HIP GPUs are available"), whatever
+    # order the test files run in.  bench.py and __graft_entry__.smoke() have the same order.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:  # noqa: BLE001
+        pass
     yield

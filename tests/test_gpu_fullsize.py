@@ -61,6 +61,22 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
 
     a, cnt_a, contigs_a, dig_a = _run(words, woff, lens, n_reads, {}, monkeypatch, True)
     ca, sa = a.assembly_counters(), a.stats()
+    # byte for byte the reference's -j1 FASTA on this read set (tests/golden/full_size.json: the unmodified
+    # reference run on the FASTQ files of synth.make_read_set_cb, whose torch twin generated the reads above)
+    golden = bench.golden_for(1, PAIRS, K, 0, "2G")
+    assert golden is not None, "tests/golden/full_size.json has no run for configs[1]"
+    fasta = hashlib.sha256()
+    n_unitigs = 0
+    for c in contigs_a:
+        if not c.redundant:
+            mate = 1 if c.read_index < PAIRS else 2
+            fasta.update(b">%d %d %d read:r%d/%d\n%s\n" % (c.contig_id, len(c.seq), c.coverage, c.read_index % PAIRS, mate, c.seq))
+            n_unitigs += 1
+    assert (n_unitigs, ca["bases_assembled"]) == (golden["unitigs"], golden["unitig_bp"])
+    assert fasta.hexdigest() == golden["fasta_sha256"]
+    assert a.counting_stats()[1] == golden["filtered_popcount"]
+    # the pre-search answered ahead of the walkers, and sanely (one answer per request at most)
+    assert 0 < sa["pre_adds"] <= sa["pre_requests"]
     vis_a = a.visited()
     assert sa["commit_rounds"] > 0 and ca["next_contig_id"] > 50_000
 
