@@ -31,8 +31,11 @@ __global__ void __launch_bounds__(256) k_foreach(F f, uint64_t n)
 	const uint32_t slot = (uint32_t)i;
 	for (; i < n; i += stride) f(i, slot);
 }
+#ifndef ABG_CLS_WAVES
+#define ABG_CLS_WAVES 1 // wavefronts per SIMD the one-item-per-lane kernels of k_foreach_w (FClassify) are compiled for at least
+#endif
 template <class F>
-__global__ void __launch_bounds__(64) k_foreach_w(F f, uint64_t n)
+__global__ void __launch_bounds__(64, ABG_CLS_WAVES) k_foreach_w(F f, uint64_t n)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
