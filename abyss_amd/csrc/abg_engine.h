@@ -65,6 +65,8 @@ struct Config {
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
 	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
+	uint32_t classify_slots = 65536;  // lanes of the classification kernel in flight (each owns 22 KB of lookAhead scratch)
+	bool heavy_first = true;          // ... and the candidates with the most such searches are walked first (Engine::presearch)
 	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
 	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
@@ -941,7 +943,10 @@ constexpr uint8_t RES_CANDIDATE = 0x80;
 // this one: hashing every k-mer from scratch costs more ALU than the probes cost memory time, and
 // the 6 G probes of a step are what bounds the kernel.  One read per lane it stays; the next
 // batch's classification is queued on a side stream ahead of the current batch's walkers.)
-constexpr uint32_t CLS_GROUP = 4; // k-mers of a read probed per round of FClassify / FRefilter
+#ifndef ABG_CLS_GROUP
+#define ABG_CLS_GROUP 4
+#endif
+constexpr uint32_t CLS_GROUP = ABG_CLS_GROUP; // k-mers of a read probed per round of FClassify / FRefilter
 template <int NW>
 struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
@@ -1118,8 +1123,10 @@ struct FPresearchScan {
 	Params p; Batch b; const uint8_t* cnt; const uint32_t* cand_read; const uint32_t* list;
 	SuccMemo memo; uint64_t* tags; uint64_t tag_mask, gen; // (gen: which filling of the memo the tags refer to)
 	PreReq<NW>* req; uint32_t* req_n; uint32_t req_cap;
+	uint32_t* weight; // [n] per candidate of the list: sides of its read's k-mers where successor() has to search (how heavy its walk will be)
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
+		uint32_t heavy = 0;
 		const uint64_t r = cand_read[list[i]];
 		const uint32_t L = b.len[r];
 		if (L < p.k) return;
@@ -1137,6 +1144,7 @@ struct FPresearchScan {
 				for (int dir = 0; dir < 2; dir++) {
 					const unsigned mask = nbr_mask_lean<NW, false>(p, tabs, cnt, u, dir == FORWARD ? SENSE : ANTISENSE);
 					if (!(mask & (mask - 1))) continue;
+					heavy++;
 					if (memo_find(memo, u.fh, u.rh, dir) >= 0) continue;
 					uint64_t tag = (u.fh ^ (u.rh * 0x9E3779B97F4A7C15ULL)) + (uint64_t)dir + gen * 0xD1B54A32D192ED03ULL;
 					tag ^= tag >> 31; tag *= 0xD6E8FEB86659FD93ULL; tag ^= tag >> 29;
@@ -1154,6 +1162,10 @@ struct FPresearchScan {
 				}
 			}
 		}
+		// (the lanes' counts summed: one ballot per bit of a count that is at most 2 x ceil(nk / lanes))
+		uint32_t total = 0;
+		for (unsigned bit = 0; bit < 10; bit++) total += (uint32_t)__builtin_popcountll(wave_ballot(((heavy >> bit) & 1u) != 0)) << bit;
+		if (lane == 0) weight[i] = total;
 	}
 };
 template <int NW>
@@ -2097,6 +2109,7 @@ class Engine {
 		if (memo_tab_.hmin) free_tab(memo_tab_);
 		if (plane_) be_.free(plane_);
 		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); be_.free(pre_tags_); }
+		if (pre_w_) be_.free(pre_w_);
 		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
@@ -3028,7 +3041,7 @@ class Engine {
 		if (walk_ready_) return;
 		if (!cend_.hmin) { // (shared by all contexts)
 			p2_batch_ = cfg_.p2_first_batch;
-			cslots_ = std::min<uint32_t>(be_.max_slots(), 65536u);
+			cslots_ = std::min<uint32_t>(be_.max_slots(), cfg_.classify_slots);
 			alloc_tab(cend_, cfg_.cend_log2);
 		}
 		wslots_ = std::min<uint32_t>(be_.max_slots(), cfg_.walk_slots);
@@ -3759,11 +3772,16 @@ class Engine {
 	// The successor() searches the walkers of `list` are about to ask for at the k-mers of their own
 	// reads, answered ahead of them, one search per wave (FPresearchScan, presearch_one).
 	template <int NW>
-	void presearch(const WalkEnv<NW>& env, const uint32_t* list_d, uint32_t n)
+	void presearch(const WalkEnv<NW>& env, uint32_t* list_d, uint32_t n)
 	{
 		if constexpr (MASKED_BUILD<NW>) return;
 		if (!cfg_.presearch || !memo_.k0 || !n || p_.trim < 2) return;
 		const uint32_t cap = cfg_.presearch_cap;
+		if (pre_w_cap_ < n) {
+			if (pre_w_) be_.free(pre_w_);
+			pre_w_cap_ = std::max<uint32_t>(n, 1u << 16);
+			pre_w_ = (uint32_t*)be_.alloc(pre_w_cap_ * 4ull);
+		}
 		if (!pre_req_) {
 			pre_req_ = be_.alloc((uint64_t)cap * (8ull * MAX_NW + 24)); // (PreReq of the widest k-mer)
 			pre_n_d_ = (uint32_t*)be_.alloc(8);
@@ -3772,11 +3790,24 @@ class Engine {
 		}
 		be_.memset(pre_n_d_, 0, 8);
 		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
-			(PreReq<NW>*)pre_req_, pre_n_d_, cap };
+			(PreReq<NW>*)pre_req_, pre_n_d_, cap, pre_w_ };
 		be_.launch_wave(n, fs, "presearch_scan");
 		uint32_t nreq = 0;
 		be_.d2h(&nreq, pre_n_d_, 4);
 		nreq = std::min(nreq, cap);
+		if (n > wslots_ && cfg_.heavy_first) {
+			// Longest first: the walkers draw their candidates from the list in order, and a launch lasts until
+			// its last walker is done -- a read in a tangle (many sides to search) that starts when the launch is
+			// half over ends half a launch after everybody else.  Results do not depend on the order.
+			std::vector<uint32_t> w(n), l(n), idx(n);
+			be_.d2h(w.data(), pre_w_, n * 4ull);
+			be_.d2h(l.data(), list_d, n * 4ull);
+			for (uint32_t i = 0; i < n; i++) idx[i] = i;
+			std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+			std::vector<uint32_t> sorted(n);
+			for (uint32_t i = 0; i < n; i++) sorted[i] = l[idx[i]];
+			be_.h2d(list_d, sorted.data(), n * 4ull);
+		}
 		if (!nreq) return;
 		pre_requests_ += nreq;
 		FPresearch<NW> fp{ env, (const PreReq<NW>*)pre_req_ };
@@ -3784,6 +3815,7 @@ class Engine {
 		if (const char* e = getenv("ABG_PRESEARCH_SLOTS")) slots = std::max(1, std::min<int>(atoi(e), (int)wslots_)); // (diagnosis)
 		be_.launch_walkers(nreq, fp, slots, "presearch", 0, false);
 	}
+	uint32_t* pre_w_ = nullptr; uint32_t pre_w_cap_ = 0;
 	void* pre_req_ = nullptr; uint32_t* pre_n_d_ = nullptr; uint64_t* pre_tags_ = nullptr; uint64_t pre_requests_ = 0;
 	static constexpr uint32_t PRE_TAG_LOG2 = 22;
 

@@ -94,6 +94,8 @@ class Session {
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
+		if (const char* e = getenv("ABG_HEAVY_FIRST")) cfg.heavy_first = atoi(e) != 0;
+		if (const char* e = getenv("ABG_CLS_SLOTS")) cfg.classify_slots = (uint32_t)std::max(64, atoi(e));
 		if (const char* e = getenv("ABG_SOLID_PLANE")) cfg.solid_plane = atoi(e) != 0;
 		if (const char* e = getenv("ABG_MEMO")) cfg.memo = atoi(e) != 0; // shared answers of successor()
 		if (const char* e = getenv("ABG_PIPELINE")) cfg.pipeline_depth = (uint32_t)std::max(1, atoi(e)); // batches of PASS 2 in flight

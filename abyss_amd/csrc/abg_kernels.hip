@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_foreach(F f, uint64_t n)
 	for (; i < n; i += stride) f(i, slot);
 }
 #ifndef ABG_CLS_WAVES
-#define ABG_CLS_WAVES 1 // wavefronts per SIMD the one-item-per-lane kernels of k_foreach_w (FClassify) are compiled for at least
+#define ABG_CLS_WAVES 3 // wavefronts per SIMD the one-item-per-lane kernels of k_foreach_w (FClassify) are compiled for at least: 170 VGPRs instead of the 180 the compiler takes unasked (two waves); 985 vs 1038 ms per configs[1] step, four and more waves lose to their spills
 #endif
 template <class F>
 __global__ void __launch_bounds__(64, ABG_CLS_WAVES) k_foreach_w(F f, uint64_t n)

@@ -115,6 +115,7 @@ class StagedTorchComm:
                     self.write(buf + dsp[q], parts[q].numpy()[:cnt[q]])
             self.calls["all_gather_v"] += 1
             self.calls["bytes"] += sum(cnt)
+            self.calls["bytes_all_gather_v"] = self.calls.get("bytes_all_gather_v", 0) + sum(cnt)
             return 0
         except Exception as e:  # an exception must not unwind through the C caller
             print("StagedTorchComm.all_gather_v:", repr(e), flush=True)
@@ -132,6 +133,7 @@ class StagedTorchComm:
             self.write(buf, np.ascontiguousarray(t.numpy().astype(npdt)).view(np.uint8))
             self.calls["all_reduce"] += 1
             self.calls["bytes"] += int(count) * np.dtype(npdt).itemsize
+            self.calls["bytes_all_reduce"] = self.calls.get("bytes_all_reduce", 0) + int(count) * np.dtype(npdt).itemsize
             return 0
         except Exception as e:
             print("StagedTorchComm.all_reduce:", repr(e), flush=True)

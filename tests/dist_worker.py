@@ -73,10 +73,12 @@ def case_golden(name, rank, world):
                        claim_log2=16, p2_first=128, mask=mask_of(g))
     hc.attach()
     hc.load(g.buf, g.off)
+    pass1 = dict(hc.comm.calls)  # what PASS 1 sent through the communicator (buffer sizes handed to the collectives)
     fp = hc.counting_stats()[1]
     results, contigs = hc.assemble(g.buf, g.off)
     c = hc.assembly_counters()
     ok = {
+        "comm_pass1": pass1, "kmer_ops": int(sum(max(0, len(r) - kw["k"] + 1) for r in g.reads)),
         "filtered_popcount": fp == g.meta["filtered_popcount"],
         "fasta": api.format_fasta(contigs, g.ids) == g.fasta,
         "readlog": api.format_read_log(results, g.ids) == g.readlog,

@@ -136,3 +136,27 @@ def test_partitioned_code_path_on_a_single_rank(name, monkeypatch):
     assert api.format_fasta(contigs, g.ids) == g.fasta
     assert api.format_read_log(results, g.ids) == g.readlog
     assert comm.calls["all_reduce"] > 0 and comm.calls["all_gather_v"] > 0
+
+
+def test_pass1_collective_bytes_follow_the_model():
+    """DESIGN.md section 7's traffic model of the partitioned PASS 1, checked instead of asserted: per k-mer op the
+    ranks exchange two bytes through one all_reduce per batch, plus one byte per op still pending in each
+    reservation round, plus -- from three ranks on; two ranks, which share one xGMI link, hash everything
+    themselves -- the op's 8-byte hash once (all-gathered slices).  A ring moves (R-1)/R of an all-gather's
+    and 2(R-1)/R of an all-reduce's buffer per rank: 12 B x (R-1) per op of a rank's own share, against
+    ~55 B for routed (op, counter) pairs whatever R is."""
+    per_op = {}
+    for world in (2, 4):
+        out = run_ranks(world, "golden", "k64")
+        assert out["fasta"] and out["ranks_agree"]
+        ops, p1 = out["kmer_ops"], out["comm_pass1"]
+        ag, ar = p1.get("bytes_all_gather_v", 0), p1.get("bytes_all_reduce", 0)
+        # (the golden k64 reads hold no non-ACGT characters, so `ops` is exactly what PASS 1 inserts)
+        if world == 2:
+            assert ag == 0, p1
+        else:
+            assert abs(ag - 8 * ops) <= 0.01 * 8 * ops + 64 * world, (world, ops, p1)
+        rounds = ar - 2 * ops  # beyond the two bytes per op: one flag byte per batch, one byte per pending op and round
+        assert 0 <= rounds <= 1.0 * ops, (world, ops, p1)
+        per_op[world] = (ag + ar) / ops
+    assert 2.0 <= per_op[2] <= 3.5 and 10.0 <= per_op[4] <= 11.5, per_op
