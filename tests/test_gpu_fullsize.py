@@ -127,3 +127,30 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
     assert dig_a == dig_c
     assert np.array_equal(vis_a, c.visited())
     c.close()
+
+
+def test_full_size_spaced_seed_run_is_the_reference_fasta():
+    """BASELINE.json configs[3] (-k96 -K32, 5 M pairs, B=2G) at its stated size: the unitig FASTA through the
+    C ABI, byte for byte the reference's -j1 output on the same read set (tests/golden/full_size.json)."""
+    import torch
+    import bench
+    device = torch.device("cuda:0")
+    genome_len = int(PAIRS * 2 * READ_LEN / 50.0)
+    words, woff, lens = bench.gen_packed_reads(genome_len, PAIRS, READ_LEN, 0.005, seed=42, device=device)
+    torch.cuda.synchronize()
+    golden = bench.golden_for(3, PAIRS, 96, 32, "2G")
+    assert golden is not None, "tests/golden/full_size.json has no run for configs[3]"
+    g = api.BloomDBG(96, bloom_bytes=BLOOM, num_hashes=4, min_cov=2, spaced_seed=api.spaced_seed_kmer_pair(96, 32))
+    g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), 2 * PAIRS)
+    assert g.counting_stats()[1] == golden["filtered_popcount"]
+    _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), 2 * PAIRS, want_results=False, want_contigs=True)
+    fasta = hashlib.sha256()
+    n = bp = 0
+    for c in contigs:
+        if not c.redundant:
+            fasta.update(b">%d %d %d read:r%d/%d\n%s\n" % (c.contig_id, len(c.seq), c.coverage, c.read_index % PAIRS, 1 if c.read_index < PAIRS else 2, c.seq))
+            n += 1
+            bp += len(c.seq)
+    assert (n, bp) == (golden["unitigs"], golden["unitig_bp"])
+    assert fasta.hexdigest() == golden["fasta_sha256"]
+    g.close()
