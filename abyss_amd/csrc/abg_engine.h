@@ -616,11 +616,12 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 	Params p; Batch b; uint64_t* h0; uint64_t T;
 	uint64_t kbase; // b.koff holds k-mer prefix sums of a longer batch: op t of this one is k-mer kbase + t there
 	uint64_t tlo;   // the ops [tlo, T) are hashed (partitioned run: each rank hashes a slice of the batch)
+	uint32_t run;   // consecutive ops per lane: one k-mer hashed from scratch, the rest rolled (Engine::hash_run_)
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
-		uint64_t t0 = tlo + g * HC_RUN;
+		uint64_t t0 = tlo + g * run;
 		if (t0 >= T) return;
-		uint64_t t1 = t0 + HC_RUN < T ? t0 + HC_RUN : T;
+		uint64_t t1 = t0 + run < T ? t0 + run : T;
 		uint64_t r = find_seq(b.koff, b.n, t0 + kbase);
 		uint64_t rend = b.koff[r + 1] - kbase;
 		unsigned k = p.k;
@@ -2335,6 +2336,16 @@ class Engine {
 	void load_packed(const Batch& b) { load_packed(b, cut_ranges(b.koff, b.n)); } // (b.koff: device_koff)
 	void load_packed(const Batch& b, const std::vector<OpRange>& ranges)
 	{
+		{
+			// Run length of FHashOps: a lane hashes one k-mer from scratch (k rounds) and rolls the rest, so longer
+			// runs are less work -- and a run that ends where the read ends starts no second hash.  The reads'
+			// k-mer count divided into the fewest equal parts of at most 32: 87 -> 29 (PASS 1 404 -> 390 ms on configs[1]).
+			uint32_t len0 = 0;
+			if (b.n) be_.d2h(&len0, b.len, 4);
+			const uint32_t nk0 = len0 >= p_.k ? len0 - p_.k + 1 : 0;
+			const uint32_t parts = (nk0 + 31) / 32;
+			hash_run_ = parts ? std::min<uint32_t>(32, std::max<uint32_t>(8, (nk0 + parts - 1) / parts)) : 8;
+		}
 		ensure_insert();
 		memo_valid_ = false; plane_valid_ = false;
 		last_rounds_ = 0;
@@ -2383,7 +2394,7 @@ class Engine {
 			const uint64_t a = std::min(T, me * chunk), bnd = std::min(T, a + chunk);
 			if (bnd > a) {
 				be_.side_scope_begin("hash_staged");
-				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, bnd, kbase, a }; be_.launch((bnd - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, bnd, kbase, a, hash_run_ }; be_.launch((bnd - a + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
 				be_.side_scope_end();
 				be_.wait_side_scope();
 			}
@@ -2394,7 +2405,7 @@ class Engine {
 		be_.memset(flag, 0, 4);
 		be_.memset(ccur_, 0, ncoarse_ * 4);
 		if (!part || R <= cfg_.dist_hash_all_ranks)
-			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0, T, kbase, 0, hash_run_ }; be_.launch((T + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
 		BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 		FBinCoarse f1{ bn };
 		be_.launch_tiles((T + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f1, "bin_coarse");
@@ -2634,6 +2645,7 @@ class Engine {
 	uint64_t* h0_ = nullptr; uint64_t* claim_[2] = { nullptr, nullptr };
 	uint32_t* pend_[2] = { nullptr, nullptr }; uint32_t* pend_n_ = nullptr; uint32_t epoch_ = 1;
 	uint64_t batch_ops_ = 0;   // ops per ordered-insert batch (ensure_insert)
+	uint32_t hash_run_ = 8;    // FHashOps: consecutive ops per lane
 	uint64_t insert_scratch_bytes_ = 0; // what ensure_insert holds
 	uint32_t claim_log2_ = 0;  // slots per claim table
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
@@ -2874,7 +2886,7 @@ class Engine {
 			be_.memset(pend_n_, 0, 8);
 			if (!staged) {
 				be_.memset(tcur_, 0, ntiles_ * 4);
-				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0, hash_run_ }; be_.launch((T + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
 				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
 				be_.memset(ccur_, 0, ncoarse_ * 4);
 				FBinCoarse f1{ bn };
@@ -2962,7 +2974,7 @@ class Engine {
 		} else if (R <= cfg_.dist_hash_all_ranks) {
 			be_.memset(tcur_, 0, ntiles_ * 4);
 			// (two ranks share one xGMI link: hashing the other half of the ops costs what receiving it does)
-			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0 }; be_.launch((T + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0, hash_run_ }; be_.launch((T + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
 		} else {
 			// equal slices (one ring all-gather); the last one may run into the slack behind the T hashes
 			const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
@@ -2971,7 +2983,7 @@ class Engine {
 			const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk);
 			be_.memset(tcur_, 0, ntiles_ * 4);
 			if (b > a)
-				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a }; be_.launch((b - a + HC_RUN - 1) / HC_RUN, f, "hash_ops"); });
+				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a, hash_run_ }; be_.launch((b - a + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
 			c_all_gather_v(h0_, c.data(), d.data());
 		}
 		if (!staged) {
