@@ -701,6 +701,102 @@ template <bool COOP> ABG_HD uint64_t uni64(uint64_t v)
 	return ((uint64_t)uni32<COOP>((uint32_t)(v >> 32)) << 32) | uni32<COOP>((uint32_t)v);
 }
 template <bool COOP, class T> ABG_HD T* uniptr(T* p) { return (T*)uni64<COOP>((uint64_t)p); }
+// ---- ntHash of up to 64 CONSECUTIVE k-mers of a packed sequence, one per lane, by prefix XOR --------
+// NTF64 / NTR64 are XORs of per-base seeds rotated by the base's offset in the k-mer
+// (nthash.hpp:220-239), and srol -- a rotation of the low 33 and of the high 31 bits -- distributes
+// over XOR.  With a_t / c_t the seeds of base t and of its complement, t counted from the first base
+// of the stretch:
+//     fh(j) = XOR_i srol^(k-1-i)(a_(j+i)) = srol^(k-1+j)( P(j+k-1) ^ P(j-1) ),   P(t) = XOR_(u<=t) srol^(-u)(a_u)
+//     rh(j) = XOR_i srol^(i)(c_(j+i))     = srol^(-j)   ( Q(j+k-1) ^ Q(j-1) ),   Q(t) = XOR_(u<=t) srol^(u)(c_u)
+// so a wave hashes n <= 64 neighbouring k-mers with two prefix scans over its n + k - 1 bases (a few bases
+// per lane) and two look-ups per lane -- some 300 operations a lane where hashing one k-mer from scratch
+// (kmer_hashes) costs 27 x 2k.  The bulk steps of the walkers and the chain searches examine exactly
+// such stretches of a read (walk_bulk, chain_bulk).  srol_by: rotation by a / b places of the two parts.
+ABG_HD uint64_t srol_by(uint64_t v, unsigned a, unsigned b)
+{
+	uint64_t lo = v & 0x1FFFFFFFFULL, hi = v >> 33;
+	if (a) lo = ((lo << a) | (lo >> (33 - a))) & 0x1FFFFFFFFULL;
+	if (b) hi = ((hi << b) | (hi >> (31 - b))) & 0x7FFFFFFFULL;
+	return (hi << 33) | lo;
+}
+ABG_HD uint64_t srol_fwd(uint64_t v, unsigned n) { return srol_by(v, n % 33, n % 31); }
+ABG_HD uint64_t srol_back(uint64_t v, unsigned n) { return srol_by(v, (33 - n % 33) % 33, (31 - n % 31) % 31); }
+constexpr unsigned STRETCH_EPL = 4; // bases per lane at most: 64 + MAX_K - 1 <= 4 x 64
+// The serial form of the same computation over arrays (hostcheck's self-test checks it against
+// kmer_hashes; the wave form below is this with the prefixes spread over the lanes).
+template <int NW>
+inline void stretch_hashes_serial(const uint32_t* words, uint64_t woff, uint32_t qlo, uint32_t n, unsigned k, uint64_t* fh, uint64_t* rh)
+{
+	const uint32_t nb = n + k - 1;
+	uint64_t P[64 + MAX_K], Q[64 + MAX_K];
+	uint64_t pf = 0, pr = 0;
+	for (uint32_t t = 0; t < nb; t++) {
+		const uint32_t bp = qlo + t;
+		const unsigned base = (words[woff + (bp >> 4)] >> (2u * (bp & 15u))) & 3u;
+		pf ^= srol_back(seed_of(base), t); pr ^= srol_fwd(seed_of(3u - base), t);
+		P[t] = pf; Q[t] = pr;
+	}
+	for (uint32_t j = 0; j < n; j++) {
+		fh[j] = srol_fwd(P[j + k - 1] ^ (j ? P[j - 1] : 0), k - 1 + j);
+		rh[j] = srol_back(Q[j + k - 1] ^ (j ? Q[j - 1] : 0), j);
+	}
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint64_t shfl64(uint64_t v, unsigned src)
+{
+	return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), (int)src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, (int)src);
+}
+// lane l < n: the strand hashes of the k-mer at base qlo + l (all 64 lanes must call)
+template <int NW>
+ABG_HD void stretch_hashes_wave(const uint32_t* __restrict__ words, uint64_t woff, uint32_t qlo, uint32_t n, unsigned k,
+    uint64_t& fh, uint64_t& rh)
+{
+	const unsigned lane = __lane_id();
+	const uint32_t nb = n + k - 1;
+	const uint32_t epl = (nb + 63) >> 6; // bases per lane: element e = lane * epl + i
+	uint64_t pf[STRETCH_EPL], pr[STRETCH_EPL];
+	uint64_t af = 0, ar = 0;
+#pragma unroll
+	for (unsigned i = 0; i < STRETCH_EPL; i++) {
+		const uint32_t t = lane * epl + i;
+		if (i < epl && t < nb) {
+			const uint32_t bp = qlo + t;
+			const unsigned base = (words[woff + (bp >> 4)] >> (2u * (bp & 15u))) & 3u;
+			af ^= srol_back(seed_of(base), t); ar ^= srol_fwd(seed_of(3u - base), t);
+		}
+		pf[i] = af; pr[i] = ar;
+	}
+	// exclusive scan of the lanes' totals
+	uint64_t sf = af, sr = ar;
+#pragma unroll
+	for (unsigned d = 1; d < 64; d <<= 1) {
+		const uint64_t tf = shfl64(sf, lane >= d ? lane - d : lane), tr = shfl64(sr, lane >= d ? lane - d : lane);
+		if (lane >= d) { sf ^= tf; sr ^= tr; }
+	}
+	sf ^= af; sr ^= ar;
+#pragma unroll
+	for (unsigned i = 0; i < STRETCH_EPL; i++) { pf[i] ^= sf; pr[i] ^= sr; }
+	// P / Q at the two ends of this lane's k-mer: elements l + k - 1 and l - 1
+	auto fetch = [&](uint32_t t, uint64_t& vf, uint64_t& vr) {
+		const unsigned src = t / epl, idx = t - src * epl;
+		vf = 0; vr = 0;
+#pragma unroll
+		for (unsigned i = 0; i < STRETCH_EPL; i++) {
+			if (i >= epl) break; // (wave-uniform)
+			const uint64_t xf = shfl64(pf[i], src & 63u), xr = shfl64(pr[i], src & 63u);
+			if (idx == i) { vf = xf; vr = xr; }
+		}
+	};
+	const uint32_t l = lane < n ? lane : 0;
+	uint64_t hf, hr, lf, lr;
+	fetch(l + k - 1, hf, hr);
+	fetch(l ? l - 1 : 0, lf, lr);
+	if (!l) { lf = 0; lr = 0; }
+	fh = srol_fwd(hf ^ lf, k - 1 + l);
+	rh = srol_back(hr ^ lr, l);
+}
+#endif
+
 // a copy of the parameters whose fields the compiler knows to be wave-uniform
 template <bool COOP> ABG_HD Params uniform_params(const Params& p)
 {
@@ -1677,7 +1773,22 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 		};
 #pragma unroll
 		for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		uint64_t st_fh = 0, st_rh = 0; // (see walk_bulk: the chunk's hashes by prefix scans over the read's bases)
+		if (COOP) {
+			stretch_hashes_wave<NW>(g.words, woff, up ? pos : pos - (n - 1u), n, k, st_fh, st_rh);
+			if (!up) { const unsigned src = lane0 < n ? n - 1u - lane0 : lane0; st_fh = shfl64(st_fh, src); st_rh = shfl64(st_rh, src); }
+			if (!same) { const uint64_t t = st_fh; st_fh = st_rh; st_rh = t; }
+		}
+#endif
 		for (uint32_t l = lane0; l < n; l += lstep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (COOP) {
+				my_s = window_kmer<NW>(g.words, woff, up ? pos + l : pos - l, k);
+				if (!same) my_s = kmer_revcomp_fast(my_s, k);
+				my_fh = st_fh; my_rh = st_rh;
+			} else
+#endif
 			vertex_at(l, my_s, my_fh, my_rh);
 			terms();
 			const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);

@@ -1150,9 +1150,17 @@ struct FPresearchScan {
 			const uint32_t j = j0 + lane;
 			Vtx<NW> u;
 			unsigned want[2] = { 0, 0 };
+#if defined(__HIP_DEVICE_COMPILE__)
+			uint64_t st_fh, st_rh; // (the 64 k-mers' hashes at once: stretch_hashes_wave)
+			stretch_hashes_wave<NW>(b.words, woff, j0, nk - j0 < 64u ? nk - j0 : 64u, p.k, st_fh, st_rh);
+#endif
 			if (j < nk) {
 				u.s = window_kmer<NW>(b.words, woff, j, p.k);
+#if defined(__HIP_DEVICE_COMPILE__)
+				u.fh = st_fh; u.rh = st_rh;
+#else
 				kmer_hashes(u.s, p.k, u.fh, u.rh);
+#endif
 				vtx_set_d(u, 0, 0);
 				for (int dir = 0; dir < 2; dir++) {
 					const unsigned mask = nbr_mask_lean<NW, false>(p, tabs, cnt, u, dir == FORWARD ? SENSE : ANTISENSE);

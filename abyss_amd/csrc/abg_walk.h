@@ -322,7 +322,24 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 	};
 #pragma unroll
 	for (int j = 0; j < KW<NW>; j++) my_s.w[j] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	// the strand hashes of the chunk's k-mers, all lanes at once (stretch_hashes_wave: two prefix scans over the
+	// read's bases instead of one k-round hash per lane); lane l examines position pos +/- l
+	uint64_t st_fh = 0, st_rh = 0;
+	if (COOP) {
+		stretch_hashes_wave<NW>(gwords, woff, up ? pos : pos - (n - 1u), n, k, st_fh, st_rh);
+		if (!up) { const unsigned src = lane0 < n ? n - 1u - lane0 : lane0; st_fh = shfl64(st_fh, src); st_rh = shfl64(st_rh, src); }
+		if (!same) { const uint64_t t = st_fh; st_fh = st_rh; st_rh = t; } // (the reverse complement's hashes are the strand hashes swapped)
+	}
+#endif
 	for (uint32_t l = lane0; l < n; l += lstep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (COOP) {
+			my_s = window_kmer<NW>(gwords, woff, up ? pos + l : pos - l, k);
+			if (!same) my_s = kmer_revcomp_fast(my_s, k);
+			my_fh = st_fh; my_rh = st_rh;
+		} else
+#endif
 		vertex_at(l, my_s, my_fh, my_rh);
 		terms();
 		const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);

@@ -106,6 +106,20 @@ static uint64_t selftest_kmer_nw(unsigned k, const uint32_t* words, uint32_t len
 		for (int q = 0; q < abg::KW<NW>; q++) bad += (w.w[q] != v.s.w[q]) + (r0.w[q] != r1.w[q]);
 		bad += (fh != v.fh) + (rh != v.rh);
 	}
+	// the prefix-XOR form of the same hashes over stretches of consecutive k-mers (stretch_hashes_serial: the
+	// arithmetic of the device's stretch_hashes_wave), from every start and for several lengths
+	for (uint32_t q = 0; q + k <= len; q += 3) {
+		for (uint32_t n : { 1u, 2u, 33u, 64u }) {
+			if (q + n + k - 1 > len) continue;
+			uint64_t fh[64], rh[64];
+			abg::stretch_hashes_serial<NW>(words, 0, q, n, k, fh, rh);
+			for (uint32_t j = 0; j < n; j++) {
+				uint64_t f0, r0;
+				abg::kmer_hashes(abg::window_kmer<NW>(words, 0, q + j, k), k, f0, r0);
+				bad += (fh[j] != f0) + (rh[j] != r0);
+			}
+		}
+	}
 	return bad;
 }
 

@@ -660,3 +660,19 @@ def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
     st = hc.stats()
     assert st["tiled_ops"] > 0 and st["tiled_pending"] > 254
     assert np.array_equal(o.counters(), hc.counters())
+
+
+def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
+    """hc_selftest_kmer: window_kmer vs batch_kmer, kmer_revcomp_fast vs kmer_revcomp, kmer_hashes vs vtx_rehash,
+    and the prefix-XOR hashes of stretches of consecutive k-mers (stretch_hashes_serial: the arithmetic of the
+    device's stretch_hashes_wave, which walk_bulk / chain_bulk / FPresearchScan use) vs kmer_hashes."""
+    l = C.CDLL(build.build_hostcheck())
+    l.hc_selftest_kmer.restype = C.c_uint64
+    l.hc_selftest_kmer.argtypes = [C.c_uint, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(5)
+    L = 300
+    pad = np.zeros(((L + 15) // 16) * 16, dtype=np.uint64)
+    pad[:L] = rng.integers(0, 4, size=L)
+    words = np.concatenate([(pad.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32), np.zeros(4, dtype=np.uint32)])
+    for k in (21, 32, 33, 64, 65, 96, 127, 128, 150, 192):
+        assert l.hc_selftest_kmer(k, words.ctypes.data, L) == 0, k
