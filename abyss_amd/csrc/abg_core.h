@@ -797,6 +797,41 @@ ABG_HD void stretch_hashes_wave(const uint32_t* __restrict__ words, uint64_t wof
 }
 #endif
 
+// The vertex of k bases fetched one by one (get(i), i < k): gather_kmer + vtx_rehash.  A cooperative caller
+// has base i in lane i while gathering, so the strand hashes come out of the same pass -- every lane rotates
+// its base's seed into place (NTF64 / NTR64 term by term, nthash.hpp:220-239) and six XOR butterflies sum
+// them -- instead of a k-round hash repeated by all 64 lanes afterwards.
+template <int NW, class Get>
+ABG_HD Vtx<NW> gather_vertex(const Params& p, bool coop, Get get)
+{
+	Vtx<NW> v;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (coop) {
+		const unsigned k = p.k, lane = __lane_id();
+		uint64_t tf = 0, tr = 0;
+#pragma unroll
+		for (int j = 0; j < KW<NW>; j++) v.s.w[j] = 0;
+#pragma unroll
+		for (int c = 0; c < (KW<NW> + 1) / 2; c++) {
+			if (64u * c >= k) continue;
+			const unsigned i = 64u * c + lane;
+			const unsigned b = i < k ? get(i) : 0u;
+			const uint64_t lo = __ballot((b & 1u) != 0), hi = __ballot((b & 2u) != 0);
+			v.s.w[2 * c] = interleave32(lo, hi);
+			if (2 * c + 1 < KW<NW>) v.s.w[2 * c + 1] = interleave32(lo >> 32, hi >> 32);
+			if (i < k) { tf ^= srol_fwd(seed_of(b & 3u), k - 1u - i); tr ^= srol_fwd(seed_of(3u - (b & 3u)), i); }
+		}
+#pragma unroll
+		for (unsigned d = 1; d < 64; d <<= 1) { tf ^= shfl64(tf, lane ^ d); tr ^= shfl64(tr, lane ^ d); }
+		v.fh = tf; v.rh = tr;
+		if constexpr (MASKED_BUILD<NW>) masked_terms(p, v.s, v.df, v.dr);
+		return v;
+	}
+#endif
+	v.s = gather_kmer<NW>(p.k, coop, get);
+	vtx_rehash(p, v);
+	return v;
+}
 // a copy of the parameters whose fields the compiler knows to be wave-uniform
 template <bool COOP> ABG_HD Params uniform_params(const Params& p)
 {

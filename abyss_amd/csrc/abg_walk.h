@@ -202,18 +202,12 @@ ABG_HD unsigned ws_base(const Params& p, const WalkState<NW>& w, uint32_t j)
 template <int NW>
 ABG_HDN Vtx<NW> ws_vertex(const Params& p, const WalkState<NW>& w, uint32_t i, bool coop = false)
 {
-	Vtx<NW> v;
-	v.s = gather_kmer<NW>(p.k, coop, [&](unsigned j) { return ws_base(p, w, i + j); });
-	vtx_rehash(p, v);
-	return v;
+	return gather_vertex<NW>(p, coop, [&](unsigned j) { return ws_base(p, w, i + j); });
 }
 template <int NW>
 ABG_HDN Vtx<NW> pool_vertex(const Params& p, const uint8_t* seq, uint64_t i, bool coop = false)
 {
-	Vtx<NW> v;
-	v.s = gather_kmer<NW>(p.k, coop, [&](unsigned j) { return (unsigned)seq[i + j] & 3u; });
-	vtx_rehash(p, v);
-	return v;
+	return gather_vertex<NW>(p, coop, [&](unsigned j) { return (unsigned)seq[i + j] & 3u; });
 }
 
 // profiling aid (ABG_WALK_DEBUG): the 100 MHz wall clock, only read when a debug buffer is attached
@@ -345,21 +339,42 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);
 		bs.key[l] = key;
 		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
-		for (unsigned base = 0; base < p.nh; base += 4) {
-			uint8_t c[8][4];
-#pragma unroll
-			for (unsigned q = 0; q < 8; q++) {
+		{
+			// Two stages.  Six of the eight neighbours do not exist, and nearly all of those fail the first
+			// hash function already: that one is probed for all eight, the other nh - 1 only for the neighbours
+			// that passed it, two of them per round (the usual survivors: the one behind and the one ahead).
+			// The same verdicts as probing everything at once for 8 + ~2 (nh - 1) positions instead of 8 nh.
+			auto nbr_h = [&](unsigned q) -> uint64_t {
 				uint64_t nfh, nrh;
 				nbr(my_s, my_fh, my_rh, q < 4 ? bsense : fsense, q & 3u, nfh, nrh);
 				nfh ^= q < 4 ? my_bdf : my_fdf; nrh ^= q < 4 ? my_bdr : my_fdr;
-				const uint64_t h = nrh < nfh ? nrh : nfh;
+				return nrh < nfh ? nrh : nfh;
+			};
+			uint8_t c0[8];
 #pragma unroll
-				for (unsigned i = 0; i < 4; i++) c[q][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h, base + i < p.nh ? base + i : 0u));
-			}
+			for (unsigned q = 0; q < 8; q++) c0[q] = (uint8_t)probe_c(p, cnt, pos_i(p, nbr_h(q), 0u));
 #pragma unroll
-			for (unsigned q = 0; q < 8; q++) {
+			for (unsigned q = 0; q < 8; q++) bad |= (c0[q] < p.kc ? 1u : 0u) << q;
+			unsigned surv = p.nh > 1 ? ~bad & 0xFFu : 0u;
+			while (COOP ? wave_any(surv != 0) : surv != 0) {
+				if (surv) {
+					const unsigned q1 = (unsigned)__builtin_ctz(surv);
+					surv &= surv - 1;
+					const unsigned q2 = surv ? (unsigned)__builtin_ctz(surv) : q1;
+					surv &= surv - 1;
+					const uint64_t h1 = nbr_h(q1), h2 = nbr_h(q2);
+					for (unsigned base = 1; base < p.nh; base += 3) {
+						uint8_t c1[3], c2[3];
 #pragma unroll
-				for (unsigned i = 0; i < 4; i++) bad |= (c[q][i] < p.kc ? 1u : 0u) << q;
+						for (unsigned i = 0; i < 3; i++) {
+							const unsigned hi = base + i < p.nh ? base + i : 0u;
+							c1[i] = (uint8_t)probe_c(p, cnt, pos_i(p, h1, hi));
+							c2[i] = (uint8_t)probe_c(p, cnt, pos_i(p, h2, hi));
+						}
+#pragma unroll
+						for (unsigned i = 0; i < 3; i++) { bad |= (c1[i] < p.kc ? 1u : 0u) << q1; bad |= (c2[i] < p.kc ? 1u : 0u) << q2; }
+					}
+				}
 			}
 		}
 		const uint64_t fs = wt_find(tab, wt_key(key), owner);

@@ -2,7 +2,7 @@
 # prefix-XOR stretch hashes in the bulk steps: parity first, then the bench (with events: per-kernel numbers)
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3l; mkdir -p $O
+O=$R/gpurun_out/r3m; mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py -x -q 2>&1 | tail -3 | cut -c1-300
 run() { # tag env...
