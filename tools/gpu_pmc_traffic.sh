@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row['Counter_Name'] != c: continue
             name = row['Kernel_Name']
-            for key in ("FHashClaim", "FInsertRound", "FClassify", "k_walkers", "k_commit", "k_insert_drain", "FContigPrep",
+            for key in ("FHashOps", "FBinCoarse", "FBinFine", "FTilePurity", "FOpTarget", "FTileApply", "FClaimList", "FHashClaim", "FInsertRound", "FClassify", "FWalk", "FPresearch<", "FPresearchScan", "FGuideBuild", "k_commit", "k_insert_drain", "FContigPrep",
                         "FPcTimeMin", "FPcDecide", "FPcApply"):
                 if key in name:
                     agg[key][0] += float(row['Counter_Value']); agg[key][1] += 1
