@@ -11,6 +11,10 @@ cd $R
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > $O/smoke.log; cat $O/smoke.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
+# the partitioned code path on one rank through RCCL (every collective an identity): what that path costs by itself
+ABG_FORCE_DIST=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/bench_forced_partitioned_1rank.json 2> $O/bench_forced.err; cut -c1-300 $O/bench_forced_partitioned_1rank.json
+# configs[3] (spaced seed) and its parity check
+timeout 300 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; cut -c1-300 $O/bench_config3.json
 # kernel trace + timeline (tools/gpu_r3_timeline.sh writes gpurun_out/r3t/)
 bash tools/gpu_r3_timeline.sh 1 > $O/timeline.log 2>&1; tail -5 $O/timeline.log | cut -c1-200
 cp gpurun_out/r3t/timeline_ps1.txt $O/timeline_config1.txt 2>/dev/null; cp gpurun_out/r3t/kernel_stats_ps1.csv $O/kernel_stats_config1.csv 2>/dev/null
