@@ -402,7 +402,9 @@ def main() -> int:
     if not per_kernel:
         # (partitioned run without a warm-up step: no per-launch events were taken -- see timed_profile)
         per_kernel = {"walk": {"achieved": None, "frac": None, "avg_launch_ms": None, "launches": 0, "ms": 0, "longest_kernel": "rewalk"}}
-    dom = max(per_kernel, key=lambda fam: per_kernel[fam]["ms"] if fam != "classify" else 0)  # (classification overlaps the walk)
+    # the dominant kernel: the one with the largest summed duration over the step (the classification runs on the
+    # side stream beside the walkers and is not on the critical path); the roofline line is its family's
+    dom = max(per_kernel, key=lambda fam: prof[per_kernel[fam]["longest_kernel"]][0] if (fam != "classify" and per_kernel[fam].get("longest_kernel") in prof) else 0)
     # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this very
     # command, tools/gpu_r2_prof.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
     # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
@@ -423,9 +425,10 @@ def main() -> int:
                 "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "launches": per_kernel[dom]["launches"],
-                "note": "dominant kernel family by time (the classification overlaps the walk on a side stream); algorithmic "
-                        "bytes of the family (SURVEY.md 8d) over the summed duration of its kernels; the walk is a "
-                        "latency-bound graph traversal of dependent random probes, not a stream (DESIGN.md)",
+                "note": "the kernel with the largest summed duration of the step (the classification overlaps the walk on a side stream); "
+                        "achieved = algorithmic bytes of its family (SURVEY.md 8d) over the summed duration of the family's kernels; "
+                        "the walk is a graph traversal of dependent random probes whose waves wait on memory 78 % of their cycles, "
+                        "not a stream (DESIGN.md section 4.2, profiles/r03_c_pmc_sq_walkers.txt)",
                 "whole_step": {"algorithmic_GB": step_bytes / 1e9, "achieved": step_bytes / 1e9 / (elapsed / a.steps),
                                "frac": step_bytes / 1e9 / (elapsed / a.steps) / HBM_PEAK_GBS},
                 "kernels": per_kernel}
