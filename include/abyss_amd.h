@@ -14,6 +14,11 @@
  * Every function returns ABG_OK (0) or a negative ABG_E* code; abg_last_error() gives the
  * message.  The reference reports errors by printing and exit(EXIT_FAILURE)
  * (Common/IOUtil.h:14-22); the host binary maps non-zero codes to that behaviour.
+ * The library itself never exits or aborts: whatever fails inside it -- a device allocation, a
+ * capacity the data exceeds, a collective, an internal invariant -- comes back as ABG_ENOMEM /
+ * ABG_EINTERNAL.  After one of those two a context is only good for abg_destroy().
+ * (Environment, for tests: ABG_MEM_LIMIT_MB gives every context created afterwards a device
+ * memory budget; a request beyond it fails like a hipMalloc that found no room.)
  *
  * The implementation is HIP for gfx950 only: abg_create() fails with ABG_ENODEV when no
  * GPU is present.  There is no CPU fallback.
