@@ -7,7 +7,24 @@
 #include <deque>
 namespace boost {
 
-template <typename G> struct graph_traits;
+/* Boost's primary template takes the associated types from the graph class itself; the reference's
+ * DirectedGraph / ContigGraph (AdjList oracle) rely on that, RollingBloomDBG.h specialises it. */
+template <typename G> struct graph_traits {
+	typedef typename G::vertex_descriptor vertex_descriptor;
+	typedef typename G::edge_descriptor edge_descriptor;
+	typedef typename G::adjacency_iterator adjacency_iterator;
+	typedef typename G::out_edge_iterator out_edge_iterator;
+	typedef typename G::in_edge_iterator in_edge_iterator;
+	typedef typename G::vertex_iterator vertex_iterator;
+	typedef typename G::edge_iterator edge_iterator;
+	typedef typename G::directed_category directed_category;
+	typedef typename G::edge_parallel_category edge_parallel_category;
+	typedef typename G::traversal_category traversal_category;
+	typedef typename G::vertices_size_type vertices_size_type;
+	typedef typename G::edges_size_type edges_size_type;
+	typedef typename G::degree_size_type degree_size_type;
+	static vertex_descriptor null_vertex() { return G::null_vertex(); }
+};
 
 struct directed_tag {};
 struct undirected_tag {};
@@ -51,6 +68,10 @@ public:
 };
 
 template <typename T> inline void function_requires() {}
+namespace detail {
+inline bool is_directed(directed_tag) { return true; }
+inline bool is_directed(undirected_tag) { return false; }
+}
 
 } // namespace boost
 
