@@ -57,6 +57,8 @@ def symbols():
         "abg_attach_comm", "abg_share_reads", "abg_rccl_unique_id", "abg_rccl_comm_create", "abg_rccl_comm_destroy",
         "abg_dev_copy", "abg_dev_alloc", "abg_dev_free", "abg_output_graph_seqs",
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
+        "abg_overlap_create", "abg_overlap_destroy", "abg_overlap_last_error", "abg_overlap_join", "abg_overlap_edges",
+        "abg_overlap_profile", "abg_overlap_profile_get",
     ]
 
 
@@ -108,5 +110,14 @@ def load(path: str | None = None):
     lib.abg_output_graph_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64, TEXT_CB, vp, u64p, u64p]
     lib.abg_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     lib.abg_dev_free.argtypes = [vp, vp]
+    lib.abg_overlap_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.abg_overlap_destroy.argtypes = [vp]
+    lib.abg_overlap_destroy.restype = None
+    lib.abg_overlap_last_error.argtypes = [vp]
+    lib.abg_overlap_last_error.restype = C.c_char_p
+    lib.abg_overlap_join.argtypes = [vp, C.c_uint32, C.c_uint64, vp, vp, C.c_int, u64p]
+    lib.abg_overlap_edges.argtypes = [vp, vp, vp]
+    lib.abg_overlap_profile.argtypes = [vp, C.c_int]
+    lib.abg_overlap_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
     _lib = lib
     return lib

@@ -294,6 +294,76 @@ class BloomDBG:
         return ms.value, n.value
 
 
+def pack_ends(seqs: Sequence[bytes], overlap: int) -> Tuple[np.ndarray, np.ndarray]:
+    """First and last `overlap` bases of every sequence as the 2-bit keys abg_overlap_join takes
+    (Kmer(seq.substr(...)), AdjList.cpp:210-211): [n, W] uint64, base j at bits 2(j%32) of word j/32."""
+    n, W = len(seqs), (overlap + 31) // 32
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    out = []
+    for take in (lambda s: s[:overlap], lambda s: s[len(s) - overlap:]):
+        ends = np.frombuffer(b"".join(take(s) for s in seqs), dtype=np.uint8).reshape(n, overlap) if n else np.zeros((0, overlap), np.uint8)
+        c = code[ends]
+        if (c == 255).any():
+            raise ValueError("unexpected character in a contig end")
+        pad = np.zeros((n, W * 32), dtype=np.uint64)
+        pad[:, :overlap] = c
+        out.append(np.ascontiguousarray((pad.reshape(n, W, 32) << (2 * np.arange(32, dtype=np.uint64))).sum(axis=2, dtype=np.uint64)))
+    return out[0], out[1]
+
+
+class OverlapJoin:
+    """AdjList's join of contig ends overlapping by exactly k-1 bases, on one GPU
+    (buildOverlapGraph, AdjList/AdjList.cpp:233-263; include/abyss_amd.h abg_overlap_*)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.abg_overlap_create(device, C.byref(self._h))
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_overlap_last_error(None)
+            self._h = None
+            raise AbyssAmdError("abg_overlap_create failed (%d): %s" % (rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.abg_overlap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_overlap_last_error(self._h)
+            raise AbyssAmdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def join(self, overlap: int, head: np.ndarray, tail: np.ndarray, strand_specific: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """(offsets [2n+1], targets): out-edges of vertex s (2i = i+, 2i+1 = i-) are targets[offsets[s]:offsets[s+1]]."""
+        head = np.ascontiguousarray(head, dtype=np.uint64)
+        tail = np.ascontiguousarray(tail, dtype=np.uint64)
+        n = head.shape[0] if head.ndim == 2 else 0
+        ne = C.c_uint64()
+        self._check(self._lib.abg_overlap_join(self._h, overlap, n, head.ctypes.data, tail.ctypes.data, int(strand_specific), C.byref(ne)),
+                    "abg_overlap_join")
+        off = np.zeros(2 * n + 1, dtype=np.uint64)
+        tgt = np.zeros(ne.value, dtype=np.uint32)
+        self._check(self._lib.abg_overlap_edges(self._h, off.ctypes.data, tgt.ctypes.data if ne.value else None), "abg_overlap_edges")
+        return off, tgt
+
+    def profile(self, on: bool = True) -> None:
+        self._lib.abg_overlap_profile(self._h, int(on))
+
+    def profile_get(self, name: str) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        self._lib.abg_overlap_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
 def counting_bloom_file(counters: np.ndarray, k: int, num_hashes: int) -> bytes:
     """`operator<<` of CountingBloomFilter<uint8_t> (CountingBloomFilter.hpp:344-379): the TOML-ish
     header in the key order cpptoml emits, then the raw counters."""

@@ -1,6 +1,6 @@
 """Build helpers: compile the HIP library (product) and the checkers (test infrastructure).
 
-The product is one shared library, ``abyss_amd/lib/libabyss_amd.so``, built in-tree with
+The product is one shared library, ``abyss_amd/lib/libabyss_amd.so`` (plus the host binaries over its C ABI in ``abyss_amd/bin``), built in-tree with
 ``hipcc --offload-arch=gfx950`` from ``abyss_amd/csrc/abg_kernels.hip``; hipcc
 cross-compiles without a GPU.  The checkers (``oracle/liboracle.so``, ``oracle/abg_oracle``,
 ``oracle/_ref/*`` when /root/reference is present, ``tests/hostcheck/libhostcheck.so``) are
@@ -73,6 +73,9 @@ def build_cli(force: bool = False) -> str:
         _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o",
               os.path.join(BIN_DIR, "abyss-bloom"), os.path.join(CSRC, "host", "bloom_main.cc"),
               "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
+        _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o",
+              os.path.join(BIN_DIR, "AdjList"), os.path.join(CSRC, "host", "adjlist_main.cc"),
+              "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
     return out
 
 
@@ -87,6 +90,7 @@ def build_oracle(force: bool = False) -> None:
 
 
 READER_CHECK = os.path.join(ROOT, "tests", "hostcheck", "reader_check")
+ADJLIST_CHECK = os.path.join(ROOT, "tests", "hostcheck", "adjlist_check")
 
 
 def build_hostcheck(force: bool = False) -> str:
@@ -96,6 +100,11 @@ def build_hostcheck(force: bool = False) -> str:
     rsrc = os.path.join(ROOT, "tests", "hostcheck", "reader_check.cc")
     if force or _newer(READER_CHECK, [rsrc, os.path.join(CSRC, "host", "fasta_reader.h")]):
         _run(["g++", "-std=c++17", "-O2", "-o", READER_CHECK, rsrc])
+    asrc = os.path.join(ROOT, "tests", "hostcheck", "adjlist_check.cc")
+    if force or _newer(ADJLIST_CHECK, [asrc, HOSTCHECK, os.path.join(CSRC, "host", "adjlist_core.h"),
+                                       os.path.join(CSRC, "host", "fasta_reader.h")]):
+        _run(["g++", "-std=c++17", "-O2", "-o", ADJLIST_CHECK, asrc, "-L" + os.path.dirname(HOSTCHECK), "-lhostcheck",
+              "-Wl,-rpath,$ORIGIN"])
     return HOSTCHECK
 
 

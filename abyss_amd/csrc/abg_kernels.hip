@@ -16,6 +16,7 @@
 #include <unistd.h>
 
 #include "abg_host.h"
+#include "abg_overlap.h"
 
 #include <chrono>
 #include <map>
@@ -404,6 +405,22 @@ struct HipBackend {
 		size_t bytes = cub_tmp_bytes;
 		check(hipcub::DeviceScan::InclusiveSum(cub_tmp, bytes, data, data, (int)n, stream), "DeviceScan");
 		end("scan");
+	}
+	// (keys, values) sorted by key, stable; values 32-bit (AdjList's join: abg_overlap.h)
+	void sort_pairs_u64_u32(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n)
+	{
+		if (!n) return;
+		begin("sort_pairs");
+		size_t need = 0;
+		check(hipcub::DeviceRadixSort::SortPairs(nullptr, need, kin, kout, vin, vout, (int)n, 0, 64, stream), "DeviceRadixSort");
+		if (need > cub_tmp_bytes) {
+			if (cub_tmp) { hipStreamSynchronize(stream); hipFree(cub_tmp); }
+			cub_tmp_bytes = need * 2;
+			check(hipMalloc(&cub_tmp, cub_tmp_bytes), "hipMalloc");
+		}
+		size_t bytes = cub_tmp_bytes;
+		check(hipcub::DeviceRadixSort::SortPairs(cub_tmp, bytes, kin, kout, vin, vout, (int)n, 0, 64, stream), "DeviceRadixSort");
+		end("sort_pairs");
 	}
 	uint32_t max_slots() const { return cus * 8 * 256; }
 	uint64_t device_mem_bytes() const { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (uint64_t)tot : 0; }
@@ -1044,6 +1061,90 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 		out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds;
 		return ABG_OK;
 	});
+}
+
+// ---- the AdjList stage: k-1 overlaps of contig ends (abg_overlap.h) ----
+} // extern "C"
+struct abg_overlap {
+	HipBackend be;
+	abg::OverlapJoin<HipBackend> join;
+	std::string error;
+	explicit abg_overlap(int dev) : be(dev), join(be) {}
+};
+namespace {
+std::string g_overlap_create_error;
+template <class F>
+int guarded_ov(abg_overlap* o, F&& body)
+{
+	try {
+		return body();
+	} catch (const abg::Failure& f) {
+		o->error = f.msg;
+		return f.code;
+	} catch (const std::bad_alloc&) {
+		o->error = "host memory exhausted";
+		return ABG_ENOMEM;
+	} catch (const std::exception& e) {
+		o->error = e.what();
+		return ABG_EINTERNAL;
+	}
+}
+} // namespace
+extern "C" {
+int abg_overlap_create(int device, abg_overlap** out)
+{
+	if (!out) return ABG_EINVAL;
+	*out = nullptr;
+	abg_overlap* o = nullptr;
+	try {
+		o = new abg_overlap(device);
+	} catch (const std::exception& e) {
+		g_overlap_create_error = e.what();
+		return ABG_EINTERNAL;
+	}
+	if (!o->be.ok()) {
+		g_overlap_create_error = o->be.why();
+		delete o;
+		return ABG_ENODEV;
+	}
+	*out = o;
+	return ABG_OK;
+}
+void abg_overlap_destroy(abg_overlap* o) { delete o; }
+const char* abg_overlap_last_error(const abg_overlap* o) { return o ? o->error.c_str() : g_overlap_create_error.c_str(); }
+int abg_overlap_join(abg_overlap* o, uint32_t overlap, uint64_t n_contigs, const uint64_t* head_keys, const uint64_t* tail_keys,
+    int strand_specific, uint64_t* n_edges)
+{
+	if (!o || !n_edges || (n_contigs && (!head_keys || !tail_keys))) return ABG_EINVAL;
+	if (overlap < 1 || overlap > 32 * abg::OV_MAX_WORDS) { o->error = "overlap length out of range (1..256)"; return ABG_EINVAL; }
+	if (n_contigs >= (1ull << 30)) { o->error = "too many contigs (vertex ids are 32-bit)"; return ABG_EINVAL; }
+	return guarded_ov(o, [&]() -> int {
+		o->join.run(overlap, n_contigs, head_keys, tail_keys, strand_specific != 0);
+		*n_edges = o->join.edges();
+		return ABG_OK;
+	});
+}
+int abg_overlap_edges(abg_overlap* o, uint64_t* offsets, uint32_t* targets)
+{
+	if (!o) return ABG_EINVAL;
+	return guarded_ov(o, [&]() -> int {
+		o->join.fetch(offsets, targets);
+		return ABG_OK;
+	});
+}
+int abg_overlap_profile(abg_overlap* o, int on)
+{
+	if (!o) return ABG_EINVAL;
+	o->be.profiling = on != 0;
+	return ABG_OK;
+}
+int abg_overlap_profile_get(abg_overlap* o, const char* name, double* total_ms, uint64_t* launches)
+{
+	if (!o || !name) return ABG_EINVAL;
+	auto it = o->be.prof.find(name);
+	if (total_ms) *total_ms = it != o->be.prof.end() ? it->second.ms : 0;
+	if (launches) *launches = it != o->be.prof.end() ? it->second.launches : 0;
+	return ABG_OK;
 }
 
 } // extern "C"

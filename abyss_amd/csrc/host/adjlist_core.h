@@ -1,0 +1,510 @@
+// adjlist_core.h -- host side of the drop-in `AdjList` (the stage abyss-pe runs on the unitig
+// FASTA right after abyss-bloom-dbg, bin/abyss-pe:575-577): options, contig reading, the
+// suffix-array overlaps of fewer than k-1 bases, and the graph writers.  The join of contig ends
+// that overlap by exactly k-1 bases -- the part that touches every contig -- is the caller's
+// `Join` (abg_overlap_join on the GPU in the product binary; tests/hostcheck substitutes the same
+// device logic run serially).
+//
+// Reference behaviour restated here (ABySS 2.3.10):
+//   AdjList/AdjList.cpp:36-133,323-395  options, usage, -m handling
+//   AdjList/AdjList.cpp:137-189         addOverlapsSA: overlaps of [m, k-1) bases among blunt vertices
+//   AdjList/AdjList.cpp:192-230         readContigs (FOLD_CASE, flattenAmbiguityCodes, `LEN COV` comment)
+//   Common/SuffixArray.h                suffixes of length >= m, sorted by (strcmp, vertex)
+//   Common/Sequence.h:50-73             flattenAmbiguityCodes
+//   Graph/AdjIO.h:32-66  DotIO.h:14-101  GfaIO.h:15-211  AsqgIO.h:13-70  SAMIO.h:18-70   writers
+//   Graph/GraphUtil.h:27-64, Common/Histogram.cpp:45-95   -v statistics
+#pragma once
+
+#include "fasta_reader.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <getopt.h>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_set>
+#include <vector>
+#include <cmath>
+
+namespace abgadj {
+
+#define ABG_ADJ_PROGRAM "AdjList"
+#define ABG_ADJ_VERSION "2.3.10"
+
+enum Format { ADJ = 0, ASQG, DOT, GFA1, GFA2, SAM }; // Graph/Options.h (the ones AdjList offers)
+
+struct Options {
+	unsigned k = 0, singleKmer = 0, minOverlap = 50;
+	int format = ADJ, ss = 0, verbose = 0;
+	std::vector<std::string> files;
+	std::string commandLine;
+};
+
+// k-1 join: (overlap, n, head keys, tail keys, ss) -> CSR (offsets [2n+1], targets); see include/abyss_amd.h
+typedef std::function<void(uint32_t, uint64_t, const uint64_t*, const uint64_t*, bool, std::vector<uint64_t>&, std::vector<uint32_t>&)> Join;
+
+struct Edge { uint32_t v; int d; };
+
+struct Graph {
+	unsigned k = 0;
+	std::vector<std::string> name;               // per contig
+	std::vector<unsigned> length, coverage;      // per contig
+	std::vector<uint64_t> head, tail;            // per contig, W words each: first / last k-1 bases
+	uint32_t W = 0;
+	std::vector<uint64_t> off;                   // k-1 overlaps, CSR over the source vertex
+	std::vector<uint32_t> tgt;
+	std::vector<std::vector<Edge>> extra;        // shorter overlaps of blunt vertices (empty unless -m < k-1)
+	uint64_t n() const { return name.size(); }
+	uint64_t nv() const { return 2 * n(); }
+	uint64_t degree(uint64_t u) const
+	{
+		const uint64_t d = off[u + 1] - off[u];
+		return d || extra.empty() ? d : extra[u].size();
+	}
+	template <class F> void for_out(uint64_t u, F f) const
+	{
+		if (off[u + 1] > off[u] || extra.empty()) {
+			for (uint64_t e = off[u]; e < off[u + 1]; e++) f(tgt[e], -(int)(k - 1));
+		} else {
+			for (const Edge& e : extra[u]) f(e.v, e.d);
+		}
+	}
+	uint64_t edges() const
+	{
+		uint64_t e = tgt.size();
+		for (auto& x : extra) e += x.size();
+		return e;
+	}
+	std::string vname(uint64_t u) const { return name[u >> 1] + ((u & 1) ? '-' : '+'); }
+};
+
+static const char USAGE_MESSAGE[] =
+"Usage: " ABG_ADJ_PROGRAM " -k<kmer> [OPTION]... [FILE]...\n"
+"Find overlaps of [m,k) bases. Contigs may be read from FILE(s)\n"
+"or standard input. Output is written to standard output.\n"
+"Overlaps of exactly k-1 bases are found by a sort-and-join on the GPU.\n"
+"Overlaps of fewer than k-1 bases are found using a suffix array.\n"
+"\n"
+" Options:\n"
+"\n"
+"  -k, --kmer=N          the length of a k-mer\n"
+"  -m, --min-overlap=M   require a minimum overlap of M bases [50]\n"
+"                        value of 0 is interpreted as k - 1\n"
+"      --adj             output the graph in ADJ format [default]\n"
+"      --asqg            output the graph in ASQG format\n"
+"      --dot             output the graph in GraphViz format\n"
+"      --gfa             output the graph in GFA1 format\n"
+"      --gfa1            output the graph in GFA1 format\n"
+"      --gfa2            output the graph in GFA2 format\n"
+"      --gv              output the graph in GraphViz format\n"
+"      --sam             output the graph in SAM format\n"
+"      --SS              expect contigs to be oriented correctly\n"
+"      --no-SS           no assumption about contig orientation\n"
+"  -v, --verbose         display verbose output\n"
+"      --help            display this help and exit\n"
+"      --version         output version information and exit\n"
+"      --gpu=N           HIP device ordinal [0]\n"
+"\n"
+"-K (paired de Bruijn graph) and --db are not supported by this build.\n";
+
+// AdjList.cpp:323-378.  Returns false when the caller should exit with `*status`.
+inline bool parse_options(int argc, char** argv, Options& o, int* device, int* status)
+{
+	{
+		std::ostringstream ss;
+		for (int i = 0; i < argc; i++) ss << (i ? " " : "") << argv[i];
+		o.commandLine = ss.str();
+	}
+	enum { OPT_HELP = 1, OPT_VERSION, OPT_DB, OPT_LIBRARY, OPT_STRAIN, OPT_SPECIES, OPT_GPU };
+	static int format = ADJ, ss = 0;
+	static const struct option longopts[] = {
+		{ "kmer", required_argument, NULL, 'k' }, { "single-kmer", required_argument, NULL, 'K' },
+		{ "min-overlap", required_argument, NULL, 'm' },
+		{ "adj", no_argument, &format, ADJ }, { "asqg", no_argument, &format, ASQG }, { "dot", no_argument, &format, DOT },
+		{ "gfa", no_argument, &format, GFA1 }, { "gfa1", no_argument, &format, GFA1 }, { "gfa2", no_argument, &format, GFA2 },
+		{ "gv", no_argument, &format, DOT }, { "sam", no_argument, &format, SAM },
+		{ "SS", no_argument, &ss, 1 }, { "no-SS", no_argument, &ss, 0 },
+		{ "verbose", no_argument, NULL, 'v' }, { "help", no_argument, NULL, OPT_HELP }, { "version", no_argument, NULL, OPT_VERSION },
+		{ "db", required_argument, NULL, OPT_DB }, { "library", required_argument, NULL, OPT_LIBRARY },
+		{ "strain", required_argument, NULL, OPT_STRAIN }, { "species", required_argument, NULL, OPT_SPECIES },
+		{ "gpu", required_argument, NULL, OPT_GPU },
+		{ NULL, 0, NULL, 0 }
+	};
+	bool die = false;
+	for (int c; (c = getopt_long(argc, argv, "k:K:m:v", longopts, NULL)) != -1;) {
+		std::istringstream arg(optarg != NULL ? optarg : "");
+		switch (c) {
+		case '?': die = true; break;
+		case 'k': arg >> o.k; break;
+		case 'K': arg >> o.singleKmer; break;
+		case 'm': arg >> o.minOverlap; break;
+		case 'v': o.verbose++; break;
+		case OPT_HELP: fputs(USAGE_MESSAGE, stdout); *status = EXIT_SUCCESS; return false;
+		case OPT_VERSION: fputs(ABG_ADJ_PROGRAM " (ABySS, abyss_amd) " ABG_ADJ_VERSION "\n", stdout); *status = EXIT_SUCCESS; return false;
+		case OPT_DB: case OPT_LIBRARY: case OPT_STRAIN: case OPT_SPECIES: {
+			std::string s; arg >> s;
+			fprintf(stderr, ABG_ADJ_PROGRAM ": warning: the database options are ignored (built without sqlite)\n");
+			break;
+		}
+		case OPT_GPU: arg >> *device; break;
+		}
+		if (optarg != NULL && !arg.eof()) {
+			fprintf(stderr, ABG_ADJ_PROGRAM ": invalid option: `-%c%s'\n", (char)c, optarg);
+			*status = EXIT_FAILURE;
+			return false;
+		}
+	}
+	o.format = format;
+	o.ss = ss;
+	if (o.k <= 0) { fprintf(stderr, ABG_ADJ_PROGRAM ": missing -k,--kmer option\n"); die = true; }
+	if (o.singleKmer > 0) { fprintf(stderr, ABG_ADJ_PROGRAM ": -K (paired de Bruijn graph) is not supported\n"); die = true; }
+	if (!die && o.k < 2) { fprintf(stderr, ABG_ADJ_PROGRAM ": -k must be at least 2\n"); die = true; }
+	if (!die && o.k - 1 > 256) { fprintf(stderr, ABG_ADJ_PROGRAM ": -k must be at most 257\n"); die = true; }
+	if (die) {
+		fprintf(stderr, "Try `" ABG_ADJ_PROGRAM " --help' for more information.\n");
+		*status = EXIT_FAILURE;
+		return false;
+	}
+	if (o.minOverlap == 0) o.minOverlap = o.k - 1;
+	o.minOverlap = std::min(o.minOverlap, o.k - 1);
+	for (; optind < argc; optind++) o.files.push_back(argv[optind]);
+	if (o.files.empty()) o.files.push_back("-");
+	return true;
+}
+
+inline int base_code(char c)
+{
+	switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+// Kmer(seq.substr(at, len)): 2 bits per base, base j at bits 2(j%32) of word j/32 (baseToCode, Common/Sequence.cpp:96-105)
+inline void pack_key(const std::string& s, size_t at, unsigned len, uint64_t* out, unsigned W)
+{
+	for (unsigned w = 0; w < W; w++) out[w] = 0;
+	for (unsigned j = 0; j < len; j++) {
+		const int c = base_code(s[at + j]);
+		if (c < 0) {
+			fprintf(stderr, "error: unexpected character: '%c'\n", s[at + j]);
+			exit(EXIT_FAILURE);
+		}
+		out[j >> 5] |= (uint64_t)c << (2 * (j & 31));
+	}
+}
+inline std::string key_string(const uint64_t* w, unsigned len, bool rc)
+{
+	std::string s(len, 'A');
+	for (unsigned j = 0; j < len; j++) {
+		const unsigned c = (unsigned)(w[j >> 5] >> (2 * (j & 31))) & 3u;
+		if (rc) s[len - 1 - j] = "TGCA"[c]; else s[j] = "ACGT"[c];
+	}
+	return s;
+}
+inline std::string revcomp(const std::string& s)
+{
+	std::string r(s.rbegin(), s.rend());
+	for (auto& c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+	return r;
+}
+
+// readContigs, AdjList.cpp:192-230
+inline void read_contigs(const std::string& path, const Options& o, Graph& g, std::unordered_set<std::string>& seen)
+{
+	if (o.verbose > 0) fprintf(stderr, "Reading `%s'...\n", path.c_str());
+	abghost::ReaderOptions ro;
+	ro.trimMasked = 0; // AdjList.cpp:387
+	abghost::FastaReader in(path, ro);
+	const unsigned overlap = o.k - 1, W = g.W;
+	std::string id, comment, seq;
+	while (in.read(id, comment, seq)) {
+		if (isdigit((unsigned char)seq[0])) {
+			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': colour-space contigs are not supported\n", path.c_str());
+			exit(EXIT_FAILURE);
+		}
+		for (auto& c : seq) { // flattenAmbiguityCodes(seq), N untouched
+			switch (c) {
+			case 'M': case 'R': case 'W': case 'V': case 'H': case 'D': c = 'A'; break;
+			case 'S': case 'Y': case 'B': c = 'C'; break;
+			case 'K': c = 'G'; break;
+			default: break;
+			}
+		}
+		if (seq.length() <= overlap) { // (an assertion of the reference)
+			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': contig `%s' is %zu bases long: contigs must be longer than k-1 = %u\n",
+			    path.c_str(), id.c_str(), seq.length(), overlap);
+			exit(EXIT_FAILURE);
+		}
+		if (!seen.insert(id).second) { // (g_contigNames.insert asserts on a duplicate)
+			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': duplicate contig ID `%s'\n", path.c_str(), id.c_str());
+			exit(EXIT_FAILURE);
+		}
+		const size_t at = g.head.size();
+		g.head.resize(at + W);
+		g.tail.resize(at + W);
+		pack_key(seq, 0, overlap, &g.head[at], W);
+		pack_key(seq, seq.length() - overlap, overlap, &g.tail[at], W);
+		unsigned length = 0, coverage = 0; // getCoverage, AdjList.cpp:127-133
+		{
+			std::istringstream ss(comment);
+			ss >> length >> coverage;
+		}
+		g.name.push_back(id);
+		g.length.push_back((unsigned)seq.length());
+		g.coverage.push_back(coverage);
+		if (g.n() >= (1ull << 30)) { fprintf(stderr, ABG_ADJ_PROGRAM ": too many contigs\n"); exit(EXIT_FAILURE); }
+	}
+}
+
+// Histogram::bin + barplot (Common/Histogram.cpp:45-95) over the out-degrees; printGraphStats (Graph/GraphUtil.h:43-64)
+inline void print_graph_stats(FILE* out, const Graph& g)
+{
+	std::map<int, uint64_t> h;
+	for (uint64_t u = 0; u < g.nv(); u++) h[(int)g.degree(u)]++;
+	const unsigned v = (unsigned)g.nv(), e = (unsigned)g.edges();
+	auto sig = [](float x, int prec) { // operator<<(float) under setprecision(prec): %g
+		char b[64];
+		snprintf(b, sizeof b, "%.*g", prec, x);
+		return std::string(b);
+	};
+	fprintf(out, "V=%u E=%u E/V=%s\n", v, e, sig((float)e / v, 3).c_str());
+	if (h.empty()) return;
+	const int mn = h.begin()->first, mx = h.rbegin()->first;
+	std::vector<uint64_t> bins;
+	{
+		const unsigned nb = (unsigned)mx + 1;
+		const int per = (int)ceilf((float)(mx - mn) / nb);
+		int next = mn + per;
+		uint64_t count = 0;
+		for (auto& kv : h) {
+			if (kv.first >= next) { bins.push_back(count); count = 0; next += per; }
+			count += kv.second;
+		}
+		if (count > 0) bins.push_back(count);
+	}
+	static const char* bars[10] = { " ", "_", "\342\226\201", "\342\226\202", "\342\226\203", "\342\226\204", "\342\226\205", "\342\226\206", "\342\226\207", "\342\226\210" };
+	std::vector<std::string> cells;
+	const uint64_t top = 1 + *std::max_element(bins.begin(), bins.end());
+	for (uint64_t b : bins) cells.push_back(bars[10 * b / top]);
+	while (!cells.empty() && cells.back() == " ") cells.pop_back();
+	std::string plot;
+	for (auto& c : cells) plot += c;
+	uint64_t n = 0, n0 = 0, n1 = 0, n234 = 0;
+	for (auto& kv : h) {
+		n += kv.second;
+		if (kv.first == 0) n0 += kv.second;
+		else if (kv.first == 1) n1 += kv.second;
+		else if (kv.first <= 4) n234 += kv.second;
+	}
+	const uint64_t n5 = n - (n0 + n1 + n234);
+	fprintf(out, "Degree: %s\n        01234\n0: %s%% 1: %s%% 2-4: %s%% 5+: %s%% max: %d\n", plot.c_str(),
+	    sig((float)100 * n0 / n, 2).c_str(), sig((float)100 * n1 / n, 2).c_str(), sig((float)100 * n234 / n, 2).c_str(),
+	    sig((float)100 * n5 / n, 2).c_str(), mx);
+}
+
+// addOverlapsSA, AdjList.cpp:137-189: overlaps of [m, k-1) bases between the vertices without a k-1 overlap
+inline void add_short_overlaps(const Options& o, Graph& g)
+{
+	const unsigned len = o.k - 1, W = g.W;
+	std::vector<uint32_t> blunt;
+	for (uint64_t u = 0; u < g.nv(); u++) if (g.off[u + 1] == g.off[u]) blunt.push_back((uint32_t)u);
+	// the last k-1 bases of every blunt vertex: reverseComplement(prefixes[u^1])
+	std::vector<std::string> suffix(blunt.size());
+	for (size_t b = 0; b < blunt.size(); b++) {
+		const uint32_t u = blunt[b];
+		suffix[b] = (u & 1) ? key_string(&g.head[(size_t)(u >> 1) * W], len, true) : key_string(&g.tail[(size_t)(u >> 1) * W], len, false);
+	}
+	// SuffixArray::insert + construct: the proper suffixes of length >= m, by (strcmp, vertex)
+	typedef std::pair<const char*, uint32_t> Entry;
+	std::vector<Entry> sa;
+	for (size_t b = 0; b < blunt.size(); b++)
+		for (unsigned at = 1; at + o.minOverlap <= len; at++) sa.push_back(Entry(suffix[b].c_str() + at, blunt[b]));
+	std::sort(sa.begin(), sa.end(), [](const Entry& a, const Entry& b) {
+		const int c = strcmp(a.first, b.first);
+		return c < 0 || (c == 0 && a.second < b.second);
+	});
+	g.extra.assign(g.nv(), std::vector<Edge>());
+	struct Cmp {
+		bool operator()(const Entry& a, const char* b) const { return strcmp(a.first, b) < 0; }
+		bool operator()(const char* a, const Entry& b) const { return strcmp(a, b.first) < 0; }
+	};
+	for (size_t b = 0; b < blunt.size(); b++) {
+		const uint32_t v = blunt[b] ^ 1u; // the complement: its FIRST k-1 bases are rc(suffix)
+		const std::string vseq = revcomp(suffix[b]);
+		std::set<uint32_t> seen;
+		for (std::string q(vseq, 0, vseq.size() - 1); q.size() >= o.minOverlap && !q.empty(); q.erase(q.size() - 1)) {
+			auto range = std::equal_range(sa.begin(), sa.end(), q.c_str(), Cmp());
+			for (auto it = range.first; it != range.second; ++it) {
+				const uint32_t u = it->second;
+				if (o.ss && ((u ^ v) & 1u)) continue;
+				if (seen.insert(u).second) g.extra[u].push_back(Edge{ v, -(int)q.size() }); // the longest overlap of a pair
+			}
+			if (q.size() == 1) break; // (chop asserts length > 1)
+		}
+	}
+}
+
+// ---- writers ----
+struct Out {
+	std::string buf;
+	FILE* f;
+	explicit Out(FILE* f) : f(f) { buf.reserve(1u << 20); }
+	~Out() { flush(); }
+	void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
+	Out& operator<<(const std::string& s) { buf += s; if (buf.size() > (1u << 20) - 4096) flush(); return *this; }
+	Out& operator<<(const char* s) { buf += s; return *this; }
+	Out& operator<<(char c) { buf += c; return *this; }
+	Out& operator<<(unsigned long long x) { buf += std::to_string(x); return *this; }
+	Out& operator<<(unsigned long x) { buf += std::to_string(x); return *this; }
+	Out& operator<<(unsigned x) { buf += std::to_string(x); return *this; }
+	Out& operator<<(int x) { buf += std::to_string(x); return *this; }
+};
+
+inline void write_adj(Out& out, const Graph& g) // Graph/AdjIO.h:32-66
+{
+	const int def = -(int)(g.k - 1);
+	for (uint64_t i = 0; i < g.n(); i++) {
+		out << g.name[i] << ' ' << g.length[i] << ' ' << g.coverage[i];
+		for (unsigned sense = 0; sense < 2; sense++) {
+			out << "\t;";
+			g.for_out(2 * i + sense, [&](uint32_t v, int d) {
+				out << ' ' << g.vname(v ^ sense);
+				if (d != def) out << " [d=" << d << ']';
+			});
+		}
+		out << '\n';
+	}
+}
+inline void write_dot(Out& out, const Graph& g) // Graph/DotIO.h:14-101
+{
+	const int def = -(int)(g.k - 1);
+	out << "digraph adj {\n";
+	out << "graph [k=" << g.k << "]\nedge [d=" << def << "]\n";
+	for (uint64_t u = 0; u < g.nv(); u++)
+		out << '"' << g.vname(u) << "\" [l=" << g.length[u >> 1] << " C=" << g.coverage[u >> 1] << "]\n";
+	for (uint64_t u = 0; u < g.nv(); u++)
+		g.for_out(u, [&](uint32_t v, int d) {
+			out << '"' << g.vname(u) << "\" -> \"" << g.vname(v) << '"';
+			if (d != def) out << " [d=" << d << ']';
+			out << '\n';
+		});
+	out << "}\n";
+}
+inline void write_gfa1(Out& out, const Graph& g) // Graph/GfaIO.h:15-66
+{
+	out << "H\tVN:Z:1.0\n";
+	for (uint64_t i = 0; i < g.n(); i++) {
+		out << "S\t" << g.name[i] << "\t*\tLN:i:" << g.length[i];
+		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
+		out << '\n';
+	}
+	for (uint64_t u = 0; u < g.nv(); u++)
+		g.for_out(u, [&](uint32_t v, int d) {
+			if (u > (uint64_t)(v ^ 1u)) return; // only the canonical edge
+			out << "L\t" << g.name[u >> 1] << '\t' << ((u & 1) ? '-' : '+') << '\t' << g.name[v >> 1] << '\t' << ((v & 1) ? '-' : '+');
+			if (d <= 0) out << '\t' << -d << "M\n"; else out << "\t*\n";
+		});
+}
+inline void write_gfa2(Out& out, const Graph& g) // Graph/GfaIO.h:69-118,129-155,191-211
+{
+	out << "H\tVN:Z:2.0\n";
+	for (uint64_t i = 0; i < g.n(); i++) {
+		out << "S\t" << g.name[i] << '\t' << g.length[i] << "\t*";
+		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
+		out << '\n';
+	}
+	for (uint64_t u = 0; u < g.nv(); u++)
+		g.for_out(u, [&](uint32_t v, int d) {
+			if (u > (uint64_t)(v ^ 1u)) return;
+			const unsigned overlap = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
+			const bool us = u & 1, vs = v & 1;
+			const unsigned ustart = us ? 0 : ulen - overlap, uend = us ? overlap : ulen;
+			const unsigned vstart = !vs ? 0 : vlen - overlap, vend = !vs ? overlap : vlen;
+			out << "E\t*\t" << g.vname(u) << '\t' << g.vname(v);
+			out << '\t' << ustart; if (ustart == ulen) out << '$';
+			out << '\t' << uend; if (uend == ulen) out << '$';
+			out << '\t' << vstart; if (vstart == vlen) out << '$';
+			out << '\t' << vend; if (vend == vlen) out << '$';
+			out << '\t' << overlap << "M\n";
+		});
+}
+inline void write_asqg(Out& out, const Graph& g) // Graph/AsqgIO.h:13-70
+{
+	out << "HT\tVN:i:1\n";
+	for (uint64_t i = 0; i < g.n(); i++) {
+		out << "VT\t" << g.name[i] << "\t*\tLN:i:" << g.length[i];
+		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
+		out << '\n';
+	}
+	for (uint64_t u = 0; u < g.nv(); u++)
+		g.for_out(u, [&](uint32_t v, int d) {
+			if (u > (uint64_t)(v ^ 1u)) return;
+			const unsigned overlap = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
+			const bool us = u & 1, vs = v & 1;
+			out << "ED\t" << g.name[u >> 1] << ' ' << g.name[v >> 1]
+			    << ' ' << (us ? 0u : ulen - overlap) << ' ' << (int)((us ? overlap : ulen) - 1) << ' ' << ulen
+			    << ' ' << (!vs ? 0u : vlen - overlap) << ' ' << (int)((!vs ? overlap : vlen) - 1) << ' ' << vlen
+			    << ' ' << (us != vs ? 1 : 0) << " -1\n";
+		});
+}
+inline void write_sam(Out& out, const Graph& g, const std::string& commandLine) // Graph/SAMIO.h:18-70
+{
+	out << "@HD\tVN:1.0\n@PG\tID:" ABG_ADJ_PROGRAM "\tVN:" ABG_ADJ_VERSION "\tCL:" << commandLine << '\n';
+	for (uint64_t i = 0; i < g.n(); i++) {
+		out << "@SQ\tSN:" << g.name[i] << "\tLN:" << g.length[i];
+		if (g.coverage[i] > 0) out << "\tXC:" << g.coverage[i];
+		out << '\n';
+	}
+	for (uint64_t u = 0; u < g.nv(); u++)
+		g.for_out(u, [&](uint32_t v, int d) {
+			if (d > 0) return;
+			const bool us = u & 1, vs = v & 1;
+			const unsigned alen = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
+			const unsigned pos = 1 + (us ? 0 : ulen - alen), clip = vlen - alen;
+			out << g.name[v >> 1] << '\t' << (us == vs ? 0 : 0x10) << '\t' << g.name[u >> 1] << '\t' << pos << "\t255\t";
+			if (us) out << clip << 'H' << alen << "M\t"; else out << alen << 'M' << clip << "H\t";
+			out << "*\t0\t0\t*\t*\n";
+		});
+}
+
+// main(), AdjList.cpp:307-420, after option parsing
+inline int run(const Options& o, const Join& join, FILE* fout)
+{
+	Graph g;
+	g.k = o.k;
+	g.W = (o.k - 1 + 31) / 32;
+	{
+		std::unordered_set<std::string> seen;
+		for (auto& f : o.files) read_contigs(f, o, g, seen);
+	}
+	if (o.verbose > 0) fprintf(stderr, "Finding overlaps of exactly k-1 bp...\n");
+	join(o.k - 1, g.n(), g.head.data(), g.tail.data(), o.ss != 0, g.off, g.tgt);
+	if (g.off.size() != g.nv() + 1 || g.off.back() != g.tgt.size()) {
+		fprintf(stderr, ABG_ADJ_PROGRAM ": the overlap join returned an inconsistent result\n");
+		return EXIT_FAILURE;
+	}
+	if (o.verbose > 0) print_graph_stats(stderr, g);
+	if (o.minOverlap < o.k - 1) {
+		if (o.verbose > 0) fprintf(stderr, "Finding overlaps of fewer than k-1 bp...\n");
+		add_short_overlaps(o, g);
+		if (o.verbose > 0) print_graph_stats(stderr, g);
+	}
+	{
+		Out out(fout);
+		switch (o.format) {
+		case ADJ: write_adj(out, g); break;
+		case DOT: write_dot(out, g); break;
+		case GFA1: write_gfa1(out, g); break;
+		case GFA2: write_gfa2(out, g); break;
+		case ASQG: write_asqg(out, g); break;
+		case SAM: write_sam(out, g, o.commandLine); break;
+		}
+	}
+	if (fflush(fout) != 0 || ferror(fout)) { fprintf(stderr, ABG_ADJ_PROGRAM ": error writing the output\n"); return EXIT_FAILURE; }
+	return EXIT_SUCCESS;
+}
+
+} // namespace abgadj

@@ -1,0 +1,47 @@
+// AdjList -- drop-in for the reference's AdjList (AdjList/AdjList.cpp), the stage abyss-pe runs on
+// the unitigs of abyss-bloom-dbg: the overlaps of exactly k-1 bases come from abg_overlap_join on
+// the GPU (include/abyss_amd.h), everything else is adjlist_core.h.  No CPU fallback: without a
+// HIP device the program fails.
+#include "adjlist_core.h"
+
+#include "abyss_amd.h"
+
+int main(int argc, char** argv)
+{
+	abgadj::Options opt;
+	int device = 0, status = 0;
+	if (!abgadj::parse_options(argc, argv, opt, &device, &status)) return status;
+	abg_overlap* ov = nullptr;
+	int rc = abg_overlap_create(device, &ov);
+	if (rc != ABG_OK) {
+		fprintf(stderr, ABG_ADJ_PROGRAM ": %s\n", abg_overlap_last_error(nullptr));
+		return EXIT_FAILURE;
+	}
+	const bool timing = getenv("ABG_ADJ_TIMING") != nullptr;
+	if (timing) abg_overlap_profile(ov, 1);
+	abgadj::Join join = [&](uint32_t overlap, uint64_t n, const uint64_t* head, const uint64_t* tail, bool ss,
+	                        std::vector<uint64_t>& off, std::vector<uint32_t>& tgt) {
+		uint64_t ne = 0;
+		int r = abg_overlap_join(ov, overlap, n, head, tail, ss ? 1 : 0, &ne);
+		if (r == ABG_OK) {
+			off.assign(2 * n + 1, 0);
+			tgt.assign(ne, 0);
+			r = abg_overlap_edges(ov, off.data(), tgt.data());
+		}
+		if (r != ABG_OK) {
+			fprintf(stderr, ABG_ADJ_PROGRAM ": %s\n", abg_overlap_last_error(ov));
+			exit(EXIT_FAILURE);
+		}
+	};
+	status = abgadj::run(opt, join, stdout);
+	if (timing) {
+		for (const char* name : { "overlap_keys", "sort_pairs", "overlap_count", "scan", "overlap_fill" }) {
+			double ms = 0;
+			uint64_t launches = 0;
+			abg_overlap_profile_get(ov, name, &ms, &launches);
+			fprintf(stderr, "[timing] %-14s %8.3f ms  %llu launches\n", name, ms, (unsigned long long)launches);
+		}
+	}
+	abg_overlap_destroy(ov);
+	return status;
+}

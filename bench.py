@@ -85,6 +85,18 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
         t0 = time.time()
         r = subprocess.run(args + ["r1.fq", "r2.fq"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         wall = time.time() - t0
+        adj = None
+        if r.returncode == 0 and golden and "adjlist" in golden:
+            # abyss-pe's next step on the unitigs just written (AdjList $(alopt) --dot, bin/abyss-pe:575-577)
+            open(os.path.join(td, "unitigs-1.fa"), "wb").write(r.stdout)
+            t0 = time.time()
+            ra = subprocess.run([os.path.join(build.BIN_DIR, "AdjList")] + golden["adjlist"]["options"].split() + ["unitigs-1.fa"],
+                                cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ABG_ADJ_TIMING="1"))
+            adj = {"what": "abyss_amd/bin/AdjList %s on those unitigs, process start to graph written" % golden["adjlist"]["options"],
+                   "rc": ra.returncode, "wall_ms": round((time.time() - t0) * 1e3), "edges": ra.stdout.count(b" -> "),
+                   "dot_sha256": hashlib.sha256(ra.stdout).hexdigest(),
+                   "matches_reference_dot": bool(hashlib.sha256(ra.stdout).hexdigest() == golden["adjlist"]["dot_sha256"]),
+                   "kernels_ms": {l.split()[1]: float(l.split()[2]) for l in ra.stderr.decode().splitlines() if l.startswith("[timing]")}}
     kmers = 2 * a.pairs * (read_len - a.k + 1)
     out = {"what": "abyss_amd/bin/abyss-bloom-dbg on the FASTQ files of this read set (two %.2f GB files, page cache warm), process "
                    "start to last unitig written" % (a.pairs * (2 * read_len + 12) / 1e9),
@@ -93,6 +105,8 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
            "files_written_in_s": round(prep, 1), "measured": "in this run"}
     if golden:
         out["matches_reference_fasta"] = bool(out["fasta_sha256"] == golden["fasta_sha256"])
+    if adj:
+        out["adjlist"] = adj
     return out
 
 

@@ -292,6 +292,34 @@ typedef struct abg_stats {
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 
+/* ---- the stage after the unitigs: AdjList's k-1 overlap join (AdjList/AdjList.cpp) ------------
+ * The reference keeps, per contig i, the vertices i+ (2i) and i- (2i+1), the first k-1 bases of
+ * every vertex in `prefixes` and the vertices by their last k-1 bases in an unordered_map
+ * (readContigs, AdjList.cpp:192-230); buildOverlapGraph (:233-263) then adds, for v = 0..2n-1 and
+ * every u in suffixMap[prefixes[v]] in insertion order, the edge (v^1) -> (u^1) with distance
+ * -(k-1), skipping pairs of different sense under --SS.  abg_overlap_join computes exactly those
+ * edges on the GPU, as a CSR over the source vertex with every adjacency list in the reference's
+ * order; a maintainer replaces the loop of :245-257 by one call and an add_edge per target.
+ *
+ * head_keys / tail_keys: HOST arrays of n_contigs keys of W = ceil(overlap / 32) uint64 words, the
+ * first and the last `overlap` (= k-1) bases of every contig as read (Kmer(seq.substr(...)),
+ * :210-211), 2 bits per base (A C G T = 0 1 2 3), base j at bits 2*(j%32) of word j/32.
+ * A context owns a HIP stream and its scratch; the result of the last join stays in device memory
+ * until the next join or abg_overlap_destroy. */
+typedef struct abg_overlap abg_overlap;
+int abg_overlap_create(int device, abg_overlap** out);
+void abg_overlap_destroy(abg_overlap* o);
+const char* abg_overlap_last_error(const abg_overlap* o); /* o may be NULL: the last failed abg_overlap_create */
+int abg_overlap_join(abg_overlap* o, uint32_t overlap, uint64_t n_contigs, const uint64_t* head_keys,
+    const uint64_t* tail_keys, int strand_specific, uint64_t* n_edges);
+/* offsets: 2 * n_contigs + 1 entries (out-edges of vertex s are targets[offsets[s] .. offsets[s+1]));
+ * targets: n_edges entries.  Either may be NULL. */
+int abg_overlap_edges(abg_overlap* o, uint64_t* offsets, uint32_t* targets);
+/* kernel timing as abg_profile_enable / abg_profile_get: "overlap_keys", "sort_pairs",
+ * "overlap_count", "scan", "overlap_fill" */
+int abg_overlap_profile(abg_overlap* o, int on);
+int abg_overlap_profile_get(abg_overlap* o, const char* name, double* total_ms, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

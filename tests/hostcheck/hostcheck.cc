@@ -5,6 +5,7 @@
 // without a GPU.  It is built only by tests/ (g++), never linked into libabyss_amd.so,
 // and is not a fallback: the product library refuses to run without a HIP device.
 #include "../../abyss_amd/csrc/abg_host.h"
+#include "../../abyss_amd/csrc/abg_overlap.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +38,13 @@ struct SerialBackend {
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void inclusive_sum_u64(uint64_t* d, uint64_t n) { for (uint64_t i = 1; i < n; i++) d[i] += d[i - 1]; }
+	void sort_pairs_u64_u32(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n)
+	{
+		std::vector<uint64_t> o(n);
+		for (uint64_t i = 0; i < n; i++) o[i] = i;
+		std::stable_sort(o.begin(), o.end(), [&](uint64_t a, uint64_t b) { return kin[a] < kin[b]; });
+		for (uint64_t i = 0; i < n; i++) { kout[i] = kin[o[i]]; vout[i] = vin[o[i]]; }
+	}
 	uint32_t max_slots() const { return 1; }
 	uint64_t device_mem_bytes() const { return 0; } // (unknown: no cap)
 	void d2d(void* d, const void* s, size_t n) { memmove(d, s, n); }
@@ -239,6 +247,18 @@ uint64_t hc_mod_check(uint64_t m, const uint64_t* hs, uint64_t n)
 	uint64_t bad = 0;
 	for (uint64_t i = 0; i < n; i++) bad += abg::mod64(d, hs[i]) != hs[i] % m;
 	return bad;
+}
+
+// AdjList's k-1 overlap join (abg_overlap.h) through the serial backend; off: 2n+1 entries, tgt: *ne on return
+// (call with tgt == NULL first to learn *ne)
+int hc_overlap_join(uint32_t overlap, uint64_t n, const uint64_t* head, const uint64_t* tail, int ss, uint64_t* off, uint32_t* tgt, uint64_t* ne)
+{
+	SerialBackend be;
+	abg::OverlapJoin<SerialBackend> j(be);
+	j.run(overlap, n, head, tail, ss != 0);
+	*ne = j.edges();
+	j.fetch(off, tgt);
+	return 0;
 }
 
 } // extern "C"

@@ -75,6 +75,24 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
     assert (n_unitigs, ca["bases_assembled"]) == (golden["unitigs"], golden["unitig_bp"])
     assert fasta.hexdigest() == golden["fasta_sha256"]
     assert a.counting_stats()[1] == golden["filtered_popcount"]
+    # ... and abyss-pe's next step on those unitigs (AdjList -k64 -m50 --dot, bin/abyss-pe:238-246,575-577):
+    # the drop-in AdjList writes the overlap graph the reference AdjList wrote for the reference's FASTA
+    if "adjlist" in golden:
+        import subprocess
+        import tempfile
+        from abyss_amd import build
+        with tempfile.TemporaryDirectory() as td:
+            fa = os.path.join(td, "unitigs-1.fa")
+            with open(fa, "wb") as f:
+                for c in contigs_a:
+                    if not c.redundant:
+                        mate = 1 if c.read_index < PAIRS else 2
+                        f.write(b">%d %d %d read:r%d/%d\n%s\n" % (c.contig_id, len(c.seq), c.coverage, c.read_index % PAIRS, mate, c.seq))
+            r = subprocess.run([os.path.join(build.BIN_DIR, "AdjList")] + golden["adjlist"]["options"].split() + [fa],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout.count(b" -> ") == golden["adjlist"]["edges"]
+            assert hashlib.sha256(r.stdout).hexdigest() == golden["adjlist"]["dot_sha256"]
     # the pre-search answered ahead of the walkers, and sanely (one answer per request at most)
     assert 0 < sa["pre_adds"] <= sa["pre_requests"]
     vis_a = a.visited()
