@@ -83,3 +83,37 @@ def test_pipeline_rule_writes_the_same_file_as_the_direct_call(tmp_path):
     r = subprocess.run(["sh", "-c", rule], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert r.returncode == 0, r.stderr.decode()
     assert (tmp_path / "asm-1.fa").read_bytes() == direct.stdout and direct.stdout.count(b">") > 300
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PE), reason="the reference tree is not on this machine")
+@pytest.mark.parametrize("k,extra,want", [(32, [], ["-k32", "-m0", "--dot", "asm-1.fa"]),
+                                           (64, ["SS=--SS"], ["--SS", "-k64", "-m50", "--dot", "asm-1.fa"]),
+                                           (96, ["v=-v", "graph=gfa2"], ["-v", "-k96", "-m50", "--gfa2", "asm-1.fa"])])
+def test_abyss_pe_issues_the_adjlist_command_line_our_binary_accepts(tmp_path, k, extra, want):
+    """The step after `-1.fa` (bin/abyss-pe:238-246,575-577): `AdjList $(alopt) --$g asm-1.fa >asm-1.$g`."""
+    build.build_cli()
+    real = os.path.join(build.BIN_DIR, "AdjList")
+    d = tmp_path / "shim"
+    d.mkdir()
+    rec = tmp_path / "argv.txt"
+    sh = d / "AdjList"
+    sh.write_text("#!/bin/sh\nprintf '%%s\\n' \"$@\" > %s\nexec %s \"$@\"\n" % (rec, real))
+    sh.chmod(sh.stat().st_mode | stat.S_IXUSR)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "k%d.fa" % k)
+    (tmp_path / "asm-1.fa").write_bytes(open(golden, "rb").read())
+    g = "gfa2" if "graph=gfa2" in extra else "dot"
+    env = dict(os.environ, PATH="%s:%s" % (d, os.environ["PATH"]))
+    r = subprocess.run(["make", "-rRf", REF_PE, "name=asm", "k=%d" % k, "B=100M", "j=1", "in=r1.fq r2.fq"] + extra + ["asm-1.%s" % g],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    out = (r.stdout + r.stderr).decode()
+    assert rec.exists(), out
+    assert rec.read_text().split("\n")[:-1] == want
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        assert r.returncode == 0, out
+    else:
+        assert r.returncode != 0 and "no HIP device" in out and "invalid option" not in out, out
