@@ -183,6 +183,10 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
                     help="skip the drop-in binary's FASTQ-in / FASTA-out run on this read set (about 20 s: writes the two FASTQ files)")
+    ap.add_argument("--invariants", action="store_true",
+                    help="after the timed steps, add digests of the last step's device state to the line (popcounts of the counting filter, "
+                         "sha256 of the counting and the visited filter, read and unitig counters): what two runs of one workload -- "
+                         "e.g. plain and ABG_FORCE_DIST=1 -- must agree on where no reference run exists (configs[2])")
     ap.add_argument("--no-events", action="store_true",
                     help="time the steps without HIP events around every launch (no per-kernel numbers: shows what the events cost)")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
@@ -489,6 +493,17 @@ def main() -> int:
                 out["cpu_baseline"]["reference_full_config"] = dict(json.load(open(src)), replayed=True, source="profiles/r02_cpu_reference_config1.json",
                                                                     note="measured at commit 27c3426 on the read set of synth.make_read_set (the sequential generator); "
                                                                          "same recipe and size as the one timed here")
+        if a.invariants and g is not None:
+            import hashlib
+            pc, fpc = g.counting_stats()
+            vis = g.visited()
+            c = g.assembly_counters()
+            out["invariants"] = {"popcount": pc, "filtered_popcount": fpc,
+                                 # (the counter array itself only while it is a few GB: 38 GB of host memory for a digest is not worth a dead box)
+                                 "counters_sha256": hashlib.sha256(g.counters()).hexdigest() if g.size <= (4 << 30) else None,
+                                 "visited_sha256": hashlib.sha256(vis).hexdigest(),
+                                 "assembly_counters": {k: int(v) for k, v in c.items()}}
+            del vis
         if world == 1 and a.end_to_end and a.config in (1, 3):
             out["end_to_end"] = end_to_end(a, genome_len, read_len, err, device, golden)
         # whatever native libraries buffered on stdout (RCCL's version banner) goes out first: the
