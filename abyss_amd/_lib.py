@@ -50,7 +50,7 @@ def symbols():
     """Every entry point include/abyss_amd.h declares."""
     return [
         "abg_params_init", "abg_create", "abg_destroy", "abg_last_error", "abg_reset", "abg_filter_size",
-        "abg_load_seqs", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
+        "abg_load_seqs", "abg_load_seqs_v", "abg_keep_reads", "abg_assemble_kept", "abg_load_packed", "abg_counting_stats", "abg_counters_export",
         "abg_counters_import", "abg_visited_export", "abg_visited_import", "abg_assemble_seqs", "abg_assemble_seqs_v",
         "abg_assemble_packed", "abg_cascade_export", "abg_get_counters", "abg_set_counters", "abg_hash_seq",
         "abg_contains_seq",
@@ -85,6 +85,9 @@ def load(path: str | None = None):
     lib.abg_filter_size.argtypes = [vp, u64p]
     lib.abg_load_seqs.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
     lib.abg_load_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    lib.abg_load_seqs_v.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    lib.abg_keep_reads.argtypes = [vp, C.c_int, C.c_uint64]
+    lib.abg_assemble_kept.argtypes = [vp, vp, CONTIG_CB, vp]
     lib.abg_counting_stats.argtypes = [vp, u64p, u64p]
     lib.abg_counters_export.argtypes = [vp, u8p]
     lib.abg_counters_import.argtypes = [vp, u8p]

@@ -131,6 +131,28 @@ class BloomDBG:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._check(self._lib.abg_load_seqs(self._ctx, buf, offsets.ctypes.data, len(offsets) - 1), "abg_load_seqs")
 
+    def load_chunks(self, chunks) -> None:
+        """PASS 1 over several (buf, offsets) chunks in one call (abg_load_seqs_v)."""
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for _, o in chunks]
+        nc = len(chunks)
+        seqs_v = (C.c_char_p * nc)(*[C.c_char_p(b) for b, _ in chunks])
+        off_v = (C.c_void_p * nc)(*[o.ctypes.data for o in offs])
+        n_v = (C.c_uint64 * nc)(*[len(o) - 1 for o in offs])
+        self._check(self._lib.abg_load_seqs_v(self._ctx, nc, C.cast(seqs_v, C.c_void_p), C.cast(off_v, C.c_void_p),
+                                              C.cast(n_v, C.c_void_p)), "abg_load_seqs_v")
+
+    def keep_reads(self, on: bool = True, expected_bases: int = 0) -> None:
+        """The reads of the load calls that follow stay on the device, packed, for assemble_kept (abg_keep_reads)."""
+        self._check(self._lib.abg_keep_reads(self._ctx, int(on), expected_bases), "abg_keep_reads")
+
+    def assemble_kept(self, n: int) -> Tuple[np.ndarray, List[ContigRecord]]:
+        """PASS 2 over the n reads loaded since keep_reads(), as one read stream (abg_assemble_kept)."""
+        results = np.zeros(max(n, 1), dtype=np.uint8)
+        contigs: List[ContigRecord] = []
+        cb = self._collector(contigs)
+        self._check(self._lib.abg_assemble_kept(self._ctx, results.ctypes.data, cb, None), "abg_assemble_kept")
+        return results[:n], contigs
+
     def load_packed(self, words_ptr: int, woff_ptr: int, len_ptr: int, n: int) -> None:
         self._check(self._lib.abg_load_packed(self._ctx, words_ptr, woff_ptr, len_ptr, n), "abg_load_packed")
 

@@ -48,6 +48,7 @@ struct Config {
 	uint32_t claim_log2 = 30;         // PASS 1 claim slots per table (x2 tables, 8 B each: 16 GiB; false conflicts fall with the load)
 	uint32_t drain_threshold = 1u << 12; // pending ops at or below which the retry tail runs in one workgroup
 	uint64_t compact_threshold = 1u << 20; // rounds with at least this many ops flag their losers and compact them (FInsertRound)
+	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS

@@ -12,6 +12,8 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <future>
+#include <memory>
 #include <thread>
 
 namespace abg {
@@ -50,7 +52,7 @@ class Session {
 
 	template <class... A>
 	explicit Session(A&&... a) : be(std::forward<A>(a)...) {}
-	~Session() { delete eng; }
+	~Session() { try { drain(); } catch (...) {} keep_drop(false); delete eng; }
 
 	int create(const abg_params& p)
 	{
@@ -95,6 +97,7 @@ class Session {
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
 		if (const char* e = getenv("ABG_HEAVY_FIRST")) cfg.heavy_first = atoi(e) != 0;
+		if (const char* e = getenv("ABG_ASYNC_LOAD")) cfg.async_load = atoi(e) != 0;
 		if (const char* e = getenv("ABG_CLS_SLOTS")) cfg.classify_slots = (uint32_t)std::max(64, atoi(e));
 		if (const char* e = getenv("ABG_SOLID_PLANE")) cfg.solid_plane = atoi(e) != 0;
 		if (const char* e = getenv("ABG_MEMO")) cfg.memo = atoi(e) != 0; // shared answers of successor()
@@ -112,7 +115,10 @@ class Session {
 	}
 
 	// ------------------------------------------------------------------ PASS 1
-	int load_seqs(const char* seqs, const uint64_t* off, uint64_t n)
+	int load_seqs(const char* seqs, const uint64_t* off, uint64_t n) { return load_seqs_v(1, &seqs, &off, &n); }
+	// the same over several buffers, taken one after the other (a reader's blocks as they lie: no
+	// concatenation on the caller's side)
+	int load_seqs_v(uint32_t nchunks, const char* const* seqs_v, const uint64_t* const* off_v, const uint64_t* n_v)
 	{
 		const uint32_t k = cfg.k;
 		// longest piece handed to the device as one sequence; longer ACGT runs are cut into
@@ -120,21 +126,42 @@ class Session {
 		const uint32_t max_piece = (uint32_t)std::min<uint64_t>(1u << 20, cfg.insert_batch_kmers + k - 1);
 		// packing is host work per base: the reads are split over threads, every thread packs its
 		// range into a batch of its own, and the batches are joined in order
-		const std::vector<uint64_t> cut = split_reads(off, n);
-		std::vector<HostBatch> parts(cut.size() - 1);
+		struct Part { uint32_t c; uint64_t a, b; };
+		std::vector<Part> plan;
+		std::vector<uint64_t> base(nchunks + 1, 0);
+		for (uint32_t c = 0; c < nchunks; c++) {
+			base[c + 1] = base[c] + n_v[c];
+			if (!n_v[c]) continue;
+			const std::vector<uint64_t> cut = split_reads(off_v[c], n_v[c]);
+			for (size_t t = 0; t + 1 < cut.size(); t++) plan.push_back(Part{ c, cut[t], cut[t + 1] });
+		}
+		const bool keeping = keep_.on && !keep_.failed;
+		// kept reads (keep_reads): what PASS 2 will want of this call's reads.  A read that is ACGT throughout
+		// and at least k long is one piece of the batch (or, longer than a piece may be, packed once more on
+		// the side); every other read has its verdict now (bloom-dbg.h:804,808).
+		std::vector<KeptPart> kparts(keeping ? plan.size() : 0);
+		std::vector<uint8_t> verdict(keeping ? base[nchunks] : 0, (uint8_t)RR_UNINITIALIZED);
+		std::vector<HostBatch> parts(plan.size());
+		const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
+		const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = tnow();
 		run_parts(parts.size(), [&](size_t t) {
 			HostBatch& hb = parts[t];
+			const Part& pt = plan[t];
+			const char* seqs = seqs_v[pt.c];
+			const uint64_t* off = off_v[pt.c];
 			{
-				const uint64_t nr = cut[t + 1] - cut[t], bases = off[cut[t + 1]] - off[cut[t]];
+				const uint64_t nr = pt.b - pt.a, bases = off[pt.b] - off[pt.a];
 				hb.words.reserve(bases / 16 + nr + 1); hb.woff.reserve(nr + 1); hb.len.reserve(nr); hb.koff.reserve(nr + 1);
+				if (keeping) { kparts[t].read.reserve(nr); kparts[t].piece.reserve(nr); kparts[t].len.reserve(nr); }
 			}
 			std::string up;
 			std::vector<std::pair<uint64_t, uint64_t>> runs;
 			std::vector<uint8_t> bad;
-			for (uint64_t i = cut[t]; i < cut[t + 1]; i++) {
+			for (uint64_t i = pt.a; i < pt.b; i++) {
 				const char* s = seqs + off[i];
 				uint64_t L = off[i + 1] - off[i];
-				if (L < k) continue; // RollingHashIterator.h:37-40
+				if (L < k) { if (keeping) verdict[base[pt.c] + i] = (uint8_t)RR_SHORTER_THAN_K; continue; } // RollingHashIterator.h:37-40
 				// (case is folded by the code table; the upper-cased copy is only needed under a spaced seed)
 				const char* text = s;
 				if (!cfg.spaced_seed.empty()) {
@@ -142,6 +169,20 @@ class Session {
 					for (auto& ch : up) ch = (char)toupper((unsigned char)ch); // RollingHashIterator.h:132
 					text = up.data();
 				}
+				bool clean = false;
+				if (keeping) {
+					uint8_t any = 0;
+					for (uint64_t q = 0; q < L; q++) any |= codes_.t[(unsigned char)s[q]];
+					clean = !(any & 0x80);
+					if (!clean) verdict[base[pt.c] + i] = (uint8_t)RR_NON_ACGT;
+				}
+				if (clean && L <= max_piece) {
+					// (all of it is one run of k-mers, whatever the seed)
+					kparts[t].read.push_back(base[pt.c] + i); kparts[t].piece.push_back(hb.n()); kparts[t].len.push_back((uint32_t)L);
+					hb.add_ascii(text, (uint32_t)L, k);
+					continue;
+				}
+				if (clean) { kparts[t].extra.add_ascii(text, (uint32_t)L, k); kparts[t].extra_read.push_back(base[pt.c] + i); }
 				valid_runs(text, L, runs, bad);
 				for (auto& run : runs) {
 					// k-mers run.first .. run.second - 1 start in this piece
@@ -155,13 +196,199 @@ class Session {
 				}
 			}
 		});
-		HostBatch joined;
-		const HostBatch& hb = join_parts(parts, joined);
-		if (hb.n()) flush_load(hb); // (the engine cuts it into ordered-insert batches of insert_batch_kmers)
+		// The device's share -- upload, the ordered insert, the kept store's book-keeping -- runs on a thread of
+		// its own while the caller goes on (to parse and pack the next chunk: packing is host work as long
+		// as a chunk's PASS 1).  One at a time, in call order; every other entry point waits for it first
+		// (drain), and what it throws surfaces there.
+		auto st = std::make_shared<LoadStage>();
+		st->rbase.assign(parts.size() + 1, 0);
+		for (size_t t = 0; t < parts.size(); t++) st->rbase[t + 1] = st->rbase[t] + parts[t].n();
+		const double t1 = tnow();
+		if (!parts.empty()) {
+			HostBatch joined;
+			const HostBatch& hb = join_parts(parts, joined);
+			st->hb = (&hb == &joined) ? std::move(joined) : std::move(parts[0]);
+		}
+		st->keeping = keeping; st->kparts = std::move(kparts); st->verdict = std::move(verdict); st->n_reads = base[nchunks];
+		st->t_pack = t1 - t0; st->t_join = tnow() - t1; st->nparts = parts.size();
+		drain();
+		pending_ = std::async(std::launch::async, [this, st]() { be.bind_thread(); load_stage(*st); });
+		// (a partitioned run's collectives are the caller's code: they stay on the caller's thread)
+		// and only a caller that asked for the pipeline (abg_keep_reads) gets it: otherwise the call returns
+		// with its work done and its errors its own
+		if (!cfg.async_load || comm_attached_ || !keeping) drain();
 		return ABG_OK;
 	}
+	// waits for the device's share of the last load call (and rethrows what it threw)
+	void drain() { if (pending_.valid()) pending_.get(); }
+  private:
+	struct KeptPart { std::vector<uint64_t> read, piece; std::vector<uint32_t> len; HostBatch extra; std::vector<uint64_t> extra_read; };
+	struct LoadStage {
+		HostBatch hb; std::vector<uint64_t> rbase; bool keeping = false; std::vector<KeptPart> kparts; std::vector<uint8_t> verdict;
+		uint64_t n_reads = 0; double t_pack = 0, t_join = 0; size_t nparts = 0;
+	};
+	std::future<void> pending_;
+	bool comm_attached_ = false;
+	void load_stage(LoadStage& st)
+	{
+		const HostBatch& hb = st.hb;
+		const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
+		const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t2 = tnow();
+		if (!st.keeping || keep_.failed) {
+			if (hb.n()) flush_load(hb); // (the engine cuts it into ordered-insert batches of insert_batch_kmers)
+			if (timing) fprintf(stderr, "[host] load: %zu parts, pack %.3f s, join %.3f s, upload + device %.3f s\n", st.nparts, st.t_pack, st.t_join, tnow() - t2);
+			return;
+		}
+		std::vector<KeptPart>& kparts = st.kparts;
+		const std::vector<uint64_t>& rbase = st.rbase;
+		// the batch's words go to the kept store and stay there; PASS 1 reads them where they are
+		uint64_t extra_words = 0;
+		for (auto& kp : kparts) extra_words += kp.extra.words.size();
+		const uint64_t at = keep_.used;
+		if (!keep_room(hb.words.size() + extra_words + 16)) {
+			// no room on the device: PASS 1 goes on as if nothing were kept; assemble_kept will say so
+			keep_drop(true);
+			if (hb.n()) flush_load(hb);
+			return;
+		}
+		if (hb.n()) {
+			DevBatch d;
+			d.words = nullptr;
+			uint32_t* w = (uint32_t*)keep_.words + at;
+			be.h2d(w, hb.words.data(), hb.words.size() * 4);
+			d.woff = be.alloc(hb.woff.size() * 8);
+			d.len = be.alloc(std::max<size_t>(hb.len.size(), 1) * 4);
+			d.koff = be.alloc(hb.koff.size() * 8);
+			be.h2d(d.woff, hb.woff.data(), hb.woff.size() * 8);
+			be.h2d(d.len, hb.len.data(), hb.len.size() * 4);
+			be.h2d(d.koff, hb.koff.data(), hb.koff.size() * 8);
+			d.b = Batch{ w, (const uint64_t*)d.woff, (const uint32_t*)d.len, (const uint64_t*)d.koff, hb.n() };
+			const double t3 = tnow();
+			eng->load_packed(d.b, hb.koff.data());
+			be.free(d.woff); be.free(d.len); be.free(d.koff);
+			if (timing) fprintf(stderr, "[host] load: %zu parts, pack %.3f s, join %.3f s, upload %.3f s, device %.3f s\n", st.nparts, st.t_pack, st.t_join, t3 - t2, tnow() - t3);
+		}
+		keep_.used = at + hb.words.size();
+		const uint64_t r0 = keep_.n_reads;
+		for (size_t t = 0; t < kparts.size(); t++) {
+			KeptPart& kp = kparts[t];
+			for (size_t j = 0; j < kp.read.size(); j++) {
+				keep_.orig.push_back(r0 + kp.read[j]);
+				keep_.woff.push_back(at + hb.woff[rbase[t] + kp.piece[j]]);
+				keep_.len.push_back(kp.len[j]);
+			}
+			if (kp.extra.n()) { // (reads longer than a piece: a copy of their own behind the batch, in read order with the others)
+				be.h2d((uint32_t*)keep_.words + keep_.used, kp.extra.words.data(), kp.extra.words.size() * 4);
+				for (size_t j = 0; j < kp.extra.n(); j++) {
+					keep_.orig.push_back(r0 + kp.extra_read[j]);
+					keep_.woff.push_back(keep_.used + kp.extra.woff[j]);
+					keep_.len.push_back(kp.extra.len[j]);
+				}
+				keep_.used += kp.extra.words.size();
+				keep_.unordered = true;
+			}
+		}
+		keep_.res.insert(keep_.res.end(), st.verdict.begin(), st.verdict.end());
+		keep_.n_reads += st.n_reads;
+	}
+  public:
+	// ---- reads kept on the device between the passes (include/abyss_amd.h: abg_keep_reads)
+	int keep_reads(int on, uint64_t expected_bases)
+	{
+		drain();
+		keep_drop(false);
+		keep_.on = on != 0;
+		if (!keep_.on) return ABG_OK;
+		const uint64_t mem = be.device_mem_bytes();
+		if (mem && expected_bases / 4 > mem / 8) { keep_.on = false; return fail(ABG_ENOMEM, "the reads would take more than an eighth of the device's memory: not kept"); }
+		keep_.hint_words = expected_bases / 16 + expected_bases / 1024 + 1024;
+		return ABG_OK;
+	}
+	uint64_t kept_reads() { drain(); return keep_.on ? keep_.n_reads : 0; }
+	int assemble_kept(uint8_t* results, abg_contig_cb cb, void* user)
+	{
+		drain();
+		if (!keep_.on) return fail(ABG_EINVAL, "no reads are kept (abg_keep_reads)");
+		if (keep_.failed) return fail(ABG_ENOMEM, "the kept reads were dropped: no device memory for them");
+		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
+		const uint64_t n = keep_.n_reads, n2 = keep_.orig.size();
+		if (keep_.unordered) {
+			// (long reads were appended behind their part's batch: back into read order)
+			std::vector<uint64_t> idx(n2);
+			for (uint64_t j = 0; j < n2; j++) idx[j] = j;
+			std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return keep_.orig[a] < keep_.orig[b]; });
+			std::vector<uint64_t> o2(n2), w2(n2); std::vector<uint32_t> l2(n2);
+			for (uint64_t j = 0; j < n2; j++) { o2[j] = keep_.orig[idx[j]]; w2[j] = keep_.woff[idx[j]]; l2[j] = keep_.len[idx[j]]; }
+			keep_.orig.swap(o2); keep_.woff.swap(w2); keep_.len.swap(l2);
+			keep_.unordered = false;
+		}
+		// the reference counts every read in readsProcessed (bloom-dbg.h:1045), also the
+		// ones rejected at loading time; the engine counts the ones it sees
+		Counters c0 = eng->counters();
+		c0.reads_processed += n - n2;
+		eng->set_counters(c0);
+		std::vector<uint8_t>& res = keep_.res;
+		if (n2) {
+			keep_.woff.push_back(keep_.used); // (one past the last: the store's end)
+			void* woff_d = be.alloc((n2 + 1) * 8);
+			void* len_d = be.alloc(n2 * 4);
+			be.h2d(woff_d, keep_.woff.data(), (n2 + 1) * 8);
+			be.h2d(len_d, keep_.len.data(), n2 * 4);
+			keep_.woff.pop_back();
+			Batch b{ (const uint32_t*)keep_.words, (const uint64_t*)woff_d, (const uint32_t*)len_d, (const uint64_t*)woff_d /* unused in pass 2 */, n2 };
+			std::vector<uint8_t> pres(n2);
+			std::function<void(const ContigOut&)> sink;
+			if (cb) sink = [&](const ContigOut& o) {
+				abg_contig c;
+				c.contig_id = o.contig_id; c.read_index = keep_.orig[o.read_index];
+				c.seq = o.seq.c_str(); c.length = (uint32_t)o.seq.size(); c.coverage = o.coverage;
+				c.redundant = o.redundant; c.left_ext = o.left_ext; c.right_ext = o.right_ext;
+				c.left_code = o.left_code; c.right_code = o.right_code; c.seed_pos = o.seed_pos;
+				cb(user, &c);
+			};
+			eng->assemble_packed(b, pres.data(), sink);
+			be.free(woff_d); be.free(len_d);
+			for (uint64_t j = 0; j < n2; j++) res[keep_.orig[j]] = pres[j];
+		}
+		if (results && n) memcpy(results, res.data(), n);
+		keep_drop(false);
+		keep_.on = false;
+		return ABG_OK;
+	}
+  private:
+	struct Keep {
+		bool on = false, failed = false, unordered = false;
+		void* words = nullptr; uint64_t cap = 0, used = 0, hint_words = 0; // device store of 2-bit words
+		std::vector<uint64_t> woff, orig; std::vector<uint32_t> len;      // per kept (clean) read: where, which read
+		std::vector<uint8_t> res;                                         // per read loaded: verdict known at loading time, or 0
+		uint64_t n_reads = 0;
+	} keep_;
+	bool keep_room(uint64_t more)
+	{
+		if (keep_.used + more <= keep_.cap) return true;
+		uint64_t cap = std::max<uint64_t>({ keep_.hint_words, keep_.cap * 2, keep_.used + more, 1ull << 20 });
+		void* w = be.try_alloc(cap * 4);
+		if (!w && cap > keep_.used + more) { cap = keep_.used + more; w = be.try_alloc(cap * 4); }
+		if (!w) return false;
+		if (keep_.used) be.d2d(w, keep_.words, keep_.used * 4);
+		be.sync();
+		if (keep_.words) be.free(keep_.words);
+		keep_.words = w; keep_.cap = cap;
+		return true;
+	}
+	void keep_drop(bool failed)
+	{
+		if (keep_.words) { be.sync(); be.free(keep_.words); }
+		const bool on = keep_.on;
+		const uint64_t hint = keep_.hint_words;
+		keep_ = Keep();
+		keep_.on = on; keep_.failed = failed; keep_.hint_words = hint;
+	}
+  public:
 	int load_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)
 	{
+		drain();
 		if (!n) return ABG_OK;
 		// (the k-mer prefix sums and the batches' op ranges are made on the device: the reads are there,
 		// and a host loop over tens of millions of lengths per call is time the device would idle)
@@ -177,10 +404,12 @@ class Session {
 	// ------------------------------------------------------------------ partitioned run
 	int attach_comm(const abg_comm& c)
 	{
+		drain();
 		if (!c.all_gather_v || !c.all_reduce) return fail(ABG_EINVAL, "communicator lacks a collective");
 		typename Engine<BE>::Comm ec;
 		ec.rank = c.rank; ec.world = c.world; ec.stream_ordered = c.stream_ordered != 0; ec.user = c.user;
 		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce;
+		comm_attached_ = true;
 		if (!eng->attach_comm(ec)) return fail(ABG_EINVAL, "bad rank / world (at most " + std::to_string(MAX_RANKS) + " ranks; not available on a cascading filter)");
 		return ABG_OK;
 	}
@@ -548,7 +777,7 @@ class Session {
 	static unsigned host_threads()
 	{
 		if (const char* e = getenv("ABG_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
-		return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+		return std::min(48u, std::max(1u, std::thread::hardware_concurrency()));
 	}
 	static std::vector<uint64_t> split_reads(const uint64_t* off, uint64_t n)
 	{

@@ -230,6 +230,7 @@ struct HipBackend {
 	}
 	bool ok() const { return good; }
 	std::string why() const { return reason; }
+	void bind_thread() { (void)hipSetDevice(device); } // a thread the library made itself: the device is per thread
 	static void check(hipError_t e, const char* what)
 	{
 		if (e != hipSuccess) {
@@ -717,9 +718,11 @@ namespace {
 // The C ABI's promise -- a return code and abg_last_error(), never an exit: whatever the engine or the
 // backend throws on its way (abg::Failure, std::bad_alloc) ends here.
 template <class F>
-int guarded(abg_ctx* ctx, F&& body)
+int guarded(abg_ctx* ctx, F&& body, bool drain = true)
 {
 	try {
+		// (the device's share of the last abg_load_seqs* call may still be running: Session::load_seqs_v)
+		if (ctx && drain) ctx->s.drain();
 		return body();
 	} catch (const abg::Failure& f) {
 		if (ctx) ctx->s.error = f.msg;
@@ -800,6 +803,31 @@ int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint6
 	return guarded(ctx, [&]() -> int {
 		(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
 		return ctx->s.load_seqs(seqs, offsets, n);
+	}, false);
+}
+int abg_load_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, const uint64_t* const* offsets, const uint64_t* n)
+{
+	if (!ctx || (nchunks && (!seqs || !offsets || !n))) return ABG_EINVAL;
+	return guarded(ctx, [&]() -> int {
+		for (uint32_t c = 0; c < nchunks; c++) if (n[c] && (!seqs[c] || !offsets[c])) return ABG_EINVAL;
+		(void)hipSetDevice(ctx->s.be.device); // (the caller may be a thread that has not touched the device yet)
+		return ctx->s.load_seqs_v(nchunks, seqs, offsets, n);
+	}, false);
+}
+int abg_keep_reads(abg_ctx* ctx, int on, uint64_t expected_bases)
+{
+	if (!ctx) return ABG_EINVAL;
+	return guarded(ctx, [&]() -> int {
+		(void)hipSetDevice(ctx->s.be.device);
+		return ctx->s.keep_reads(on, expected_bases);
+	});
+}
+int abg_assemble_kept(abg_ctx* ctx, uint8_t* results, abg_contig_cb cb, void* user)
+{
+	if (!ctx) return ABG_EINVAL;
+	return guarded(ctx, [&]() -> int {
+		(void)hipSetDevice(ctx->s.be.device);
+		return ctx->s.assemble_kept(results, cb, user);
 	});
 }
 int abg_load_packed(abg_ctx* ctx, const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)

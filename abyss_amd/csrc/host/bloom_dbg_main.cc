@@ -126,6 +126,14 @@ struct Chunk { // one batch of sequences for the C ABI; the ids likewise as one 
 		for (size_t e : b.seq_end) off.push_back(sb + e);
 		for (size_t e : b.id_end) id_end.push_back(ib + e);
 	}
+	// ... taken over as it is: the block's strings become the chunk's (no copy of the bases)
+	void take_block(abghost::SequenceReader::Block& b)
+	{
+		seqs = std::move(b.seqs); idbuf = std::move(b.ids); id_end.assign(b.id_end.begin(), b.id_end.end());
+		off.clear(); off.reserve(b.seq_end.size() + 1); off.push_back(0);
+		off.insert(off.end(), b.seq_end.begin(), b.seq_end.end());
+	}
+	void drop_seqs() { std::string().swap(seqs); std::vector<uint64_t>().swap(off); } // (the ids stay: n(), id())
 	size_t n() const { return id_end.size(); }
 	std::string id(size_t i) const { const uint64_t a = i ? id_end[i - 1] : 0; return idbuf.substr(a, id_end[i] - a); }
 	size_t bytes() const { return seqs.size() + idbuf.size() + 16 * n(); }
@@ -483,6 +491,21 @@ int main(int argc, char** argv)
 	std::vector<Chunk> kept;
 	bool keep = prebuilt.empty();
 	for (int i = optind; i < argc; ++i) if (!strcmp(argv[i], ":") || !strcmp(argv[i], "-")) keep = false;
+	// ... and when nothing needs the bases on the host afterwards (the -T trace prints a read's seed k-mer),
+	// they are kept where PASS 1 put them instead: packed, on the device (abg_keep_reads), and the parser's
+	// blocks go to the library as they lie (abg_load_seqs_v) -- `kept` then only holds the ids.
+	bool packed_keep = keep && tracePath.empty() && readsPerCheckpoint == 0 && !getenv("ABG_NO_PACKED_KEEP");
+	if (packed_keep) {
+		uint64_t expect = 0;
+		for (int i = optind; i < argc; ++i) {
+			struct stat st;
+			const char* prog; const char* flag;
+			if (stat(argv[i], &st) == 0 && S_ISREG(st.st_mode)) expect += (uint64_t)st.st_size * (abghost::Prefetch::compressed(argv[i], &prog, &flag) ? 3 : 1);
+		}
+		if (abg_keep_reads(ctx, 1, expect / 2) != ABG_OK) packed_keep = false; // (more than the device should hold: the host keeps them)
+	}
+	std::vector<Chunk> cur_v, loading_v; // packed_keep: the chunk being filled / loaded, as the parser's blocks
+	size_t cur_bases = 0;
 	size_t kept_bytes = 0;
 	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE) / gpus; // (every rank keeps its own copy)
 	// PASS 1 of a chunk runs on a thread of its own while the reader parses the next chunk (one chunk
@@ -495,6 +518,11 @@ int main(int argc, char** argv)
 		loader.join();
 		check(load_rc, ctx, "load"); // (exit() from the loader thread would run the static destructors beside live threads)
 		host_mark("chunk loaded");
+		if (packed_keep) {
+			for (Chunk& c : loading_v) { c.drop_seqs(); kept.push_back(std::move(c)); }
+			loading_v.clear();
+			return;
+		}
 		if (keep) {
 			kept_bytes += loading.bytes();
 			if (kept_bytes > keep_limit) { keep = false; kept.clear(); kept.shrink_to_fit(); }
@@ -511,6 +539,18 @@ int main(int argc, char** argv)
 		loader = std::thread([&]() {
 			const double tl = host_now();
 			load_rc = abg_load_seqs(ctx, loading.seqs.data(), loading.off.data(), loading.n());
+			g_in_load += host_now() - tl;
+		});
+	};
+	auto loaded_v = [&]() {
+		load_done();
+		loading_v = std::move(cur_v);
+		cur_v.clear(); cur_bases = 0;
+		loader = std::thread([&]() {
+			std::vector<const char*> sv; std::vector<const uint64_t*> ov; std::vector<uint64_t> nv;
+			for (const Chunk& c : loading_v) { sv.push_back(c.seqs.data()); ov.push_back(c.off.data()); nv.push_back(c.n()); }
+			const double tl = host_now();
+			load_rc = abg_load_seqs_v(ctx, (uint32_t)sv.size(), sv.data(), ov.data(), nv.data());
 			g_in_load += host_now() - tl;
 		});
 	};
@@ -565,7 +605,26 @@ int main(int argc, char** argv)
 			if (verbose) fprintf(stderr, "Reading `%s'...\n", argv[i]);
 			abghost::SequenceReader in(argv[i], ropt, threads);
 			uint64_t n = 0;
-			if (in.has_blocks()) { // the parser threads' records wholesale
+			if (packed_keep) {
+				if (in.has_blocks()) {
+					abghost::SequenceReader::Block blk;
+					while (in.next_block(blk)) {
+						n += blk.seq_end.size();
+						cur_v.emplace_back();
+						cur_v.back().take_block(blk);
+						cur_bases += cur_v.back().seqs.size();
+						if (cur_bases >= CHUNK_BASES) loaded_v();
+					}
+				} else {
+					while (in.read(id, comment, seq)) {
+						if (cur_v.empty() || cur_v.back().seqs.size() >= (64u << 20)) cur_v.emplace_back();
+						cur_v.back().add(id, seq); n++;
+						cur_bases += seq.size();
+						if (cur_bases >= CHUNK_BASES) loaded_v();
+					}
+				}
+				if (!cur_v.empty()) loaded_v();
+			} else if (in.has_blocks()) { // the parser threads' records wholesale
 				abghost::SequenceReader::Block blk;
 				while (in.next_block(blk)) {
 					chunk.add_block(blk); n += blk.seq_end.size();
@@ -680,7 +739,28 @@ int main(int argc, char** argv)
 		if (readlog) for (size_t i = 0; i < c.n(); i++) fprintf(readlog, "%s\t%s\n", c.id(i).c_str(), rr[results[i]]);
 	};
 	auto flush = [&]() { assemble(chunk); chunk.clear(); };
-	if (keep && !kept.empty()) {
+	if (packed_keep) {
+		// the reads PASS 1 left on the device, all of them in one pass
+		o.chunks = &kept; o.first.assign(1, 0);
+		for (const Chunk& c : kept) o.first.push_back(o.first.back() + c.n());
+		results.assign(o.first.back(), 0);
+		const double ta = host_now();
+		const int rc = abg_assemble_kept(ctx, results.data(), on_contig, &o);
+		g_in_asm += host_now() - ta;
+		if (rc == ABG_ENOMEM) {
+			// (the device had no room to keep them after all: the input is read again, as the reference reads it)
+			if (verbose) fprintf(stderr, "%s; reading the input again\n", abg_last_error(ctx));
+			o.chunks = NULL; kept.clear(); keep = false; first_asm = optind;
+		} else {
+			check(rc, ctx, "assemble");
+			host_mark("kept reads assembled");
+			if (readlog)
+				for (size_t q = 0; q < kept.size(); q++)
+					for (size_t i = 0; i < kept[q].n(); i++) fprintf(readlog, "%s\t%s\n", kept[q].id(i).c_str(), rr[results[o.first[q] + i]]);
+			o.chunks = NULL;
+			first_asm = argc; // nothing left to read
+		}
+	} else if (keep && !kept.empty()) {
 		// the records kept from PASS 1, all of them in one pass (one guide, one walk schedule)
 		std::vector<const char*> sv; std::vector<const uint64_t*> ov; std::vector<uint64_t> nv;
 		o.chunks = &kept; o.first.assign(1, 0);
@@ -740,7 +820,9 @@ int main(int argc, char** argv)
 	if (trace) fclose(trace);
 	if (readlog) fclose(readlog);
 	if (out != stdout) fclose(out); else fflush(stdout);
+	host_mark("output closed");
 	abg_destroy(ctx);
+	host_mark("context destroyed");
 	if (use_comm) abg_rccl_comm_destroy(&comm);
 	// (the handler reaps the other ranks and ends the job if one of them fails)
 	while (rank == 0 && g_children_left > 0) usleep(1000);

@@ -132,6 +132,28 @@ int abg_filter_size(const abg_ctx* ctx, uint64_t* counters);
  * RollingHashIterator (RollingHashIterator.h:35-97). */
 int abg_load_seqs(abg_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t n);
 
+/* the same over a read set held in `nchunks` buffers, taken one after the other (a reader's blocks as
+ * they lie) */
+int abg_load_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, const uint64_t* const* offsets,
+    const uint64_t* n);
+
+/* The reference reads its input twice (loadBloomFilter, then assemble: bloom-dbg.cc:519-547).  With
+ * abg_keep_reads(ctx, 1, expected_bases) the reads of the abg_load_seqs / abg_load_seqs_v calls that
+ * follow stay on the device as PASS 1 packed them (2 bits a base), and abg_assemble_kept runs PASS 2 over
+ * all of them as ONE read stream -- what abg_assemble_seqs_v over the same buffers would do, without
+ * packing and uploading them a second time.  results (may be NULL) holds one byte per read loaded since
+ * abg_keep_reads, abg_contig.read_index counts through them.  expected_bases (0: unknown) sizes the
+ * store.  abg_keep_reads fails with ABG_ENOMEM when the reads would take more than an eighth of the
+ * device's memory; if the store cannot grow later, loading goes on without it and abg_assemble_kept
+ * returns ABG_ENOMEM (the caller reads its input again, as the reference does).  abg_assemble_kept and
+ * abg_keep_reads(ctx, 0, 0) release the store.
+ * While reads are kept, a load call returns once its sequences are packed (the buffers may then be
+ * reused); the upload and the ordered insert run beside the caller's work on the next chunk, one call's
+ * at a time and in call order.  Every other entry point waits for it first, and a failure of that
+ * deferred part is returned by the next call on the context, whichever it is. */
+int abg_keep_reads(abg_ctx* ctx, int on, uint64_t expected_bases);
+int abg_assemble_kept(abg_ctx* ctx, uint8_t* results, abg_contig_cb cb, void* user);
+
 /* PASS 1 on sequences already resident in device memory in the packed layout:
  * 2 bits per base (A,C,G,T = 0..3), 16 bases per uint32 word, every sequence starting on
  * a word boundary.  d_words/d_woff/d_len are device pointers (woff has n + 1 entries);

@@ -28,6 +28,7 @@ struct SerialSync {
 struct SerialBackend {
 	bool ok() const { return true; }
 	std::string why() const { return ""; }
+	void bind_thread() {}
 	void* alloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
 	void* try_alloc(size_t n) { return malloc(n ? n : 1); }
 	void free(void* p) { ::free(p); }
@@ -91,6 +92,8 @@ struct SerialBackend {
 };
 
 typedef abg::Session<SerialBackend> Sess;
+// (every entry waits for the device stage of the last load call first, as the C ABI does: Session::load_seqs_v)
+static Sess* S(void* h) { Sess* s = (Sess*)h; s->drain(); return s; }
 
 // k-mer helpers of the bulk steps against the per-base forms: window_kmer vs batch_kmer,
 // kmer_revcomp_fast vs kmer_revcomp, kmer_hashes vs vtx_rehash.  `words` holds one packed sequence
@@ -165,64 +168,70 @@ void* hc_create_cascade(unsigned k, unsigned nh, unsigned levels, uint64_t level
 	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }
 	return s;
 }
-uint8_t* hc_cascade_level(void* h, unsigned l) { return ((Sess*)h)->eng->cascade_level_dev(l); }
+uint8_t* hc_cascade_level(void* h, unsigned l) { return S(h)->eng->cascade_level_dev(l); }
 void hc_destroy(void* h) { delete (Sess*)h; }
-void hc_reset(void* h) { ((Sess*)h)->eng->reset(); }
-uint64_t hc_size(void* h) { return ((Sess*)h)->eng->size(); }
-uint8_t* hc_counters(void* h) { return ((Sess*)h)->eng->counters_dev(); }
-uint8_t* hc_visited(void* h) { return ((Sess*)h)->eng->visited_dev(); }
-int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n) { return ((Sess*)h)->load_seqs(seqs, off, n); }
-uint64_t hc_insert_rounds(void* h) { return ((Sess*)h)->eng->stats().insert_rounds; }
-int hc_popcounts(void* h, uint64_t* a, uint64_t* b) { ((Sess*)h)->eng->popcounts(a, b); return 0; }
+void hc_reset(void* h) { S(h)->eng->reset(); }
+uint64_t hc_size(void* h) { return S(h)->eng->size(); }
+uint8_t* hc_counters(void* h) { return S(h)->eng->counters_dev(); }
+uint8_t* hc_visited(void* h) { return S(h)->eng->visited_dev(); }
+int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n) { return S(h)->load_seqs(seqs, off, n); }
+uint64_t hc_insert_rounds(void* h) { return S(h)->eng->stats().insert_rounds; }
+int hc_popcounts(void* h, uint64_t* a, uint64_t* b) { S(h)->eng->popcounts(a, b); return 0; }
 int hc_assemble_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,
     abg_contig_cb cb, void* user)
 {
-	return ((Sess*)h)->assemble_seqs(seqs, off, n, results, cb, user);
+	return S(h)->assemble_seqs(seqs, off, n, results, cb, user);
 }
 int hc_assemble_seqs_v(void* h, uint32_t nchunks, const char* const* seqs, const uint64_t* const* off, const uint64_t* n,
     uint8_t* results, abg_contig_cb cb, void* user)
 {
-	return ((Sess*)h)->assemble_seqs_v(nchunks, seqs, off, n, results, cb, user);
+	return S(h)->assemble_seqs_v(nchunks, seqs, off, n, results, cb, user);
 }
+int hc_load_seqs_v(void* h, uint32_t nchunks, const char* const* seqs, const uint64_t* const* off, const uint64_t* n)
+{
+	return S(h)->load_seqs_v(nchunks, seqs, off, n);
+}
+int hc_keep_reads(void* h, int on, uint64_t expected_bases) { return S(h)->keep_reads(on, expected_bases); }
+int hc_assemble_kept(void* h, uint8_t* results, abg_contig_cb cb, void* user) { return S(h)->assemble_kept(results, cb, user); }
 int hc_contains_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint8_t* val, uint64_t cap, uint64_t* n)
 {
-	return ((Sess*)h)->contains_seq(seq, len, pos, val, cap, n);
+	return S(h)->contains_seq(seq, len, pos, val, cap, n);
 }
 int hc_hash_seq(void* h, const char* seq, uint64_t len, uint32_t* pos, uint64_t* hashes, uint64_t cap, uint64_t* n)
 {
-	return ((Sess*)h)->hash_seq(seq, len, pos, hashes, cap, n);
+	return S(h)->hash_seq(seq, len, pos, hashes, cap, n);
 }
 // partitioned run (two or more hostcheck sessions, one per process, joined by a communicator)
-int hc_attach_comm(void* h, const abg_comm* c) { return ((Sess*)h)->attach_comm(*c); }
+int hc_attach_comm(void* h, const abg_comm* c) { return S(h)->attach_comm(*c); }
 int hc_share_reads(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n,
     const uint32_t** gw, const uint64_t** gwoff, const uint32_t** glen, uint64_t* ntot)
 {
-	return ((Sess*)h)->share_reads(w, woff, len, n, gw, gwoff, glen, ntot);
+	return S(h)->share_reads(w, woff, len, n, gw, gwoff, glen, ntot);
 }
 int hc_load_packed(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n)
 {
-	return ((Sess*)h)->load_packed(w, woff, len, n);
+	return S(h)->load_packed(w, woff, len, n);
 }
 int hc_assemble_packed(void* h, const uint32_t* w, const uint64_t* woff, const uint32_t* len, uint64_t n,
     uint8_t* results, abg_contig_cb cb, void* user)
 {
-	return ((Sess*)h)->assemble_packed(w, woff, len, n, results, cb, user);
+	return S(h)->assemble_packed(w, woff, len, n, results, cb, user);
 }
 int hc_output_graph_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n, abg_text_cb cb, void* user,
     uint64_t* nodes, uint64_t* edges)
 {
-	return ((Sess*)h)->output_graph_seqs(seqs, off, n, cb, user, nodes, edges);
+	return S(h)->output_graph_seqs(seqs, off, n, cb, user, nodes, edges);
 }
 void hc_get_counters(void* h, abg_counters* out)
 {
-	abg::Counters c = ((Sess*)h)->eng->counters();
+	abg::Counters c = S(h)->eng->counters();
 	out->solid_reads = c.solid_reads; out->visited_reads = c.visited_reads;
 	out->reads_processed = c.reads_processed; out->bases_assembled = c.bases_assembled;
 	out->next_contig_id = c.contig_id;
 }
 void hc_get_stats(void* h, abg_stats* out)
 {
-	auto s = ((Sess*)h)->eng->stats();
+	auto s = S(h)->eng->stats();
 	out->insert_rounds = s.insert_rounds; out->walk_rounds = s.rounds; out->candidates = s.candidates;
 	out->walked = s.walked; out->rewalked = s.rewalked; out->commit_breaks = s.breaks; out->commit_rounds = s.commit_rounds; out->generated = s.generated;
 	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;

@@ -183,6 +183,32 @@ def test_read_set_in_several_buffers_is_one_pass():
     assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace
 
 
+@pytest.mark.parametrize("name", ["k40_mixed", "k64", "k48_K16"])
+def test_reads_kept_on_the_device_between_the_passes(name):
+    """abg_keep_reads / abg_load_seqs_v / abg_assemble_kept: the reads go in once, in several buffers and
+    calls (the device's share of a call running beside the next call's packing), and PASS 2 takes them
+    from where PASS 1 put them -- the reference's outputs, verdicts of the rejected reads included."""
+    gc = GoldenCase(name)
+    g = api.BloomDBG(**gc.kwargs(), spaced_seed=mask_of(gc))
+    g.keep_reads(True, len(gc.buf))
+    cut = [0, 0, 1, 777, 2000, gc.n]
+    chunks = [(bytes(gc.buf[int(gc.off[a]):int(gc.off[b])]), gc.off[a:b + 1] - gc.off[a]) for a, b in zip(cut, cut[1:])]
+    g.load_chunks(chunks[:2])
+    g.load_chunks(chunks[2:3])
+    g.load(*chunks[3])
+    g.load_chunks(chunks[4:])
+    assert g.counting_stats()[1] == gc.meta["filtered_popcount"]
+    results, contigs = g.assemble_kept(gc.n)
+    assert api.format_fasta(contigs, gc.ids) == gc.fasta
+    assert api.format_read_log(results, gc.ids) == gc.readlog
+    assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace
+    with pytest.raises(api.AbyssAmdError):
+        g.assemble_kept(0)  # nothing is kept any more
+    # and a store the device has no room for is refused up front
+    with pytest.raises(api.AbyssAmdError):
+        g.keep_reads(True, 1 << 42)
+
+
 def test_export_import_roundtrip_and_idempotence():
     # size-independent properties on a larger set: (1) filters survive export/import into a
     # fresh context and give the same assembly (the -i prebuilt path, bloom-dbg.cc:302-343);

@@ -95,6 +95,32 @@ class HostCheck:
                                          res.ctypes.data, _lib.CONTIG_CB(cb), None) == 0
         return res, out
 
+    def keep_reads(self, on=True, expected_bases=0):
+        self.l.hc_keep_reads.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        return self.l.hc_keep_reads(self.h, int(on), expected_bases)
+
+    def load_chunks(self, chunks):
+        """abg_load_seqs_v: several (buf, off) chunks, one call."""
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for _, o in chunks]
+        nc = len(chunks)
+        seqs_v = (C.c_char_p * nc)(*[b for b, _ in chunks])
+        off_v = (C.c_void_p * nc)(*[o.ctypes.data for o in offs])
+        n_v = (C.c_uint64 * nc)(*[len(o) - 1 for o in offs])
+        self.l.hc_load_seqs_v.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert self.l.hc_load_seqs_v(self.h, nc, C.cast(seqs_v, C.c_void_p), C.cast(off_v, C.c_void_p), C.cast(n_v, C.c_void_p)) == 0
+
+    def assemble_kept(self, n):
+        res = np.zeros(max(n, 1), dtype=np.uint8)
+        out = []
+
+        def cb(_u, c):
+            c = c.contents
+            out.append(api.ContigRecord(c.contig_id, c.read_index, c.seq, c.coverage, bool(c.redundant), c.left_ext,
+                                        c.right_ext, c.left_code, c.right_code, c.seed_pos))
+        self.l.hc_assemble_kept.argtypes = [C.c_void_p, C.c_void_p, _lib.CONTIG_CB, C.c_void_p]
+        rc = self.l.hc_assemble_kept(self.h, res.ctypes.data, _lib.CONTIG_CB(cb), None)
+        return rc, res[:n], out
+
     def hash_seq(self, seq):
         cap = max(len(seq), 1)
         pos = np.zeros(cap, dtype=np.uint32)
@@ -676,3 +702,47 @@ def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
     words = np.concatenate([(pad.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32), np.zeros(4, dtype=np.uint32)])
     for k in (21, 32, 33, 64, 65, 96, 127, 128, 150, 192):
         assert l.hc_selftest_kmer(k, words.ctypes.data, L) == 0, k
+
+
+@pytest.mark.parametrize("k,mask", [(33, None), (40, "k40"), (48, "K16")])
+def test_reads_kept_on_the_device_between_the_passes_assemble_like_the_read_stream(k, mask, monkeypatch):
+    """abg_keep_reads / abg_load_seqs_v / abg_assemble_kept against the oracle fed the same stream:
+    reads with N, short reads, lower case, a read longer than a PASS-1 piece, empty chunks, several
+    load calls, the packing split over threads."""
+    monkeypatch.setenv("ABG_HOST_SPLIT", "3")
+    m1, m2 = synth.make_read_set(12000, 30.0, err=0.004, genome_seed=k, read_seed=k + 5)
+    reads = [bytes(r) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
+    rng = np.random.default_rng(k)
+    genome = synth.codes_to_ascii(synth.make_genome(12000, seed=k)[0][None, :])[0].tobytes()
+    for i in rng.choice(len(reads), 40, replace=False):
+        r = bytearray(reads[i])
+        r[int(rng.integers(len(r)))] = ord("N")
+        reads[i] = bytes(r)
+    for i in rng.choice(len(reads), 30, replace=False):
+        reads[i] = reads[i].lower()
+    reads[17] = reads[17][:k - 1]
+    reads[400] = b""
+    reads[800] = genome[1000:6000]          # longer than a piece when insert_batch is small
+    reads[801] = genome[2000:3000] + b"N" + genome[3001:7000]
+    seed = {"k40": None, "K16": api.spaced_seed_kmer_pair(48, 16), None: None}[mask]
+    cuts = [0, 0, 700, 701, 1500, 1900, 1900, len(reads)]
+    chunks = [api.concat_seqs(reads[a:b]) for a, b in zip(cuts, cuts[1:])]
+    buf, off = api.concat_seqs(reads)
+    o = ob.Oracle(k, counters=1 << 21, mask=seed.encode()) if seed else ob.Oracle(k, counters=1 << 21)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    hc = HostCheck(k, 1 << 21, insert_batch=3000, claim_log2=14, p2_first=200, mask=seed)
+    assert hc.keep_reads(True, sum(len(r) for r in reads)) == 0
+    hc.load_chunks(chunks[:3])
+    hc.load_chunks(chunks[3:4])
+    hc.load_chunks(chunks[4:])
+    assert np.array_equal(o.counters(), hc.counters())
+    rc, rh, ch = hc.assemble_kept(len(reads))
+    assert rc == 0
+    assert np.array_equal(ro, rh)
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
+    assert o.assembly_counters() == hc.assembly_counters()
+    assert {1, 2} <= set(np.unique(rh).tolist())  # SHORTER_THAN_K and NON_ACGT verdicts came from loading time
+    # nothing is kept any more
+    rc, _, _ = hc.assemble_kept(0)
+    assert rc != 0
