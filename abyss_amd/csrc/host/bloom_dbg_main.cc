@@ -542,10 +542,14 @@ int main(int argc, char** argv)
 			g_in_load += host_now() - tl;
 		});
 	};
+	// (the first chunks of a kept-reads run are small, so that the device starts while the parser has
+	// read a fraction of a second's worth; then they double up to CHUNK_BASES)
+	size_t chunk_target = 32u << 20;
 	auto loaded_v = [&]() {
 		load_done();
 		loading_v = std::move(cur_v);
 		cur_v.clear(); cur_bases = 0;
+		chunk_target = std::min(CHUNK_BASES, chunk_target * 2);
 		loader = std::thread([&]() {
 			std::vector<const char*> sv; std::vector<const uint64_t*> ov; std::vector<uint64_t> nv;
 			for (const Chunk& c : loading_v) { sv.push_back(c.seqs.data()); ov.push_back(c.off.data()); nv.push_back(c.n()); }
@@ -613,14 +617,14 @@ int main(int argc, char** argv)
 						cur_v.emplace_back();
 						cur_v.back().take_block(blk);
 						cur_bases += cur_v.back().seqs.size();
-						if (cur_bases >= CHUNK_BASES) loaded_v();
+						if (cur_bases >= chunk_target) loaded_v();
 					}
 				} else {
 					while (in.read(id, comment, seq)) {
 						if (cur_v.empty() || cur_v.back().seqs.size() >= (64u << 20)) cur_v.emplace_back();
 						cur_v.back().add(id, seq); n++;
 						cur_bases += seq.size();
-						if (cur_bases >= CHUNK_BASES) loaded_v();
+						if (cur_bases >= chunk_target) loaded_v();
 					}
 				}
 				if (!cur_v.empty()) loaded_v();
