@@ -2493,6 +2493,7 @@ class Engine {
 		}
 		p2_.solid_bits = 1; cnt2_ = plane_;
 	}
+	uint64_t ovf_seen_[2] = { 0, 0 }; // partitioned run: the walkers' pool / record overflow counters as last read
 	uint8_t* plane_ = nullptr; bool plane_valid_ = false;
 	Params p2_; const uint8_t* cnt2_ = nullptr; // what the probing kernels of PASS 2 get: p_ / cnt_, or the plane
 
@@ -2669,7 +2670,6 @@ class Engine {
 	bool walk_ready_ = false;
 	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
-	uint64_t ovf_seen_[2] = { 0, 0 }; // the walkers' pool / record overflow counters as last read
 	uint64_t wtab_per_walker_ = 1536; // planning figure: vertices one walker enters (config 2 averages ~1100)
 	uint32_t* wclaims_ = nullptr;
 	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
@@ -3931,13 +3931,23 @@ class Engine {
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.
 				stats_.overflows++;
-				// what ran out?  The walkers count pool and record overflows; anything else is the vertex
-				// table (plan for longer walks from now on) or, when not even the first candidate got
-				// through, a walker's own stack or path buffer.
-				uint64_t ovf[2] = { 0, 0 };
-				be_.d2h(ovf, wstats_ + WSTAT_OVF_POOL, 16);
-				const bool pool_out = ovf[0] != ovf_seen_[0], recs_out = ovf[1] != ovf_seen_[1];
-				ovf_seen_[0] = ovf[0]; ovf_seen_[1] = ovf[1];
+				// what ran out?  This context's own allocation counters say whether it was its contig pool or its
+				// records (a walker that finds no room leaves the counter past the capacity; the shared
+				// WSTAT_OVF_* counters are statistics only: with several batches in flight another context's
+				// walkers bump them too); anything else is the vertex table (plan for longer walks from now on)
+				// or, when not even the first candidate got through, a walker's own stack or path buffer.
+				uint64_t pool_now = 0; uint32_t recs_now = 0;
+				be_.d2h(&pool_now, pool_used_, 8);
+				be_.d2h(&recs_now, rec_used_, 4);
+				bool pool_out = pool_now > pool_cap_, recs_out = recs_now > rec_cap_;
+				if (dist()) {
+					// (a partitioned run has merged the ranks' records by now and set the counters to the merged sizes;
+					// it runs one batch at a time, so the shared counters are this batch's)
+					uint64_t ovf[2] = { 0, 0 };
+					be_.d2h(ovf, wstats_ + WSTAT_OVF_POOL, 16);
+					pool_out = pool_out || ovf[0] != ovf_seen_[0]; recs_out = recs_out || ovf[1] != ovf_seen_[1];
+					ovf_seen_[0] = ovf[0]; ovf_seen_[1] = ovf[1];
+				}
 				if (pool_out) {
 					be_.free(pool_); be_.free(kh_);
 					pool_cap_ *= 2;
