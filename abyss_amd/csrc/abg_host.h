@@ -212,11 +212,11 @@ class Session {
 		st->keeping = keeping; st->kparts = std::move(kparts); st->verdict = std::move(verdict); st->n_reads = base[nchunks];
 		st->t_pack = t1 - t0; st->t_join = tnow() - t1; st->nparts = parts.size();
 		drain();
+		// Only a caller that asked for the pipeline (abg_keep_reads) gets it: otherwise the call does its
+		// device work itself and returns with it done and its errors its own.  A partitioned run's
+		// collectives are the caller's code: they stay on the caller's thread.
+		if (!cfg.async_load || comm_attached_ || !keeping) { load_stage(*st); return ABG_OK; }
 		pending_ = std::async(std::launch::async, [this, st]() { be.bind_thread(); load_stage(*st); });
-		// (a partitioned run's collectives are the caller's code: they stay on the caller's thread)
-		// and only a caller that asked for the pipeline (abg_keep_reads) gets it: otherwise the call returns
-		// with its work done and its errors its own
-		if (!cfg.async_load || comm_attached_ || !keeping) drain();
 		return ABG_OK;
 	}
 	// waits for the device's share of the last load call (and rethrows what it threw)
