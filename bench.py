@@ -424,7 +424,7 @@ def main() -> int:
     # side stream beside the walkers and is not on the critical path); the roofline line is its family's
     dom = max(per_kernel, key=lambda fam: prof[per_kernel[fam]["longest_kernel"]][0] if (fam != "classify" and per_kernel[fam].get("longest_kernel") in prof) else 0)
     # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this very
-    # command, tools/gpu_r2_prof.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
+    # command, tools/gpu_pmc_traffic.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
     # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
     traffic = traffic_src = None
     tsrc = os.path.join(ROOT, "profiles", "r03_e_pmc_traffic.json")
