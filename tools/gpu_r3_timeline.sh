@@ -47,6 +47,28 @@ for s, e, n, q in p2:
     if s > run_end: gaps += s - run_end
     run_end = max(run_end, e)
 print('idle (no kernel running) in PASS 2: %.1f ms' % (gaps / 1e6))
+# PASS 1: what its wall time is made of -- busy time per stream, time with nothing running anywhere,
+# and the time the MAIN stream (the one with the tile kernels) has nothing running
+p1 = ev[:g]
+tile_q = next((q for s, e, n, q in p1 if 'FTileApply' in n), None)
+tot1 = {}
+for s, e, n, q in p1: tot1[n] = tot1.get(n, 0) + (e - s) / 1e6
+print('PASS 1 totals:', ', '.join('%s %.1f' % kv for kv in sorted(tot1.items(), key=lambda kv: -kv[1])[:14]))
+idle_all = 0; run_end = p1[0][0]
+for s, e, n, q in p1:
+    if s > run_end: idle_all += s - run_end
+    run_end = max(run_end, e)
+main = [(s, e, n) for s, e, n, q in p1 if q == tile_q]
+idle_main = 0; gaps_main = []; run_end = main[0][0]
+for s, e, n in main:
+    if s > run_end: idle_main += s - run_end; gaps_main.append(((s - run_end) / 1e6, n))
+    run_end = max(run_end, e)
+busy_main = sum(e - s for s, e, n in main) / 1e6
+print('PASS 1: %.1f ms; main stream busy %.1f ms in %d kernels, idle %.1f ms in %d gaps; nothing running on any stream %.1f ms' % (
+    (p1[-1][1] - p1[0][0]) / 1e6, busy_main, len(main), idle_main / 1e6, len(gaps_main), idle_all / 1e6))
+by = {}
+for d, n in gaps_main: by[n] = (by.get(n, (0, 0))[0] + d, by.get(n, (0, 0))[1] + 1)
+print('main-stream gaps by the kernel that follows:', ', '.join('%s %.1f ms / %d' % (n, v[0], v[1]) for n, v in sorted(by.items(), key=lambda kv: -kv[1][0])[:10]))
 PY
 done
-head -c 6000 $O/timeline_ps${1:-1}.txt
+tail -n 6 $O/timeline_ps${1:-1}.txt | cut -c1-600
