@@ -6,22 +6,29 @@
 
 #include "abyss_amd.h"
 
+#include <future>
+
 int main(int argc, char** argv)
 {
 	abgadj::Options opt;
 	int device = 0, status = 0;
 	if (!abgadj::parse_options(argc, argv, opt, &device, &status)) return status;
+	// (the device comes up -- HIP start-up, a quarter of a second -- while the contigs are read)
 	abg_overlap* ov = nullptr;
-	int rc = abg_overlap_create(device, &ov);
-	if (rc != ABG_OK) {
-		fprintf(stderr, ABG_ADJ_PROGRAM ": %s\n", abg_overlap_last_error(nullptr));
-		return EXIT_FAILURE;
-	}
+	std::future<int> up = std::async(std::launch::async, [&]() { return abg_overlap_create(device, &ov); });
 	const bool timing = getenv("ABG_ADJ_TIMING") != nullptr;
-	if (timing) abg_overlap_profile(ov, 1);
+	auto device_ready = [&]() {
+		if (!up.valid()) return;
+		if (up.get() != ABG_OK) {
+			fprintf(stderr, ABG_ADJ_PROGRAM ": %s\n", abg_overlap_last_error(nullptr));
+			exit(EXIT_FAILURE);
+		}
+		if (timing) abg_overlap_profile(ov, 1);
+	};
 	abgadj::Join join = [&](uint32_t overlap, uint64_t n, const uint64_t* head, const uint64_t* tail, bool ss,
 	                        std::vector<uint64_t>& off, std::vector<uint32_t>& tgt) {
 		uint64_t ne = 0;
+		device_ready();
 		int r = abg_overlap_join(ov, overlap, n, head, tail, ss ? 1 : 0, &ne);
 		if (r == ABG_OK) {
 			off.assign(2 * n + 1, 0);
@@ -34,6 +41,7 @@ int main(int argc, char** argv)
 		}
 	};
 	status = abgadj::run(opt, join, stdout);
+	device_ready(); // (no contigs, no join: still the device's verdict)
 	if (timing) {
 		for (const char* name : { "overlap_keys", "sort_pairs", "overlap_count", "scan", "overlap_fill" }) {
 			double ms = 0;

@@ -471,6 +471,13 @@ class SequenceReader {
 		}
 	}
 
+	// Starts reading and parsing the first window now, on the reader's background thread, instead of at
+	// the first read() / next_block(): a caller with start-up work of its own does it meanwhile.
+	void prime()
+	{
+		if (m_seq || (m_mem && m_done) || m_next.valid() || !m_blocks.empty()) return;
+		m_next = std::async(std::launch::async, [this]() { return parse_window(); });
+	}
 	// The records a parser thread produced, as they lie: concatenated strings and their end offsets.
 	struct Block {
 		std::string ids, comments, seqs;

@@ -128,5 +128,10 @@ def test_binary_errors_like_the_reference(tmp_path, _built):
     write_fasta(fa, [("0", "", b"ACGTACGTNA")])
     r = subprocess.run([ADJLIST, "-k4", fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"unexpected character: 'N'" in r.stderr
+    write_fasta(fa, [("0", "", b"ACGTACGTTA")])
+    r = subprocess.run([ADJLIST, "-k4", "--gpu=99", fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"out of range" in r.stderr
+    # (nothing to join, still no device: the device's verdict is not skipped)
+    open(fa, "wb").close()
     r = subprocess.run([ADJLIST, "-k4", "--gpu=99", fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"out of range" in r.stderr
