@@ -366,6 +366,7 @@ class Session {
 	} keep_;
 	bool keep_room(uint64_t more)
 	{
+		if (keep_.used && getenv("ABG_KEEP_FAIL")) return false; // (tests: no room for anything after the first call's reads)
 		if (keep_.used + more <= keep_.cap) return true;
 		uint64_t cap = std::max<uint64_t>({ keep_.hint_words, keep_.cap * 2, keep_.used + more, 1ull << 20 });
 		void* w = be.try_alloc(cap * 4);

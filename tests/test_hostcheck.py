@@ -746,3 +746,27 @@ def test_reads_kept_on_the_device_between_the_passes_assemble_like_the_read_stre
     # nothing is kept any more
     rc, _, _ = hc.assemble_kept(0)
     assert rc != 0
+
+
+def test_kept_reads_dropped_for_lack_of_room_leave_pass1_intact(monkeypatch):
+    """The store cannot grow (ABG_KEEP_FAIL): loading goes on without it, abg_assemble_kept says ABG_ENOMEM,
+    and the caller assembles from its own buffers as if nothing had been kept."""
+    k = 35
+    m1, m2 = synth.make_read_set(9000, 25.0, err=0.004, genome_seed=k, read_seed=k + 5)
+    reads = [bytes(r) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
+    chunks = [api.concat_seqs(reads[:500]), api.concat_seqs(reads[500:])]
+    buf, off = api.concat_seqs(reads)
+    o = ob.Oracle(k, counters=1 << 20)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    monkeypatch.setenv("ABG_KEEP_FAIL", "1")
+    hc = HostCheck(k, 1 << 20, insert_batch=20000, claim_log2=14, p2_first=200)
+    assert hc.keep_reads(True, 0) == 0
+    hc.load_chunks(chunks[:1])   # fits the store's first allocation
+    hc.load_chunks(chunks[1:])   # would have to grow it: dropped
+    assert np.array_equal(o.counters(), hc.counters())
+    rc, _, _ = hc.assemble_kept(len(reads))
+    assert rc == _lib.ABG_ENOMEM
+    rh, ch = hc.assemble_chunks(chunks)
+    assert np.array_equal(ro, rh) and [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
+    assert o.assembly_counters() == hc.assembly_counters()
