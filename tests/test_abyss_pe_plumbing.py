@@ -117,3 +117,26 @@ def test_abyss_pe_issues_the_adjlist_command_line_our_binary_accepts(tmp_path, k
         assert r.returncode == 0, out
     else:
         assert r.returncode != 0 and "no HIP device" in out and "invalid option" not in out, out
+
+
+@pytest.mark.gpu
+def test_the_two_rules_in_a_row_write_the_reference_overlap_graph(tmp_path):
+    """`%-1.fa` then `%-1.dot` as abyss-pe issues them (bin/abyss-pe:553-555,575-577), both drop-ins from
+    PATH; the graph is what the reference's AdjList (or, without it, its restatement) makes of the unitigs."""
+    import adjlist_oracle as ao
+    cli = build.build_cli()
+    _write_reads(tmp_path, genome=120000, cov=30.0)
+    env = dict(os.environ, PATH="%s:%s" % (os.path.dirname(cli), os.environ["PATH"]))
+    for rule in ("abyss-bloom-dbg -k40 -q3 -b64M -j4 r1.fq r2.fq > asm-1.fa", "AdjList -k40 -m0 --dot asm-1.fa > asm-1.dot",
+                 "AdjList -k40 -m20 --adj asm-1.fa > asm-1.adj"):
+        r = subprocess.run(["sh", "-c", rule], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+    recs = ao.read_fasta(str(tmp_path / "asm-1.fa"))
+    assert len(recs) > 100
+    contigs, out = ao.build(recs, 40, 0)
+    assert (tmp_path / "asm-1.dot").read_bytes() == ao.format_dot(contigs, out)
+    contigs, out = ao.build(recs, 40, 20)
+    assert (tmp_path / "asm-1.adj").read_bytes() == ao.format_adj(contigs, out)
+    if os.path.exists(ao.REF_ADJLIST):
+        r = subprocess.run([ao.REF_ADJLIST, "-k40", "-m0", "--dot", "asm-1.fa"], cwd=tmp_path, stdout=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == (tmp_path / "asm-1.dot").read_bytes()
