@@ -128,6 +128,41 @@ def case_oracle(k, G, counters, cov, err, insert_batch, rank, world, shared, p2_
     return ok, hc
 
 
+def case_kept(rank, world):
+    """Reads kept in every rank's store between the passes (abg_keep_reads / abg_load_seqs_v /
+    abg_assemble_kept) in a partitioned run: every rank loads every read (several buffers, two calls,
+    reads with N and short ones among them) and assembles from its store."""
+    k = 37
+    m1, m2 = synth.make_read_set(11000, 25.0, err=0.005, genome_seed=k, read_seed=k + 3)
+    reads = [bytes(r) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
+    reads[5] = reads[5][:40] + b"N" + reads[5][41:]
+    reads[77] = reads[77][:20]
+    reads[300] = reads[300].lower()
+    buf, off = api.concat_seqs(reads)
+    cuts = [0, 1, 400, 401, 1500, len(reads)]
+    chunks = [api.concat_seqs(reads[a:b]) for a, b in zip(cuts, cuts[1:])]
+    hc = DistHostCheck(k, 1 << 20, insert_batch=15000, claim_log2=12, p2_first=64)
+    hc.attach()
+    assert hc.keep_reads(True, len(buf)) == 0
+    hc.load_chunks(chunks[:3])
+    hc.load_chunks(chunks[3:])
+    cnt = hc.counters()
+    rc, rh, ch = hc.assemble_kept(len(reads))
+    assert rc == 0
+    o = ob.Oracle(k, counters=1 << 20)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    ok = {
+        "counting_filter": bool(np.array_equal(o.counters(), cnt)),
+        "results": bool(np.array_equal(ro, rh)),
+        "contigs": [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch],
+        "visited": bool(np.array_equal(o.visited(), hc.visited())),
+        "assembly_counters": o.assembly_counters() == hc.assembly_counters(),
+        "n_contigs": len(co),
+    }
+    return ok, hc
+
+
 def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -167,6 +202,8 @@ def main():
         hc.load(buf, off)
         a, b = o.counters(), hc.counters()
         ok = {"counting_filter": bool(np.array_equal(a, b)), "saturated": int(b.max())}
+    elif what == "kept":
+        ok, hc = case_kept(rank, world)
     elif what == "shared":
         ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=True)
     else:

@@ -106,6 +106,13 @@ def test_partitioned_counters_saturate_like_the_reference_world3():
     assert out["stats"]["tiled_ops"] > 0 and out["stats"]["tiled_pending"] > 254, out["stats"]
 
 
+def test_partitioned_run_assembles_the_reads_kept_in_the_ranks_stores_world2():
+    out = run_ranks(2, "kept")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["n_contigs"] > 10 and out["comm_calls"]["all_reduce"] > 0
+
+
 def test_partitioned_run_on_gathered_read_shares_world3():
     """Each rank holds a slice of the packed read set (one of them none at all); abg_share_reads
     all-gathers them in rank order."""
