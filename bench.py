@@ -7,16 +7,17 @@ conservative-update insert of every read k-mer into the counting Bloom filter), 
 (classify reads, walk unitigs, commit contigs in read order).  N = number of read k-mers,
 each counted once although both passes touch it.
 
-Workload: BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads, k=64,
+Workload: one GPU times BASELINE.json configs[1], "E. coli-scale synthetic: 5 M x 2x150 bp reads, k=64,
 B=2G, H=4" (30 Mbp genome, 50x, 0.5 % substitution errors); --config 2 / 3 select configs[2]
-(200 M pairs, B=40G) / configs[3] (-k96 -K32).  With --gpus N (one process per GPU) ONE job N
-times as big (reads, genome and filter: weak scaling, the shape of configs[2]) is split over the
-ranks: every rank holds 1/N of the reads, the counting filter is range-partitioned by position
-over the ranks' HBM during PASS 1 (RCCL all_gather of the 2-bit reads, one all_reduce(MIN) of a
-byte per k-mer op and round), gathered for PASS 2, whose walks are split over the ranks and merged
-before the ordered commit; the unitigs are bit-identical to a 1-GPU run of
-that job.  --scaling strong splits the fixed configs[1] job instead; --mode replicas runs N
-independent copies of the job (no collective on the data path).
+(200 M pairs, B=40G) / configs[3] (-k96 -K32).  With --gpus N (one process per GPU; run without a
+launcher, bench.py starts its N ranks itself) ONE job is split over the ranks -- by default
+configs[2], the configuration BASELINE.json lists for the partitioned filter, strong-scaled
+("scaling": "strong"; its one-GPU point is replayed from profiles/ in `strong_scaling`): every rank
+holds 1/N of the reads, the counting filter is range-partitioned by position over the ranks' HBM
+during PASS 1 (RCCL), gathered for PASS 2, whose walks are split over the ranks and merged before the
+ordered commit; the unitigs are bit-identical to a 1-GPU run of that job.
+--scaling weak makes the job N times --pairs / --bloom instead; --mode replicas runs N independent
+copies of the job (no collective on the data path).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -168,12 +169,20 @@ def aggregate(elapsed: float, kmers_local: int, steps: int, world: int, device=N
     return float(t.item()), int(n.item())
 
 
+def launcher_command(gpus: int, argv, port: str = None):
+    """What `python bench.py --gpus N` turns itself into when no launcher set WORLD_SIZE: one rank per GPU over RCCL,
+    the way the driver starts an N-GPU run."""
+    port = port or os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3],
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3],
                     help="BASELINE.json configs[N]: 1 = E. coli-scale (5 M pairs, k=64, B=2G; the default and the benchmark), "
                          "2 = human-chr-scale (200 M pairs, k=64, B=40G), 3 = spaced seed (5 M pairs, -k96 -K32, B=2G)")
     ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (overrides --config)")
@@ -191,13 +200,25 @@ def main() -> int:
                     help="time the steps without HIP events around every launch (no per-kernel numbers: shows what the events cost)")
     ap.add_argument("--mode", choices=["partitioned", "replicas"], default="partitioned",
                     help="N > 1: one job with the filter partitioned over the ranks (strong scaling) or N independent jobs")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="partitioned mode: a job N times as big (--pairs and --bloom per rank: the shape of BASELINE.json "
-                         "configs[2]; the default -- partitioning exists to hold filters one GPU cannot), or the fixed "
-                         "--pairs / --bloom job over N ranks (strong)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="partitioned mode: the fixed --config / --pairs / --bloom job over N ranks (strong: the default -- "
+                         "north_star's experiment is BASELINE.json configs[2] over 1/2/4/8 GPUs), or a job N times as big "
+                         "(weak: --pairs and --bloom are per rank)")
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher
+        return subprocess.call(launcher_command(a.gpus, sys.argv[1:]),
+                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    if a.gpus != int(os.environ.get("WORLD_SIZE", "1")) and int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %s ranks: timing what was started\n" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.config is None:
+        # one GPU: configs[1], the configuration the metric is quoted on.  Several GPUs, one partitioned job: configs[2], the
+        # configuration BASELINE.json lists for the partitioned filter ("200 M x 2x150 bp, k=64, B=40G ... over 8xMI355X via RCCL"),
+        # strong-scaled; its one-GPU point is on file (profiles/r03_d_bench_config2_invariants.json)
+        a.config = 2 if (world_env > 1 and a.mode == "partitioned" and a.pairs is None) else 1
     preset = {1: (5_000_000, 64, "2G", 0, "E. coli-scale"), 2: (200_000_000, 64, "40G", 0, "human-chr-scale"),
               3: (5_000_000, 96, "2G", 32, "spaced-seed")}[a.config]
     a.pairs = preset[0] if a.pairs is None else a.pairs
@@ -420,9 +441,9 @@ def main() -> int:
     if not per_kernel:
         # (partitioned run without a warm-up step: no per-launch events were taken -- see timed_profile)
         per_kernel = {"walk": {"achieved": None, "frac": None, "avg_launch_ms": None, "launches": 0, "ms": 0, "longest_kernel": "rewalk"}}
-    # the dominant kernel: the one with the largest summed duration over the step (the classification runs on the
-    # side stream beside the walkers and is not on the critical path); the roofline line is its family's
-    dom = max(per_kernel, key=lambda fam: prof[per_kernel[fam]["longest_kernel"]][0] if (fam != "classify" and per_kernel[fam].get("longest_kernel") in prof) else 0)
+    # the dominant kernel: the one with the largest summed duration over the step, whatever stream it runs on; the
+    # roofline line is its family's
+    dom = max(per_kernel, key=lambda fam: prof[per_kernel[fam]["longest_kernel"]][0] if per_kernel[fam].get("longest_kernel") in prof else 0)
     # HBM bytes from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this very
     # command, tools/gpu_pmc_traffic.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
     # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
@@ -455,7 +476,9 @@ def main() -> int:
         out = {
             "metric": METRIC, "value": total_kmers / elapsed / 1e6, "unit": "Mk-mers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": a.scaling if (partitioned or (world == 1 and a.mode == "partitioned")) else "weak",
+            "higher_is_better": True,
+            # one GPU: nothing is scaled; N ranks of one partitioned job: as asked; N independent replicas: weak by construction
+            "scaling": None if world == 1 else (a.scaling if partitioned else "weak"),
             "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s synthetic: %d x 2x%d bp reads, k=%d%s, B=%s, H=4, %s"
@@ -479,6 +502,15 @@ def main() -> int:
             out["parity"] = parity
         if no_events is not None:
             out["no_events"] = no_events
+        if partitioned and world > 1 and a.scaling == "strong":
+            # the one-GPU point of this very job, measured in an earlier run and REPLAYED from the committed file (the driver
+            # computes its own efficiency from the per-N lines; this one is for a reader of a single line)
+            one = {1: "r03_e_bench_default.json", 2: "r03_d_bench_config2_invariants.json", 3: "r03_e_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
+            src = os.path.join(ROOT, "profiles", one) if one else None
+            if src and os.path.exists(src) and a.pairs == preset[0] and a.k == preset[1]:
+                v1 = json.load(open(src))["value"]
+                out["strong_scaling"] = {"one_gpu_value": v1, "one_gpu_source": "profiles/" + one, "replayed": True,
+                                         "speedup": out["value"] / v1, "efficiency": out["value"] / v1 / world}
         if partitioned:
             out["config"]["ranks_agree"] = ranks_agree
             out["kernel_ms_note"] = "rank 0, last warm-up step (the timed steps run without per-launch events)"

@@ -39,3 +39,20 @@ def test_aggregate_single_rank():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.aggregate(1.25, 87, 3, 1) == (1.25, 261)
+
+
+def test_gpus_flag_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 8` (no torchrun around it) must not time one GPU and call it eight."""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.main() == 0
+    (cmd, env), = calls
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
