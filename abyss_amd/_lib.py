@@ -7,7 +7,7 @@ import os
 from . import build
 
 ABG_OK = 0
-ABG_EINVAL, ABG_ENODEV, ABG_ENOMEM, ABG_EINTERNAL = -1, -2, -3, -4
+ABG_EINVAL, ABG_ENODEV, ABG_ENOMEM, ABG_EINTERNAL, ABG_EAGAIN = -1, -2, -3, -4, -5
 
 
 class Params(C.Structure):

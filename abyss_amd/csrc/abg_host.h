@@ -135,7 +135,7 @@ class Session {
 			const std::vector<uint64_t> cut = split_reads(off_v[c], n_v[c]);
 			for (size_t t = 0; t + 1 < cut.size(); t++) plan.push_back(Part{ c, cut[t], cut[t + 1] });
 		}
-		const bool keeping = keep_.on && !keep_.failed;
+		const bool keeping = keep_on_ && !keep_failed_;
 		// kept reads (keep_reads): what PASS 2 will want of this call's reads.  A read that is ACGT throughout
 		// and at least k long is one piece of the batch (or, longer than a piece may be, packed once more on
 		// the side); every other read has its verdict now (bloom-dbg.h:804,808).
@@ -235,7 +235,7 @@ class Session {
 		const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
 		const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 		const double t2 = tnow();
-		if (!st.keeping || keep_.failed) {
+		if (!st.keeping || keep_failed_) {
 			if (hb.n()) flush_load(hb); // (the engine cuts it into ordered-insert batches of insert_batch_kmers)
 			if (timing) fprintf(stderr, "[host] load: %zu parts, pack %.3f s, join %.3f s, upload + device %.3f s\n", st.nparts, st.t_pack, st.t_join, tnow() - t2);
 			return;
@@ -298,19 +298,19 @@ class Session {
 	{
 		drain();
 		keep_drop(false);
-		keep_.on = on != 0;
-		if (!keep_.on) return ABG_OK;
+		keep_on_ = on != 0;
+		if (!keep_on_) return ABG_OK;
 		const uint64_t mem = be.device_mem_bytes();
-		if (mem && expected_bases / 4 > mem / 8) { keep_.on = false; return fail(ABG_ENOMEM, "the reads would take more than an eighth of the device's memory: not kept"); }
+		if (mem && expected_bases / 4 > mem / 8) { keep_on_ = false; return fail(ABG_ENOMEM, "the reads would take more than an eighth of the device's memory: not kept"); }
 		keep_.hint_words = expected_bases / 16 + expected_bases / 1024 + 1024;
 		return ABG_OK;
 	}
-	uint64_t kept_reads() { drain(); return keep_.on ? keep_.n_reads : 0; }
+	uint64_t kept_reads() { drain(); return keep_on_ ? keep_.n_reads : 0; }
 	int assemble_kept(uint8_t* results, abg_contig_cb cb, void* user)
 	{
 		drain();
-		if (!keep_.on) return fail(ABG_EINVAL, "no reads are kept (abg_keep_reads)");
-		if (keep_.failed) return fail(ABG_ENOMEM, "the kept reads were dropped: no device memory for them");
+		if (!keep_on_) return fail(ABG_EINVAL, "no reads are kept (abg_keep_reads)");
+		if (keep_failed_) return fail(ABG_EAGAIN, "the kept reads were dropped (no device memory for them): read the input again");
 		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
 		const uint64_t n = keep_.n_reads, n2 = keep_.orig.size();
 		if (keep_.unordered) {
@@ -353,12 +353,15 @@ class Session {
 		}
 		if (results && n) memcpy(results, res.data(), n);
 		keep_drop(false);
-		keep_.on = false;
+		keep_on_ = false;
 		return ABG_OK;
 	}
   private:
+	// (on / failed live outside Keep: a load call reads them on the caller's thread while the previous call's
+	// device share -- which may drop the store -- still runs on the library's)
+	std::atomic<bool> keep_on_{ false }, keep_failed_{ false };
 	struct Keep {
-		bool on = false, failed = false, unordered = false;
+		bool unordered = false;
 		void* words = nullptr; uint64_t cap = 0, used = 0, hint_words = 0; // device store of 2-bit words
 		std::vector<uint64_t> woff, orig; std::vector<uint32_t> len;      // per kept (clean) read: where, which read
 		std::vector<uint8_t> res;                                         // per read loaded: verdict known at loading time, or 0
@@ -381,10 +384,9 @@ class Session {
 	void keep_drop(bool failed)
 	{
 		if (keep_.words) { be.sync(); be.free(keep_.words); }
-		const bool on = keep_.on;
 		const uint64_t hint = keep_.hint_words;
 		keep_ = Keep();
-		keep_.on = on; keep_.failed = failed; keep_.hint_words = hint;
+		keep_failed_ = failed; keep_.hint_words = hint;
 	}
   public:
 	int load_packed(const uint32_t* d_words, const uint64_t* d_woff, const uint32_t* d_len, uint64_t n)

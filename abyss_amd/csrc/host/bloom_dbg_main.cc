@@ -660,13 +660,16 @@ int main(int argc, char** argv)
 			if (verbose) fprintf(stderr, "Loaded %llu reads from `%s` into Bloom filter\n", (unsigned long long)n, argv[i]);
 		}
 		load_done();
+		// (while reads are kept, the device's share of the LAST load call still runs on the library's thread and its
+		// failure would come back from whichever call is next: this one waits for it and is checked)
+		{ uint64_t m = 0; check(abg_filter_size(ctx, &m), ctx, "load"); }
 	} else {
 		if (prebuilt.size() != counters) { fprintf(stderr, PROGRAM ": Bloom file size does not match its header\n"); exit(EXIT_FAILURE); }
 		check(abg_counters_import(ctx, prebuilt.data()), ctx, "import");
 	}
 	if (verbose) {
 		uint64_t pop = 0, filt = 0;
-		abg_counting_stats(ctx, &pop, &filt);
+		check(abg_counting_stats(ctx, &pop, &filt), ctx, "counting filter statistics");
 		fprintf(stderr, "Bloom filter FPR: %.3g%%\n", 100.0 * pow((double)pop / (double)counters, p.num_hashes));
 		fprintf(stderr, "Counting Bloom filter stats:\n\t#counters               = %llu\n\t#size (B)               = %llu\n"
 		    "\tthreshold               = %u\n\tpopcount                = %llu\n\tFPR                     = %.3g%%\n",
@@ -767,8 +770,9 @@ int main(int argc, char** argv)
 		const double ta = host_now();
 		const int rc = abg_assemble_kept(ctx, results.data(), on_contig, &o);
 		g_in_asm += host_now() - ta;
-		if (rc == ABG_ENOMEM) {
-			// (the device had no room to keep them after all: the input is read again, as the reference reads it)
+		if (rc == ABG_EAGAIN) {
+			// (the device had no room to keep them after all -- said before PASS 2 touched anything: the input is
+			// read again, as the reference reads it; every other failure, ABG_ENOMEM inside PASS 2 included, is final)
 			if (verbose) fprintf(stderr, "%s; reading the input again\n", abg_last_error(ctx));
 			o.chunks = NULL; kept.clear(); keep = false; first_asm = optind;
 		} else {

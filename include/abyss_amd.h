@@ -16,7 +16,8 @@
  * (Common/IOUtil.h:14-22); the host binary maps non-zero codes to that behaviour.
  * The library itself never exits or aborts: whatever fails inside it -- a device allocation, a
  * capacity the data exceeds, a collective, an internal invariant -- comes back as ABG_ENOMEM /
- * ABG_EINTERNAL.  After one of those two a context is only good for abg_destroy().
+ * ABG_EINTERNAL.  After one of those two a context is only good for abg_destroy() (the one exception is
+ * spelt out at abg_keep_reads: a store of kept reads that cannot grow is dropped without failing anything).
  * (Environment, for tests: ABG_MEM_LIMIT_MB gives every context created afterwards a device
  * memory budget; a request beyond it fails like a hipMalloc that found no room.)
  *
@@ -38,6 +39,7 @@ extern "C" {
 #define ABG_ENODEV (-2)   /* no usable HIP device */
 #define ABG_ENOMEM (-3)   /* device or host allocation failed */
 #define ABG_EINTERNAL (-4)
+#define ABG_EAGAIN (-5)   /* abg_assemble_kept: the store of kept reads was dropped; nothing was assembled, the context is intact */
 
 #define ABG_MAX_KMER 192  /* configure.ac:151 (MAX_KMER) */
 #define ABG_MAX_HASHES 32 /* configure.ac:156 (MAX_HASHES) */
@@ -144,8 +146,10 @@ int abg_load_seqs_v(abg_ctx* ctx, uint32_t nchunks, const char* const* seqs, con
  * packing and uploading them a second time.  results (may be NULL) holds one byte per read loaded since
  * abg_keep_reads, abg_contig.read_index counts through them.  expected_bases (0: unknown) sizes the
  * store.  abg_keep_reads fails with ABG_ENOMEM when the reads would take more than an eighth of the
- * device's memory; if the store cannot grow later, loading goes on without it and abg_assemble_kept
- * returns ABG_ENOMEM (the caller reads its input again, as the reference does).  abg_assemble_kept and
+ * device's memory (the context stays usable: nothing is kept, that is all); if the store cannot grow later,
+ * loading goes on without it -- PASS 1 is complete and correct -- and abg_assemble_kept returns ABG_EAGAIN
+ * before touching anything: the caller reads its input again, as the reference does.  Any OTHER failure of
+ * abg_assemble_kept (ABG_ENOMEM inside PASS 2 included) is final as everywhere else.  abg_assemble_kept and
  * abg_keep_reads(ctx, 0, 0) release the store.
  * While reads are kept, a load call returns once its sequences are packed (the buffers may then be
  * reused); the upload and the ordered insert run beside the caller's work on the next chunk, one call's

@@ -173,7 +173,7 @@ def test_cli_checkpoints_match_reference_binary(tmp_path):
 
 
 def test_cli_reads_its_input_again_when_the_device_cannot_keep_the_reads(tmp_path):
-    """abg_assemble_kept -> ABG_ENOMEM (forced: ABG_KEEP_FAIL): the binary falls back to the reference's
+    """abg_assemble_kept -> ABG_EAGAIN (forced: ABG_KEEP_FAIL): the binary falls back to the reference's
     second pass over the files and writes the same FASTA and read log."""
     m1, m2 = synth.make_read_set(150000, 30.0)
     synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)

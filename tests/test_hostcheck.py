@@ -749,7 +749,7 @@ def test_reads_kept_on_the_device_between_the_passes_assemble_like_the_read_stre
 
 
 def test_kept_reads_dropped_for_lack_of_room_leave_pass1_intact(monkeypatch):
-    """The store cannot grow (ABG_KEEP_FAIL): loading goes on without it, abg_assemble_kept says ABG_ENOMEM,
+    """The store cannot grow (ABG_KEEP_FAIL): loading goes on without it, abg_assemble_kept says ABG_EAGAIN,
     and the caller assembles from its own buffers as if nothing had been kept."""
     k = 35
     m1, m2 = synth.make_read_set(9000, 25.0, err=0.004, genome_seed=k, read_seed=k + 5)
@@ -766,7 +766,7 @@ def test_kept_reads_dropped_for_lack_of_room_leave_pass1_intact(monkeypatch):
     hc.load_chunks(chunks[1:])   # would have to grow it: dropped
     assert np.array_equal(o.counters(), hc.counters())
     rc, _, _ = hc.assemble_kept(len(reads))
-    assert rc == _lib.ABG_ENOMEM
+    assert rc == _lib.ABG_EAGAIN
     rh, ch = hc.assemble_chunks(chunks)
     assert np.array_equal(ro, rh) and [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
     assert o.assembly_counters() == hc.assembly_counters()
