@@ -50,6 +50,7 @@ struct Config {
 	uint64_t compact_threshold = 1u << 20; // rounds with at least this many ops flag their losers and compact them (FInsertRound)
 	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
+	bool benign_sharers = true;       // ... and k-mers that share a counter they cannot write are settled by the tiles as well (op_verdict)
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
 	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
@@ -550,16 +551,19 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
 constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
 struct TilePair { uint64_t h; uint32_t t; uint32_t off; };          // (off: offset within the tile | hash index << 16)
+constexpr uint32_t LEAD_BIT = 0x80000000u;                          // TileEnv::lead: this op is the earliest of its k-mer's ops in the batch
 struct TileEnv {
 	Params p; uint8_t* cnt;
 	uint64_t lo, m;                   // the counters [lo, m) are tiled (a rank's own range; the whole filter: 0, m)
 	const uint64_t* h0;
 	TilePair* bins; uint32_t cap;     // [ntiles][cap]
 	uint32_t* tcur;                   // [ntiles] pairs in each bin
-	uint32_t* lead;                   // [T] ops of the k-mer this op leads (0: not a leader / not settled here)
-	uint8_t* opflag;                  // [T] 1: the op's k-mer shares a counter with another k-mer
+	uint32_t* lead;                   // [T] ops n of this op's k-mer in the batch, from any counter only that k-mer touches (0: none known); | LEAD_BIT on the earliest of them
+	uint8_t* opflag;                  // [T] bit j: counter j of the op's k-mer is shared with another k-mer of the batch (0xFF: some counter is, nh > 8)
 	uint8_t* tgt;                     // [T] leaders: the value their counters are raised to (0: nothing to do)
+	uint8_t* pendf;                   // [T] 1: the op goes through the reservation rounds (FOpTarget / FDistTarget)
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
+	uint32_t benign = 1;              // op_verdict: k-mers that cannot write their shared counters are settled by the tiles too
 };
 // canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
 // rolled (NTC64, nthash.hpp:242-257,275-279).  Under a spaced seed the rolled state is the UNMASKED
@@ -694,9 +698,9 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 				const uint32_t slot = atomic_add_u32(&cur[cb], 1);
 				if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
 				TilePair& r = b.coarse[(uint64_t)cb * b.ccap + slot];
-				// (off: offset within the tile | tile within the coarse bin << 16)
+				// (off: offset within the tile | tile within the coarse bin << 16 (cshift <= 12 bits) | hash index << 28)
 				r.h = h; r.t = (uint32_t)t;
-				r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | ((uint32_t)((pos >> TILE_BITS) & ((1u << b.cshift) - 1)) << 16);
+				r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | ((uint32_t)((pos >> TILE_BITS) & ((1u << b.cshift) - 1)) << 16) | ((uint32_t)j << 28);
 			}
 		}
 	}
@@ -718,17 +722,17 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 		const TilePair* src = b.coarse + (uint64_t)cb * b.ccap;
 		for (uint32_t i = tid; i < nfine; i += nt) hist[i] = 0;
 		sy.barrier();
-		for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[src[i].off >> 16], 1);
+		for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[(src[i].off >> 16) & (nfine - 1)], 1);
 		sy.barrier();
 		const uint64_t tile0 = (uint64_t)cb << b.cshift;
 		for (uint32_t i = tid; i < nfine; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.e.tcur[tile0 + i], hist[i]) : 0;
 		sy.barrier();
 		for (uint32_t i = i0 + tid; i < i1; i += nt) {
 			TilePair r = src[i];
-			const uint32_t f = r.off >> 16;
+			const uint32_t f = (r.off >> 16) & (nfine - 1);
 			const uint32_t slot = atomic_add_u32(&cur[f], 1);
 			if (slot >= b.e.cap) { b.e.flags[0] = 1; continue; }
-			r.off &= 0xFFFFu;
+			r.off = (r.off & 0xFFFFu) | ((r.off >> 28) << 16); // (offset within the tile | hash index << 16)
 			b.e.bins[(tile0 + f) * b.e.cap + slot] = r;
 		}
 	}
@@ -800,31 +804,62 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		const uint32_t inf = info[s];
 		// (a counter with 254 pairs or more is treated like a shared one: the partitioned run passes
 		// the leaders' op counts between the ranks in a byte)
-		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= 254) { e.opflag[r.t] = 1; return; }
-		if ((uint32_t)(first[s] & 0xFFFu) != i) return;
-		// the earliest op of the counter's one k-mer leads its ops: the counter holds one pair per op and
-		// per hash function of the k-mer that lands here
+		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= 254) {
+			// shared: bit j of the op's flag byte (several tiles may flag one op at once: a word-wide OR)
+			const uint32_t j = (r.off >> 16) & 0xFu;
+			const uint32_t bit = e.p.nh <= 8 ? (1u << j) : 0xFFu;
+			atomic_or_u32((uint32_t*)e.opflag + (r.t >> 2), bit << (8 * (r.t & 3u)));
+			return;
+		}
+		// only this k-mer's ops touch the counter: it holds one pair per op and per hash function of the
+		// k-mer that lands here, so every op of the k-mer learns how many they are; the earliest leads them
 		uint32_t d = 0;
 		const uint64_t pos = e.lo + ((tile << TILE_BITS) | (r.off & 0xFFFFu));
 		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, r.h, q) == pos;
-		e.lead[r.t] = (inf & 0x7FFFFFFFu) / (d ? d : 1);
+		const uint32_t n = (inf & 0x7FFFFFFFu) / (d ? d : 1);
+		const bool first_op = (uint32_t)(first[s] >> 12) == r.t; // (the earliest op of the counter; its two pairs say the same)
+		e.lead[r.t] = n | (first_op ? LEAD_BIT : 0u);
 	});
 }
-struct FOpTarget { // one op per item: leaders of k-mers with pure counters only compute their target
+// What becomes of an op once every tile has judged its pairs.  n = the ops of its k-mer K in the batch.
+//  * No counter of K is shared: the n ops commute with everything else in the batch; the leader raises
+//    the counters to min(m + n, 255) (see above), the others are done.
+//  * Some are shared (set S; P = the rest, not empty): K's ops write a shared counter only if it equals
+//    K's running minimum at one of them.  Counters only grow, and K's minimum over P runs m_P, m_P + 1,
+//    ..., below tg = min(m_P + n, 255).  So if every counter of S holds at least tg NOW, no op of K ever
+//    finds one of them at its minimum (or the minimum is 255 and nothing is written at all): K's ops
+//    raise P exactly as if S were not there, read nothing anybody else writes in this batch and write
+//    nothing anybody else reads -- they commute with the rest like the ops of a k-mer with pure counters
+//    only.  (The typical case: a sequencing-error k-mer at count 1 landing on a counter a genome k-mer
+//    has taken to 30.)  The other k-mers on S still see S as shared and go to the rounds.
+//  * Anything else -- and every op when a bin overflowed -- goes through the reservation rounds.
+// Every op of K reads the same flags, the same n and the same counters (nothing writes them between
+// the previous batch's rounds and tile_apply), so all of K's ops get the same verdict.
+ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend)
+{
+	tgt = 0; pend = 1;
+	if (e.flags[0]) return;
+	const uint32_t fl = e.opflag[t], L = e.lead[t], n = L & ~LEAD_BIT;
+	if (fl && (!n || e.p.nh > 8 || !e.benign)) return;
+	if (!fl && !(L & LEAD_BIT)) { pend = 0; return; } // (its k-mer's leader does the raising)
+	const uint64_t h = e.h0[t];
+	unsigned mp = 256, ms = 256;
+	for (unsigned j = 0; j < e.p.nh; j++) {
+		const unsigned c = e.cnt[pos_i(e.p, h, j)];
+		if ((fl >> j) & 1u) ms = c < ms ? c : ms; else mp = c < mp ? c : mp;
+	}
+	const unsigned tg = mp + n > 255 ? 255u : mp + n;
+	if (fl && ms < tg) return;
+	pend = 0;
+	if ((L & LEAD_BIT) && mp < 255) tgt = (uint8_t)tg;
+}
+struct FOpTarget { // one op per item: its target (leaders) and whether it is left to the reservation rounds
 	TileEnv e;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
-		// (ops of k-mers that share a counter go to the reservation rounds: the caller compacts opflag)
-		if (e.opflag[t] || e.flags[0]) { e.tgt[t] = 0; return; }
-		const uint32_t n = e.lead[t];
-		uint8_t tg = 0;
-		if (n) {
-			const uint64_t h = e.h0[t];
-			unsigned mn = 255;
-			for (unsigned j = 0; j < e.p.nh; j++) { unsigned c = e.cnt[pos_i(e.p, h, j)]; mn = c < mn ? c : mn; }
-			if (mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
-		}
-		e.tgt[t] = tg;
+		uint8_t tg, pd;
+		op_verdict(e, t, tg, pd);
+		e.tgt[t] = tg; e.pendf[t] = pd;
 	}
 };
 // `lds`: TILE_COUNTERS bytes
@@ -880,7 +915,7 @@ struct FDistPack {
 	TileEnv e; uint64_t T; uint8_t* buf;
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
-		const uint32_t n = e.lead[t];
+		const uint32_t n = (e.lead[t] & LEAD_BIT) ? (e.lead[t] & ~LEAD_BIT) : 0u; // (what the op LEADS)
 		buf[t] = (uint8_t)(e.opflag[t] ? 255u : n);
 		uint8_t v = 0;
 		if (n) {
@@ -905,7 +940,7 @@ struct FDistTarget { // FOpTarget from the combined bytes
 		if (t == 0 && buf[2 * T]) e.flags[0] = 1;
 		const bool flag = buf[t] == 255;
 		const unsigned n = buf[t], mn = 255u - buf[T + t];
-		e.opflag[t] = flag ? 1 : 0;
+		e.pendf[t] = flag ? 1 : 0;
 		uint8_t tg = 0;
 		if (!flag && !buf[2 * T] && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
 		e.tgt[t] = tg;
@@ -2391,7 +2426,7 @@ class Engine {
 		uint32_t* flag = pend_n_ + 2 + stage_flag_;
 		uint64_t* h0 = h0_alt_;
 		const bool part = dist();
-		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, flag };
+		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u };
 		const uint64_t R = part ? (uint64_t)comm_.world : 1, me = part ? (uint64_t)comm_.rank : 0;
 		if (part && R > cfg_.dist_hash_all_ranks) {
 			// partitioned run: this rank's slice of the hashes on the side stream, the all-gather on the main
@@ -2660,7 +2695,7 @@ class Engine {
 	uint32_t claim_log2_ = 0;  // slots per claim table
 	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
 	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
-	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr;
+	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr; uint8_t* pendf_ = nullptr;
 	// a second set of hashes, bins and bin cursors: the batch being staged on the side stream (stage_bins)
 	uint64_t* h0_alt_ = nullptr; TilePair* bins_alt_ = nullptr; uint32_t* tcur_alt_ = nullptr;
 	// PASS 2 resources
@@ -2803,8 +2838,9 @@ class Engine {
 				}
 			}
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
-			opflag_ = (uint8_t*)be_.alloc(nb);
+			opflag_ = (uint8_t*)be_.alloc(nb + 8); // (flagged with word-wide ORs)
 			tgt_ = (uint8_t*)be_.alloc(nb);
+			pendf_ = (uint8_t*)be_.alloc(nb);
 			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
 		}
 		h0_ = (uint64_t*)be_.alloc((nb + 8 * R + 8) * 8);
@@ -2834,12 +2870,12 @@ class Engine {
 		if (dist()) dres_ = (uint8_t*)be_.alloc(std::max<uint64_t>(nb, (uint64_t)cfg_.drain_threshold * 32));
 		dlost_ = (uint8_t*)be_.alloc(nb);
 		insert_scratch_bytes_ = nb * (8 + 4 + 4 + 1) + (16ull << claim_log2_);
-		if (tiled_) insert_scratch_bytes_ += ((uint64_t)ncoarse_ * coarse_cap_ + ntiles_ * tile_cap_ * (bins_alt_ ? 2 : 1)) * sizeof(TilePair) + nb * (bins_alt_ ? 14 : 6);
+		if (tiled_) insert_scratch_bytes_ += ((uint64_t)ncoarse_ * coarse_cap_ + ntiles_ * tile_cap_ * (bins_alt_ ? 2 : 1)) * sizeof(TilePair) + nb * (bins_alt_ ? 15 : 7);
 	}
 	void free_insert()
 	{
 		if (!h0_) return;
-		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); tiled_ = false; }
+		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); be_.free(pendf_); tiled_ = false; }
 		if (tred_) { be_.free(tred_); tred_ = nullptr; }
 		if (bins_alt_) { be_.free(bins_alt_); be_.free(tcur_alt_); be_.free(h0_alt_); bins_alt_ = nullptr; tcur_alt_ = nullptr; h0_alt_ = nullptr; }
 		if (dres_) { be_.free(dres_); dres_ = nullptr; }
@@ -2889,9 +2925,9 @@ class Engine {
 			// the k-mers that share no counter with another k-mer of the batch are settled tile by
 			// tile; what is left goes through the reservation rounds below
 			if (!staged) flag_word = 1;
-			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + flag_word };
+			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u };
 			be_.memset(lead_, 0, T * 4);
-			be_.memset(opflag_, 0, T);
+			be_.memset(opflag_, 0, (T + 3) & ~3ull);
 			be_.memset(pend_n_, 0, 8);
 			if (!staged) {
 				be_.memset(tcur_, 0, ntiles_ * 4);
@@ -2908,7 +2944,7 @@ class Engine {
 			{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
 			{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
-			be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
+			be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
 			// the next batch's hashing and binning starts here, beside the rounds (queued before tile_apply it
 			// slows that down by as much as it gains: 453-463 vs 446-452 ms per configs[1] step)
 			if (stage_next_) { stage_next_(); stage_next_ = nullptr; }
@@ -2974,9 +3010,9 @@ class Engine {
 	{
 		cnt_partial_ = true;
 		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pend_n_ + flag_word };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u };
 		be_.memset(lead_, 0, T * 4);
-		be_.memset(opflag_, 0, T);
+		be_.memset(opflag_, 0, (T + 3) & ~3ull);
 		be_.memset(pend_n_, 0, 8);
 		if (staged) {
 			// (hashes gathered and the own range's pairs binned while the batch before went through its rounds: stage_bins)
@@ -3009,7 +3045,7 @@ class Engine {
 		c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
 		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
 		{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
-		be_.compact_flagged(nullptr, opflag_, T, pend_[1], pend_n_);
+		be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_);
 		if (stage_next_) { stage_next_(); stage_next_ = nullptr; } // (the next batch, beside this one's rounds)
 		uint32_t nn[4] = { 0, 0, 0, 0 };
 		be_.d2h(nn, pend_n_, 16);

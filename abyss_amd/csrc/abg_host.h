@@ -93,6 +93,7 @@ class Session {
 		if (const char* e = getenv("ABG_PAR_COMMIT_MAX_GB")) cfg.par_commit_max_bytes = strtoull(e, 0, 10) << 30; // e.g. 160 for B=40G on a 288 GB GPU
 		if (const char* e = getenv("ABG_COMPACT_THRESHOLD")) cfg.compact_threshold = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
+		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
