@@ -77,7 +77,7 @@ struct Config {
 	bool memo = true;
 	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
-	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide)
+	uint32_t guide_stride = 8;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide): at 50x a genome k-mer still gets ~6 hints; 4 -> 8: guide_build 27 -> 14 ms, the walkers +3 (16: +60)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
@@ -550,7 +550,14 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // touches, and keep their order among themselves in the reservation rounds.
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
 constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
-struct TilePair { uint64_t h; uint32_t t; uint32_t off; };          // (off: offset within the tile | hash index << 16)
+// An (op, counter) pair as the bins hold it: the op's canonical hash and "op id | hash function << 28" -- 12 bytes.
+// The counter is not stored: it is pos_i(h, j), some twenty integer instructions wherever a pair is looked at,
+// against four bytes written twice and read three times per pair and batch (the bins are what PASS 1 moves most of).
+struct TilePair { uint32_t hlo, hhi, tj; };
+constexpr uint32_t TP_T_BITS = 28, TP_T_MASK = (1u << TP_T_BITS) - 1; // (a batch holds at most 2^28 ops, a k-mer at most 16 hash functions)
+ABG_HD uint64_t tp_h(const TilePair& r) { return ((uint64_t)r.hhi << 32) | r.hlo; }
+ABG_HD uint32_t tp_t(const TilePair& r) { return r.tj & TP_T_MASK; }
+ABG_HD uint32_t tp_j(const TilePair& r) { return r.tj >> TP_T_BITS; }
 constexpr uint32_t LEAD_BIT = 0x80000000u;                          // TileEnv::lead: this op is the earliest of its k-mer's ops in the batch
 struct TileEnv {
 	Params p; uint8_t* cnt;
@@ -662,7 +669,7 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 // pairs per COARSE bin (a run of 2^cshift tiles) in LDS, reserves room in every coarse bin with one
 // global atomic, and writes the pairs there in runs.  Pass 2: a workgroup takes BIN_CHUNK_PAIRS
 // pairs of one coarse bin and does the same over that bin's tiles.
-constexpr uint32_t BIN_CHUNK_OPS = 2048, BIN_CHUNK_PAIRS = 8192, BIN_MAX_COARSE = 2048, BIN_MAX_FINE = 4096;
+constexpr uint32_t BIN_CHUNK_OPS = 2048, BIN_CHUNK_PAIRS = 4096, BIN_MAX_COARSE = 2048, BIN_MAX_FINE = 4096;
 struct BinEnv {
 	TileEnv e; uint64_t T;
 	TilePair* coarse; uint32_t ccap; uint32_t* ccur; // [ncoarse][ccap], [ncoarse]
@@ -698,15 +705,13 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 				const uint32_t slot = atomic_add_u32(&cur[cb], 1);
 				if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
 				TilePair& r = b.coarse[(uint64_t)cb * b.ccap + slot];
-				// (off: offset within the tile | tile within the coarse bin << 16 (cshift <= 12 bits) | hash index << 28)
-				r.h = h; r.t = (uint32_t)t;
-				r.off = (uint32_t)(pos & (TILE_COUNTERS - 1)) | ((uint32_t)((pos >> TILE_BITS) & ((1u << b.cshift) - 1)) << 16) | ((uint32_t)j << 28);
+				r.hlo = (uint32_t)h; r.hhi = (uint32_t)(h >> 32); r.tj = (uint32_t)t | ((uint32_t)j << TP_T_BITS);
 			}
 		}
 	}
 };
 struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin + q); fast memory: 2 x 2^cshift words
-	static constexpr uint32_t FAST = 2 * BIN_MAX_FINE * 4, THREADS = 256;
+	static constexpr uint32_t FAST = 2 * BIN_MAX_FINE * 4, THREADS = 512, PER = BIN_CHUNK_PAIRS / THREADS;
 	BinEnv b; uint32_t chunks_per_bin;
 	template <class Sync> ABG_HDN void operator()(uint64_t item, void* fast, Sync& sy) const
 	{
@@ -720,20 +725,42 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + nfine;
 		const uint32_t tid = sy.tid(), nt = sy.nthreads();
 		const TilePair* src = b.coarse + (uint64_t)cb * b.ccap;
+		// the tile (within the coarse bin) a pair belongs to
+		auto fine_of = [&](const TilePair& r) -> uint32_t {
+			return (uint32_t)((pos_i(b.e.p, tp_h(r), tp_j(r)) - b.e.lo) >> TILE_BITS) & (nfine - 1);
+		};
 		for (uint32_t i = tid; i < nfine; i += nt) hist[i] = 0;
 		sy.barrier();
-		for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[(src[i].off >> 16) & (nfine - 1)], 1);
+		// a thread keeps its pairs (and their tiles) in registers between the count and the scatter: the coarse bin is
+		// read once; a serial caller (one thread) reads it twice instead
+		const bool keep = nt >= THREADS;
+		TilePair mine[PER]; uint32_t fine[PER];
+		if (keep) {
+#pragma unroll
+			for (uint32_t u = 0; u < PER; u++) {
+				const uint32_t i = i0 + tid + u * nt;
+				if (i < i1) { mine[u] = src[i]; fine[u] = fine_of(mine[u]); atomic_add_u32(&hist[fine[u]], 1); }
+			}
+		} else {
+			for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[fine_of(src[i])], 1);
+		}
 		sy.barrier();
 		const uint64_t tile0 = (uint64_t)cb << b.cshift;
 		for (uint32_t i = tid; i < nfine; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.e.tcur[tile0 + i], hist[i]) : 0;
 		sy.barrier();
-		for (uint32_t i = i0 + tid; i < i1; i += nt) {
-			TilePair r = src[i];
-			const uint32_t f = (r.off >> 16) & (nfine - 1);
+		auto put = [&](const TilePair& r, uint32_t f) {
 			const uint32_t slot = atomic_add_u32(&cur[f], 1);
-			if (slot >= b.e.cap) { b.e.flags[0] = 1; continue; }
-			r.off = (r.off & 0xFFFFu) | ((r.off >> 28) << 16); // (offset within the tile | hash index << 16)
+			if (slot >= b.e.cap) { b.e.flags[0] = 1; return; }
 			b.e.bins[(tile0 + f) * b.e.cap + slot] = r;
+		};
+		if (keep) {
+#pragma unroll
+			for (uint32_t u = 0; u < PER; u++) {
+				const uint32_t i = i0 + tid + u * nt;
+				if (i < i1) put(mine[u], fine[u]);
+			}
+		} else {
+			for (uint32_t i = i0 + tid; i < i1; i += nt) put(src[i], fine_of(src[i]));
 		}
 	}
 };
@@ -764,61 +791,62 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	// a serial caller (one thread, all pairs) looks everything up again instead
 	const bool keep = nt >= TILE_PURITY_THREADS;
 	TilePair mine[TILE_PURITY_PER];
-	uint32_t slot[TILE_PURITY_PER];
+	uint32_t slot[TILE_PURITY_PER]; // (table slot | offset within the tile << 16)
+	auto off_of = [&](const TilePair& r) -> uint32_t { return (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1); };
 	auto slot_of = [&](uint32_t off) -> uint32_t {
 		uint32_t s = ((off * 0x9E3779B1u) >> 20) & (TILE_TAB - 1);
 		for (;;) {
 			const uint32_t cur = cas_u32(&key[s], PUR_EMPTY, off);
-			if (cur == PUR_EMPTY || cur == off) return s;
+			if (cur == PUR_EMPTY || cur == off) return s | (off << 16);
 			s = (s + 1) & (TILE_TAB - 1);
 		}
 	};
-	auto pairs = [&](auto&& body) { // body(pair, index in the bin, its slot)
+	auto pairs = [&](auto&& body) { // body(pair, index in the bin, its slot, its offset)
 		if (keep) {
 #pragma unroll
 			for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
 				const uint32_t i = tid + q * nt;
-				if (i < n) body(mine[q], i, slot[q]);
+				if (i < n) body(mine[q], i, slot[q] & 0xFFFFu, slot[q] >> 16);
 			}
 		} else {
-			for (uint32_t i = tid; i < n; i += nt) body(bin[i], i, slot_of(bin[i].off & 0xFFFFu));
+			for (uint32_t i = tid; i < n; i += nt) { const uint32_t so = slot_of(off_of(bin[i])); body(bin[i], i, so & 0xFFFFu, so >> 16); }
 		}
 	};
 	if (keep) {
 #pragma unroll
 		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
 			const uint32_t i = tid + q * nt;
-			if (i < n) { mine[q] = bin[i]; slot[q] = slot_of(mine[q].off & 0xFFFFu); }
+			if (i < n) { mine[q] = bin[i]; slot[q] = slot_of(off_of(mine[q])); }
 		}
 	}
-	pairs([&](const TilePair& r, uint32_t i, uint32_t s) {
-		atomic_min_u64(&first[s], ((uint64_t)r.t << 12) | i);
+	pairs([&](const TilePair& r, uint32_t i, uint32_t s, uint32_t) {
+		atomic_min_u64(&first[s], ((uint64_t)tp_t(r) << 12) | i);
 		atomic_add_u32(&info[s], 1);
 	});
 	sy.barrier();
-	pairs([&](const TilePair& r, uint32_t, uint32_t s) {
-		if (r.h != bin[(uint32_t)(first[s] & 0xFFFu)].h) atomic_or_u32(&info[s], 0x80000000u);
+	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
+		const TilePair& f = bin[(uint32_t)(first[s] & 0xFFFu)];
+		if (r.hlo != f.hlo || r.hhi != f.hhi) atomic_or_u32(&info[s], 0x80000000u);
 	});
 	sy.barrier();
-	pairs([&](const TilePair& r, uint32_t i, uint32_t s) {
-		const uint32_t inf = info[s];
+	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t off) {
+		const uint32_t inf = info[s], t = tp_t(r);
 		// (a counter with 254 pairs or more is treated like a shared one: the partitioned run passes
 		// the leaders' op counts between the ranks in a byte)
 		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= 254) {
 			// shared: bit j of the op's flag byte (several tiles may flag one op at once: a word-wide OR)
-			const uint32_t j = (r.off >> 16) & 0xFu;
-			const uint32_t bit = e.p.nh <= 8 ? (1u << j) : 0xFFu;
-			atomic_or_u32((uint32_t*)e.opflag + (r.t >> 2), bit << (8 * (r.t & 3u)));
+			const uint32_t bit = e.p.nh <= 8 ? (1u << tp_j(r)) : 0xFFu;
+			atomic_or_u32((uint32_t*)e.opflag + (t >> 2), bit << (8 * (t & 3u)));
 			return;
 		}
 		// only this k-mer's ops touch the counter: it holds one pair per op and per hash function of the
 		// k-mer that lands here, so every op of the k-mer learns how many they are; the earliest leads them
 		uint32_t d = 0;
-		const uint64_t pos = e.lo + ((tile << TILE_BITS) | (r.off & 0xFFFFu));
-		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, r.h, q) == pos;
-		const uint32_t n = (inf & 0x7FFFFFFFu) / (d ? d : 1);
-		const bool first_op = (uint32_t)(first[s] >> 12) == r.t; // (the earliest op of the counter; its two pairs say the same)
-		e.lead[r.t] = n | (first_op ? LEAD_BIT : 0u);
+		const uint64_t pos = e.lo + ((tile << TILE_BITS) | off);
+		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, tp_h(r), q) == pos;
+		const uint32_t cnt_k = (inf & 0x7FFFFFFFu) / (d ? d : 1);
+		const bool first_op = (uint32_t)(first[s] >> 12) == t; // (the earliest op of the counter; its two pairs say the same)
+		e.lead[t] = cnt_k | (first_op ? LEAD_BIT : 0u);
 	});
 }
 // What becomes of an op once every tile has judged its pairs.  n = the ops of its k-mer K in the batch.
@@ -879,12 +907,12 @@ ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 	sy.barrier();
 	bool any = false;
 	for (uint32_t i = tid; i < n; i += nt) {
-		const TilePair& r = bin[i];
-		const uint8_t tg = e.tgt[r.t];
+		const TilePair r = bin[i];
+		const uint8_t tg = e.tgt[tp_t(r)];
 		if (!tg) continue;
 		// (a pure counter has one writer -- its k-mer's leader, possibly through two hash functions
 		// with the same value -- so plain byte stores do)
-		const uint32_t off = r.off & 0xFFFFu;
+		const uint32_t off = (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1);
 		if (lds[off] < tg) { lds[off] = tg; any = true; }
 	}
 	if (sy.any(any)) {
@@ -1272,8 +1300,9 @@ struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave 
 	}
 };
 template <int NW>
-struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum minCount
+struct FContigPrep { // per contig record: k-mer hashes for the commit and (with_cov) Sum minCount
 	Params p; const uint8_t* cnt; ContigRec* recs; uint32_t first; const uint8_t* pool; uint64_t* kh;
+	uint32_t with_cov; // 0: the parallel commit sums the coverage of the contigs it inserts (FPcApply) -- most records are redundant copies
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
 		ContigRec& rec = recs[first + i];
@@ -1283,7 +1312,7 @@ struct FContigPrep { // per contig record: k-mer hashes for the commit and Sum m
 		uint32_t cov = 0; // getSeqAbsoluteKmerCoverage (bloom-dbg.h:92-109): a pure function of the solid filter
 		for (uint32_t j0 = lane * PREP_RUN; j0 < cnk; j0 += nlanes * PREP_RUN)
 			kmer_hash_run(p, [&](unsigned q) { return (unsigned)seq[q]; }, j0, j0 + PREP_RUN < cnk ? j0 + PREP_RUN : cnk,
-			    [&](uint32_t j, uint64_t h) { out[j] = h; cov += solid_min_count(p, cnt, h); });
+			    [&](uint32_t j, uint64_t h) { out[j] = h; if (with_cov) cov += solid_min_count(p, cnt, h); });
 		if (cov) atomic_add_u32(&rec.coverage, cov);
 	}
 };
@@ -1720,6 +1749,7 @@ struct ParCommit {
 	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
 	ContigRec* recs; const uint8_t* pool; uint8_t* result;
 	const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff; const uint8_t* read_flag;
+	const uint8_t* cnt8;   // the counting filter (FPcApply: coverage of the inserted contigs)
 	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
 	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp;
 	                       // or NULL: the stamps live in the hash table below, keyed by bit position
@@ -2069,16 +2099,21 @@ struct FPcApply { // one wave per candidate before the break: results, visited b
 				if (lane == 0) rec.redundant = rec.ins ? 0 : 1;
 				if (!rec.ins) continue;
 				nins++; bases += rec.len;
-				// addKmersToBloom (bloom-dbg.h:79-90)
+				// addKmersToBloom (bloom-dbg.h:79-90), and getSeqAbsoluteKmerCoverage (bloom-dbg.h:92-109) of what is output
 				const uint64_t* ch = e.kh + rec.seq_off;
 				const uint32_t cnk = rec.len - e.p.k + 1;
+				uint32_t cov = 0;
 				for (uint32_t j = lane; j < cnk; j += nlanes) {
 					uint64_t h = ch[j];
+					unsigned mn = 255;
 					for (unsigned q = 0; q < e.p.nh; q++) {
 						uint64_t pos = pos_i(e.p, h, q);
 						atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
+						if (e.cnt8) { const unsigned c = e.cnt8[pos]; mn = c < mn ? c : mn; }
 					}
+					if (e.cnt8) cov += mn;
 				}
+				if (cov) atomic_add_u32(&rec.coverage, cov);
 			}
 		}
 		if (lane == 0) { e.cnt[i] = nrec; e.cnt2[i] = nins; e.cnt3[i] = bases; }
@@ -2804,6 +2839,7 @@ class Engine {
 		if (cfg_.tiled_insert && !casc_.bits && p_.nh <= 16) {
 			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114));
 			T = std::min<uint64_t>(T, 2048ull * ntiles_ * R / p_.nh);
+			T = std::min<uint64_t>(T, 1ull << TP_T_BITS); // (a pair holds its op in 28 bits)
 			if (T >= 1024) {
 				tiled_ = true;
 				batch_ops_ = T;
@@ -3278,7 +3314,7 @@ class Engine {
 		e.own_lo = part ? own_lo_ : 0; e.own_span = part ? own_span_ : ~0ULL; e.part_c = part_c; e.part_r = part_r;
 		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
-		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_;
+		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_; e.cnt8 = cnt_;
 		e.Tk = nullptr; e.Tv = nullptr; e.Tmask = 0;
 		if (t_hashed()) {
 			// the bits this commit can stamp: (k-mers of the contigs in the pool) x H
@@ -3490,7 +3526,7 @@ class Engine {
 		be_.d2h(&nrec, rec_used_, 4);
 		nrec = std::min(nrec, rec_cap_);
 		if (nrec > prepped) {
-			FContigPrep<NW> f{ p_, cnt_, recs_, prepped, pool_, kh_ };
+			FContigPrep<NW> f{ p_, cnt_, recs_, prepped, pool_, kh_, use_par_commit() ? 0u : 1u };
 			be_.launch_wave(nrec - prepped, f, "contig_prep");
 			prepped = nrec;
 		}
@@ -3503,7 +3539,7 @@ class Engine {
 		be_.d2h(&lr, rec_used_, 4);
 		lr = std::min(lr, rec_cap_);
 		if (lr > g_rec_) {
-			FContigPrep<NW> f{ p_, cnt_, recs_, g_rec_, pool_, kh_ };
+			FContigPrep<NW> f{ p_, cnt_, recs_, g_rec_, pool_, kh_, use_par_commit() ? 0u : 1u };
 			be_.launch_wave(lr - g_rec_, f, "contig_prep");
 		}
 	}
