@@ -82,6 +82,7 @@ struct Config {
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
+	uint32_t dist_route_min_ranks = 4;     // ... from this many ranks on, the (op, counter) pairs are routed to their owners (Engine::insert_tiles_routed); 0: never
 	uint64_t keep_insert_scratch_bytes = 16ull << 30; // PASS 1's scratch is given back before PASS 2 when larger than this
 	uint64_t par_commit_max_bytes = 16ull << 30; // ... unless that would take more than this: then a stamp per bit the commit touches (hashed)
 	int verbose = 0;
@@ -548,6 +549,7 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // counter below that to it -- one update raises the counters equal to the minimum by one and
 // leaves the others, which are above it, alone.  All remaining ops touch counters no such k-mer
 // touches, and keep their order among themselves in the reservation rounds.
+constexpr int MAX_RANKS = 16;
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
 constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
 // An (op, counter) pair as the bins hold it: the op's canonical hash and "op id | hash function << 28" -- 12 bytes.
@@ -676,7 +678,7 @@ struct BinEnv {
 	uint32_t cshift, ncoarse;
 };
 struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoarse words
-	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 256;
+	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 256, PER = BIN_CHUNK_OPS / THREADS, MAXH = 4;
 	BinEnv b;
 	template <class Sync> ABG_HDN void operator()(uint64_t c, void* fast, Sync& sy) const
 	{
@@ -684,28 +686,57 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 		const uint32_t tid = sy.tid(), nt = sy.nthreads();
 		const uint64_t t0 = c * BIN_CHUNK_OPS, t1 = t0 + BIN_CHUNK_OPS < b.T ? t0 + BIN_CHUNK_OPS : b.T;
 		const uint64_t span = b.e.m - b.e.lo;
+		const unsigned nh = b.e.p.nh;
+		// the coarse bin of counter j of hash h, or ~0 when the counter is another rank's
+		auto coarse_of = [&](uint64_t h, unsigned j) -> uint32_t {
+			const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo; // (a counter outside [lo, m) is another rank's)
+			return pos < span ? (uint32_t)((pos >> TILE_BITS) >> b.cshift) : 0xFFFFFFFFu;
+		};
+		auto put = [&](uint64_t h, uint64_t t, unsigned j, uint32_t cb) {
+			const uint32_t slot = atomic_add_u32(&cur[cb], 1);
+			if (slot >= b.ccap) { b.e.flags[0] = 1; return; }
+			TilePair& r = b.coarse[(uint64_t)cb * b.ccap + slot];
+			r.hlo = (uint32_t)h; r.hhi = (uint32_t)(h >> 32); r.tj = (uint32_t)t | ((uint32_t)j << TP_T_BITS);
+		};
 		for (uint32_t i = tid; i < b.ncoarse; i += nt) hist[i] = 0;
 		sy.barrier();
-		for (uint64_t t = t0 + tid; t < t1; t += nt) {
-			const uint64_t h = b.e.h0[t];
-			for (unsigned j = 0; j < b.e.p.nh; j++) {
-				const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo; // (a counter outside [lo, m) is another rank's)
-				if (pos < span) atomic_add_u32(&hist[(pos >> TILE_BITS) >> b.cshift], 1);
+		// a thread keeps its ops' hashes and coarse bins in registers between the count and the scatter (up to MAXH hash
+		// functions: the positions are some twenty instructions each); a serial caller works them out twice instead
+		const bool keep = nt >= THREADS && nh <= MAXH;
+		uint64_t hh[PER]; uint32_t cbv[PER][MAXH];
+		if (keep) {
+#pragma unroll
+			for (uint32_t u = 0; u < PER; u++) {
+				const uint64_t t = t0 + tid + (uint64_t)u * nt;
+				if (t >= t1) continue;
+				hh[u] = b.e.h0[t];
+#pragma unroll
+				for (unsigned j = 0; j < MAXH; j++) {
+					cbv[u][j] = j < nh ? coarse_of(hh[u], j) : 0xFFFFFFFFu;
+					if (cbv[u][j] != 0xFFFFFFFFu) atomic_add_u32(&hist[cbv[u][j]], 1);
+				}
+			}
+		} else {
+			for (uint64_t t = t0 + tid; t < t1; t += nt) {
+				const uint64_t h = b.e.h0[t];
+				for (unsigned j = 0; j < nh; j++) { const uint32_t cb = coarse_of(h, j); if (cb != 0xFFFFFFFFu) atomic_add_u32(&hist[cb], 1); }
 			}
 		}
 		sy.barrier();
 		for (uint32_t i = tid; i < b.ncoarse; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.ccur[i], hist[i]) : 0;
 		sy.barrier();
-		for (uint64_t t = t0 + tid; t < t1; t += nt) {
-			const uint64_t h = b.e.h0[t];
-			for (unsigned j = 0; j < b.e.p.nh; j++) {
-				const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo;
-				if (pos >= span) continue;
-				const uint32_t cb = (uint32_t)((pos >> TILE_BITS) >> b.cshift);
-				const uint32_t slot = atomic_add_u32(&cur[cb], 1);
-				if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
-				TilePair& r = b.coarse[(uint64_t)cb * b.ccap + slot];
-				r.hlo = (uint32_t)h; r.hhi = (uint32_t)(h >> 32); r.tj = (uint32_t)t | ((uint32_t)j << TP_T_BITS);
+		if (keep) {
+#pragma unroll
+			for (uint32_t u = 0; u < PER; u++) {
+				const uint64_t t = t0 + tid + (uint64_t)u * nt;
+				if (t >= t1) continue;
+#pragma unroll
+				for (unsigned j = 0; j < MAXH; j++) if (cbv[u][j] != 0xFFFFFFFFu) put(hh[u], t, j, cbv[u][j]);
+			}
+		} else {
+			for (uint64_t t = t0 + tid; t < t1; t += nt) {
+				const uint64_t h = b.e.h0[t];
+				for (unsigned j = 0; j < nh; j++) { const uint32_t cb = coarse_of(h, j); if (cb != 0xFFFFFFFFu) put(h, t, j, cb); }
 			}
 		}
 	}
@@ -825,11 +856,14 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	});
 	sy.barrier();
 	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
-		const TilePair& f = bin[(uint32_t)(first[s] & 0xFFFu)];
-		if (r.hlo != f.hlo || r.hhi != f.hhi) atomic_or_u32(&info[s], 0x80000000u);
+		// another k-mer on the counter -- or the earliest op a second time, through another of its hash functions
+		// (about one k-mer in 10^8: its counters then count as shared, which is always safe, and a pure counter
+		// holds exactly one pair per op of its k-mer)
+		const TilePair f = bin[(uint32_t)(first[s] & 0xFFFu)];
+		if (r.hlo != f.hlo || r.hhi != f.hhi || ((r.tj ^ f.tj) != 0 && tp_t(r) == tp_t(f))) atomic_or_u32(&info[s], 0x80000000u);
 	});
 	sy.barrier();
-	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t off) {
+	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
 		const uint32_t inf = info[s], t = tp_t(r);
 		// (a counter with 254 pairs or more is treated like a shared one: the partitioned run passes
 		// the leaders' op counts between the ranks in a byte)
@@ -839,14 +873,10 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 			atomic_or_u32((uint32_t*)e.opflag + (t >> 2), bit << (8 * (t & 3u)));
 			return;
 		}
-		// only this k-mer's ops touch the counter: it holds one pair per op and per hash function of the
-		// k-mer that lands here, so every op of the k-mer learns how many they are; the earliest leads them
-		uint32_t d = 0;
-		const uint64_t pos = e.lo + ((tile << TILE_BITS) | off);
-		for (unsigned q = 0; q < e.p.nh; q++) d += pos_i(e.p, tp_h(r), q) == pos;
-		const uint32_t cnt_k = (inf & 0x7FFFFFFFu) / (d ? d : 1);
-		const bool first_op = (uint32_t)(first[s] >> 12) == t; // (the earliest op of the counter; its two pairs say the same)
-		e.lead[t] = cnt_k | (first_op ? LEAD_BIT : 0u);
+		// only this k-mer's ops touch the counter, one pair each: every op of the k-mer learns how many they
+		// are; the earliest leads them
+		const bool first_op = (uint32_t)(first[s] >> 12) == t;
+		e.lead[t] = (inf & 0x7FFFFFFFu) | (first_op ? LEAD_BIT : 0u);
 	});
 }
 // What becomes of an op once every tile has judged its pairs.  n = the ops of its k-mer K in the batch.
@@ -985,6 +1015,147 @@ struct FClaimOwned { // FClaim / FClaimList on the counters of [lo, lo + span) o
 			const uint64_t q = pos_i(p, h, j);
 			if (q - lo < span) atomic_min_u64(&claim[q & cmask], v);
 		}
+	}
+};
+
+
+// ---- the routed form of a partitioned batch (Engine::insert_tiles_routed): instead of every rank holding every
+// op's hash and picking out the pairs on its own counters, a rank hashes its slice of the ops and SENDS each
+// (op, counter) pair to the rank that owns the counter -- one personalised exchange (abg_comm::all_to_all_v) of
+// 12-byte records, the role Parallel/NetworkSequenceCollection.cpp:1499-1506 (computeNodeID) + one MPI message per
+// k-mer play in the reference.  What comes back the same way: two bytes per pair (FRouteReply: the FDistPack
+// bytes, per pair), then one byte per pair out again (the leader's target).  A rank bins, judges and applies
+// what it received; binning work and exchanged bytes per rank fall as 1 / ranks.
+struct RouteEnv {
+	Params p; const uint64_t* h0;
+	uint64_t a, b;               // this rank hashed the ops [a, b) of the batch
+	uint64_t chunk; uint32_t world; // position pos belongs to rank pos / chunk
+	TilePair* send; uint32_t cap;   // [world][cap] records by destination
+	uint32_t* scur;              // [world] records per destination
+	uint32_t* slot;              // [(b - a) * nh] where each (op, hash function) went: destination * cap + index (~0: nowhere, overflow)
+	uint32_t* flags;             // [0] a destination's room ran out
+};
+struct FRoutePack { // item: a chunk of BIN_CHUNK_OPS of the rank's own ops; a workgroup-local counting sort by destination
+	static constexpr uint32_t FAST = 2 * MAX_RANKS * 4, THREADS = 256;
+	RouteEnv r;
+	ABG_HD uint32_t dest(uint64_t pos) const
+	{
+		uint32_t q = 0;
+		while (q + 1 < r.world && pos >= (uint64_t)(q + 1) * r.chunk) q++;
+		return q;
+	}
+	template <class Sync> ABG_HDN void operator()(uint64_t c, void* fast, Sync& sy) const
+	{
+		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + MAX_RANKS;
+		const uint32_t tid = sy.tid(), nt = sy.nthreads();
+		const uint64_t t0 = r.a + c * BIN_CHUNK_OPS, t1 = t0 + BIN_CHUNK_OPS < r.b ? t0 + BIN_CHUNK_OPS : r.b;
+		for (uint32_t i = tid; i < r.world; i += nt) hist[i] = 0;
+		sy.barrier();
+		for (uint64_t t = t0 + tid; t < t1; t += nt) {
+			const uint64_t h = r.h0[t];
+			for (unsigned j = 0; j < r.p.nh; j++) atomic_add_u32(&hist[dest(pos_i(r.p, h, j))], 1);
+		}
+		sy.barrier();
+		for (uint32_t i = tid; i < r.world; i += nt) cur[i] = hist[i] ? atomic_add_u32(&r.scur[i], hist[i]) : 0;
+		sy.barrier();
+		for (uint64_t t = t0 + tid; t < t1; t += nt) {
+			const uint64_t h = r.h0[t];
+			for (unsigned j = 0; j < r.p.nh; j++) {
+				const uint32_t q = dest(pos_i(r.p, h, j));
+				const uint32_t s = atomic_add_u32(&cur[q], 1);
+				uint32_t where = 0xFFFFFFFFu;
+				if (s >= r.cap) r.flags[0] = 1;
+				else {
+					where = q * r.cap + s;
+					TilePair& o = r.send[where];
+					o.hlo = (uint32_t)h; o.hhi = (uint32_t)(h >> 32); o.tj = (uint32_t)t | ((uint32_t)j << TP_T_BITS);
+				}
+				r.slot[(t - r.a) * r.p.nh + j] = where;
+			}
+		}
+	}
+};
+struct FBinCoarseRec { // FBinCoarse over received records: item = a chunk of BIN_CHUNK_PAIRS of them, each ONE pair on a counter of this rank
+	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 256;
+	BinEnv b; const TilePair* recs; uint64_t nrec;
+	template <class Sync> ABG_HDN void operator()(uint64_t c, void* fast, Sync& sy) const
+	{
+		uint32_t* hist = (uint32_t*)fast; uint32_t* cur = hist + b.ncoarse;
+		const uint32_t tid = sy.tid(), nt = sy.nthreads();
+		const uint64_t i0 = c * BIN_CHUNK_PAIRS, i1 = i0 + BIN_CHUNK_PAIRS < nrec ? i0 + BIN_CHUNK_PAIRS : nrec;
+		const uint64_t span = b.e.m - b.e.lo;
+		auto coarse_of = [&](const TilePair& r) -> uint32_t {
+			const uint64_t pos = pos_i(b.e.p, tp_h(r), tp_j(r)) - b.e.lo;
+			return pos < span ? (uint32_t)((pos >> TILE_BITS) >> b.cshift) : 0xFFFFFFFFu; // (never: the sender computed the same owner)
+		};
+		for (uint32_t i = tid; i < b.ncoarse; i += nt) hist[i] = 0;
+		sy.barrier();
+		for (uint64_t i = i0 + tid; i < i1; i += nt) {
+			const uint32_t cb = coarse_of(recs[i]);
+			if (cb == 0xFFFFFFFFu) { b.e.flags[0] = 1; continue; }
+			atomic_add_u32(&hist[cb], 1);
+		}
+		sy.barrier();
+		for (uint32_t i = tid; i < b.ncoarse; i += nt) cur[i] = hist[i] ? atomic_add_u32(&b.ccur[i], hist[i]) : 0;
+		sy.barrier();
+		for (uint64_t i = i0 + tid; i < i1; i += nt) {
+			const TilePair r = recs[i];
+			const uint32_t cb = coarse_of(r);
+			if (cb == 0xFFFFFFFFu) continue;
+			const uint32_t slot = atomic_add_u32(&cur[cb], 1);
+			if (slot >= b.ccap) { b.e.flags[0] = 1; continue; }
+			b.coarse[(uint64_t)cb * b.ccap + slot] = r;
+		}
+	}
+};
+struct FRouteReply { // one received record per item: what its owner's tiles found out about the op (the two FDistPack bytes)
+	TileEnv e; const TilePair* recs; uint8_t* rep;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const TilePair r = recs[i];
+		const uint32_t t = tp_t(r), L = e.lead[t];
+		const bool shared = e.opflag[t] != 0, leader = (L & LEAD_BIT) != 0;
+		rep[2 * i] = (uint8_t)(shared ? 255u : leader ? (L & ~LEAD_BIT) : 0u); // (n < 254: tile_purity)
+		rep[2 * i + 1] = leader ? (uint8_t)(255u - e.cnt[pos_i(e.p, tp_h(r), tp_j(r))]) : (uint8_t)0;
+	}
+};
+struct FRouteCombine { // one of the rank's own ops per item: the replies of its nh pairs -> verdict, and the target back out to each pair
+	Params p; const uint32_t* slot; const uint8_t* rep; uint8_t* tgt_out; uint8_t* pendf; // (pendf: [own ops])
+	ABG_HD void operator()(uint64_t u, uint32_t) const
+	{
+		unsigned A = 0, B = 0;
+		for (unsigned j = 0; j < p.nh; j++) {
+			const uint32_t s = slot[u * p.nh + j];
+			const unsigned a = rep[2ull * s], b = rep[2ull * s + 1];
+			A = a > A ? a : A; B = b > B ? b : B;
+		}
+		const bool shared = A == 255;
+		const unsigned n = A, mn = 255u - B;
+		uint8_t tg = 0;
+		if (!shared && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
+		pendf[u] = shared ? 1 : 0;
+		for (unsigned j = 0; j < p.nh; j++) tgt_out[slot[u * p.nh + j]] = tg;
+	}
+};
+struct FRouteTgt { // one received record per item: the target its op's hashing rank sent back
+	const TilePair* recs; const uint8_t* tgt_in; uint8_t* tgt;
+	ABG_HD void operator()(uint64_t i, uint32_t) const { tgt[tp_t(recs[i])] = tgt_in[i]; }
+};
+struct FRoutePendRec { // the rank's own ops that go to the rounds, as records for everybody: {hash, op}
+	const uint64_t* h0; const uint32_t* list; uint64_t a; TilePair* out;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint64_t t = a + list[i], h = h0[t];
+		out[i].hlo = (uint32_t)h; out[i].hhi = (uint32_t)(h >> 32); out[i].tj = (uint32_t)t;
+	}
+};
+struct FRoutePendTake { // ... and everybody's, gathered in rank (= op) order: the hashes into place, the op list
+	const TilePair* recs; uint64_t* h0; uint32_t* pend;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const TilePair r = recs[i];
+		h0[r.tj] = tp_h(r);
+		pend[i] = r.tj;
 	}
 };
 
@@ -1422,7 +1593,6 @@ struct FPredict {
 // Partitioned run: contig records gathered from the other ranks keep their rank-local numbering;
 // bring pool offsets and record links into the merged numbering.  Records [g_rec + rbase[q],
 // g_rec + rbase[q + 1]) came from rank q, whose pool block moved from g_pool to g_pool + pbase[q].
-constexpr int MAX_RANKS = 16;
 struct FRecFix {
 	ContigRec* recs; uint32_t g_rec; uint32_t world;
 	uint32_t rbase[MAX_RANKS + 1]; uint64_t pbase[MAX_RANKS + 1];
@@ -2246,6 +2416,7 @@ class Engine {
 		void* user = nullptr;
 		int (*all_gather_v)(void*, void*, const uint64_t*, const uint64_t*, void*) = nullptr;
 		int (*all_reduce)(void*, void*, uint64_t, int32_t, int32_t, void*) = nullptr;
+		int (*all_to_all_v)(void*, const void*, const uint64_t*, const uint64_t*, void*, const uint64_t*, const uint64_t*, void*) = nullptr;
 	};
 	enum { DT_U8 = 0, DT_U32 = 1, DT_U64 = 2, OP_SUM = 0, OP_MAX = 1, OP_MIN = 2 };
 	bool attach_comm(const Comm& c)
@@ -2432,7 +2603,7 @@ class Engine {
 		// and binned on the side stream while this one's tiles are judged and applied and its left-over
 		// ops go through the reservation rounds (small kernels and host round trips that leave the
 		// machine idle).  Two sets of hashes and bins take turns.
-		const bool pipe = tiled_ && bins_alt_ != nullptr;
+		const bool pipe = tiled_ && bins_alt_ != nullptr && !routed();
 		for (size_t i = 0; i < ranges.size(); i++) {
 			if (!pipe) { insert_range(b, ranges[i], false); continue; }
 			if (i == 0) stage_bins(b, ranges[0]);
@@ -2577,7 +2748,9 @@ class Engine {
 		uint64_t nwords = 0;
 		be_.d2h(&nwords, b.woff + b.n, 8);
 		const uint64_t bases = nwords * 16, minus = b.n * (uint64_t)(p_.k - 1);
-		const uint64_t kmers = (bases > minus ? bases - minus : b.n) / cfg_.guide_stride;
+		// (slots for a quarter of the reads' k-mers, whatever the stride: what stays in the table is a genome's worth of
+		// solid k-mers, and in a direct-mapped table every second one of them lost to a collision is a bulk step not taken)
+		const uint64_t kmers = (bases > minus ? bases - minus : b.n) / std::min<uint32_t>(cfg_.guide_stride, 4u);
 		uint32_t log2 = 16;
 		while ((1ull << log2) < kmers && log2 < cfg_.guide_log2_max) log2++;
 		if (!guide_tab_ || log2 != guide_log2_) {
@@ -2673,6 +2846,14 @@ class Engine {
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
 	uint32_t* sh_words_ = nullptr; uint64_t* sh_woff_ = nullptr; uint32_t* sh_len_ = nullptr; uint64_t* sh_koff_ = nullptr;
 	uint8_t* dres_ = nullptr; uint8_t* dlost_ = nullptr; // PASS 1: one byte per pending op
+	// routed form (insert_tiles_routed): records by destination, records received, where each own pair went, replies and targets both ways
+	TilePair* rsend_ = nullptr; TilePair* rrecv_ = nullptr; uint32_t rcap_ = 0; uint64_t rrecv_cap_ = 0; uint32_t* rslot_ = nullptr; uint32_t* rcur_ = nullptr;
+	uint8_t* rrep_out_ = nullptr; uint8_t* rrep_in_ = nullptr; uint8_t* rtgt_out_ = nullptr; uint8_t* rtgt_in_ = nullptr; uint8_t* rpendf_ = nullptr;
+	uint64_t rown_ = 0; // ops a rank hashes per batch, at most
+	bool routed() const
+	{
+		return dist() && cfg_.dist_route_min_ranks && (uint32_t)comm_.world >= cfg_.dist_route_min_ranks && (comm_.all_to_all_v || comm_.world == 1) && p_.nh <= 16;
+	}
 	uint32_t g_rec_ = 0; uint64_t g_pool_ = 0;           // PASS 2: records / pool bytes every rank holds
   public:
   private:
@@ -2698,6 +2879,18 @@ class Engine {
 		be_.begin("comm_all_reduce");
 		if (comm_.all_reduce(comm_.user, buf, n, dtype, op, be_.stream_handle())) c_fail("all_reduce");
 		be_.end("comm_all_reduce");
+	}
+	// send_counts[q] bytes at send + send_displs[q] to rank q; recv_counts[q] bytes from rank q to recv + recv_displs[q]
+	void c_all_to_all_v(const void* send, const uint64_t* sc, const uint64_t* sd, void* recv, const uint64_t* rc, const uint64_t* rd)
+	{
+		if (comm_.world == 1) { // (ABG_FORCE_DIST on one rank: the exchange is a copy)
+			if (sc[0]) be_.d2d((char*)recv + rd[0], (const char*)send + sd[0], sc[0]);
+			return;
+		}
+		if (!comm_.stream_ordered) be_.sync();
+		be_.begin("comm_all_to_all");
+		if (comm_.all_to_all_v(comm_.user, send, sc, sd, recv, rc, rd, be_.stream_handle())) c_fail("all_to_all_v");
+		be_.end("comm_all_to_all");
 	}
 	void host_all_reduce_sum(uint64_t* v, uint32_t n)
 	{
@@ -2878,6 +3071,23 @@ class Engine {
 			tgt_ = (uint8_t*)be_.alloc(nb);
 			pendf_ = (uint8_t*)be_.alloc(nb);
 			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
+			if (routed()) {
+				// a rank hashes a slice of at most rown_ ops and sends nh records each; a destination gets 1 / R of them on average
+				rown_ = (((nb + R - 1) / R + 7) & ~7ull);
+				const uint64_t mean = rown_ * p_.nh / R;
+				uint64_t sq = 1;
+				while (sq * sq < mean) sq++;
+				rcap_ = (uint32_t)(mean + 8 * sq + 1024);
+				if (const char* e = getenv("ABG_ROUTE_CAP")) rcap_ = (uint32_t)std::max(1, atoi(e)); // (tests: a destination's room runs out)
+				rsend_ = (TilePair*)be_.alloc((uint64_t)R * rcap_ * sizeof(TilePair));
+				rrecv_cap_ = (uint64_t)R * rcap_;
+				rrecv_ = (TilePair*)be_.alloc(rrecv_cap_ * sizeof(TilePair));
+				rslot_ = (uint32_t*)be_.alloc(rown_ * p_.nh * 4);
+				rcur_ = (uint32_t*)be_.alloc((MAX_RANKS + 2) * 4);
+				rrep_out_ = (uint8_t*)be_.alloc(rrecv_cap_ * 2); rrep_in_ = (uint8_t*)be_.alloc((uint64_t)R * rcap_ * 2);
+				rtgt_out_ = (uint8_t*)be_.alloc((uint64_t)R * rcap_); rtgt_in_ = (uint8_t*)be_.alloc(rrecv_cap_);
+				rpendf_ = (uint8_t*)be_.alloc(rown_ + 8);
+			}
 		}
 		h0_ = (uint64_t*)be_.alloc((nb + 8 * R + 8) * 8);
 		// The claim tables of the reservation rounds: the false-conflict rate falls with the load, so
@@ -2913,6 +3123,10 @@ class Engine {
 		if (!h0_) return;
 		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); be_.free(pendf_); tiled_ = false; }
 		if (tred_) { be_.free(tred_); tred_ = nullptr; }
+		if (rsend_) {
+			be_.free(rsend_); be_.free(rrecv_); be_.free(rslot_); be_.free(rcur_); be_.free(rrep_out_); be_.free(rrep_in_); be_.free(rtgt_out_); be_.free(rtgt_in_); be_.free(rpendf_);
+			rsend_ = nullptr;
+		}
 		if (bins_alt_) { be_.free(bins_alt_); be_.free(tcur_alt_); be_.free(h0_alt_); bins_alt_ = nullptr; tcur_alt_ = nullptr; h0_alt_ = nullptr; }
 		if (dres_) { be_.free(dres_); dres_ = nullptr; }
 		be_.free(dlost_);
@@ -2945,7 +3159,8 @@ class Engine {
 		uint64_t* ccur = claim_[0];
 		uint64_t* cnext = claim_[1];
 		if (dist()) {
-			if (tiled_) insert_tiles_dist(v, T, cmask, kbase, staged, staged ? flag_word : 1);
+			if (tiled_ && routed()) insert_tiles_routed(v, T, cmask, kbase);
+			else if (tiled_) insert_tiles_dist(v, T, cmask, kbase, staged, staged ? flag_word : 1);
 			else {
 				FHashClaimT<true> fc{ p_, v, h0_, T, ccur, cmask, epoch_, own_lo_, own_span_, kbase };
 				be_.launch((T + HC_RUN - 1) / HC_RUN, fc, "hash_claim");
@@ -3094,6 +3309,115 @@ class Engine {
 			be_.launch(npend, fc, "claim_list");
 		}
 		insert_rounds_dist(T, cmask, pin, npend);
+	}
+
+	// The tiles of insert_range over a range-partitioned filter, ROUTED: a rank hashes its slice of the batch's ops and
+	// sends every (op, counter) pair to the rank that owns the counter (FRoutePack, one all_to_all_v of 12-byte records);
+	// each rank bins what it received into its tiles and judges it there (FBinCoarseRec, FBinFine, tile_purity as ever);
+	// two bytes per pair travel back (FRouteReply: shared / leads n ops, 255 - the counter), the hashing rank folds its
+	// nh replies into the op's verdict and target (FRouteCombine) and sends the target to the pairs' owners, who apply it
+	// to their tiles.  The ops left over are made known to everybody ({hash, op}, all-gathered in op order) and go through
+	// the partitioned reservation rounds.  Per op of a rank's own share: nh x (12 + 2 + 1) bytes out or in, to or from the
+	// ranks owning its counters, whatever the number of ranks; no rank looks at an op it neither hashed nor owns a counter of.
+	// If any room runs out anywhere (a destination's records, a bin), every rank falls back to the whole batch through the
+	// rounds (the hashes are all-gathered for that): nothing has been applied by then.
+	void insert_tiles_routed(const Batch& v, uint64_t T, uint64_t cmask, uint64_t kbase)
+	{
+		cnt_partial_ = true;
+		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
+		const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
+		const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk), nown = b - a;
+		uint32_t* rflag = rcur_ + MAX_RANKS; // [0] some room ran out on this rank
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u };
+		be_.memset(lead_, 0, T * 4);
+		be_.memset(opflag_, 0, (T + 3) & ~3ull);
+		be_.memset(tcur_, 0, ntiles_ * 4);
+		be_.memset(ccur_, 0, ncoarse_ * 4);
+		be_.memset(rcur_, 0, (MAX_RANKS + 2) * 4);
+		if (nown) {
+			dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, b, kbase, a, hash_run_ }; be_.launch((nown + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
+			RouteEnv re{ p_, h0_, a, b, own_chunk_, (uint32_t)R, rsend_, rcap_, rcur_, rslot_, rflag };
+			FRoutePack f{ re };
+			be_.launch_tiles((nown + BIN_CHUNK_OPS - 1) / BIN_CHUNK_OPS, f, "route_pack");
+		}
+		// who sends how much to whom (and whether anybody ran out of room): one small all-reduce on the host's behalf
+		std::vector<uint32_t> sc32(MAX_RANKS + 2, 0);
+		be_.d2h(sc32.data(), rcur_, (MAX_RANKS + 2) * 4);
+		std::vector<uint64_t> mat(R * R + 1, 0);
+		for (uint64_t q = 0; q < R; q++) mat[me * R + q] = std::min<uint64_t>(sc32[q], rcap_);
+		mat[R * R] = sc32[MAX_RANKS];
+		host_all_reduce_sum(mat.data(), (uint32_t)(R * R + 1));
+		bool fallback = mat[R * R] != 0;
+		std::vector<uint64_t> sc(R), sd(R), rc(R), rd(R);
+		uint64_t nrec = 0;
+		for (uint64_t q = 0; q < R; q++) { sc[q] = mat[me * R + q]; sd[q] = q * rcap_; rc[q] = mat[q * R + me]; rd[q] = nrec; nrec += rc[q]; }
+		if (!fallback && nrec > rrecv_cap_) fallback = true; // (cannot happen while every sender keeps within rcap_: R x rcap_ is the room)
+		auto bytes = [&](const std::vector<uint64_t>& x, uint64_t w) { std::vector<uint64_t> y(x); for (auto& e : y) e *= w; return y; };
+		if (!fallback) {
+			c_all_to_all_v(rsend_, bytes(sc, sizeof(TilePair)).data(), bytes(sd, sizeof(TilePair)).data(), rrecv_, bytes(rc, sizeof(TilePair)).data(), bytes(rd, sizeof(TilePair)).data());
+			if (nrec) {
+				BinEnv bn{ te, T, coarse_, coarse_cap_, ccur_, cshift_, ncoarse_ };
+				FBinCoarseRec f1{ bn, rrecv_, nrec };
+				be_.launch_tiles((nrec + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS, f1, "bin_coarse");
+				const uint32_t cpb = (coarse_cap_ + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS;
+				FBinFine f2{ bn, cpb };
+				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
+				FTilePurity f3{ te };
+				be_.launch_tiles(ntiles_, f3, "tile_purity");
+			}
+			// a bin that ran over anywhere sends the whole batch through the rounds on every rank
+			uint64_t ovf = 0;
+			{ uint32_t fl = 0; be_.d2h(&fl, rflag, 4); ovf = fl; }
+			host_all_reduce_sum(&ovf, 1);
+			fallback = ovf != 0;
+		}
+		if (fallback) {
+			stats_.tile_overflows++;
+			if (getenv("ABG_ROUTE_DEBUG")) fprintf(stderr, "[route] rank %d fallback: T %llu pack flag %llu nrec %llu cap %u tile_cap %u coarse_cap %u ntiles %llu\n", comm_.rank, (unsigned long long)T, (unsigned long long)mat[R * R], (unsigned long long)nrec, rcap_, tile_cap_, coarse_cap_, (unsigned long long)ntiles_);
+			std::vector<uint64_t> c(R, chunk * 8), d(R);
+			for (uint64_t q = 0; q < R; q++) d[q] = q * chunk * 8;
+			c_all_gather_v(h0_, c.data(), d.data());
+			FClaimOwned fc{ p_, h0_, nullptr, claim_[0], cmask, epoch_, own_lo_, own_span_ };
+			be_.launch(T, fc, "claim_list");
+			insert_rounds_dist(T, cmask, nullptr, T);
+			return;
+		}
+		if (nrec) { FRouteReply f{ te, rrecv_, rrep_out_ }; be_.launch(nrec, f, "route_reply"); }
+		c_all_to_all_v(rrep_out_, bytes(rc, 2).data(), bytes(rd, 2).data(), rrep_in_, bytes(sc, 2).data(), bytes(sd, 2).data());
+		if (nown) { FRouteCombine f{ p_, rslot_, rrep_in_, rtgt_out_, rpendf_ }; be_.launch(nown, f, "op_target"); }
+		c_all_to_all_v(rtgt_out_, sc.data(), sd.data(), rtgt_in_, rc.data(), rd.data());
+		if (nrec) {
+			FRouteTgt f{ rrecv_, rtgt_in_, tgt_ };
+			be_.launch(nrec, f, "route_tgt");
+			FTileApply fa{ te };
+			be_.launch_tiles(ntiles_, fa, "tile_apply");
+		}
+		// the ops left over: each rank's own (in op order), made known to all
+		be_.memset(pend_n_, 0, 8);
+		if (nown) be_.compact_flagged(nullptr, rpendf_, nown, pend_[0], pend_n_);
+		uint32_t mine = 0;
+		be_.d2h(&mine, pend_n_, 4);
+		std::vector<uint64_t> pc(R, 0);
+		pc[me] = mine;
+		host_all_reduce_sum(pc.data(), (uint32_t)R);
+		uint64_t npend = 0;
+		std::vector<uint64_t> gc(R), gd(R);
+		for (uint64_t q = 0; q < R; q++) { gd[q] = npend * sizeof(TilePair); gc[q] = pc[q] * sizeof(TilePair); npend += pc[q]; }
+		stats_.tiled_ops += T; stats_.tiled_pending += npend;
+		if (npend) {
+			// (the send buffer is free again: the gathered records go there -- at most T of them, so make room if need be)
+			TilePair* g = rsend_;
+			TilePair* big = nullptr;
+			if (npend > R * (uint64_t)rcap_) { big = (TilePair*)be_.alloc(npend * sizeof(TilePair)); g = big; }
+			if (mine) { FRoutePendRec f{ h0_, pend_[0], a, (TilePair*)((char*)g + gd[me]) }; be_.launch(mine, f, "route_pend"); }
+			c_all_gather_v(g, gc.data(), gd.data());
+			FRoutePendTake f{ g, h0_, pend_[1] };
+			be_.launch(npend, f, "route_pend");
+			if (big) { be_.sync(); be_.free(big); }
+			FClaimOwned fc{ p_, h0_, pend_[1], claim_[0], cmask, epoch_, own_lo_, own_span_ };
+			be_.launch(npend, fc, "claim_list");
+		}
+		insert_rounds_dist(T, cmask, pend_[1], npend);
 	}
 	// The reservation rounds of insert_range over a range-partitioned filter: the same rounds,
 	// every rank running every pending op against the counters it owns, one all_reduce(MIN) of a

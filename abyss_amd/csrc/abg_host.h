@@ -93,6 +93,7 @@ class Session {
 		if (const char* e = getenv("ABG_PAR_COMMIT_MAX_GB")) cfg.par_commit_max_bytes = strtoull(e, 0, 10) << 30; // e.g. 160 for B=40G on a 288 GB GPU
 		if (const char* e = getenv("ABG_COMPACT_THRESHOLD")) cfg.compact_threshold = strtoull(e, 0, 10);
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
+		if (const char* e = getenv("ABG_DIST_ROUTE_MIN")) cfg.dist_route_min_ranks = (uint32_t)atoi(e); // partitioned run: pairs routed to their owners from this many ranks on (0: never)
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
@@ -412,7 +413,7 @@ class Session {
 		if (!c.all_gather_v || !c.all_reduce) return fail(ABG_EINVAL, "communicator lacks a collective");
 		typename Engine<BE>::Comm ec;
 		ec.rank = c.rank; ec.world = c.world; ec.stream_ordered = c.stream_ordered != 0; ec.user = c.user;
-		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce;
+		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce; ec.all_to_all_v = c.all_to_all_v;
 		comm_attached_ = true;
 		if (!eng->attach_comm(ec)) return fail(ABG_EINVAL, "bad rank / world (at most " + std::to_string(MAX_RANKS) + " ranks; not available on a cascading filter)");
 		return ABG_OK;

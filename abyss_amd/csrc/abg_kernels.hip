@@ -631,6 +631,8 @@ struct RcclApi {
 	decltype(&ncclBroadcast) Broadcast = nullptr;
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string why;
 	bool load()
@@ -646,7 +648,7 @@ struct RcclApi {
 		if (!h) { why = std::string("cannot open librccl: ") + dlerror(); return false; }
 #define ABG_SYM(f) f = (decltype(f))dlsym(h, "nccl" #f); if (!f) { why = "librccl lacks nccl" #f; h = nullptr; return false; }
 		ABG_SYM(GetUniqueId) ABG_SYM(CommInitRank) ABG_SYM(CommDestroy) ABG_SYM(AllReduce) ABG_SYM(AllGather)
-		ABG_SYM(Broadcast) ABG_SYM(GroupStart) ABG_SYM(GroupEnd) ABG_SYM(GetErrorString)
+		ABG_SYM(Broadcast) ABG_SYM(GroupStart) ABG_SYM(GroupEnd) ABG_SYM(Send) ABG_SYM(Recv) ABG_SYM(GetErrorString)
 #undef ABG_SYM
 		return true;
 	}
@@ -702,6 +704,26 @@ int rccl_all_reduce(void* user, void* buf, uint64_t count, int32_t dtype, int32_
 	if (dtype < 0 || dtype > 2 || op < 0 || op > 2) return -1;
 	ncclResult_t r = g_rccl.AllReduce(buf, buf, count, dt[dtype], ops[op], c->comm, (hipStream_t)stream);
 	return r == ncclSuccess ? 0 : rccl_fail(r, "ncclAllReduce");
+}
+
+// the routed exchanges: one ncclSend / ncclRecv pair per peer in ONE group -- over xGMI that is seven point-to-point
+// transfers in flight at once, one per link, instead of a ring; the part a rank keeps for itself is a device copy
+int rccl_all_to_all_v(void* user, const void* send, const uint64_t* sc, const uint64_t* sd, void* recv, const uint64_t* rc,
+    const uint64_t* rd, void* stream)
+{
+	RcclComm* c = (RcclComm*)user;
+	hipStream_t st = (hipStream_t)stream;
+	if (sc[c->rank] != rc[c->rank]) return -1;
+	if (sc[c->rank] && hipMemcpyAsync((char*)recv + rd[c->rank], (const char*)send + sd[c->rank], sc[c->rank], hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+	ncclResult_t r = g_rccl.GroupStart();
+	if (r != ncclSuccess) return rccl_fail(r, "ncclGroupStart");
+	for (int q = 0; q < c->world; q++) {
+		if (q == c->rank) continue;
+		if (sc[q]) { r = g_rccl.Send((const char*)send + sd[q], sc[q], ncclUint8, q, c->comm, st); if (r != ncclSuccess) { g_rccl.GroupEnd(); return rccl_fail(r, "ncclSend"); } }
+		if (rc[q]) { r = g_rccl.Recv((char*)recv + rd[q], rc[q], ncclUint8, q, c->comm, st); if (r != ncclSuccess) { g_rccl.GroupEnd(); return rccl_fail(r, "ncclRecv"); } }
+	}
+	r = g_rccl.GroupEnd();
+	return r == ncclSuccess ? 0 : rccl_fail(r, "ncclGroupEnd");
 }
 
 std::mutex g_err_mutex;
@@ -997,6 +1019,7 @@ int abg_rccl_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int
 	out->rank = rank; out->world = world; out->stream_ordered = 1; out->user = c;
 	out->all_gather_v = rccl_all_gather_v;
 	out->all_reduce = rccl_all_reduce;
+	out->all_to_all_v = rccl_all_to_all_v;
 	return ABG_OK;
 }
 int abg_rccl_comm_destroy(abg_comm* comm)

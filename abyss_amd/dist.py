@@ -22,11 +22,13 @@ SUM, MAX, MIN = 0, 1, 2
 
 AGV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
 AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                     C.POINTER(C.c_uint64), C.c_void_p)
 
 
 class CommStruct(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("stream_ordered", C.c_int32), ("reserved_", C.c_int32),
-                ("user", C.c_void_p), ("all_gather_v", AGV_FN), ("all_reduce", AR_FN)]
+                ("user", C.c_void_p), ("all_gather_v", AGV_FN), ("all_reduce", AR_FN), ("all_to_all_v", A2A_FN)]
 
 
 class RcclComm:
@@ -72,10 +74,11 @@ class LocalComm:
 
     def __init__(self):
         self.rank, self.world = 0, 1
-        self.calls = {"all_gather_v": 0, "all_reduce": 0}
+        self.calls = {"all_gather_v": 0, "all_reduce": 0, "all_to_all_v": 0}
         self._agv = AGV_FN(lambda *_a: self._count("all_gather_v"))
         self._ar = AR_FN(lambda *_a: self._count("all_reduce"))
-        self.struct = CommStruct(0, 1, 0, 0, None, self._agv, self._ar)
+        self._a2a = A2A_FN(lambda *_a: self._count("all_to_all_v"))  # (never called: one rank's exchange is a copy inside the engine)
+        self.struct = CommStruct(0, 1, 0, 0, None, self._agv, self._ar, self._a2a)
 
     def _count(self, what):
         self.calls[what] += 1
@@ -91,10 +94,11 @@ class StagedTorchComm:
         import torch.distributed as dist
         self.read, self.write, self.group = read, write, group
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.calls = {"all_gather_v": 0, "all_reduce": 0, "bytes": 0}
+        self.calls = {"all_gather_v": 0, "all_reduce": 0, "all_to_all_v": 0, "bytes": 0}
         self._agv = AGV_FN(self._all_gather_v)
         self._ar = AR_FN(self._all_reduce)
-        self.struct = CommStruct(self.rank, self.world, 0, 0, None, self._agv, self._ar)
+        self._a2a = A2A_FN(self._all_to_all_v)
+        self.struct = CommStruct(self.rank, self.world, 0, 0, None, self._agv, self._ar, self._a2a)
 
     def _all_gather_v(self, _user, buf, counts, displs, _stream):
         import torch
@@ -119,6 +123,33 @@ class StagedTorchComm:
             return 0
         except Exception as e:  # an exception must not unwind through the C caller
             print("StagedTorchComm.all_gather_v:", repr(e), flush=True)
+            return -1
+
+    def _all_to_all_v(self, _user, send, scounts, sdispls, recv, rcounts, rdispls, _stream):
+        import torch
+        import torch.distributed as dist
+        try:
+            sc = [int(scounts[q]) for q in range(self.world)]
+            sd = [int(sdispls[q]) for q in range(self.world)]
+            rc = [int(rcounts[q]) for q in range(self.world)]
+            rd = [int(rdispls[q]) for q in range(self.world)]
+            parts = [self.read(send + sd[q], sc[q]) if sc[q] else np.zeros(0, dtype=np.uint8) for q in range(self.world)]
+            out = torch.empty(sum(rc), dtype=torch.uint8)
+            dist.all_to_all_single(out, torch.from_numpy(np.concatenate(parts)) if sum(sc) else torch.empty(0, dtype=torch.uint8),
+                                   output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            o = out.numpy()
+            at = 0
+            for q in range(self.world):
+                if rc[q]:
+                    self.write(recv + rd[q], np.ascontiguousarray(o[at:at + rc[q]]))
+                at += rc[q]
+            self.calls["all_to_all_v"] += 1
+            off_rank = sum(sc) - sc[self.rank]  # (what leaves this rank: its own part is a local copy)
+            self.calls["bytes"] += off_rank
+            self.calls["bytes_all_to_all_v"] = self.calls.get("bytes_all_to_all_v", 0) + off_rank
+            return 0
+        except Exception as e:
+            print("StagedTorchComm.all_to_all_v:", repr(e), flush=True)
             return -1
 
     def _all_reduce(self, _user, buf, count, dtype, op, _stream):

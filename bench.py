@@ -351,7 +351,7 @@ def main() -> int:
     names = ["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "guide_build",
              "hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
              "insert_drain", "classify", "read_prep", "presearch_scan", "presearch", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
-             "share_fix",
+             "share_fix", "route_pack", "route_reply", "route_tgt", "route_pend", "comm_all_to_all",
              "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names} if (warm_prof and g is not None) else None
@@ -415,7 +415,7 @@ def main() -> int:
     # achieved rate = its algorithmic bytes / the summed duration of its kernels.
     families = {
         "pass1": (["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "hash_claim",
-                   "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load", "insert_drain"],
+                   "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load", "insert_drain", "route_pack", "route_reply", "route_tgt", "route_pend"],
                   (per_kmer_bases + 2 * H * share) * kmers_all),
         "classify": (["classify", "reclassify"],
                      (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share),
@@ -487,7 +487,7 @@ def main() -> int:
                        "baseline_config": a.config, "genome_bp": genome_len, "coverage": cov, "error_rate": err,
                        "read_kmers": kmers_all if partitioned else kmers,
                        "parallelism": ("filter range-partitioned over %d ranks in PASS 1 (%s), gathered for PASS 2; walks split"
-                                       % (world, "RCCL all_gather + all_reduce on the engine's stream" if a.comm == "rccl"
+                                       % (world, ("RCCL on the engine's stream: (op, counter) pairs routed to the owning ranks by all-to-all (ncclSend/ncclRecv groups)" if world >= 4 else "RCCL all_gather + all_reduce on the engine's stream") if a.comm == "rccl"
                                           else "torch.distributed on host copies")) if partitioned
                        else ("replicas x%d (independent jobs)" % world if world > 1 else "single GPU"),
                        "unitigs": unitigs, "unitig_bp": bases},

@@ -249,6 +249,13 @@ typedef struct abg_comm {
 	int (*all_gather_v)(void* user, void* buf, const uint64_t* counts, const uint64_t* displs, void* stream);
 	/* in place, element-wise over `count` elements of abg_dtype with abg_redop */
 	int (*all_reduce)(void* user, void* buf, uint64_t count, int32_t dtype, int32_t op, void* stream);
+	/* personalised exchange (may be NULL: the engine then keeps to the two collectives above): send_counts[q]
+	 * bytes at send + send_displs[q] go to rank q, recv_counts[q] bytes from rank q arrive at recv +
+	 * recv_displs[q]; the two buffers do not overlap.  This is what routes k-mer probes to the ranks that own
+	 * their counters (the reference's precedent: Parallel/NetworkSequenceCollection.cpp:1499-1506 computeNodeID
+	 * + one MPI message per k-mer operation; here one exchange per batch of operations). */
+	int (*all_to_all_v)(void* user, const void* send, const uint64_t* send_counts, const uint64_t* send_displs,
+	    void* recv, const uint64_t* recv_counts, const uint64_t* recv_displs, void* stream);
 } abg_comm;
 #define ABG_MAX_RANKS 16
 

@@ -145,7 +145,7 @@ def test_partitioned_code_path_on_a_single_rank(name, monkeypatch):
     assert comm.calls["all_reduce"] > 0 and comm.calls["all_gather_v"] > 0
 
 
-def test_pass1_collective_bytes_follow_the_model():
+def test_pass1_collective_bytes_follow_the_model(monkeypatch):
     """DESIGN.md section 7's traffic model of the partitioned PASS 1, checked instead of asserted: per k-mer op the
     ranks exchange two bytes through one all_reduce per batch, plus one byte per op still pending in each
     reservation round, plus -- from three ranks on; two ranks, which share one xGMI link, hash everything
@@ -153,6 +153,7 @@ def test_pass1_collective_bytes_follow_the_model():
     and 2(R-1)/R of an all-reduce's buffer per rank: 12 B x (R-1) per op of a rank's own share, against
     ~55 B for routed (op, counter) pairs whatever R is."""
     per_op = {}
+    monkeypatch.setenv("ABG_DIST_ROUTE_MIN", "0")  # (this is the all-gather form's model; the routed form's is the next test)
     for world in (2, 4):
         out = run_ranks(world, "golden", "k64")
         assert out["fasta"] and out["ranks_agree"]
@@ -167,3 +168,74 @@ def test_pass1_collective_bytes_follow_the_model():
         assert 0 <= rounds <= 1.0 * ops, (world, ops, p1)
         per_op[world] = (ag + ar) / ops
     assert 2.0 <= per_op[2] <= 3.5 and 10.0 <= per_op[4] <= 11.5, per_op
+
+
+# ---- the routed form (Engine::insert_tiles_routed): (op, counter) pairs sent to the ranks that own the counters ----
+@pytest.mark.parametrize("world,args", [(2, ("golden", "k64")), (3, ("golden", "k40_mixed")), (2, ("golden", "k48_K16")), (3, ("tiny_filter",)),
+                                        (3, ("saturate_tiled",)), (2, ("kept",)), (3, ("shared",))])
+def test_routed_pairs_reproduce_the_reference_run(world, args, monkeypatch):
+    """From four ranks on the pairs are routed by default (the 5- and 8-rank cases above run that way); here the same
+    on two and three ranks: every batch's pairs through abg_comm::all_to_all_v, replies and targets back the same way."""
+    monkeypatch.setenv("ABG_DIST_ROUTE_MIN", "2")
+    out = run_ranks(world, *args)
+    for key in [k for k in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "counting_filter", "results", "contigs", "visited",
+                            "assembly_counters") if k in out] + ["ranks_agree"]:
+        assert out[key], (key, out)
+    assert out["comm_calls"]["all_to_all_v"] >= 3 and out["stats"]["tiled_ops"] > 0, out
+
+
+def test_routed_pairs_fall_back_when_a_destination_runs_out_of_room(monkeypatch):
+    """ABG_ROUTE_CAP: a sender's room for one destination is too small -> every rank takes the whole batch through the
+    reservation rounds (hashes all-gathered), nothing having been applied."""
+    monkeypatch.setenv("ABG_DIST_ROUTE_MIN", "2")
+    monkeypatch.setenv("ABG_ROUTE_CAP", "500")
+    out = run_ranks(3, "oracle")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["stats"]["tile_overflows"] > 0, out["stats"]
+
+
+def test_routed_code_path_on_a_single_rank(monkeypatch):
+    """ABG_FORCE_DIST=1 + routing on one rank: pack, the exchanges as copies, bins from records, replies, targets."""
+    import ctypes as C
+    from abyss_amd import api, dist as adist
+    from test_hostcheck import HostCheck
+    from util import GoldenCase, mask_of
+    monkeypatch.setenv("ABG_FORCE_DIST", "1")
+    monkeypatch.setenv("ABG_DIST_ROUTE_MIN", "1")
+    g = GoldenCase("k64")
+    kw = g.kwargs()
+    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000, claim_log2=16, p2_first=128,
+                   mask=mask_of(g))
+    comm = adist.LocalComm()
+    hc.l.hc_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+    assert hc.l.hc_attach_comm(hc.h, C.byref(comm.struct)) == 0
+    hc.load(g.buf, g.off)
+    assert hc.counting_stats()[1] == g.meta["filtered_popcount"]
+    results, contigs = hc.assemble(g.buf, g.off)
+    assert api.format_fasta(contigs, g.ids) == g.fasta and api.format_read_log(results, g.ids) == g.readlog
+    st = hc.stats()
+    assert st["tiled_ops"] > 0 and st["tile_overflows"] == 0 and 0 < st["tiled_pending"] < st["tiled_ops"], st
+
+
+def test_routed_pass1_bytes_follow_the_model():
+    """What a rank sends in the routed PASS 1, counted by the communicator: per op of its OWN share nh pairs of 12 + 1 bytes out
+    and 2 bytes back, the (R-1)/R of them that live on other ranks; the ops left for the rounds as 12-byte records to everybody;
+    a byte per pending op and round through all_reduce.  No term grows with R: ~60 B per own op at nh = 4 whatever the number of
+    ranks, against 12 B x (R-1) for the all-gather form (84 B at R = 8) -- and no rank hashes or bins an op that is not its own."""
+    for world in (4, 8):
+        out = run_ranks(world, "golden", "k64")
+        assert out["fasta"] and out["ranks_agree"], out
+        ops, p1 = out["kmer_ops"], out["comm_pass1"]
+        if out["stats"]["tile_overflows"]:
+            # (4,000 reads of a 20 kbp genome put ~16 copies of every k-mer into a batch: on eight ranks' eight tiles each a bin
+            # runs over now and then and that batch takes the fallback -- which is then exercised too; the model is checked on four)
+            assert world == 8 and p1["all_to_all_v"] > 0
+            continue
+        own = ops / world
+        a2a = p1["bytes_all_to_all_v"] / own
+        want = 4 * (12 + 2 + 1) * (world - 1) / world
+        assert 0.93 * want <= a2a <= 1.07 * want, (world, a2a, want, p1)
+        pending = out["stats"]["tiled_pending"]
+        assert p1.get("bytes_all_gather_v", 0) <= 12 * pending + 64 * world * p1["all_gather_v"], (world, p1, pending)
+        assert p1["bytes_all_reduce"] <= 3.0 * pending + 4096 * p1["all_reduce"], (world, p1, pending)

@@ -36,9 +36,23 @@ def test_rccl_single_rank_partitioned_path_reproduces_reference_runs_and_oracle(
     assert all(v > 0 for v in out["launches"].values()), out["launches"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_sharing_one_gpu_match_oracle(world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+def test_rccl_single_rank_routed_path_reproduces_reference_runs_and_oracle():
+    """The routed form of PASS 1 (Engine::insert_tiles_routed) with the real kernels -- FRoutePack, FBinCoarseRec,
+    FRouteReply / FRouteCombine / FRouteTgt, the pending records -- on one rank, each exchange a device copy."""
+    env = dict(os.environ, ABG_FORCE_DIST="1", ABG_DIST_ROUTE_MIN="1")
+    r = subprocess.run([sys.executable, WORKER, "rccl1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    out = result_of(r)
+    for key in ("k64", "k40_mixed", "k48_K16", "share_total", "counting_filter", "results", "contigs", "visited",
+                "assembly_counters"):
+        assert out[key], (key, out)
+    assert out["launches"]["route_pack"] > 0 and out["launches"]["route_reply"] > 0, out["launches"]
+
+
+@pytest.mark.parametrize("world,route", [(2, "0"), (3, "0"), (2, "2"), (3, "2")])
+def test_ranks_sharing_one_gpu_match_oracle(world, route):
+    """route "2": the (op, counter) pairs are routed to the ranks that own the counters (abg_comm::all_to_all_v, here
+    through gloo on host copies); "0": the all-gather form."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ABG_DIST_ROUTE_MIN=route)
     env.pop("ABG_FORCE_DIST", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(29700 + world), WORKER, "staged"],
@@ -48,6 +62,7 @@ def test_ranks_sharing_one_gpu_match_oracle(world):
         assert out[key], (key, out)
     assert out["n_contigs"] > 10
     assert out["comm_calls"]["all_reduce"] > 0
+    assert (out["comm_calls"].get("all_to_all_v", 0) > 0) == (route != "0"), out["comm_calls"]
 
 
 def _gpus():
