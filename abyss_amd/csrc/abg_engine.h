@@ -77,10 +77,11 @@ struct Config {
 	bool memo = true;
 	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
-	uint32_t guide_stride = 8;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide): at 50x a genome k-mer still gets ~6 hints; 4 -> 8: guide_build 27 -> 14 ms, the walkers +3 (16: +60)
+	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
+	bool overlap_purity = true;            // ... and its tiles judged there too (tile_purity reads nothing but the bins)
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
 	uint32_t dist_route_min_ranks = 4;     // ... from this many ranks on, the (op, counter) pairs are routed to their owners (Engine::insert_tiles_routed); 0: never
 	uint64_t keep_insert_scratch_bytes = 16ull << 30; // PASS 1's scratch is given back before PASS 2 when larger than this
@@ -2610,7 +2611,9 @@ class Engine {
 			be_.wait_side_scope();
 			// (what was staged is now current; the other set takes the next batch)
 			std::swap(h0_, h0_alt_); std::swap(bins_, bins_alt_); std::swap(tcur_, tcur_alt_); stage_flag_ ^= 1u;
+			if (lead_alt_) { std::swap(lead_, lead_alt_); std::swap(opflag_, opflag_alt_); }
 			const bool staged = staged_ok_;
+			purity_done_ = staged && staged_purity_;
 			const uint32_t cur_flag = stage_flag_ ^ 1u; // the flag word the batch just staged wrote
 			// (queued behind this batch's tile kernels -- see insert_range -- so that it runs beside the rounds, not beside them)
 			stage_next_ = nullptr;
@@ -2632,7 +2635,8 @@ class Engine {
 		uint32_t* flag = pend_n_ + 2 + stage_flag_;
 		uint64_t* h0 = h0_alt_;
 		const bool part = dist();
-		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_, opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u };
+		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_alt_ ? lead_alt_ : lead_,
+			opflag_alt_ ? opflag_alt_ : opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u };
 		const uint64_t R = part ? (uint64_t)comm_.world : 1, me = part ? (uint64_t)comm_.rank : 0;
 		if (part && R > cfg_.dist_hash_all_ranks) {
 			// partitioned run: this rank's slice of the hashes on the side stream, the all-gather on the main
@@ -2662,12 +2666,22 @@ class Engine {
 		const uint32_t cpb = (coarse_cap_ + BIN_CHUNK_PAIRS - 1) / BIN_CHUNK_PAIRS;
 		FBinFine f2{ bn, cpb };
 		be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
-		// (tile_purity, which reads nothing but the bins either, stays with the batch: staged as well it made
-		// the side stream the longer branch -- 461 vs 452 ms per configs[1] step)
+		// tile_purity reads nothing but the bins either: judged here too, into a second set of per-op outputs.  (Round 2
+		// measured this as a loss -- the side stream was the longer branch then, 461 vs 452 ms per configs[1] step; with
+		// 12-byte pairs and the one-read fine binning it is the shorter one, and the main stream keeps target, apply, rounds.)
+		staged_purity_ = false;
+		if (lead_alt_) {
+			be_.memset(lead_alt_, 0, T * 4);
+			be_.memset(opflag_alt_, 0, (T + 3) & ~3ull);
+			FTilePurity fp{ te };
+			be_.launch_tiles(ntiles_, fp, "tile_purity");
+			staged_purity_ = true;
+		}
 		be_.side_scope_end();
 		staged_ok_ = true;
 	}
 	bool staged_ok_ = false; uint32_t stage_flag_ = 0;
+	bool purity_done_ = false; // the batch about to be inserted had its tiles judged while it was staged
 	std::function<void()> stage_next_; // stages the next batch; insert_range calls it once its tile kernels are queued
 
 	// ---- PASS 2 on a device-resident packed batch of reads.  results_host (b.n bytes,
@@ -2926,6 +2940,8 @@ class Engine {
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr; uint8_t* pendf_ = nullptr;
 	// a second set of hashes, bins and bin cursors: the batch being staged on the side stream (stage_bins)
 	uint64_t* h0_alt_ = nullptr; TilePair* bins_alt_ = nullptr; uint32_t* tcur_alt_ = nullptr;
+	uint32_t* lead_alt_ = nullptr; uint8_t* opflag_alt_ = nullptr; // ... and, when its tiles are judged there as well, of what tile_purity leaves per op
+	bool staged_purity_ = false;
 	// PASS 2 resources
 	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
@@ -3064,6 +3080,10 @@ class Engine {
 				if (bins_alt_) {
 					tcur_alt_ = (uint32_t*)be_.alloc(ntiles_ * 4 + 64);
 					h0_alt_ = (uint64_t*)be_.alloc((nb + 8 * R + 8) * 8);
+					if (cfg_.overlap_purity && !routed()) {
+						lead_alt_ = (uint32_t*)be_.alloc(nb * 4);
+						opflag_alt_ = (uint8_t*)be_.alloc(nb + 8);
+					}
 				}
 			}
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
@@ -3128,6 +3148,7 @@ class Engine {
 			rsend_ = nullptr;
 		}
 		if (bins_alt_) { be_.free(bins_alt_); be_.free(tcur_alt_); be_.free(h0_alt_); bins_alt_ = nullptr; tcur_alt_ = nullptr; h0_alt_ = nullptr; }
+		if (lead_alt_) { be_.free(lead_alt_); be_.free(opflag_alt_); lead_alt_ = nullptr; opflag_alt_ = nullptr; }
 		if (dres_) { be_.free(dres_); dres_ = nullptr; }
 		be_.free(dlost_);
 		be_.free(h0_);
@@ -3177,8 +3198,11 @@ class Engine {
 			// tile; what is left goes through the reservation rounds below
 			if (!staged) flag_word = 1;
 			TileEnv te{ p_, cnt_, 0, m_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u };
-			be_.memset(lead_, 0, T * 4);
-			be_.memset(opflag_, 0, (T + 3) & ~3ull);
+			const bool judged = staged && purity_done_;
+			if (!judged) {
+				be_.memset(lead_, 0, T * 4);
+				be_.memset(opflag_, 0, (T + 3) & ~3ull);
+			}
 			be_.memset(pend_n_, 0, 8);
 			if (!staged) {
 				be_.memset(tcur_, 0, ntiles_ * 4);
@@ -3192,7 +3216,7 @@ class Engine {
 				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 			}
 			// (the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
-			{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+			if (!judged) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
 			{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
 			be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
@@ -3262,8 +3286,11 @@ class Engine {
 		cnt_partial_ = true;
 		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
 		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u };
-		be_.memset(lead_, 0, T * 4);
-		be_.memset(opflag_, 0, (T + 3) & ~3ull);
+		const bool judged = staged && purity_done_;
+		if (!judged) {
+			be_.memset(lead_, 0, T * 4);
+			be_.memset(opflag_, 0, (T + 3) & ~3ull);
+		}
 		be_.memset(pend_n_, 0, 8);
 		if (staged) {
 			// (hashes gathered and the own range's pairs binned while the batch before went through its rounds: stage_bins)
@@ -3291,7 +3318,7 @@ class Engine {
 			FBinFine f2{ bn, cpb };
 			be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 		}
-		{ FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+		if (!judged) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 		{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
 		c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
 		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }

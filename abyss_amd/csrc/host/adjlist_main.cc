@@ -7,6 +7,13 @@
 #include "abyss_amd.h"
 
 #include <future>
+#include <unistd.h>
+
+// The device comes up on a thread of its own while the contigs are read, and the reader's error paths (a bad character, a
+// duplicate id, ...) leave through exit() like the reference's: exit() then waits here for that thread, so that the static
+// destructors never run beside a HIP runtime that is still starting.
+static std::future<int> g_device_up;
+static void wait_for_device() { if (g_device_up.valid()) g_device_up.wait(); }
 
 int main(int argc, char** argv)
 {
@@ -15,7 +22,9 @@ int main(int argc, char** argv)
 	if (!abgadj::parse_options(argc, argv, opt, &device, &status)) return status;
 	// (the device comes up -- HIP start-up, a quarter of a second -- while the contigs are read)
 	abg_overlap* ov = nullptr;
-	std::future<int> up = std::async(std::launch::async, [&]() { return abg_overlap_create(device, &ov); });
+	atexit(wait_for_device);
+	g_device_up = std::async(std::launch::async, [&]() { return abg_overlap_create(device, &ov); });
+	std::future<int>& up = g_device_up;
 	const bool timing = getenv("ABG_ADJ_TIMING") != nullptr;
 	auto device_ready = [&]() {
 		if (!up.valid()) return;
@@ -50,6 +59,8 @@ int main(int argc, char** argv)
 			fprintf(stderr, "[timing] %-14s %8.3f ms  %llu launches\n", name, ms, (unsigned long long)launches);
 		}
 	}
+	fflush(NULL);
+	if (!getenv("ABG_ORDERLY_EXIT")) _exit(status); // (as abyss-bloom-dbg: the output is written; the kernel reclaims the device faster than we can)
 	abg_overlap_destroy(ov);
 	return status;
 }

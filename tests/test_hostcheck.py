@@ -463,7 +463,6 @@ def test_device_sized_fast_memory_runs_the_chain_searches(monkeypatch):
     """HC_FAST_BYTES=16384: the walkers get what LDS gives them on the device, so successor()'s chain
     searches (chain_true_branches, chain_bulk) and the bulk scratch run as they do there."""
     monkeypatch.setenv("HC_FAST_BYTES", "20480")
-    monkeypatch.setenv("ABG_GUIDE_STRIDE", "4")  # (the default, every 8th read, is tuned for 30-50x read sets; the 4,000-read fixtures are thinly covered)
     for name in ("k64", "k96", "k25_h3_kc3_t40", "k48_K16", "k50_qr11"):
         g = GoldenCase(name)
         kw = g.kwargs()
