@@ -1172,6 +1172,42 @@ ABG_HD unsigned nbr_mask_cached(const Params& p, const SeedTabs& t, const uint8_
 	return sense == SENSE ? (ok & 0xFu) : (ok >> 4);
 	}
 }
+// Both masks of a vertex from ONE probe round, without the cache: bits 0-3 the neighbours in SENSE direction,
+// bits 4-7 the ones in ANTISENSE direction (lanes 0-31 / 32-63 of a cooperative caller).  trueBranch asks for the
+// neighbours ahead of a vertex when it enters it and for the ones behind when it comes back from a dead end below
+// it -- a second dependent round trip per vertex of a failed branch unless both come with the first.
+// (Not under a spaced seed or with more than 8 hash functions: returns 0x100 and the caller asks per direction.)
+template <int NW, bool COOP>
+ABG_HD unsigned nbr_mask_both(const Params& p, const SeedTabs& t, const uint8_t* __restrict__ cnt, const Vtx<NW>& v)
+{
+	if constexpr (MASKED_BUILD<NW>) { (void)t; (void)cnt; (void)v; return 0x100u; }
+	else {
+	if (p.nh > 8) return 0x100u;
+	unsigned ok = 0xFFu;
+	uint64_t fb_s, rb_s, fb_a, rb_a;
+	nbr_base(t, v, p.k, SENSE, fb_s, rb_s);
+	nbr_base(t, v, p.k, ANTISENSE, fb_a, rb_a);
+	if (COOP) {
+		const unsigned lane = lane_id(), s = lane >> 5, b = (lane >> 3) & 3u, i = lane & 7u;
+		uint64_t fh, rh;
+		nbr_hash(t, s ? ANTISENSE : SENSE, s ? fb_a : fb_s, s ? rb_a : rb_s, b, fh, rh);
+		const uint64_t h = rh < fh ? rh : fh;
+		bool bad = false;
+		if (i < p.nh) bad = probe_c(p, cnt, pos_i(p, h, i)) < p.kc;
+		const uint64_t bm = wave_ballot(bad);
+#pragma unroll
+		for (unsigned q = 0; q < 8; q++)
+			if ((bm >> (8 * q)) & 0xFFu) ok &= ~(1u << q);
+	} else {
+		for (unsigned q = 0; q < 8; q++) {
+			uint64_t fh, rh;
+			nbr_hash(t, q < 4 ? SENSE : ANTISENSE, q < 4 ? fb_s : fb_a, q < 4 ? rb_s : rb_a, q & 3u, fh, rh);
+			if (!solid_contains(p, cnt, rh < fh ? rh : fh)) ok &= ~(1u << q);
+		}
+	}
+	return ok;
+	}
+}
 template <int NW>
 ABG_HD Vtx<NW> nbr_vertex_lean(const Params& p, const SeedTabs& t, const Vtx<NW>& v, int sense, unsigned b)
 {
@@ -1442,6 +1478,7 @@ struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
 	Vtx<NW> v;
 	uint8_t mask, next;
 };
+constexpr uint32_t WALK_DBG_N = 20; // per-walker profiling counters (ABG_WALK_DEBUG)
 constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
 constexpr uint32_t LA_FAST = 96;      // ... of which this many live in a walker's fast memory
 // The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on
@@ -1471,6 +1508,7 @@ struct SearchScratch {
 	uint64_t dbg_chain;    // profiling aid: clock ticks in chain_true_branches (when dbg_on)
 	uint32_t dbg_on;
 	uint64_t dbg_la; uint32_t dbg_la_calls; // ... in the lookAhead calls of trueBranch
+	uint64_t dbg_mask, dbg_memo; uint32_t dbg_mask_n; // ... waiting for the neighbour masks of trueBranch's vertices (and how many probe rounds), in the memo
 	LAFrame<NW>* la;       // [FP_TRIM + 1] lookAhead frames (LDS on the device: private arrays indexed at
 	                       // run time would live in per-lane scratch, 64 copies per cooperative wave)
 	VKey* la_visited;      // [LA_MAX_VISITED] (global memory)
@@ -1586,6 +1624,9 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 	unsigned cdepth = 0;
 	int cdir = (int)uni32<COOP>((uint32_t)dir0);
 	for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		const uint64_t te0 = sc.dbg_on ? wall_clock64() : 0;
+#endif
 		// ---- entry of a call (u, v=cv, depth=cdepth, dir=cdir)
 		// visited.find(v): scan the keys of the active calls (no early exit: the loads pipeline)
 		bool on_stack = false;
@@ -1611,7 +1652,21 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 			f.v = cv;
 			f.depth = (uint16_t)cdepth; f.dir = (uint8_t)cdir; f.stage = 0; f.next = 0;
 			f.have_other = 0; f.mask_other = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+			const uint64_t tm0 = sc.dbg_on ? wall_clock64() : 0;
+			if (sc.dbg_on) sc.dbg_memo += tm0 - te0; // (ABG_WALK_DEBUG: the entry of a call up to its probe round, booked under "memo")
+#endif
+			const unsigned both = mcache ? 0x100u : nbr_mask_both<NW, COOP>(p, tabs, cnt, cv);
+			if (both < 0x100u) {
+				// (both directions from the one round trip: the way back from a dead end does not wait again)
+				f.mask_same = (uint8_t)(cdir == FORWARD ? (both & 0xFu) : (both >> 4));
+				f.mask_other = (uint8_t)(cdir == FORWARD ? (both >> 4) : (both & 0xFu));
+				f.have_other = 1;
+			} else
 			f.mask_same = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, cv, cdir == FORWARD ? SENSE : ANTISENSE, mcache);
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (sc.dbg_on) { sc.dbg_mask += wall_clock64() - tm0; sc.dbg_mask_n++; }
+#endif
 		}
 		// ---- resume frames until one of them makes a new call
 		bool called = false;
@@ -1651,8 +1706,16 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
 				f.next = 0;
-				f.mask_other = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE, mcache);
-				f.have_other = 1;
+				if (!uni32<COOP>((uint32_t)f.have_other)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+					const uint64_t tm0 = sc.dbg_on ? wall_clock64() : 0;
+#endif
+					f.mask_other = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE, mcache);
+#if defined(__HIP_DEVICE_COMPILE__)
+					if (sc.dbg_on) { sc.dbg_mask += wall_clock64() - tm0; sc.dbg_mask_n++; }
+#endif
+					f.have_other = 1;
+				}
 			}
 			// stage 1: other-direction children, skipping the vertex we came from
 			{

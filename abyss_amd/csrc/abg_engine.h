@@ -79,6 +79,7 @@ struct Config {
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
+	bool async_guide = false;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide): measured 862 vs 866 ms per step, i.e. nothing -- the first launch's walkers pay for the hints they do not find yet
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
 	bool overlap_purity = true;            // ... and its tiles judged there too (tile_purity reads nothing but the bins)
@@ -2710,6 +2711,7 @@ class Engine {
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
 		deliveries_wait(); // (the last batch's contigs are with the caller)
 		be_.sync_side();
+		be_.wait_side_scope(); // (the guide's build, if it went to the side stream)
 		pre_n_ = 0; prefetch_ = nullptr;
 		use_ctx(0);
 		guide_.tab = nullptr; // its hints point into this call's reads
@@ -2775,10 +2777,16 @@ class Engine {
 		}
 		be_.memset(guide_tab_, 0, 8ull << log2);
 		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
+		// The hints are plain 8-byte stores that the walkers check against the read they point to: a table still being
+		// filled is a table with fewer hints, nothing else.  So the build goes to the side stream and PASS 2 starts beside
+		// it (the first batch's classification, pre-search and heaviest walkers do not look at the guide much);
+		// assemble_packed waits for it before it returns.
+		if (cfg_.async_guide) be_.side_scope_begin("guide_build");
 		dispatch_nw([&](auto nw) {
 			FGuideBuild<decltype(nw)::value> f{ p2_, b, cnt2_, guide_tab_, guide_.mask, cfg_.guide_stride };
 			be_.launch_wave(sampled, f, "guide_build");
 		});
+		if (cfg_.async_guide) be_.side_scope_end();
 		guide_.tab = guide_tab_;
 		guide_slots_ = guide_.mask + 1;
 	}
@@ -4148,21 +4156,21 @@ class Engine {
 			be_.launch_wave(nc, f, "read_prep");
 		}
 		r.debug = getenv("ABG_WALK_DEBUG") != nullptr;
-		if (r.debug) { dbg_ = (uint64_t*)be_.alloc(nc * 128ull); be_.memset(dbg_, 0, nc * 128ull); }
+		if (r.debug) { dbg_ = (uint64_t*)be_.alloc(nc * 8ull * WALK_DBG_N); be_.memset(dbg_, 0, nc * 8ull * WALK_DBG_N); }
 		r.base = 0; r.round_started = false;
 	}
 	void dump_walkers(BatchRun& r, const char* what, uint32_t nwalk)
 	{
 		if (!r.debug) return;
 		const uint32_t nc = r.nc;
-		std::vector<uint64_t> d(nc * 16ull);
-		be_.d2h(d.data(), dbg_, nc * 128ull);
-		uint64_t best = 0, bi = 0, nn = 0, sum[16] = { 0 };
+		std::vector<uint64_t> d(nc * (uint64_t)WALK_DBG_N);
+		be_.d2h(d.data(), dbg_, nc * 8ull * WALK_DBG_N);
+		uint64_t best = 0, bi = 0, nn = 0, sum[WALK_DBG_N] = { 0 };
 		for (uint32_t i = 0; i < nc; i++) {
-			const uint64_t* x = &d[i * 16ull];
+			const uint64_t* x = &d[i * (uint64_t)WALK_DBG_N];
 			if (!x[0]) continue;
 			nn++;
-			for (int q = 0; q < 16; q++) sum[q] += x[q];
+			for (int q = 0; q < (int)WALK_DBG_N; q++) sum[q] += x[q];
 			if (x[0] > best) { best = x[0]; bi = i; }
 		}
 		auto line = [&](const char* tag, const uint64_t* x) {
@@ -4173,13 +4181,15 @@ class Engine {
 		};
 		fprintf(stderr, "[walkdbg] %s n=%u ran=%llu\n", what, nwalk, (unsigned long long)nn);
 		line("sum", sum);
-		fprintf(stderr, "[walkdbg]   lookAhead inside trueBranch: %.2f ms in %llu calls; bulk examine phase %.2f ms\n", sum[13] / 1e5, (unsigned long long)sum[14], sum[15] / 1e5);
+		fprintf(stderr, "[walkdbg]   lookAhead inside trueBranch: %.2f ms in %llu calls; bulk examine phase %.2f ms; trueBranch waiting for neighbour masks %.2f ms in %llu probe rounds; call entries %.2f ms\n", sum[13] / 1e5, (unsigned long long)sum[14], sum[15] / 1e5,
+		    sum[16] / 1e5, (unsigned long long)sum[17], sum[18] / 1e5);
 		{
-			const uint64_t* x = &d[bi * 16ull];
-			fprintf(stderr, "[walkdbg]   slowest walker's lookAhead: %.2f ms in %llu calls\n", x[13] / 1e5, (unsigned long long)x[14]);
+			const uint64_t* x = &d[bi * (uint64_t)WALK_DBG_N];
+			fprintf(stderr, "[walkdbg]   slowest walker's lookAhead: %.2f ms in %llu calls; its trueBranch: %.2f ms waiting for neighbour masks (%llu probe rounds), %.2f ms in call entries (identity, on-stack scan, frame push)\n", x[13] / 1e5, (unsigned long long)x[14],
+			    x[16] / 1e5, (unsigned long long)x[17], x[18] / 1e5);
 		}
-		line("slowest", &d[bi * 16ull]);
-		be_.memset(dbg_, 0, nc * 128ull);
+		line("slowest", &d[bi * (uint64_t)WALK_DBG_N]);
+		be_.memset(dbg_, 0, nc * 8ull * WALK_DBG_N);
 	}
 
 	// Prologue of a round over the candidates [r.base, nc) -- nothing of them walked yet -- up to and

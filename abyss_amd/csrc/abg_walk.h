@@ -836,7 +836,7 @@ ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& sc
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
 	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
 	sc.overflow = 0;
-	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
+	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0; sc.dbg_mask = 0; sc.dbg_mask_n = 0; sc.dbg_memo = 0;
 	sc.coop = e.coop;
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 }
@@ -1078,11 +1078,11 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 #else
 		const uint64_t t_end = 0;
 #endif
-		uint64_t* d = e.dbg + (uint64_t)c * 16;
+		uint64_t* d = e.dbg + (uint64_t)c * WALK_DBG_N;
 		d[0] = t_end - t_start; d[1] = total_steps; d[2] = sc.dbg_search; d[3] = sc.dbg_calls;
 		d[4] = sc.dbg_nodes; d[5] = w.t_bulk; d[6] = contig; d[7] = w.t_post;
 		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
-		d[13] = sc.dbg_la; d[14] = sc.dbg_la_calls; d[15] = w.t_bp[1];
+		d[13] = sc.dbg_la; d[14] = sc.dbg_la_calls; d[15] = w.t_bp[1]; d[16] = sc.dbg_mask; d[17] = sc.dbg_mask_n; d[18] = sc.dbg_memo;
 	}
 }
 
