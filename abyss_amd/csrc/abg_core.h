@@ -689,6 +689,8 @@ ABG_HD Kmer<NW> gather_kmer(unsigned k, bool coop, Get get)
 
 // A value that is the same in every lane of a cooperative wave, read back through lane 0 so that
 // the compiler knows it (scalar registers, scalar ALU); the identity for other callers.
+// (uni32 / uni64 are not only a hint: some callers hold a value in lane 0 only -- a ticket drawn by one lane -- and
+// broadcast it this way.  A build that made them the identity walked garbage.)
 template <bool COOP> ABG_HD uint32_t uni32(uint32_t v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
