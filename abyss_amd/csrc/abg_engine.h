@@ -82,6 +82,7 @@ struct Config {
 	bool async_guide = false;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide): measured 862 vs 866 ms per step, i.e. nothing -- the first launch's walkers pay for the hints they do not find yet
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
+	bool stage_early = false;              // ... starting beside this batch's op_target / tile_apply instead of beside its rounds
 	bool overlap_purity = true;            // ... and its tiles judged there too (tile_purity reads nothing but the bins)
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
 	uint32_t dist_route_min_ranks = 4;     // ... from this many ranks on, the (op, counter) pairs are routed to their owners (Engine::insert_tiles_routed); 0: never
@@ -3212,6 +3213,8 @@ class Engine {
 				be_.memset(opflag_, 0, (T + 3) & ~3ull);
 			}
 			be_.memset(pend_n_, 0, 8);
+			// (the next batch's staging from the START of this batch's main-stream work, not from after tile_apply)
+			if (cfg_.stage_early && stage_next_) { stage_next_(); stage_next_ = nullptr; }
 			if (!staged) {
 				be_.memset(tcur_, 0, ntiles_ * 4);
 				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0, hash_run_ }; be_.launch((T + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
