@@ -576,6 +576,7 @@ struct TileEnv {
 	uint8_t* pendf;                   // [T] 1: the op goes through the reservation rounds (FOpTarget / FDistTarget)
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
 	uint32_t benign = 1;              // op_verdict: k-mers that cannot write their shared counters are settled by the tiles too
+	uint32_t lead_js = 2;             // tile_purity: pairs of the first lead_js hash functions write `lead` (a partitioned run: all -- every rank must know)
 };
 // canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
 // rolled (NTC64, nthash.hpp:242-257,275-279).  Under a spaced seed the rolled state is the UNMASKED
@@ -674,14 +675,16 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 // pairs per COARSE bin (a run of 2^cshift tiles) in LDS, reserves room in every coarse bin with one
 // global atomic, and writes the pairs there in runs.  Pass 2: a workgroup takes BIN_CHUNK_PAIRS
 // pairs of one coarse bin and does the same over that bin's tiles.
-constexpr uint32_t BIN_CHUNK_OPS = 2048, BIN_CHUNK_PAIRS = 4096, BIN_MAX_COARSE = 2048, BIN_MAX_FINE = 4096;
+// (8192 ops a workgroup: its ~70 pairs per coarse bin leave as runs of ~850 bytes -- at 2048 ops the runs were 216 bytes and the
+// bins' write traffic 2.2 times their size)
+constexpr uint32_t BIN_CHUNK_OPS = 8192, BIN_CHUNK_PAIRS = 4096, BIN_MAX_COARSE = 2048, BIN_MAX_FINE = 4096;
 struct BinEnv {
 	TileEnv e; uint64_t T;
 	TilePair* coarse; uint32_t ccap; uint32_t* ccur; // [ncoarse][ccap], [ncoarse]
 	uint32_t cshift, ncoarse;
 };
 struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoarse words
-	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 256, PER = BIN_CHUNK_OPS / THREADS, MAXH = 4;
+	static constexpr uint32_t FAST = 2 * BIN_MAX_COARSE * 4, THREADS = 1024, PER = BIN_CHUNK_OPS / THREADS, MAXH = 4;
 	BinEnv b;
 	template <class Sync> ABG_HDN void operator()(uint64_t c, void* fast, Sync& sy) const
 	{
@@ -877,7 +880,10 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 			return;
 		}
 		// only this k-mer's ops touch the counter, one pair each: every op of the k-mer learns how many they
-		// are; the earliest leads them
+		// are; the earliest leads them.  An op's pure counters all say the same, and every one of these stores is a
+		// 32-byte write transaction to a random place: the first two hash functions speak for all (an op whose first
+		// two counters are BOTH shared learns nothing and goes to the rounds -- op_verdict reads n == 0 as that)
+		if (tp_j(r) >= e.lead_js) return;
 		const bool first_op = (uint32_t)(first[s] >> 12) == t;
 		e.lead[t] = (inf & 0x7FFFFFFFu) | (first_op ? LEAD_BIT : 0u);
 	});
@@ -2638,7 +2644,7 @@ class Engine {
 		uint64_t* h0 = h0_alt_;
 		const bool part = dist();
 		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_alt_ ? lead_alt_ : lead_,
-			opflag_alt_ ? opflag_alt_ : opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u };
+			opflag_alt_ ? opflag_alt_ : opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u, part ? 16u : 2u };
 		const uint64_t R = part ? (uint64_t)comm_.world : 1, me = part ? (uint64_t)comm_.rank : 0;
 		if (part && R > cfg_.dist_hash_all_ranks) {
 			// partitioned run: this rank's slice of the hashes on the side stream, the all-gather on the main
@@ -3296,7 +3302,7 @@ class Engine {
 	{
 		cnt_partial_ = true;
 		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u, 16u };
 		const bool judged = staged && purity_done_;
 		if (!judged) {
 			be_.memset(lead_, 0, T * 4);
@@ -3366,7 +3372,7 @@ class Engine {
 		const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
 		const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk), nown = b - a;
 		uint32_t* rflag = rcur_ + MAX_RANKS; // [0] some room ran out on this rank
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u, 16u };
 		be_.memset(lead_, 0, T * 4);
 		be_.memset(opflag_, 0, (T + 3) & ~3ull);
 		be_.memset(tcur_, 0, ntiles_ * 4);
