@@ -80,6 +80,7 @@ struct Config {
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
 	bool async_guide = false;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide): measured 862 vs 866 ms per step, i.e. nothing -- the first launch's walkers pay for the hints they do not find yet
+	bool link_duplicates = true;      // the commit decides a contig's copies among a batch's records by their original (Engine::link_duplicates)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
 	bool stage_early = false;              // ... starting beside this batch's op_target / tile_apply instead of beside its rounds
@@ -1465,6 +1466,7 @@ ABG_HDN uint64_t read_kmer_hash(const Params& p, const Batch& b, uint64_t r, uin
 	return scratch_hash(p, [&](unsigned i) { return batch_base(b, r, j + i); });
 }
 constexpr uint32_t PREP_RUN = 8; // consecutive k-mers per lane
+ABG_HD uint64_t dup_mix(uint64_t x) { x ^= x >> 31; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29; x *= 0x9E3779B97F4A7C15ULL; x ^= x >> 32; return x | 1; }
 template <int NW>
 struct FReadPrep { // canonical hashes of the candidates' read k-mers (one wave per candidate)
 	Params p; Batch b; const uint32_t* cand_read; const uint64_t* rkoff; uint64_t* rkh; uint32_t first;
@@ -1490,10 +1492,76 @@ struct FContigPrep { // per contig record: k-mer hashes for the commit and (with
 		uint64_t* out = kh + rec.seq_off;
 		uint32_t cnk = rec.len - p.k + 1;
 		uint32_t cov = 0; // getSeqAbsoluteKmerCoverage (bloom-dbg.h:92-109): a pure function of the solid filter
+		uint64_t fp = 0;  // (see link_duplicates)
 		for (uint32_t j0 = lane * PREP_RUN; j0 < cnk; j0 += nlanes * PREP_RUN)
 			kmer_hash_run(p, [&](unsigned q) { return (unsigned)seq[q]; }, j0, j0 + PREP_RUN < cnk ? j0 + PREP_RUN : cnk,
-			    [&](uint32_t j, uint64_t h) { out[j] = h; if (with_cov) cov += solid_min_count(p, cnt, h); });
+			    [&](uint32_t j, uint64_t h) { out[j] = h; fp += dup_mix(h); if (with_cov) cov += solid_min_count(p, cnt, h); });
 		if (cov) atomic_add_u32(&rec.coverage, cov);
+		if (fp) atomic_add_u64(&rec.fp, fp);
+	}
+};
+
+// ---- copies of one contig among a batch's records (Engine::link_duplicates).  The candidates of a batch are walked side by
+// side, nothing committed between them, so a unitig reached from several reads of the batch is recorded once per read: on
+// configs[1] 166 M record k-mers for 31.7 M unitig k-mers.  The commit decides every record, and every decision about a long
+// contig is made of one probe (and one time stamp) per k-mer and hash function.  A record D whose k-mers are exactly those of a
+// record O of a LOWER candidate shares O's fate where O's is known: if O is inserted -- at an earlier position -- every bit of D
+// is set before D's turn, so D is dropped; what was settled for O ahead of the commit (all k-mers visited already) holds for D.
+// Only where O is not inserted (its read turned out visited, or it was dropped itself) is D looked at bit by bit.
+struct FDupKeys { // sort key of every record: contigs too short for the bit test, and records already linked, never group
+	const ContigRec* recs; uint32_t k; uint64_t* key; uint32_t* val;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const ContigRec& r = recs[i];
+		key[i] = r.len < k + FP_TRIM - 1 ? ~0ULL - i : dup_mix(r.fp ^ ((uint64_t)r.len << 40));
+		val[i] = (uint32_t)i;
+	}
+};
+struct FDupLink { // one sorted position per item: the lowest-candidate record of its group of equal keys
+	ContigRec* recs; const uint64_t* key; const uint32_t* val; uint64_t n; uint32_t first_new; // records >= first_new are linked
+	ABG_HD void operator()(uint64_t q, uint32_t) const
+	{
+		const uint32_t me = val[q];
+		if (me < first_new) return;
+		const uint64_t k = key[q];
+		uint64_t g = q;
+		for (unsigned s = 0; s < 64 && g > 0 && key[g - 1] == k; s++) g--;
+		uint32_t best = REC_END, best_cand = recs[me].cand;
+		for (unsigned s = 0; s < 128 && g < n && key[g] == k; s++, g++) {
+			const uint32_t o = val[g];
+			if (o != me && recs[o].cand < best_cand && recs[o].len == recs[me].len && recs[o].fp == recs[me].fp) { best = o; best_cand = recs[o].cand; }
+		}
+		recs[me].dup_of = best;
+	}
+};
+struct FDupVerify { // one wave per record: the link holds only if the two hash sequences are equal, read the same or the opposite way
+	ContigRec* recs; const uint64_t* kh; uint32_t k; uint32_t first_new;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		ContigRec& d = recs[first_new + i];
+		const uint32_t o = d.dup_of;
+		if (o == REC_END) return;
+		const uint64_t* a = kh + d.seq_off; const uint64_t* b = kh + recs[o].seq_off;
+		const uint32_t nk = d.len - k + 1;
+		bool fwd = true, rev = true;
+		for (uint32_t j = lane; j < nk; j += nlanes) { const uint64_t x = a[j]; fwd = fwd & (x == b[j]); rev = rev & (x == b[nk - 1 - j]); }
+		fwd = wave_all_lanes(fwd, nlanes); rev = wave_all_lanes(rev, nlanes);
+		if (!fwd && !rev && lane == 0) d.dup_of = REC_END;
+	}
+};
+struct FDupInherit { // after FPreCommit: what was settled ahead for the original holds for its copies (one candidate per item)
+	const uint32_t* status; const uint32_t* first_rec; ContigRec* recs; uint32_t first, c_begin;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = first + (uint32_t)i;
+		if (status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
+			ContigRec& rec = recs[ri];
+			if (rec.dup_of == REC_END) continue;
+			const ContigRec& o = recs[rec.dup_of];
+			if (o.cand < c_begin) { rec.dup_of = REC_END; continue; } // (committed in an earlier call: its bits are in the filter, the ordinary tests see them)
+			if (o.pre_redundant) rec.pre_redundant = 1;
+		}
 	}
 };
 // Settles, in parallel and against the current visited snapshot, what the ordered commit
@@ -1521,6 +1589,7 @@ struct FPreCommit {
 	ContigRec* recs; const uint8_t* vis; const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff;
 	uint8_t* read_flag; uint32_t first;
 	uint64_t lo, span; uint8_t* part_c; uint8_t* part_r; // (whole filter: 0, ~0, NULL, NULL)
+	uint32_t skip_dups; // records linked to a lower candidate's copy (in this commit's range) inherit its verdict (FDupInherit)
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
 		uint32_t c = first + (uint32_t)i;
@@ -1540,6 +1609,7 @@ struct FPreCommit {
 			ContigRec& rec = recs[ri];
 			uint32_t cnk = rec.len - p.k + 1;
 			if (rec.len < p.k + FP_TRIM - 1 || rec.pre_redundant) continue;
+			if (skip_dups && rec.dup_of != REC_END && recs[rec.dup_of].cand >= first) continue;
 			bool red = true;
 			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains_owned(p, vis, kh[rec.seq_off + j], lo, span);
 			red = wave_all_lanes(red, nlanes);
@@ -2016,8 +2086,23 @@ struct FPcStamp { // commit positions, the optimistic first assumption, the list
 			rec.time = t;
 			const bool is_short = rec.len < e.p.k + FP_TRIM - 1;
 			rec.ins = (!e.read_flag[c] && (is_short || !rec.pre_redundant)) ? 1u : 0u;
+			if (rec.ins && rec.dup_of != REC_END) {
+				// a copy of a lower candidate's contig: dropped if that one is (assumed) inserted
+				const ContigRec& o = e.recs[rec.dup_of];
+				if (!e.read_flag[o.cand] && !o.pre_redundant) rec.ins = 0;
+			}
+			rec.ins_prev = rec.ins;
 			if (is_short) e.short_list[atomic_add_u32(&e.scal[2], 1)] = ri;
 		}
+	}
+};
+struct FPcSnapshot { // ins as the pass before left it (the copies of a contig decide by their original's)
+	ParCommit e;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		if (e.status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) e.recs[ri].ins_prev = e.recs[ri].ins;
 	}
 };
 struct FPcTimeMin { // T: one wave per candidate
@@ -2124,6 +2209,8 @@ struct FPcDecide { // one wave per candidate: re-decide the read and its contigs
 					      pc_end_before(e, canonical_end_key(e.p, seq + rec.len - k), rec.time);
 				} else if (rec.pre_redundant) {
 					red = true;
+				} else if (rec.dup_of != REC_END && e.recs[rec.dup_of].ins_prev) {
+					red = true; // its lower copy holds every one of its bits, earlier (ContigRec::dup_of)
 				} else {
 					const uint64_t* ch = e.kh + rec.seq_off;
 					const uint32_t cnk = rec.len - k + 1;
@@ -3628,7 +3715,7 @@ class Engine {
 		cs.break_at = c_begin; cs.pad_ = 0; cs.cend_count = cend_count_;
 		be_.h2d(cstate_, &cs, sizeof cs);
 		{
-			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr };
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr, 0u };
 			be_.launch_wave(c_end - c_begin, f, "precommit");
 		}
 		CommitEnv<NW> e;
@@ -3758,6 +3845,7 @@ class Engine {
 				be_.launch(1, f, "pc_short");
 			}
 			be_.memset(e.scal, 0, 4);
+			if (round && !part && cfg_.link_duplicates) { FPcSnapshot f{ e }; be_.launch(n, f, "pc_stamp"); }
 			{ FPcTimeMin f{ e }; be_.launch_wave(n, f, "pc_timemin"); }
 			if (part) {
 				be_.memset(part_buf, 1, (uint64_t)n0 + nrec);
@@ -3896,8 +3984,24 @@ class Engine {
 		if (nrec > prepped) {
 			FContigPrep<NW> f{ p_, cnt_, recs_, prepped, pool_, kh_, use_par_commit() ? 0u : 1u };
 			be_.launch_wave(nrec - prepped, f, "contig_prep");
+			if (use_par_commit()) link_duplicates(prepped, nrec);
 			prepped = nrec;
 		}
+	}
+	// Links every new long record (index >= first_new) to the lowest candidate's record with the same k-mers, if there is one
+	// (FDupKeys / FDupLink / FDupVerify): a sort of the records' fingerprints, a look at each group of equal ones, and a comparison
+	// of the two hash sequences for every link.  Plain (not partitioned) runs with the parallel commit only.
+	void link_duplicates(uint32_t first_new, uint32_t nrec)
+	{
+		if (!cfg_.link_duplicates || dist() || nrec <= first_new || nrec < 2) return;
+		uint64_t* key = (uint64_t*)be_.alloc(nrec * 16ull); uint64_t* key2 = key + nrec;
+		uint32_t* val = (uint32_t*)be_.alloc(nrec * 8ull); uint32_t* val2 = val + nrec;
+		{ FDupKeys f{ recs_, p_.k, key, val }; be_.launch(nrec, f, "dup_link"); }
+		be_.sort_pairs_u64_u32(key, key2, val, val2, nrec);
+		{ FDupLink f{ recs_, key2, val2, nrec, first_new }; be_.launch(nrec, f, "dup_link"); }
+		{ FDupVerify f{ recs_, kh_, p_.k, first_new }; be_.launch_wave(nrec - first_new, f, "dup_link"); }
+		be_.sync(); // (the sort's buffers go back)
+		be_.free(key); be_.free(val);
 	}
 	// partitioned run: the records this rank's walkers appended after the merged ones
 	template <int NW>

@@ -137,6 +137,9 @@ struct ContigRec {
 	uint64_t contig_id;   // filled by the commit
 	uint32_t time;        // parallel commit: position of this contig in the commit order of its range
 	uint32_t ins;         // parallel commit: the contig is (assumed to be) inserted into the visited set
+	uint32_t ins_prev;    // ... as the pass before left it (FPcSnapshot: what the copies of a contig look at)
+	uint32_t dup_of;      // a record of a LOWER candidate holding exactly this contig's k-mers (REC_END: none; Engine::link_duplicates)
+	uint64_t fp;          // sum of mixed k-mer hashes: equal for equal k-mer multisets (FContigPrep)
 };
 constexpr uint32_t REC_END = 0xFFFFFFFFu;
 
@@ -1025,6 +1028,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			rec.left_ext = lext; rec.right_ext = rext;
 			rec.left_code = (uint8_t)lcode; rec.right_code = (uint8_t)rcode;
 			rec.redundant = 0; rec.pre_redundant = 0; rec.coverage = 0; rec.contig_id = ~0ULL;
+			rec.ins_prev = 0; rec.dup_of = REC_END; rec.fp = 0;
 			if (last == REC_END) first = ri; else e.recs[last].next = ri;
 			last = ri;
 			// ---- assembledKmers.insert(contigPath): vertices trimmed off the ends are not

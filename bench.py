@@ -351,7 +351,7 @@ def main() -> int:
     names = ["hash_bin_staged", "hash_ops", "bin_coarse", "bin_fine", "tile_purity", "op_target", "dist_pack", "tile_apply", "claim_list", "guide_build",
              "hash_claim", "insert_round", "insert_retry", "insert_apply", "compact", "drain_vals", "drain_load",
              "insert_drain", "classify", "read_prep", "presearch_scan", "presearch", "walk", "rewalk", "merge_fix", "comm_all_reduce", "comm_all_gather",
-             "share_fix", "route_pack", "route_reply", "route_tgt", "route_pend", "comm_all_to_all",
+             "share_fix", "route_pack", "route_reply", "route_tgt", "route_pend", "comm_all_to_all", "dup_link",
              "reclassify", "contig_prep", "predict", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin",
              "pc_decide", "pc_break", "pc_apply", "pc_write", "popcount"]
     prof = {nm: g.profile_get(nm) for nm in names} if (warm_prof and g is not None) else None
@@ -420,7 +420,7 @@ def main() -> int:
         "classify": (["classify", "reclassify"],
                      (per_kmer_bases + 2 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers_all * share),
         "walk": (["presearch_scan", "presearch", "walk", "rewalk"], 8 * H * unitig_kmers * share),
-        "commit": (["contig_prep", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin", "pc_decide",
+        "commit": (["contig_prep", "dup_link", "precommit", "commit", "pc_count", "pc_stamp", "pc_short", "pc_timemin", "pc_decide",
                     "pc_break", "pc_apply", "pc_write"], 4 * H * unitig_kmers),
     }
     per_kernel = {}
