@@ -518,13 +518,11 @@ def main() -> int:
             out["config"]["note"] = comm_note
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1, K=a.K)
-            # like for like on the FULL read set: the unmodified reference at -j<all cores> is a 4-minute run, measured
-            # once on the GPU box and REPLAYED here from the committed file (not measured in this run)
-            src = os.path.join(ROOT, "profiles", "r02_cpu_reference_config1.json")
+            # like for like on the FULL read set: the unmodified reference at -j<all cores> is a 4-6 minute run, measured once on a
+            # GPU box's host ON THE READ SET TIMED HERE (tools/gpu_cpu_reference_full.sh) and REPLAYED from the committed file
+            src = os.path.join(ROOT, "profiles", "r04_cpu_reference_config1.json")
             if os.path.exists(src) and a.config == 1 and a.pairs == 5_000_000:
-                out["cpu_baseline"]["reference_full_config"] = dict(json.load(open(src)), replayed=True, source="profiles/r02_cpu_reference_config1.json",
-                                                                    note="measured at commit 27c3426 on the read set of synth.make_read_set (the sequential generator); "
-                                                                         "same recipe and size as the one timed here")
+                out["cpu_baseline"]["reference_full_config"] = dict(json.load(open(src)), replayed=True, source="profiles/r04_cpu_reference_config1.json")
         if a.invariants and g is not None:
             import hashlib
             pc, fpc = g.counting_stats()
