@@ -16,6 +16,7 @@
 // Like abg_core.h, everything here is ABG_HD and written against the backend interface, so
 // tests/hostcheck runs the same code serially; the product runs it on the GPU only.
 #pragma once
+#include <vector>
 
 #include "abg_core.h"
 
@@ -127,17 +128,23 @@ class OverlapJoin {
 		be_.memset(off_, 0, (nv_ + 1) * 8);
 		if (!n) { ne_ = 0; return; }
 		const size_t kb = (size_t)n * W * 8;
-		uint64_t* dh = (uint64_t*)be_.alloc(kb);
-		uint64_t* dt = (uint64_t*)be_.alloc(kb);
+		// (temporaries of this call: given back whichever way it ends -- an allocation or a launch that fails throws)
+		struct Temps {
+			BE& be; std::vector<void*> v;
+			void* get(size_t bytes) { void* p = be.alloc(bytes); v.push_back(p); return p; }
+			~Temps() { for (void* p : v) be.free(p); }
+		} tmp{ be_, {} };
+		uint64_t* dh = (uint64_t*)tmp.get(kb);
+		uint64_t* dt = (uint64_t*)tmp.get(kb);
 		be_.h2d(dh, head, kb);
 		be_.h2d(dt, tail, kb);
-		uint64_t* pk = (uint64_t*)be_.alloc(2 * kb);
-		uint64_t* sk = (uint64_t*)be_.alloc(2 * kb);
-		uint64_t* hp = (uint64_t*)be_.alloc(nv_ * 8);
-		uint64_t* hs = (uint64_t*)be_.alloc(nv_ * 8);
-		uint64_t* hs2 = (uint64_t*)be_.alloc(nv_ * 8);
-		uint32_t* id = (uint32_t*)be_.alloc(nv_ * 4);
-		uint32_t* id2 = (uint32_t*)be_.alloc(nv_ * 4);
+		uint64_t* pk = (uint64_t*)tmp.get(2 * kb);
+		uint64_t* sk = (uint64_t*)tmp.get(2 * kb);
+		uint64_t* hp = (uint64_t*)tmp.get(nv_ * 8);
+		uint64_t* hs = (uint64_t*)tmp.get(nv_ * 8);
+		uint64_t* hs2 = (uint64_t*)tmp.get(nv_ * 8);
+		uint32_t* id = (uint32_t*)tmp.get(nv_ * 4);
+		uint32_t* id2 = (uint32_t*)tmp.get(nv_ * 4);
 		be_.launch(n, FOverlapKeys{ dh, dt, km1, W, pk, sk, hp, hs, id }, "overlap_keys");
 		be_.sort_pairs_u64_u32(hs, hs2, id, id2, nv_);
 		const OverlapEnv e{ pk, sk, hp, hs2, id2, nv_, W, ss ? 1 : 0 };
@@ -147,7 +154,6 @@ class OverlapJoin {
 		tgt_ = (uint32_t*)be_.alloc(ne_ ? ne_ * 4 : 4);
 		be_.launch(nv_, FOverlapFill{ e, off_, tgt_ }, "overlap_fill");
 		be_.sync();
-		for (void* p : { (void*)dh, (void*)dt, (void*)pk, (void*)sk, (void*)hp, (void*)hs, (void*)hs2, (void*)id, (void*)id2 }) be_.free(p);
 	}
 	uint64_t vertices() const { return nv_; }
 	uint64_t edges() const { return ne_; }

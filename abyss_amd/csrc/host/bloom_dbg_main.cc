@@ -518,10 +518,12 @@ int main(int argc, char** argv)
 		}
 		if (abg_keep_reads(ctx, 1, expect / 2) != ABG_OK) packed_keep = false; // (more than the device should hold: the host keeps them)
 	}
-	std::vector<Chunk> cur_v, loading_v; // packed_keep: the chunk being filled / loaded, as the parser's blocks
+	const bool packed_path = packed_keep; // (how PASS 1's chunks are fed; packed_keep may be given up on the way)
+	std::vector<Chunk> cur_v, loading_v; // packed_path: the chunk being filled / loaded, as the parser's blocks
 	size_t cur_bases = 0;
 	size_t kept_bytes = 0;
-	const size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE) / gpus; // (every rank keeps its own copy)
+	size_t keep_limit = (size_t)sysconf(_SC_PHYS_PAGES) / 4 * (size_t)sysconf(_SC_PAGE_SIZE) / gpus; // (every rank keeps its own copy)
+	if (const char* e = getenv("ABG_KEEP_LIMIT_BYTES")) keep_limit = (size_t)strtoull(e, NULL, 10); // (tests: the host gives up keeping)
 	// PASS 1 of a chunk runs on a thread of its own while the reader parses the next chunk (one chunk
 	// in flight: the chunks go in in order)
 	std::thread loader;
@@ -532,9 +534,21 @@ int main(int argc, char** argv)
 		loader.join();
 		check(load_rc, ctx, "load"); // (exit() from the loader thread would run the static destructors beside live threads)
 		host_mark("chunk loaded");
-		if (packed_keep) {
-			for (Chunk& c : loading_v) { c.drop_seqs(); kept.push_back(std::move(c)); }
+		if (packed_path) {
+			// (the bases stay on the device; the host keeps the ids -- and gives the whole arrangement up when even those outgrow its share
+			// of the machine's memory: the device store may hold a billion reads, every rank of a --gpus run keeps its own copy of the ids)
+			for (Chunk& c : loading_v) {
+				if (!packed_keep) continue;
+				c.drop_seqs();
+				kept_bytes += c.idbuf.size() + 8 * c.n();
+				kept.push_back(std::move(c));
+			}
 			loading_v.clear();
+			if (packed_keep && kept_bytes > keep_limit) {
+				check(abg_keep_reads(ctx, 0, 0), ctx, "keep"); // (drops the device store; PASS 2 reads the input again, as the reference does)
+				packed_keep = false; keep = false;
+				kept.clear(); kept.shrink_to_fit();
+			}
 			return;
 		}
 		if (keep) {
@@ -625,7 +639,7 @@ int main(int argc, char** argv)
 			if (i == primed_arg && primed) own = std::move(primed); else own.reset(new abghost::SequenceReader(argv[i], ropt, threads));
 			abghost::SequenceReader& in = *own;
 			uint64_t n = 0;
-			if (packed_keep) {
+			if (packed_path) {
 				if (in.has_blocks()) {
 					abghost::SequenceReader::Block blk;
 					while (in.next_block(blk)) {

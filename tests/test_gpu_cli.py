@@ -179,10 +179,12 @@ def test_cli_reads_its_input_again_when_the_device_cannot_keep_the_reads(tmp_pat
     synth.write_fastq(str(tmp_path / "r1.fq"), m1, "r", 1)
     synth.write_fastq(str(tmp_path / "r2.fq"), m2, "r", 2)
     outs = []
-    for env in ({}, {"ABG_KEEP_FAIL": "1", "ABG_READER_WINDOW": "2000000"}):
+    # (ABG_KEEP_FAIL: the device store cannot grow; ABG_KEEP_LIMIT_BYTES: the ids the host keeps beside it outgrow its share of memory)
+    for env in ({}, {"ABG_KEEP_FAIL": "1", "ABG_READER_WINDOW": "2000000"}, {"ABG_KEEP_LIMIT_BYTES": "100000", "ABG_READER_WINDOW": "2000000"}):
         r = subprocess.run([cli(), "-v", "-k40", "-q3", "-b64M", "-j8", "--read-log=rl.tsv", "r1.fq", "r2.fq"], cwd=tmp_path,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr.decode()
         outs.append((r.stdout, open(tmp_path / "rl.tsv", "rb").read(), r.stderr))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][0].count(b">") > 100
+    assert outs[0][0] == outs[2][0] and outs[0][1] == outs[2][1]
     assert b"reading the input again" in outs[1][2] and b"reading the input again" not in outs[0][2]
