@@ -73,6 +73,7 @@ struct Config {
 	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
+	bool pipeline_late = true;        // ... the next batch's walkers start when this batch's are done (beside its commit), not beside them
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
 	bool memo = true;
 	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
@@ -1693,6 +1694,21 @@ struct FFirstFix { // first record of the candidates this rank walked in the lau
 	}
 };
 struct FAddU64 { uint64_t* a; uint64_t d; ABG_HD void operator()(uint64_t i, uint32_t) const { a[i] += d; } };
+// Several batches in flight: a batch's candidates were drawn against the visited filter as it was when the batch was classified.  Once the
+// batch before it is committed, the verdicts are brought up to date (FRefilter) and the candidates whose reads are covered by now are
+// struck from the launch that is already queued or running: a walker that has not started on one skips it (walk_read).  Nothing depends on
+// it -- the commit finds such a read visited at its turn with or without a walk -- it only saves the walk.
+struct FCancelStale {
+	const uint32_t* cand_read; const uint8_t* result; uint32_t* status; uint32_t first; uint32_t* count;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = first + (uint32_t)i;
+		if (result[cand_read[c]] != RES_CANDIDATE) {
+			atomic_add_u32(count + 1, 1); // (covered by now, walked or not)
+			if (status[c] == WS_NONE) { status[c] = WS_CANCELLED; atomic_add_u32(count, 1); }
+		}
+	}
+};
 
 // ---- -g: outputGraph (bloom-dbg.h:1171-1242)
 // trimSeq (bloom-dbg.h:399-451) on one clean segment: the longest run of consecutive k-mers the
@@ -2903,7 +2919,7 @@ class Engine {
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
 	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
-	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, pre_requests = 0, pre_adds = 0; };
+	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, pre_requests = 0, pre_adds = 0, cancelled = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -4094,6 +4110,7 @@ class Engine {
 		uint32_t walk_tb_cap = 0, walk_buf_cap = 0, wslots = 0;
 		uint64_t* rkh = nullptr; uint8_t* read_flag = nullptr; uint64_t* dbg = nullptr; uint32_t g_rec = 0; uint64_t g_pool = 0;
 	};
+	std::vector<int> late_; // contexts whose first round waits for the walkers of the batch before (Config::pipeline_late)
 	static constexpr int MAX_CTX = 4;
 	WalkRes res_[MAX_CTX];
 	BatchRun run_[MAX_CTX];
@@ -4162,7 +4179,12 @@ class Engine {
 					setup_batch<NW>(r);
 					// the first round's walkers start right away, on the context's own stream, unless
 					// this batch goes through alone
-					if (depth_now() > 1) start_round<NW>(r, ci, true);
+					if (depth_now() > 1) {
+						// (pipeline_late: not beside the walkers of the batch before -- every stale candidate would be walked before that batch's
+						// commit can strike it -- but when they are done, beside its commit: finish_batch starts it)
+						if (inflight.empty() || !cfg_.pipeline_late) start_round<NW>(r, ci, true);
+						else late_.push_back(ci);
+					}
 				}
 				inflight.push_back(ci);
 			}
@@ -4171,6 +4193,8 @@ class Engine {
 			use_ctx(ci);
 			BatchRun& r = run_[ci];
 			if (r.nc) finish_batch<NW>(r, ci, sink);
+			// (the batches still in flight were classified before this commit: strike what it covered from their queued walkers)
+			for (int cj : inflight) cancel_stale<NW>(run_[cj]);
 			if (results_host) {
 				be_.d2h(results_host + r.first, r.res_d, r.n);
 				if (const void* left = memchr(results_host + r.first, RES_CANDIDATE, r.n)) {
@@ -4180,6 +4204,20 @@ class Engine {
 		}
 	}
 
+	template <int NW>
+	void cancel_stale(BatchRun& r2)
+	{
+		if (!r2.nc || r2.committed >= r2.nc) return;
+		{ FRefilter<NW> f{ p_, r2.v, vis_, r2.res_d }; be_.launch(r2.n, f, "reclassify"); }
+		uint32_t* cnt = (uint32_t*)scal_;
+		be_.memset(cnt, 0, 8);
+		FCancelStale f{ r2.cand_d, r2.res_d, r2.status_d, r2.committed, cnt };
+		be_.launch(r2.nc - r2.committed, f, "reclassify");
+		uint32_t n[2] = { 0, 0 };
+		be_.d2h(n, cnt, 8);
+		stats_.cancelled += n[0];
+		if (getenv("ABG_CANCEL_DEBUG")) fprintf(stderr, "[cancel] batch of %llu reads, %u candidates: %u covered by now, %u of them not walked yet\n", (unsigned long long)r2.n, r2.nc, n[1], n[0]);
+	}
 	// Verdicts of reads [first, first + n) against the current visited snapshot, and the batch they
 	// make: the longest prefix holding at most cfg_.p2_max_candidates candidates (what the walkers'
 	// tables and the commit's positions are sized for); the rest is classified again later.
@@ -4445,6 +4483,12 @@ class Engine {
 				if (r.pending) {
 					be_.wait_walkers(ci);
 					r.pending = false;
+					if (!late_.empty()) {
+						// the next batch's walkers start now, beside this batch's commit
+						for (int cj : late_) { use_ctx(cj); if (run_[cj].nc && !run_[cj].round_started) start_round<NW>(run_[cj], cj, true); }
+						late_.clear();
+						use_ctx(ci);
+					}
 					stats_.rewalked += r.nneed_all;
 					r.batch_rewalked += r.nneed_all;
 					dump_walkers(r, "rewalk", r.nneed);

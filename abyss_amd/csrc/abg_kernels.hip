@@ -562,7 +562,11 @@ struct HipBackend {
 			return;
 		}
 		if (!wstream[ctx]) {
-			check(hipStreamCreateWithFlags(&wstream[ctx], hipStreamNonBlocking), "hipStreamCreate");
+			// (lowest priority: a batch's walkers run beside the commit of the batch before, whose small kernels on the main stream
+			// must get the slots that walker waves leave, or the commit waits for the walkers it was meant to overlap)
+			int lo = 0, hi = 0;
+			hipDeviceGetStreamPriorityRange(&lo, &hi);
+			check(hipStreamCreateWithPriority(&wstream[ctx], hipStreamNonBlocking, lo), "hipStreamCreate");
 			hipEventCreate(&wev0[ctx]); hipEventCreate(&wev1[ctx]);
 			check(hipMalloc((void**)&wticket[ctx], 8), "hipMalloc");
 		}
@@ -1109,7 +1113,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 		out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
 		out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
 		out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
-		out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds;
+		out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds; out->cancelled = s.cancelled;
 		return ABG_OK;
 	});
 }

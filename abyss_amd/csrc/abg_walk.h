@@ -121,7 +121,8 @@ enum WalkStatus : uint32_t {
 	WS_NONE = 0,      // not walked yet
 	WS_COMPLETE = 1,  // all contigs of the read recorded
 	WS_DEFERRED = 2,  // ran into a unitig claimed by a lower-numbered read
-	WS_OVERFLOW = 3   // a capacity (stack, path buffer, pool, table, records) was exceeded
+	WS_OVERFLOW = 3,  // a capacity (stack, path buffer, pool, table, records) was exceeded
+	WS_CANCELLED = 4  // not walked: an earlier batch's commit covered the read while this batch's walkers were already queued (FCancelStale)
 };
 struct ContigRec {
 	uint64_t seq_off;     // offset of the sequence in the contig pool (1 byte per base, 0..3)
@@ -880,6 +881,8 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 {
 	const Params& p = e.p;
 	const unsigned k = p.k;
+	// (several batches in flight: the commit of the batch before may have covered this read since the launch was queued)
+	if (ld_coherent(&e.status[c]) == WS_CANCELLED) return;
 	SearchScratch<NW>* scp; WalkState<NW>* wp;
 	walker_scratch(e, slot, scp, wp);
 	SearchScratch<NW>& sc = *scp;

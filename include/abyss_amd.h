@@ -322,6 +322,7 @@ typedef struct abg_stats {
 	uint64_t tiled_pending; /* ... of which this many shared a counter with another k-mer and took the reservation rounds */
 	uint64_t tile_overflows; /* ... batches whose bins overflowed (handled by the reservation rounds as a whole) */
 	uint64_t pre_requests, pre_adds; /* successor() searches requested ahead of the walkers / answers that pre-search added to the memo */
+	uint64_t cancelled;     /* candidates struck from a queued launch because an earlier batch's commit covered their reads (several batches in flight) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 
