@@ -647,6 +647,10 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 		unsigned k = p.k;
 		uint64_t fh = 0, rh = 0;
 		bool fresh = true;
+		// (the lanes of a wave write hashes a run apart: every 8-byte store is a write transaction of its own, and 870 M of them are
+		// what this kernel took its time for.  An even op's hash waits for its odd neighbour's: one 16-byte store for the two.)
+		struct alignas(16) Pair { uint64_t a, b; };
+		uint64_t held = 0; bool have = false;
 		for (uint64_t t = t0; t < t1; t++) {
 			while (t >= rend) { r++; rend = b.koff[r + 1] - kbase; fresh = true; }
 			uint32_t j = (uint32_t)(t + kbase - b.koff[r]);
@@ -667,7 +671,10 @@ struct FHashOps { // FHashClaim without the claims; the first k-mer of a lane's 
 				fh = srol1(fh) ^ seed_of(in) ^ p.seed_k[out];
 				rh = sror1(rh ^ p.seedrc_k[in] ^ seed_of(3u - out));
 			}
-			h0[t] = rh < fh ? rh : fh;
+			const uint64_t hv = rh < fh ? rh : fh;
+			if (!(t & 1) && t + 1 < t1) { held = hv; have = true; }
+			else if (have) { *(Pair*)&h0[t - 1] = Pair{ held, hv }; have = false; }
+			else h0[t] = hv;
 		}
 	}
 };
