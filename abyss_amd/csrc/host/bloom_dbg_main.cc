@@ -12,6 +12,8 @@
 #include <csignal>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
 
 #include <algorithm>
 #include <cmath>
@@ -465,6 +467,33 @@ int main(int argc, char** argv)
 		if (abg_rccl_comm_create(ident, (int32_t)rank, (int32_t)gpus, (int32_t)rank, &comm) != ABG_OK) { fprintf(stderr, PROGRAM ": %s\n", abg_last_error(NULL)); exit(EXIT_FAILURE); }
 		p.device = (int32_t)rank;
 	}
+	// One GPU: the work is done in a child process.  The parent waits for one byte -- the exit status, which the child writes once every
+	// output is flushed and closed -- and leaves with it, so that the caller (abyss-pe's next rule) goes on while the kernel takes the
+	// worker's ~25 GB of device mappings down, a quarter of a second that neither `_exit` nor freeing the memory by hand avoids.  A child
+	// that ends without sending the byte (any failure: they all leave through exit()) is waited for and its status passed on.
+	// ABG_FOREGROUND=1 keeps everything in this process; so does --gpus, whose ranks are processes of their own already.
+	int done_fd = -1;
+	if (!use_comm && !getenv("ABG_FOREGROUND")) {
+		int fd[2];
+		if (pipe(fd) == 0) {
+			fflush(NULL);
+			const pid_t pid = fork();
+			if (pid > 0) {
+				close(fd[1]);
+				unsigned char st = 0;
+				ssize_t got;
+				while ((got = read(fd[0], &st, 1)) < 0 && errno == EINTR) {}
+				if (got == 1) _exit(st);
+				int ws = 0;
+				while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {}
+				_exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + (WIFSIGNALED(ws) ? WTERMSIG(ws) : 1));
+			} else if (pid == 0) {
+				close(fd[0]);
+				done_fd = fd[1];
+				prctl(PR_SET_PDEATHSIG, SIGTERM); // (a parent that is killed takes the worker with it)
+			} else { close(fd[0]); close(fd[1]); } // (no child: carry on here)
+		}
+	}
 	p.verbose = verbose;
 	// The first window of the first input is read and parsed while the context comes up (HIP start-up and the
 	// filters' memory: 0.1-0.2 s).  Plain files only: a compressed one waits for the prefetch below.
@@ -864,6 +893,12 @@ int main(int argc, char** argv)
 		// allocations handed back one by one, then the HIP runtime's own static destructors) is a quarter of a second the
 		// pipeline waits for nothing: the kernel reclaims a process's device memory faster than the process can.
 		fflush(NULL);
+		if (done_fd >= 0) {
+			// (everything is written: the descriptors go first, so that a reader of our output sees its end, then the word to the parent)
+			close(1); close(2);
+			const unsigned char ok = EXIT_SUCCESS;
+			if (write(done_fd, &ok, 1) != 1) _exit(EXIT_FAILURE);
+		}
 		_exit(EXIT_SUCCESS);
 	}
 	abg_destroy(ctx);
