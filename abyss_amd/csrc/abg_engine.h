@@ -71,6 +71,7 @@ struct Config {
 	bool heavy_first = true;          // ... and the candidates with the most such searches are walked first (Engine::presearch)
 	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
 	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
+	uint32_t presearch_min_weight = 0; // ... and only for candidates with at least this many such searches on their reads (0: all)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
 	bool pipeline_late = true;        // ... the next batch's walkers start when this batch's are done (beside its commit), not beside them
@@ -80,7 +81,7 @@ struct Config {
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
-	bool async_guide = false;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide): measured 862 vs 866 ms per step, i.e. nothing -- the first launch's walkers pay for the hints they do not find yet
+	uint32_t async_guide = 0;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide).  1: nobody waits for it (measured 862 vs 866 ms per step, i.e. nothing: the first launch's walkers pay for the hints they do not find yet); 2: the first launch of walkers waits, the first classification and pre-search run beside it
 	bool link_duplicates = true;      // the commit decides a contig's copies among a batch's records by their original (Engine::link_duplicates)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
@@ -1390,6 +1391,7 @@ struct FPresearchScan {
 	SuccMemo memo; uint64_t* tags; uint64_t tag_mask, gen; // (gen: which filling of the memo the tags refer to)
 	PreReq<NW>* req; uint32_t* req_n; uint32_t req_cap;
 	uint32_t* weight; // [n] per candidate of the list: sides of its read's k-mers where successor() has to search (how heavy its walk will be)
+	uint32_t min_weight; // requests only for candidates at least this heavy (0: for all)
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
 		uint32_t heavy = 0;
@@ -1399,6 +1401,15 @@ struct FPresearchScan {
 		const uint32_t nk = L - p.k + 1;
 		const uint64_t woff = b.woff[r];
 		const SeedTabs tabs = seed_tabs(p);
+		// (min_weight > 0: a first pass counts the sides only; requests are made for the candidates with at least that many -- the
+		// ones whose walks end a launch -- and the others ask their few questions themselves)
+		for (uint32_t pass = min_weight ? 0u : 1u; pass < 2; pass++) {
+		if (pass == 1 && min_weight) {
+			uint32_t tot = 0;
+			for (unsigned bit = 0; bit < 10; bit++) tot += (uint32_t)__builtin_popcountll(wave_ballot(((heavy >> bit) & 1u) != 0)) << bit;
+			if (tot < min_weight) break;
+			heavy = 0;
+		}
 		for (uint32_t j0 = 0; j0 < nk; j0 += nlanes) {
 			const uint32_t j = j0 + lane;
 			Vtx<NW> u;
@@ -1419,6 +1430,7 @@ struct FPresearchScan {
 					const unsigned mask = nbr_mask_lean<NW, false>(p, tabs, cnt, u, dir == FORWARD ? SENSE : ANTISENSE);
 					if (!(mask & (mask - 1))) continue;
 					heavy++;
+					if (pass == 0) continue;
 					if (memo_find(memo, u.fh, u.rh, dir) >= 0) continue;
 					uint64_t tag = (u.fh ^ (u.rh * 0x9E3779B97F4A7C15ULL)) + (uint64_t)dir + gen * 0xD1B54A32D192ED03ULL;
 					tag ^= tag >> 31; tag *= 0xD6E8FEB86659FD93ULL; tag ^= tag >> 29;
@@ -1435,6 +1447,7 @@ struct FPresearchScan {
 					q.fh = u.fh; q.rh = u.rh; q.dir = (uint32_t)dir; q.mask = want[dir];
 				}
 			}
+		}
 		}
 		// (the lanes' counts summed: one ballot per bit of a count that is at most 2 x ceil(nk / lanes))
 		uint32_t total = 0;
@@ -4414,7 +4427,7 @@ class Engine {
 		}
 		be_.memset(pre_n_d_, 0, 8);
 		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
-			(PreReq<NW>*)pre_req_, pre_n_d_, cap, pre_w_ };
+			(PreReq<NW>*)pre_req_, pre_n_d_, cap, pre_w_, cfg_.presearch_min_weight };
 		be_.launch_wave(n, fs, "presearch_scan");
 		uint32_t nreq = 0;
 		be_.d2h(&nreq, pre_n_d_, 4);
@@ -4472,6 +4485,7 @@ class Engine {
 		r.owner_next += nc;
 		FWalk<NW> fw{ env, r.need_d };
 		if (!async) presearch<NW>(env, r.need_d, r.nneed);
+		if (cfg_.async_guide == 2) be_.wait_side_scope(); // (the guide, if its build is still running)
 		if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
 		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk", ci, async);
 		r.pending = true;

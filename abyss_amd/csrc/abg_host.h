@@ -95,7 +95,8 @@ class Session {
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
 		if (const char* e = getenv("ABG_DIST_ROUTE_MIN")) cfg.dist_route_min_ranks = (uint32_t)atoi(e); // partitioned run: pairs routed to their owners from this many ranks on (0: never)
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
-		if (const char* e = getenv("ABG_ASYNC_GUIDE")) cfg.async_guide = atoi(e) != 0; // the walkers' guide is built beside the start of PASS 2
+		if (const char* e = getenv("ABG_PRESEARCH_MIN_WEIGHT")) cfg.presearch_min_weight = (uint32_t)atoi(e); // pre-search only for candidates with at least this many searches on their reads
+		if (const char* e = getenv("ABG_ASYNC_GUIDE")) cfg.async_guide = (uint32_t)atoi(e); // the walkers' guide is built beside the start of PASS 2
 		if (const char* e = getenv("ABG_PIPELINE_LATE")) cfg.pipeline_late = atoi(e) != 0; // several batches in flight: the next one's walkers start beside this one's commit (1) or beside its walkers (0)
 		if (const char* e = getenv("ABG_LINK_DUPS")) cfg.link_duplicates = atoi(e) != 0; // the commit decides a contig's copies by their original (0: every record bit by bit)
 		if (const char* e = getenv("ABG_STAGE_EARLY")) cfg.stage_early = atoi(e) != 0; // PASS 1: the next batch is staged from the start of this one
