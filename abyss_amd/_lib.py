@@ -16,7 +16,7 @@ class Params(C.Structure):
         ("bloom_bytes", C.c_uint64), ("counters", C.c_uint64), ("spaced_seed", C.c_char_p),
         ("device", C.c_int32), ("verbose", C.c_int32), ("insert_batch_kmers", C.c_uint64),
         ("claim_log2", C.c_uint32), ("walk_slots", C.c_uint32), ("wtab_log2", C.c_uint32),
-        ("cascade_levels", C.c_uint32), ("reserved_", C.c_uint32 * 6),
+        ("cascade_levels", C.c_uint32), ("slice_filter", C.c_uint32), ("reserved_", C.c_uint32 * 5),
     ]
 
 
@@ -37,7 +37,7 @@ class Contig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("insert_rounds", "walk_rounds", "candidates", "walked", "rewalked", "commit_breaks",
-                 "commit_rounds", "generated", "bulk_calls", "bulk_steps", "lin_steps", "guide_slots", "chain_steps", "batch_cuts", "overflows", "memo_hits", "memo_adds", "tiled_ops", "tiled_pending", "tile_overflows", "pre_requests", "pre_adds", "cancelled")]
+                 "commit_rounds", "generated", "bulk_calls", "bulk_steps", "lin_steps", "guide_slots", "chain_steps", "batch_cuts", "overflows", "memo_hits", "memo_adds", "tiled_ops", "tiled_pending", "tile_overflows", "pre_requests", "pre_adds", "cancelled", "counter_bytes_held")]
 
 
 CONTIG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Contig))

@@ -29,7 +29,7 @@ namespace abg {
 // Common/IOUtil.h:14-22; that is the host binary's decision here too).  After ABG_ENOMEM /
 // ABG_EINTERNAL a context is only good for abg_destroy.
 struct Failure { int code; std::string msg; };
-constexpr int FAIL_NOMEM = -3, FAIL_INTERNAL = -4; // == ABG_ENOMEM, ABG_EINTERNAL (checked in abg_host.h)
+constexpr int FAIL_INVAL = -1, FAIL_NOMEM = -3, FAIL_INTERNAL = -4; // == ABG_EINVAL, ABG_ENOMEM, ABG_EINTERNAL (checked in abg_host.h)
 [[noreturn]] inline void fail_now(int code, const std::string& msg) { throw Failure{ code, msg }; }
 inline std::string strf(const char* fmt, unsigned long long a = 0, unsigned long long b = 0)
 {
@@ -66,6 +66,8 @@ struct Config {
 	uint32_t p2_crowded = 1u << 18;   // more candidates than this in a batch: halve the next one
 	uint32_t p2_starved_growth = 2;   // growth factor after such a batch
 	uint32_t p2_starved = 6144;       // fewer candidates than this: the batch was latency-bound, double the next one
+	uint32_t slice_filter = 0;        // partitioned run: a rank keeps only its own range of the counters and PASS 2 probes the all-gathered
+	                                  // bit plane (B beyond one GPU): 0 = when the whole filter would not fit the device, 1 = always, 2 = never
 	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
 	uint32_t classify_slots = 65536;  // lanes of the classification kernel in flight (each owns 22 KB of lookAhead scratch)
 	bool heavy_first = true;          // ... and the candidates with the most such searches are walked first (Engine::presearch)
@@ -2421,6 +2423,34 @@ struct FPcApply { // one wave per candidate before the break: results, visited b
 		if (lane == 0) { e.cnt[i] = nrec; e.cnt2[i] = nins; e.cnt3[i] = bases; }
 	}
 };
+// Coverage of the inserted contigs on a sliced filter (the ranks hold a range of the counters each): a k-mer's minimum over the
+// counters THIS rank owns, a byte per k-mer of the contig pool (255: none of them here); all_reduce(MIN); the sums.
+struct FPcCover {
+	ParCommit e; uint8_t* kmin; uint32_t sum;
+	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
+	{
+		const uint32_t c = e.c_begin + (uint32_t)i;
+		if (c >= e.brk || !e.active[i]) return;
+		for (uint32_t ri = e.first_rec[c]; ri != REC_END; ri = e.recs[ri].next) {
+			ContigRec& rec = e.recs[ri];
+			if (!rec.ins) continue;
+			const uint64_t* ch = e.kh + rec.seq_off;
+			const uint32_t cnk = rec.len - e.p.k + 1;
+			uint32_t cov = 0;
+			for (uint32_t j = lane; j < cnk; j += nlanes) {
+				if (sum) { cov += kmin[rec.seq_off + j]; continue; }
+				const uint64_t h = ch[j];
+				unsigned mn = 255;
+				for (unsigned q = 0; q < e.p.nh; q++) {
+					const uint64_t pos = pos_i(e.p, h, q);
+					if (pos - e.own_lo < e.own_span) { const unsigned v = e.cnt8[pos]; mn = v < mn ? v : mn; }
+				}
+				kmin[rec.seq_off + j] = (uint8_t)mn;
+			}
+			if (sum && cov) atomic_add_u32(&rec.coverage, cov);
+		}
+	}
+};
 struct FPcWrite { // commit order of the records and the contig ids (off = record offsets, cnt2 = id offsets)
 	ParCommit e; uint32_t* order; uint32_t order_base; uint64_t id_base;
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -2474,9 +2504,14 @@ class Engine {
 			cnt_ = (uint8_t*)be_.alloc(8);
 			vis_bytes_ = 8;
 		} else {
-			// (slack: the shards of a partitioned run are gathered in equal chunks of roundUp64(m / ranks))
-			cnt_ = (uint8_t*)be_.alloc(m_ + 64 * (MAX_RANKS + 1));
-			be_.memset(cnt_, 0, m_);
+			// a filter beyond this device: the counters wait for the communicator, whose ranks keep a range each (attach_comm)
+			const uint64_t dev = be_.device_mem_bytes();
+			cnt_deferred_ = cfg_.slice_filter == 1 || (cfg_.slice_filter == 0 && dev && (double)m_ * 1.3 > (double)dev * 0.9);
+			if (!cnt_deferred_) {
+				// (slack: the shards of a partitioned run are gathered in equal chunks of roundUp64(m / ranks))
+				cnt_ = (uint8_t*)be_.alloc(m_ + 64 * (MAX_RANKS + 1));
+				be_.memset(cnt_, 0, m_);
+			}
 			vis_bytes_ = (m_ / 8 + 4 + 3) & ~3ull;
 		}
 		vis_ = (uint8_t*)be_.alloc(vis_bytes_);
@@ -2487,7 +2522,7 @@ class Engine {
 	}
 	~Engine()
 	{
-		be_.free(cnt_); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
+		free_counters(); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
@@ -2512,7 +2547,8 @@ class Engine {
 	void reset()
 	{
 		if (casc_.bits) be_.memset(casc_.bits, 0, casc_.levels * casc_.level_words * 4);
-		else be_.memset(cnt_, 0, m_);
+		else if (sliced_) be_.memset(cnt_ + own_lo_, 0, own_span_);
+		else if (cnt_) be_.memset(cnt_, 0, m_);
 		be_.memset(vis_, 0, vis_bytes_);
 		be_.memset(cstate_, 0, sizeof(CommitState));
 		counters_ = Counters();
@@ -2535,7 +2571,7 @@ class Engine {
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	// (a partitioned run leaves only the rank's own range current until the shards are gathered)
-	uint8_t* counters_dev() { gather_counters(); memo_valid_ = false; plane_valid_ = false; /* (the caller may write) */ return cnt_; }
+	uint8_t* counters_dev() { need_whole_filter("direct access to the counters"); gather_counters(); memo_valid_ = false; plane_valid_ = false; /* (the caller may write) */ return cnt_; }
 
 	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
 	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
@@ -2560,6 +2596,22 @@ class Engine {
 		own_lo_ = std::min<uint64_t>(m_, (uint64_t)c.rank * chunk);
 		own_span_ = std::min<uint64_t>(m_, own_lo_ + chunk) - own_lo_;
 		own_chunk_ = chunk;
+		if (sliced_ || cnt_deferred_) {
+			// the sliced filter: this rank's range of the counters and nothing else.  cnt_ stays the address of counter 0 -- every
+			// kernel of the partitioned PASS 1 takes global positions and touches [own_lo_, own_lo_ + own_span_) only -- and PASS 2
+			// probes the bit plane all ranks gather (ensure_plane), asks for coverage through an all-reduce (commit_par)
+			if (!cfg_.solid_plane || (m_ & 63) || !cfg_.par_commit)
+				fail_now(FAIL_INVAL, "a sliced filter needs the bit plane, the parallel commit and a multiple of 64 counters");
+			free_counters();
+			if (plane_) { be_.free(plane_); plane_ = nullptr; }
+			win_total_ = (uint64_t)c.world * chunk + 64;
+			win_span_ = chunk + 64;
+			cnt_ = (uint8_t*)be_.alloc_window(win_total_, own_lo_, win_span_);
+			be_.memset(cnt_ + own_lo_, 0, win_span_);
+			sliced_ = true; cnt_deferred_ = false;
+			cfg_.drain_threshold = 0; // (the drain of the last pending ops replays them on scratch copies of the other ranks' counters)
+			memo_valid_ = false; plane_valid_ = false;
+		}
 		// ABG_FORCE_DIST=1: take the partitioned code path with a single rank too (its kernels,
 		// compaction, merges and collectives, each of which is then an identity) -- for tests and for
 		// measuring what the partitioned path itself costs
@@ -2578,7 +2630,24 @@ class Engine {
 		}
 		return true;
 	}
-	bool dist() const { return comm_.world > 1 || force_dist_; }
+	bool dist() const { return comm_.world > 1 || force_dist_ || sliced_; }
+	bool sliced() const { return sliced_; }
+	uint64_t counter_bytes_held() const { return sliced_ ? win_span_ : cnt_ ? m_ : 0; }
+	void need_counters() const
+	{
+		if (!cnt_) fail_now(FAIL_INVAL, "this filter does not fit the device: attach a communicator first, its ranks keep a range each (abg_attach_comm)");
+	}
+	void need_whole_filter(const char* what) const
+	{
+		need_counters();
+		if (sliced_) fail_now(FAIL_INVAL, std::string(what) + " is not available on a sliced filter (each rank holds a range of the counters)");
+	}
+	void free_counters()
+	{
+		if (sliced_) be_.free_window(cnt_, win_total_, own_lo_, win_span_);
+		else if (cnt_) be_.free(cnt_);
+		cnt_ = nullptr; sliced_ = false;
+	}
 	// All-gather of the ranks' packed read sets (rank-major order) into buffers the engine keeps
 	// until the next call: what every rank then hands to load_packed / assemble_packed.
 	Batch share_reads(const Batch& loc)
@@ -2617,6 +2686,31 @@ class Engine {
 	}
 	bool cascade_mode() const { return casc_.bits != nullptr; }
 	uint32_t cascade_levels() const { return casc_.levels; }
+	// The whole counter array to / from host memory (checkpoints, tests).  A sliced filter passes it rank by rank through one
+	// spare chunk; every rank ends up with the whole array on the HOST.
+	void counters_to_host(uint8_t* out)
+	{
+		need_counters();
+		if (!sliced_) { be_.d2h(out, counters_dev(), m_); return; }
+		uint8_t* tmp = (uint8_t*)be_.alloc(own_chunk_);
+		std::vector<uint64_t> c(comm_.world), d(comm_.world, 0);
+		for (int q = 0; q < comm_.world; q++) {
+			std::fill(c.begin(), c.end(), 0);
+			c[q] = own_chunk_;
+			if (q == comm_.rank) be_.d2d(tmp, cnt_ + own_lo_, own_chunk_);
+			c_all_gather_v(tmp, c.data(), d.data());
+			const uint64_t lo = (uint64_t)q * own_chunk_;
+			if (lo < m_) be_.d2h(out + lo, tmp, std::min<uint64_t>(own_chunk_, m_ - lo));
+		}
+		be_.free(tmp);
+	}
+	void counters_from_host(const uint8_t* in)
+	{
+		need_counters();
+		if (!sliced_) { be_.h2d(counters_dev(), in, m_); return; }
+		be_.h2d(cnt_ + own_lo_, in + own_lo_, own_span_);
+		memo_valid_ = false; plane_valid_ = false;
+	}
 	uint8_t* cascade_level_dev(uint32_t l) { return (uint8_t*)(casc_.bits + (uint64_t)l * casc_.level_words); }
 	uint8_t* visited_dev() { return vis_; }
 	uint64_t visited_bytes() const { return m_ / 8; }
@@ -2626,12 +2720,14 @@ class Engine {
 
 	void popcounts(uint64_t* nonzero, uint64_t* filtered)
 	{
+		need_counters();
 		gather_counters();
 		be_.memset(scal_, 0, 16);
-		FPopcount f{ (const uint64_t*)cnt_, p_.kc, scal_ };
-		be_.launch(m_ / 8, f, "popcount");
+		FPopcount f{ (const uint64_t*)(cnt_ + (sliced_ ? own_lo_ : 0)), p_.kc, scal_ };
+		be_.launch((sliced_ ? own_span_ : m_) / 8, f, "popcount");
 		uint64_t out[2];
 		be_.d2h(out, scal_, 16);
+		if (sliced_) host_all_reduce_sum(out, 2);
 		*nonzero = out[0];
 		*filtered = out[1];
 	}
@@ -2640,6 +2736,7 @@ class Engine {
 	void trim_runs(const Batch& b, uint32_t* best_start_h, uint32_t* best_len_h)
 	{
 		if (!b.n) return;
+		need_whole_filter("-g");
 		gather_counters();
 		uint32_t* bs = (uint32_t*)be_.alloc(b.n * 4);
 		uint32_t* bl = (uint32_t*)be_.alloc(b.n * 4);
@@ -2659,6 +2756,7 @@ class Engine {
 		ev.clear(); used.assign(starts.n, 0);
 		*edges = 0;
 		if (!starts.n) return;
+		need_whole_filter("-g");
 		gather_counters();
 		dispatch_nw([&](auto nw) { graph_bfs_nw<decltype(nw)::value>(starts, ev, used, edges); });
 	}
@@ -2718,6 +2816,7 @@ class Engine {
 	void load_packed(const Batch& b) { load_packed(b, cut_ranges(b.koff, b.n)); } // (b.koff: device_koff)
 	void load_packed(const Batch& b, const std::vector<OpRange>& ranges)
 	{
+		need_counters();
 		{
 			// Run length of FHashOps: a lane hashes one k-mer from scratch (k rounds) and rolls the rest, so longer
 			// runs are less work -- and a run that ends where the read ends starts no second hash.  The reads'
@@ -2830,6 +2929,7 @@ class Engine {
 	    const std::function<void(const ContigOut&)>& sink)
 	{
 		use_ctx(0);
+		need_counters();
 		gather_counters();
 		// (PASS 1's bins and claim tables grow with the filter -- 60 GB at B=40G: PASS 2 gets that memory)
 		if (insert_scratch_bytes_ > cfg_.keep_insert_scratch_bytes) free_insert();
@@ -2872,8 +2972,16 @@ class Engine {
 	{
 		p2_ = p_; cnt2_ = cnt_;
 		if (!cfg_.solid_plane || casc_.bits || (m_ & 63)) return;
-		if (!plane_) plane_ = (uint8_t*)be_.alloc(m_ / 8 + 64);
-		if (!plane_valid_) {
+		if (!plane_) plane_ = (uint8_t*)be_.alloc((sliced_ ? (uint64_t)comm_.world * own_chunk_ : m_) / 8 + 64);
+		if (!plane_valid_ && sliced_) {
+			// every rank judges its own counters and the ranks gather the bits: an eighth of what gather_counters moves
+			FSolidPlane f{ (const uint64_t*)(cnt_ + own_lo_), p_.kc, (uint64_t*)(plane_ + own_lo_ / 8) };
+			be_.launch(own_span_ / 64, f, "solid_plane");
+			std::vector<uint64_t> c(comm_.world), d(comm_.world);
+			for (int q = 0; q < comm_.world; q++) { d[q] = (uint64_t)q * (own_chunk_ / 8); c[q] = own_chunk_ / 8; }
+			c_all_gather_v(plane_, c.data(), d.data());
+			plane_valid_ = true; cnt_partial_ = false;
+		} else if (!plane_valid_) {
 			FSolidPlane f{ (const uint64_t*)cnt_, p_.kc, (uint64_t*)plane_ };
 			be_.launch(m_ / 64, f, "solid_plane");
 			plane_valid_ = true;
@@ -2993,6 +3101,7 @@ class Engine {
 	// ---- partitioned run
 	Comm comm_;
 	bool force_dist_ = false, comm_scaled_ = false;
+	bool sliced_ = false, cnt_deferred_ = false; uint64_t win_total_ = 0, win_span_ = 0; // the sliced filter (attach_comm)
 	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
 	uint8_t* tred_ = nullptr; // partitioned tiles: the two bytes per op of FDistPack
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
@@ -3055,7 +3164,7 @@ class Engine {
 	// the shards of the counting filter, gathered onto every rank (PASS 2 reads it at random)
 	void gather_counters()
 	{
-		if (!dist() || !cnt_partial_) return;
+		if (!dist() || !cnt_partial_ || sliced_) return;
 		std::vector<uint64_t> c(comm_.world), d(comm_.world);
 		// equal chunks (one ring all-gather); the last one runs into the slack behind the m_ counters
 		for (int q = 0; q < comm_.world; q++) { d[q] = (uint64_t)q * own_chunk_; c[q] = own_chunk_; }
@@ -3899,7 +4008,18 @@ class Engine {
 		be_.d2h(scal_h, e.scal, sizeof scal_h);
 		const uint32_t brk = std::min(scal_h[1], c_end);
 		e.brk = brk;
-		{ FPcApply f{ e }; be_.launch_wave(n, f, "pc_apply"); }
+		if (sliced_) {
+			// (FPcApply still sets the visited bits; the counters of a k-mer are spread over the ranks)
+			ParCommit ea = e; ea.cnt8 = nullptr;
+			{ FPcApply f{ ea }; be_.launch_wave(n, f, "pc_apply"); }
+			const uint64_t ext = g_pool_ + 64;
+			uint8_t* kmin = (uint8_t*)be_.alloc(ext);
+			be_.memset(kmin, 0xFF, ext);
+			{ FPcCover f{ e, kmin, 0u }; be_.launch_wave(n, f, "pc_cover"); }
+			c_all_reduce(kmin, g_pool_, DT_U8, OP_MIN);
+			{ FPcCover f{ e, kmin, 1u }; be_.launch_wave(n, f, "pc_cover"); }
+			be_.free(kmin);
+		} else { FPcApply f{ e }; be_.launch_wave(n, f, "pc_apply"); }
 		if (nshort) { FPcShort f{ e, 1 }; be_.launch(1, f, "pc_short"); }
 		// commit order, contig ids, counters
 		std::vector<uint64_t> c3(n);

@@ -72,6 +72,8 @@ class Session {
 		cfg.trim = (p.trim == 0xFFFFFFFFu) ? p.k : p.trim;
 		cfg.counters = p.counters ? p.counters : counters_for_budget(p.bloom_bytes);
 		cfg.cascade_levels = p.cascade_levels;
+		cfg.slice_filter = p.slice_filter;
+		if (const char* e = getenv("ABG_SLICE_FILTER")) cfg.slice_filter = (uint32_t)atoi(e); // partitioned run: each rank keeps its own range of the counters only (1), never (2)
 		if (p.cascade_levels && (!p.counters || p.counters % 64)) return fail(ABG_EINVAL, "cascade mode needs `counters` = bits per level, a multiple of 64");
 		if (!cfg.counters) return fail(ABG_EINVAL, "bloom_bytes / counters must be > 0");
 		cfg.verbose = p.verbose;

@@ -283,15 +283,7 @@ struct HipBackend {
 				drop_cache();
 				e = dev_malloc(&p, n);
 			}
-			if (e != hipSuccess) {
-				size_t fr = 0, tot = 0;
-				(void)hipMemGetInfo(&fr, &tot);
-				char msg[200];
-				snprintf(msg, sizeof msg, "no device memory for a block of %.2f GB (%.2f of %.2f GB free%s)", n / 1e9, fr / 1e9, tot / 1e9,
-				    mem_limit ? ", ABG_MEM_LIMIT_MB in force" : "");
-				(void)hipGetLastError();
-				abg::fail_now(abg::FAIL_NOMEM, msg);
-			}
+			if (e != hipSuccess) out_of_memory(n);
 			static const bool mem_debug = getenv("ABG_MEM_DEBUG") != nullptr;
 			if (mem_debug) {
 				size_t fr = 0, tot = 0;
@@ -309,10 +301,28 @@ struct HipBackend {
 			cache_held -= sz;
 			return p;
 		}
-		check(dev_malloc(&p, sz), "hipMalloc");
+		if (dev_malloc(&p, sz) != hipSuccess) {
+			(void)hipGetLastError();
+			drop_cache();
+			if (dev_malloc(&p, sz) != hipSuccess) out_of_memory(sz);
+		}
 		cache_size[p] = sz;
 		return p;
 	}
+	[[noreturn]] void out_of_memory(size_t n)
+	{
+		size_t fr = 0, tot = 0;
+		(void)hipMemGetInfo(&fr, &tot);
+		char msg[200];
+		snprintf(msg, sizeof msg, "no device memory for a block of %.2f GB (%.2f of %.2f GB free%s)", n / 1e9, fr / 1e9, tot / 1e9,
+		    mem_limit ? ", ABG_MEM_LIMIT_MB in force" : "");
+		(void)hipGetLastError();
+		abg::fail_now(abg::FAIL_NOMEM, msg);
+	}
+	// `span` bytes that answer to the addresses [base + lo, base + lo + span) of an array of `total` bytes no device holds as a
+	// whole (the sliced counting filter): returns base
+	void* alloc_window(uint64_t total, uint64_t lo, uint64_t span) { (void)total; return (char*)alloc(span) - lo; }
+	void free_window(void* base, uint64_t total, uint64_t lo, uint64_t span) { (void)total; (void)span; free((char*)base + lo); }
 	void free(void* p)
 	{
 		if (!p) return;
@@ -424,7 +434,12 @@ struct HipBackend {
 		end("sort_pairs");
 	}
 	uint32_t max_slots() const { return cus * 8 * 256; }
-	uint64_t device_mem_bytes() const { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? (uint64_t)tot : 0; }
+	uint64_t device_mem_bytes() const
+	{
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+		return mem_limit && mem_limit < tot ? (uint64_t)mem_limit : (uint64_t)tot; // (ABG_MEM_LIMIT_MB: a smaller device, for the tests)
+	}
 
 	void begin(const char*) { if (profiling) hipEventRecord(ev0, stream); }
 	void end(const char* name)
@@ -878,7 +893,7 @@ int abg_counters_export(abg_ctx* ctx, uint8_t* host_out)
 {
 	if (!ctx || !host_out || ctx->s.eng->cascade_mode()) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
-		ctx->s.be.d2h(host_out, ctx->s.eng->counters_dev(), ctx->s.eng->size());
+		ctx->s.eng->counters_to_host(host_out);
 		return ABG_OK;
 	});
 }
@@ -886,7 +901,7 @@ int abg_counters_import(abg_ctx* ctx, const uint8_t* host_in)
 {
 	if (!ctx || !host_in) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
-		ctx->s.be.h2d(ctx->s.eng->counters_dev(), host_in, ctx->s.eng->size());
+		ctx->s.eng->counters_from_host(host_in);
 		return ABG_OK;
 	});
 }
@@ -1114,6 +1129,7 @@ int abg_get_stats(const abg_ctx* ctx, abg_stats* out)
 		out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
 		out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
 		out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds; out->cancelled = s.cancelled;
+		out->counter_bytes_held = ctx->s.eng->counter_bytes_held();
 		return ABG_OK;
 	});
 }

@@ -87,7 +87,12 @@ typedef struct abg_params {
 	 * (`abyss-bloom build -t rolling-hash -l N`, Bloom/bloom.cc:585-602); `counters` is then the
 	 * number of BITS per level.  PASS 2 is not available in this mode. */
 	uint32_t cascade_levels;
-	uint32_t reserved_[6];
+	/* Partitioned run (abg_attach_comm) with a filter beyond one device: each rank keeps its own range of the counters only, PASS 2
+	 * probes the all-gathered bit plane "counter >= min_cov" (B/8 bytes) and sums coverage through an all-reduce.  0 = when the whole
+	 * filter would not fit this device, 1 = always, 2 = never.  A context created this way holds no counters until a communicator
+	 * is attached; -g, abg_contains_seq and a cascading filter are not available on it. */
+	uint32_t slice_filter;
+	uint32_t reserved_[5];
 } abg_params;
 
 /* AssemblyCounters, BloomDBG/AssemblyCounters.h:15-31 */
@@ -323,6 +328,7 @@ typedef struct abg_stats {
 	uint64_t tile_overflows; /* ... batches whose bins overflowed (handled by the reservation rounds as a whole) */
 	uint64_t pre_requests, pre_adds; /* successor() searches requested ahead of the walkers / answers that pre-search added to the memo */
 	uint64_t cancelled;     /* candidates struck from a queued launch because an earlier batch's commit covered their reads (several batches in flight) */
+	uint64_t counter_bytes_held; /* bytes of the counting filter this context holds: all of it, or its own range of a sliced filter (abg_params.slice_filter) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);
 

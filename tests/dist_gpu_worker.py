@@ -111,6 +111,9 @@ def rccl1():
     ok["share_total"] = nt == n
     ok.update(against_oracle(g, k, counters, buf, off, packed=(gw, go, gl, nt)))
     ok["launches"] = {nm: g.profile_get(nm)[1] for nm in ("comm_all_reduce", "comm_all_gather", "compact", "insert_apply", "merge_fix")}
+    if os.environ.get("ABG_SLICE_FILTER") == "1":
+        ok["launches"].update({nm: g.profile_get(nm)[1] for nm in ("pc_cover", "solid_plane")})
+        ok["held"] = g.stats()["counter_bytes_held"]
     if os.environ.get("ABG_DIST_ROUTE_MIN") == "1":
         ok["launches"].update({nm: g.profile_get(nm)[1] for nm in ("route_pack", "route_reply", "route_tgt")})
     g.close()

@@ -206,6 +206,14 @@ def main():
         ok, hc = case_kept(rank, world)
     elif what == "shared":
         ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=True)
+    elif what == "sliced":
+        # B beyond one device (ABG_SLICE_FILTER=1, set by the test): every rank holds its own range of the counters and nothing
+        # else -- under tests/hostcheck the rest of the array is address space without memory, so a stray access kills the rank --
+        # PASS 2 probes the gathered bit plane, coverage comes through an all-reduce
+        ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=(len(sys.argv) > 2 and sys.argv[2] == "shared"))
+        held = hc.stats()["counter_bytes_held"]
+        ok["held_fraction"] = held / float(1 << 19)
+        ok["direct_access_refused"] = not bool(hc.l.hc_counters(hc.h))
     else:
         raise SystemExit("unknown case")
     # (the walkers' own work counters are per rank: each rank walks its share of the candidates)

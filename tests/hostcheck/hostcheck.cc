@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 
 namespace {
 
@@ -32,6 +33,18 @@ struct SerialBackend {
 	void* alloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
 	void* try_alloc(size_t n) { return malloc(n ? n : 1); }
 	void free(void* p) { ::free(p); }
+	// The window of a sliced filter: the whole array is reserved as addresses nothing may touch and only the pages of
+	// [lo, lo + span) are given memory -- a kernel that reads or writes another rank's counters dies on the spot.
+	void* alloc_window(uint64_t total, uint64_t lo, uint64_t span)
+	{
+		const uint64_t pg = 4096, len = (total + pg - 1) / pg * pg + pg;
+		char* base = (char*)mmap(nullptr, len, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+		if (base == (char*)MAP_FAILED) abort();
+		const uint64_t a = lo / pg * pg, b = std::min<uint64_t>(len, (lo + span + pg - 1) / pg * pg);
+		if (mprotect(base + a, b - a, PROT_READ | PROT_WRITE)) abort();
+		return base;
+	}
+	void free_window(void* base, uint64_t total, uint64_t, uint64_t) { const uint64_t pg = 4096; munmap(base, (total + pg - 1) / pg * pg + pg); }
 	void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
 	void side_scope_begin(const char*) {} // (serial: everything runs at once, in call order)
 	void side_scope_end() {}
@@ -172,7 +185,15 @@ uint8_t* hc_cascade_level(void* h, unsigned l) { return S(h)->eng->cascade_level
 void hc_destroy(void* h) { delete (Sess*)h; }
 void hc_reset(void* h) { S(h)->eng->reset(); }
 uint64_t hc_size(void* h) { return S(h)->eng->size(); }
-uint8_t* hc_counters(void* h) { return S(h)->eng->counters_dev(); }
+uint8_t* hc_counters(void* h)
+{
+	try { return S(h)->eng->counters_dev(); } catch (const abg::Failure& f) { S(h)->error = f.msg; return nullptr; }
+}
+int hc_counters_export(void* h, uint8_t* out)
+{
+	try { S(h)->eng->counters_to_host(out); return 0; } catch (const abg::Failure& f) { S(h)->error = f.msg; return f.code; }
+}
+const char* hc_last_error(void* h) { return S(h)->error.c_str(); }
 uint8_t* hc_visited(void* h) { return S(h)->eng->visited_dev(); }
 int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n) { return S(h)->load_seqs(seqs, off, n); }
 uint64_t hc_insert_rounds(void* h) { return S(h)->eng->stats().insert_rounds; }
@@ -238,6 +259,7 @@ void hc_get_stats(void* h, abg_stats* out)
 	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
 	out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
 	out->pre_requests = s.pre_requests; out->pre_adds = s.pre_adds; out->cancelled = s.cancelled;
+	out->counter_bytes_held = S(h)->eng->counter_bytes_held();
 }
 uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)
 {

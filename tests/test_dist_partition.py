@@ -239,3 +239,43 @@ def test_routed_pass1_bytes_follow_the_model():
         pending = out["stats"]["tiled_pending"]
         assert p1.get("bytes_all_gather_v", 0) <= 12 * pending + 64 * world * p1["all_gather_v"], (world, p1, pending)
         assert p1["bytes_all_reduce"] <= 3.0 * pending + 4096 * p1["all_reduce"], (world, p1, pending)
+
+
+SLICED_CASES = [
+    (2, ("sliced",), {}),                                   # all-gather form of PASS 1
+    (8, ("sliced", "shared"), {}),                          # routed PASS 1, gathered read shares, an eighth of the counters per rank
+    (4, ("sliced",), {"ABG_ROUTE_CAP": "64"}),              # the routed exchange overflows: whole batches through the rounds
+    (4, ("golden", "k64"), {}),                             # a reference run's FASTA (coverage included), read log and trace
+    (3, ("tiny_filter",), {}),                              # long reservation chains, no drain hand-over on a sliced filter
+    (3, ("bigbatch",), {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "5"}),  # one commit over thousands of contigs, hashed stamps
+    (3, ("saturate_tiled",), {}),
+    (2, ("kept",), {}),
+]
+
+
+@pytest.mark.parametrize("world,args,env", SLICED_CASES, ids=["-".join(a) + "-w%d" % w for w, a, _ in SLICED_CASES])
+def test_filter_that_fits_no_single_rank(world, args, env, monkeypatch):
+    """abg_params.slice_filter (here ABG_SLICE_FILTER=1): B beyond one device, the regime of BASELINE configs[4] (B=500G on
+    8 GPUs).  Each rank holds its own range of the counters and NOTHING else -- under tests/hostcheck the rest of the array is
+    reserved address space without memory (SerialBackend::alloc_window), so any kernel touching another rank's counters kills
+    its rank -- PASS 2 probes the bit plane "counter >= min_cov" the ranks gather (an eighth of the counters' bytes), and the
+    coverage of the contigs it outputs comes through an all-reduce of per-k-mer minima (FPcCover).  Everything stays the
+    reference's sequential run: counting filter (exported rank by rank), read results, contigs with their coverage, visited
+    filter, AssemblyCounters."""
+    monkeypatch.setenv("ABG_SLICE_FILTER", "1")
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    out = run_ranks(world, *args)
+    keys = ("filtered_popcount", "fasta", "readlog", "trace", "counters") if args[0] == "golden" else \
+        ("counting_filter",) if args[0] == "saturate_tiled" else ("counting_filter", "results", "contigs", "visited", "assembly_counters")
+    for key in keys + ("ranks_agree",):
+        assert out[key], (key, out)
+    held = out["stats"]["counter_bytes_held"]
+    assert 0 < held, out["stats"]
+    if args[0] == "sliced":
+        # a rank's share plus 64 bytes of slack; the pointer to "the counters" is refused
+        assert out["held_fraction"] < 1.0 / world + 0.001 and out["direct_access_refused"], out
+        if "ABG_ROUTE_CAP" in env:
+            assert out["stats"]["tile_overflows"] > 0, out["stats"]
+    if world >= 4 and "ABG_ROUTE_CAP" not in env:
+        assert out["comm_calls"]["all_to_all_v"] > 0, out["comm_calls"]

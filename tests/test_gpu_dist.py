@@ -65,6 +65,36 @@ def test_ranks_sharing_one_gpu_match_oracle(world, route):
     assert (out["comm_calls"].get("all_to_all_v", 0) > 0) == (route != "0"), out["comm_calls"]
 
 
+@pytest.mark.parametrize("world,route", [(2, "0"), (3, "2")])
+def test_sliced_filter_on_ranks_sharing_one_gpu(world, route):
+    """abg_params.slice_filter (ABG_SLICE_FILTER=1): each rank allocates its own range of the counters only, PASS 2 probes the
+    gathered bit plane, coverage goes through FPcCover and an all-reduce -- the real kernels, against the oracle (the counting
+    filter is exported rank by rank).  The CPU twin of this test runs with the other ranks' counters unmapped
+    (tests/test_dist_partition.py::test_filter_that_fits_no_single_rank)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ABG_DIST_ROUTE_MIN=route, ABG_SLICE_FILTER="1")
+    env.pop("ABG_FORCE_DIST", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29710 + world), WORKER, "staged"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    out = result_of(r)
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["n_contigs"] > 10
+    assert 0 < out["stats"]["counter_bytes_held"] <= (1 << 22) // world + 128, out["stats"]
+
+
+def test_rccl_single_rank_sliced_filter_reproduces_reference_runs_and_oracle():
+    """The sliced filter through the library's RCCL communicator (one rank): the plane's all-gather, the coverage all-reduce and
+    the rank-by-rank export are RCCL calls on the engine's stream."""
+    env = dict(os.environ, ABG_FORCE_DIST="1", ABG_SLICE_FILTER="1")
+    r = subprocess.run([sys.executable, WORKER, "rccl1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    out = result_of(r)
+    for key in ("k64", "k40_mixed", "k48_K16", "share_total", "counting_filter", "results", "contigs", "visited",
+                "assembly_counters"):
+        assert out[key], (key, out)
+    assert out["launches"]["pc_cover"] > 0 and out["launches"]["solid_plane"] > 0 and out["held"] == (1 << 24) + 64, out
+
+
 def _gpus():
     try:
         import torch

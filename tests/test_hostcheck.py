@@ -52,7 +52,14 @@ class HostCheck:
         assert self.l.hc_load_seqs(self.h, buf, off.ctypes.data, len(off) - 1) == 0
 
     def counters(self):
-        return np.ctypeslib.as_array(self.l.hc_counters(self.h), (self.size,)).copy()
+        # (through the export: on a sliced filter -- tests/test_dist_partition.py -- the ranks pass their ranges around)
+        out = np.empty(self.size, dtype=np.uint8)
+        self.l.hc_counters_export.argtypes = [C.c_void_p, C.c_void_p]
+        self.l.hc_last_error.restype = C.c_char_p
+        self.l.hc_last_error.argtypes = [C.c_void_p]
+        rc = self.l.hc_counters_export(self.h, out.ctypes.data)
+        assert rc == 0, (rc, self.l.hc_last_error(self.h))
+        return out
 
     def visited(self):
         return np.ctypeslib.as_array(self.l.hc_visited(self.h), (self.size // 8,)).copy()
