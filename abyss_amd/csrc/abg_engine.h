@@ -2591,6 +2591,7 @@ class Engine {
 	{
 		if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || casc_.bits) return false;
 		comm_ = c;
+		free_insert(); // (PASS 1's scratch is laid out for the partition it was made under: the next load makes it anew)
 		uint64_t chunk = (m_ + c.world - 1) / c.world;
 		chunk = (chunk + 63) & ~63ull;
 		own_lo_ = std::min<uint64_t>(m_, (uint64_t)c.rank * chunk);
@@ -2780,6 +2781,7 @@ class Engine {
 	// op ranges of at most batch_ops_ ops along sequence boundaries, from the device's prefix sums
 	std::vector<OpRange> cut_ranges(const uint64_t* koff_d, uint64_t n)
 	{
+		need_counters();
 		ensure_insert();
 		std::vector<OpRange> out;
 		if (!n) return out;
@@ -2802,6 +2804,7 @@ class Engine {
 	// the same from a host copy of the prefix sums
 	std::vector<OpRange> cut_ranges_host(const uint64_t* koff_h, uint64_t n)
 	{
+		need_counters();
 		ensure_insert();
 		std::vector<OpRange> out;
 		for (uint64_t s = 0; s < n;) {

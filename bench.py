@@ -204,6 +204,9 @@ def main() -> int:
                     help="partitioned mode: the fixed --config / --pairs / --bloom job over N ranks (strong: the default -- "
                          "north_star's experiment is BASELINE.json configs[2] over 1/2/4/8 GPUs), or a job N times as big "
                          "(weak: --pairs and --bloom are per rank)")
+    ap.add_argument("--slice-filter", action="store_true",
+                    help="partitioned runs: each rank keeps its own range of the counting filter only (abg_params.slice_filter = 1; "
+                         "without the flag the library decides by the device's memory)")
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
@@ -217,7 +220,7 @@ def main() -> int:
     if a.config is None:
         # one GPU: configs[1], the configuration the metric is quoted on.  Several GPUs, one partitioned job: configs[2], the
         # configuration BASELINE.json lists for the partitioned filter ("200 M x 2x150 bp, k=64, B=40G ... over 8xMI355X via RCCL"),
-        # strong-scaled; its one-GPU point is on file (profiles/r03_d_bench_config2_invariants.json)
+        # strong-scaled; its one-GPU point is on file (profiles/r04_c_bench_config2_invariants.json)
         a.config = 2 if (world_env > 1 and a.mode == "partitioned" and a.pairs is None) else 1
     preset = {1: (5_000_000, 64, "2G", 0, "E. coli-scale"), 2: (200_000_000, 64, "40G", 0, "human-chr-scale"),
               3: (5_000_000, 96, "2G", 32, "spaced-seed")}[a.config]
@@ -311,7 +314,8 @@ def main() -> int:
         t_setup = time.perf_counter()
         if g is None:
             g = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local,
-                             spaced_seed=api.spaced_seed_kmer_pair(a.k, a.K) if a.K else None)
+                             spaced_seed=api.spaced_seed_kmer_pair(a.k, a.K) if a.K else None,
+                             **({"slice_filter": 1} if a.slice_filter and partitioned else {}))
             if partitioned:
                 if comm is None:  # --comm staged
                     comm = adist.StagedTorchComm(*adist.device_memory_io(g), group=dist.new_group(backend="gloo"))
@@ -505,7 +509,7 @@ def main() -> int:
         if partitioned and world > 1 and a.scaling == "strong":
             # the one-GPU point of this very job, measured in an earlier run and REPLAYED from the committed file (the driver
             # computes its own efficiency from the per-N lines; this one is for a reader of a single line)
-            one = {1: "r03_e_bench_default.json", 2: "r03_d_bench_config2_invariants.json", 3: "r03_e_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
+            one = {1: "r04_b_bench_default.json", 2: "r04_c_bench_config2_invariants.json", 3: "r04_b_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
             src = os.path.join(ROOT, "profiles", one) if one else None
             if src and os.path.exists(src) and a.pairs == preset[0] and a.k == preset[1]:
                 v1 = json.load(open(src))["value"]
@@ -513,6 +517,7 @@ def main() -> int:
                                          "speedup": out["value"] / v1, "efficiency": out["value"] / v1 / world}
         if partitioned:
             out["config"]["ranks_agree"] = ranks_agree
+            out["config"]["counter_bytes_per_rank"] = g.stats()["counter_bytes_held"]
             out["kernel_ms_note"] = "rank 0, last warm-up step (the timed steps run without per-launch events)"
         if comm_note:
             out["config"]["note"] = comm_note

@@ -195,7 +195,10 @@ int hc_counters_export(void* h, uint8_t* out)
 }
 const char* hc_last_error(void* h) { return S(h)->error.c_str(); }
 uint8_t* hc_visited(void* h) { return S(h)->eng->visited_dev(); }
-int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n) { return S(h)->load_seqs(seqs, off, n); }
+int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n)
+{
+	try { return S(h)->load_seqs(seqs, off, n); } catch (const abg::Failure& f) { S(h)->error = f.msg; return f.code; }
+}
 uint64_t hc_insert_rounds(void* h) { return S(h)->eng->stats().insert_rounds; }
 int hc_popcounts(void* h, uint64_t* a, uint64_t* b) { S(h)->eng->popcounts(a, b); return 0; }
 int hc_assemble_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n, uint8_t* results,

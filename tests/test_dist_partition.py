@@ -279,3 +279,41 @@ def test_filter_that_fits_no_single_rank(world, args, env, monkeypatch):
             assert out["stats"]["tile_overflows"] > 0, out["stats"]
     if world >= 4 and "ABG_ROUTE_CAP" not in env:
         assert out["comm_calls"]["all_to_all_v"] > 0, out["comm_calls"]
+
+
+@pytest.mark.parametrize("sliced", [False, True])
+def test_communicator_attached_after_a_load(sliced, monkeypatch):
+    """PASS 1's scratch is laid out for the partition it was allocated under: a communicator attached AFTER a load (or after a
+    load a context without counters refused) must make the next load allocate it anew -- on the device the stale layout was a
+    null pointer in a kernel (one rank, LocalComm, in process)."""
+    import ctypes as C
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding as ob
+    from abyss_amd import api, dist as adist, synth
+    from test_hostcheck import HostCheck
+    monkeypatch.setenv("ABG_FORCE_DIST", "1")
+    if sliced:
+        monkeypatch.setenv("ABG_SLICE_FILTER", "1")
+    m1, m2 = synth.make_read_set(5000, 12.0)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    hc = HostCheck(32, 1 << 20, insert_batch=20000, claim_log2=12, p2_first=64)
+    offs = np.ascontiguousarray(off, dtype=np.uint64)
+    rc = hc.l.hc_load_seqs(hc.h, buf, offs.ctypes.data, len(offs) - 1)
+    assert rc == (-1 if sliced else 0), rc  # (ABG_EINVAL: "attach a communicator first")
+    comm = adist.LocalComm()
+    hc.l.hc_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+    assert hc.l.hc_attach_comm(hc.h, C.byref(comm.struct)) == 0
+    hc.l.hc_reset.argtypes = [C.c_void_p]
+    hc.l.hc_reset(hc.h)
+    hc.load(buf, off)
+    o = ob.Oracle(32, counters=1 << 20)
+    o.load(buf, off)
+    assert np.array_equal(o.counters(), hc.counters())
+    ro, co = o.assemble(buf, off)
+    rh, ch = hc.assemble(buf, off)
+    assert np.array_equal(ro, rh) and [c.seq for c in co] == [c.seq for c in ch] and [c.coverage for c in co] == [c.coverage for c in ch]
+    assert comm.calls["all_reduce"] > 0
