@@ -30,6 +30,12 @@ CASES = [
     ("k64_m10_ss", "k64.fa", 64, 10, ["--SS"]),
     ("k96_m50", "k96.fa", 96, 50, []),
     ("k96_m20", "k96.fa", 96, 20, []),
+    # unitigs of circular replicons, tandem repeats, hairpins and homopolymers (make_structured.py): contigs that overlap
+    # themselves, their own reverse complement, and many others at once
+    ("s_plasmids_k32_m0", "s_plasmids_k32.fa", 32, 0, []),
+    ("s_tandem_k32_m5", "s_tandem_k32.fa", 32, 5, []),
+    ("s_inverted_k40_m0_ss", "s_inverted_k40.fa", 40, 0, ["--SS"]),
+    ("s_lowcomplex_k25_m0", "s_lowcomplex_k25.fa", 25, 0, []),
 ]
 FORMATS = ["adj", "dot", "gfa1", "gfa2", "asqg", "sam"]
 
@@ -39,7 +45,7 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     index = {}
     for name, fa, k, m, extra in CASES:
-        for fmt in FORMATS if name in ("k32_m0", "k64_m50", "k96_m20") else ["adj", "dot"]:
+        for fmt in FORMATS if name in ("k32_m0", "k64_m50", "k96_m20", "s_lowcomplex_k25_m0") else ["adj", "dot"]:
             r = subprocess.run([REF, "-k%d" % k, "-m%d" % m, "--" + fmt] + extra + [os.path.join(HERE, fa)],
                                stdout=subprocess.PIPE, check=True)
             # (the @PG line of SAM carries the command line of whoever ran it)

@@ -26,7 +26,7 @@ def strip_length_column(trace: bytes) -> bytes:
     return b"".join(b"\t".join(r.split(b"\t")[:1] + r.split(b"\t")[2:]) + b"\n" for r in trace.splitlines())
 
 
-@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k48_K16", "k50_qr11"])
+@pytest.mark.parametrize("name", ["k32", "k64", "k25_h3_kc3_t40", "k40_mixed", "k48_K16", "k50_qr11", "s_plasmids_k32", "s_lowcomplex_k25", "s_inverted_k40"])
 def test_cli_reproduces_golden(name, tmp_path):
     g = GoldenCase(name)
     fa = tmp_path / "reads.fa"

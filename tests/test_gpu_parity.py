@@ -55,6 +55,27 @@ def test_reproduces_reference_run(name):
     assert st["bulk_steps"] > st["lin_steps"] and st["chain_steps"] > 0 and st["memo_hits"] > 0, (name, st)
 
 
+@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16"])
+def test_reproduces_reference_run_on_cycles_repeats_and_hairpins(name):
+    """Graph shapes a random linear genome never makes (tests/golden/make_structured.py, from the unmodified reference at -j1):
+    circular replicons, tandem repeats with units shorter and longer than k, inverted repeats and hairpins, homopolymer and
+    dinucleotide runs -- what Unittest/Graph/ExtendPathTest.cpp's cycles / cyclesAndBranches / longestBranch / withTrimming
+    cases are about, as k-mer graphs."""
+    gc = GoldenCase(name)
+    g = api.BloomDBG(spaced_seed=mask_of(gc), **gc.kwargs())
+    assert g.size == gc.meta["counters"]
+    g.load(gc.buf, gc.off)
+    assert g.counting_stats()[1] == gc.meta["filtered_popcount"]
+    results, contigs = g.assemble(gc.buf, gc.off)
+    assert api.format_fasta(contigs, gc.ids) == gc.fasta
+    assert api.format_read_log(results, gc.ids) == gc.readlog
+    assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace
+    c = g.assembly_counters()
+    assert (c["reads_processed"], c["solid_reads"], c["visited_reads"]) == (
+        gc.meta["reads"], gc.meta["solid_reads"], gc.meta["visited_reads"])
+    g.close()
+
+
 @pytest.mark.parametrize("k,G,cov", [(21, 40000, 30.0), (64, 200000, 40.0), (33, 60000, 30.0), (97, 50000, 40.0),
                                      (150, 20000, 30.0)])
 def test_matches_oracle(k, G, cov):

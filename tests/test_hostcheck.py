@@ -197,6 +197,15 @@ def test_device_logic_reproduces_reference_run(name):
         g.meta["reads"], g.meta["solid_reads"], g.meta["visited_reads"])
 
 
+@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16"])
+def test_device_logic_reproduces_reference_run_on_cycles_repeats_and_hairpins(name):
+    """Graph shapes a random linear genome never makes (tests/golden/make_structured.py, from the unmodified reference at -j1):
+    circular replicons, tandem repeats with units shorter and longer than k, inverted repeats and hairpins, homopolymer and
+    dinucleotide runs -- what Unittest/Graph/ExtendPathTest.cpp's cycles / cyclesAndBranches / longestBranch / withTrimming
+    cases are about, as k-mer graphs."""
+    test_device_logic_reproduces_reference_run(name)
+
+
 @pytest.mark.parametrize("k,G", [(17, 15000), (33, 15000), (65, 15000), (97, 20000), (129, 15000), (150, 12000)])
 def test_device_logic_matches_oracle(k, G):
     m1, m2 = synth.make_read_set(G, 25.0)

@@ -120,6 +120,18 @@ def test_iterator_skips_non_acgt():
 GRAPH_GOLDEN = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))
 
 
+STRUCTURED = ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16"]
+
+
+@pytest.mark.parametrize("name", STRUCTURED)
+def test_oracle_reproduces_reference_run_on_cycles_repeats_and_hairpins(name):
+    """Graph shapes a random linear genome never makes (tests/golden/make_structured.py, from the unmodified reference at -j1):
+    circular replicons, tandem repeats with units shorter and longer than k, inverted repeats and hairpins, homopolymer and
+    dinucleotide runs -- what Unittest/Graph/ExtendPathTest.cpp's cycles / cyclesAndBranches / longestBranch / withTrimming
+    cases are about, as k-mer graphs."""
+    test_oracle_reproduces_reference_run(name)
+
+
 @pytest.mark.parametrize("name", ["k32", "k64", "k40_mixed", "k48_K16", "k25_h3_kc3_t40"])
 def test_oracle_graphviz_dump_matches_reference(name):
     """-g (outputGraph, bloom-dbg.h:1171-1242): the oracle's GraphViz text against the SHA-256 / size /
