@@ -54,6 +54,9 @@ def replicons(kind, rng):
         g = [rnd(rng, 1200), b"A" * 80, rnd(rng, 700), b"AC" * 50, rnd(rng, 700), b"T" * 45 + b"G" + b"T" * 45, rnd(rng, 900),
              b"AAG" * 30, rnd(rng, 600), b"C" * 30, rnd(rng, 1200)]
         return [(b"".join(g), False)]
+    if kind == "mixed":
+        # (the k-mer size at its limits: MAX_KMER = 192 wants long reads; a small k makes a crowded graph)
+        return [(rnd(rng, 9000), False), (rnd(rng, 1400), True), (rnd(rng, 60) * 12, False)]
     raise ValueError(kind)
 
 
@@ -85,6 +88,8 @@ CASES = [
     ("s_inverted_k40", "inverted", 40.0, 120, 0.004, ["-k40", "-b2M"]),
     ("s_lowcomplex_k25", "lowcomplex", 40.0, 100, 0.004, ["-k25", "-b2M"]),
     ("s_plasmids_k48_K16", "plasmids", 40.0, 120, 0.004, ["-k48", "-K16", "-b2M"]),
+    ("s_mixed_k192", "mixed", 60.0, 250, 0.003, ["-k192", "-b2M"]),
+    ("s_mixed_k12", "mixed", 30.0, 100, 0.004, ["-k12", "-b2M"]),
 ]
 
 
@@ -92,6 +97,8 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
     for ci, (name, kind, cov, L, err, opts) in enumerate(CASES):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         rng = np.random.default_rng(1000 + ci)
         seqs = sample(replicons(kind, rng), rng, cov, L, err)
         with tempfile.TemporaryDirectory() as td:
