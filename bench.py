@@ -17,7 +17,10 @@ holds 1/N of the reads, the counting filter is range-partitioned by position ove
 during PASS 1 (RCCL), gathered for PASS 2, whose walks are split over the ranks and merged before the
 ordered commit; the unitigs are bit-identical to a 1-GPU run of that job.
 --scaling weak makes the job N times --pairs / --bloom instead; --mode replicas runs N independent
-copies of the job (no collective on the data path).
+copies of the job (no collective on the data path).  --config 4 is configs[4] (1.2 G pairs, k=96, B=500G
+on eight GPUs): a filter beyond one GPU -- each rank keeps its own range of the counters, PASS 2 probes
+the all-gathered bit plane (abg_params.slice_filter; --slice-filter forces it at any size) -- and each
+pass is fed its reads in --chunks all-gathered pieces, so that no rank holds the read set.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -182,7 +185,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3],
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[N]: 1 = E. coli-scale (5 M pairs, k=64, B=2G; the default and the benchmark), "
                          "2 = human-chr-scale (200 M pairs, k=64, B=40G), 3 = spaced seed (5 M pairs, -k96 -K32, B=2G)")
     ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (overrides --config)")
@@ -204,6 +207,10 @@ def main() -> int:
                     help="partitioned mode: the fixed --config / --pairs / --bloom job over N ranks (strong: the default -- "
                          "north_star's experiment is BASELINE.json configs[2] over 1/2/4/8 GPUs), or a job N times as big "
                          "(weak: --pairs and --bloom are per rank)")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="feed each pass its reads in this many calls (abg_load_packed / abg_assemble_packed carry their state from call "
+                         "to call): bounds the reads a rank holds at once -- in a partitioned run the all-gathered share of a chunk "
+                         "instead of the whole read set.  Default 1; 8 for --config 4")
     ap.add_argument("--slice-filter", action="store_true",
                     help="partitioned runs: each rank keeps its own range of the counting filter only (abg_params.slice_filter = 1; "
                          "without the flag the library decides by the device's memory)")
@@ -223,7 +230,12 @@ def main() -> int:
         # strong-scaled; its one-GPU point is on file (profiles/r04_c_bench_config2_invariants.json)
         a.config = 2 if (world_env > 1 and a.mode == "partitioned" and a.pairs is None) else 1
     preset = {1: (5_000_000, 64, "2G", 0, "E. coli-scale"), 2: (200_000_000, 64, "40G", 0, "human-chr-scale"),
-              3: (5_000_000, 96, "2G", 32, "spaced-seed")}[a.config]
+              3: (5_000_000, 96, "2G", 32, "spaced-seed"),
+              # configs[4]: B = 500G is beyond one GPU -- a sliced filter over the ranks (abg_params.slice_filter decides that by
+              # itself), the reads in chunks.  Never run at size (no 8-GPU node so far); `--config 4 --pairs .. --bloom ..` scales it down
+              4: (1_200_000_000, 96, "500G", 0, "human-scale")}[a.config]
+    if a.chunks is None:
+        a.chunks = 8 if a.config == 4 else 1
     a.pairs = preset[0] if a.pairs is None else a.pairs
     a.k = preset[1] if a.k is None else a.k
     a.bloom = preset[2] if a.bloom is None else a.bloom
@@ -326,18 +338,23 @@ def main() -> int:
         g.profile_enable(profile)
         if profile:
             g.profile_reset()
-        if partitioned:
-            # part of the step: all-gather of the ranks' 2-bit reads (every rank runs every k-mer op
-            # against the counters it owns, so it needs every read)
-            rw, ro, rl, rn = g.share_reads(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads)
-        else:
-            rw, ro, rl, rn = words.data_ptr(), woff.data_ptr(), lens.data_ptr(), n_reads
+        def reads_of(c):
+            # chunk c of this rank's reads (the words stay where they are: offsets index them) -- in a partitioned run
+            # all-gathered, part of the step (every rank walks and guides over every read of the chunk)
+            lo, hi = n_reads * c // a.chunks, n_reads * (c + 1) // a.chunks
+            wp, op, lp = words.data_ptr(), woff.data_ptr() + 8 * lo, lens.data_ptr() + 4 * lo
+            return g.share_reads(wp, op, lp, hi - lo) if partitioned else (wp, op, lp, hi - lo)
         t_a = time.perf_counter()
-        g.load_packed(rw, ro, rl, rn)
+        for c in range(a.chunks):
+            rw, ro, rl, rn = reads_of(c)
+            g.load_packed(rw, ro, rl, rn)
         t_b = time.perf_counter()
         # contigs stay on the device (no per-contig callback into Python): the unitig count and
         # their total length come from the assembly counters (AssemblyCounters.h:15-31)
-        g.assemble_packed(rw, ro, rl, rn, want_results=False, want_contigs=False)
+        for c in range(a.chunks):
+            if a.chunks > 1 or not partitioned:
+                rw, ro, rl, rn = reads_of(c)  # (one chunk: what PASS 1 gathered is still there)
+            g.assemble_packed(rw, ro, rl, rn, want_results=False, want_contigs=False)
         phase_s[0] += t_b - t_a  # (both calls return with the device idle)
         phase_s[1] += time.perf_counter() - t_b
         c = g.assembly_counters()
@@ -494,7 +511,7 @@ def main() -> int:
                                        % (world, ("RCCL on the engine's stream: (op, counter) pairs routed to the owning ranks by all-to-all (ncclSend/ncclRecv groups)" if world >= 4 else "RCCL all_gather + all_reduce on the engine's stream") if a.comm == "rccl"
                                           else "torch.distributed on host copies")) if partitioned
                        else ("replicas x%d (independent jobs)" % world if world > 1 else "single GPU"),
-                       "unitigs": unitigs, "unitig_bp": bases},
+                       "unitigs": unitigs, "unitig_bp": bases, **({"chunks": a.chunks} if a.chunks > 1 else {})},
             "roofline": roofline,
             "kernel_ms": {nm: {"ms": round(v[0], 3), "launches": v[1]} for nm, v in prof.items() if v[1]},
             "engine_stats": stats,

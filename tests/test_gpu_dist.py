@@ -95,6 +95,23 @@ def test_rccl_single_rank_sliced_filter_reproduces_reference_runs_and_oracle():
     assert out["launches"]["pc_cover"] > 0 and out["launches"]["solid_plane"] > 0 and out["held"] == (1 << 24) + 64, out
 
 
+def test_bench_runs_configs4_scaled_down_on_two_ranks():
+    """`bench.py --gpus N --config 4` (k=96, B=500G, 1.2 G pairs on eight GPUs) scaled down to what two ranks sharing this
+    GPU can hold: a sliced filter, the reads in three chunks per pass (every chunk all-gathered), the launch path of the
+    driver's multi-GPU run (ranks started by bench.py itself)."""
+    env = dict(os.environ, ABG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("ABG_FORCE_DIST", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "staged", "--slice-filter", "--chunks", "3",
+                        "--config", "4", "--pairs", "300000", "--bloom", "120M", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-end-to-end"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_agree"] is True and c["chunks"] == 3 and "k=96" in c["workload"], c
+    assert 0 < c["counter_bytes_per_rank"] < 0.51 * (120 << 20) / 1.125 + 4096, c
+    assert c["unitigs"] > 1000 and d["value"] > 0
+
+
 def _gpus():
     try:
         import torch
