@@ -4477,6 +4477,7 @@ class Engine {
 		line("sum", sum);
 		fprintf(stderr, "[walkdbg]   lookAhead inside trueBranch: %.2f ms in %llu calls; bulk examine phase %.2f ms; trueBranch waiting for neighbour masks %.2f ms in %llu probe rounds; call entries %.2f ms\n", sum[13] / 1e5, (unsigned long long)sum[14], sum[15] / 1e5,
 		    sum[16] / 1e5, (unsigned long long)sum[17], sum[18] / 1e5);
+		fprintf(stderr, "[walkdbg]   the read's k-mers looked up one by one %.2f ms; inside walk_extend %.2f ms (searches and linear runs included)\n", sum[19] / 1e5, sum[20] / 1e5);
 		{
 			const uint64_t* x = &d[bi * (uint64_t)WALK_DBG_N];
 			fprintf(stderr, "[walkdbg]   slowest walker's lookAhead: %.2f ms in %llu calls; its trueBranch: %.2f ms waiting for neighbour masks (%llu probe rounds), %.2f ms in call entries (identity, on-stack scan, frame push)\n", x[13] / 1e5, (unsigned long long)x[14],

@@ -192,6 +192,7 @@ struct WalkState {
 	uint32_t bulk_overflow; // the vertex table filled up during a bulk step
 	uint32_t n_bulk_calls, n_bulk_steps, n_lin_steps; // work counters of this walker
 	uint32_t n_bulk_tries;
+	uint64_t t_seed, t_ext, t_mat;  // ... the read's k-mers looked up one after the other / inside walk_extend / the path written out
 	uint64_t t_bulk, t_lin, t_post; // profiling aid (ABG_WALK_DEBUG): clock ticks in walk_bulk / walk_linear / after the extensions
 	uint64_t t_bp[4];               // ... and inside walk_bulk: verify the hint / examine the vertices / repeats / take the steps
 };
@@ -342,6 +343,9 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		terms();
 		const VKey key = kmer_ident(p, my_s, my_fh, my_rh, my_df, my_dr);
 		bs.key[l] = key;
+		// "new to the walker": the home slot of (key, owner) is read while the probes below are in flight -- nearly always
+		// free, which settles it (only this walker enters keys of its own, and it is not entering any now)
+		const uint64_t home = ld_coherent(&tab.hmin[wt_slot(tab, wt_key(key), owner)]);
 		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
 		{
 			// Two stages.  Six of the eight neighbours do not exist, and nearly all of those fail the first
@@ -381,8 +385,11 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 				}
 			}
 		}
-		const uint64_t fs = wt_find(tab, wt_key(key), owner);
-		bool ok = fs == WT_EMPTY || (uint32_t)ld_coherent(&tab.meta[fs]) == WT_TOMB;
+		bool ok = home == WT_EMPTY;
+		if (!ok) {
+			const uint64_t fs = wt_find(tab, wt_key(key), owner);
+			ok = fs == WT_EMPTY || (uint32_t)ld_coherent(&tab.meta[fs]) == WT_TOMB;
+		}
 		const unsigned bmask = ~bad & 0xFu, fmask = (~bad >> 4) & 0xFu;
 		ok = ok && bmask != 0 && !(bmask & (bmask - 1)) && fmask != 0 && !(fmask & (fmask - 1));
 		const unsigned bb = (bmask & 1u) ? 0u : (bmask & 2u) ? 1u : (bmask & 4u) ? 2u : 3u;
@@ -838,7 +845,7 @@ ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& sc
 		sc.tbk_cap = 3 * cap;
 	}
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
-	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
+	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_seed = 0; w.t_ext = 0; w.t_mat = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
 	sc.overflow = 0;
 	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0; sc.dbg_mask = 0; sc.dbg_mask_n = 0; sc.dbg_memo = 0;
 	sc.coop = e.coop;
@@ -875,6 +882,36 @@ ABG_HDN void presearch_one(WalkEnv<NW>& e, const PreReq<NW>& q, uint32_t slot)
 	}
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// assembledKmers.find(*it) for the read's k-mers from position `it` on, 64 of them per round (bloom-dbg.h:839-843 looks
+// them up one after the other: three dependent loads each, 87 times a read -- a sixth of the walkers' time): the first
+// position whose k-mer is not in the read's assembled set, nk if there is none.  Only this walker writes entries of its
+// own, and it is not walking while it looks: the answers are those of the one-by-one loop.
+template <int NW>
+ABG_HDN uint32_t next_unassembled(const WalkEnv<NW>& e, uint64_t r, uint32_t it, uint32_t nk, uint32_t owner)
+{
+	const Params& p = e.p;
+	const uint32_t* __restrict__ words = e.batch.words;
+	const uint64_t woff = e.batch.woff[r];
+	const uint32_t lane = lane_id();
+	for (uint32_t base = it; base < nk; base += 64u) {
+		const uint32_t n = nk - base < 64u ? nk - base : 64u;
+		uint64_t fh, rh;
+		stretch_hashes_wave<NW>(words, woff, base, n, p.k, fh, rh);
+		bool missing = false;
+		if (lane < n) {
+			const Kmer<NW> s = window_kmer<NW>(words, woff, base + lane, p.k);
+			uint64_t df = 0, dr = 0;
+			if constexpr (MASKED_BUILD<NW>) masked_terms(p, s, df, dr);
+			const uint64_t fs = wt_find(e.tab, wt_key(kmer_ident(p, s, fh, rh, df, dr)), owner);
+			missing = fs == WT_EMPTY || (uint32_t)ld_coherent(&e.tab.meta[fs]) == WT_TOMB;
+		}
+		const uint64_t b = wave_ballot(missing);
+		if (b) return base + (uint32_t)__builtin_ctzll(b);
+	}
+	return nk;
+}
+#endif
 // One candidate read: the loop of processRead (bloom-dbg.h:839-879).
 template <int NW>
 ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
@@ -908,12 +945,27 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	Vtx<NW> cur;
 	cur.s = batch_kmer<NW>(e.batch, r, 0, k);
 	vtx_rehash(p, cur);
+	uint64_t ts0 = dbg_clock(e.dbg);
 	for (uint32_t it = 0; it < nk; it++) {
-		if (it > 0) vtx_shift(p, cur, SENSE, (uint32_t)batch_base(e.batch, r, it + k - 1));
-		VKey ckey = vtx_key(p, cur);
-		// assembledKmers.find(*it), bloom-dbg.h:842
-		uint64_t fs = wt_find(e.tab, ckey, owner);
-		if (fs != WT_EMPTY && (uint32_t)ld_coherent(&e.tab.meta[fs]) != WT_TOMB) continue;
+		VKey ckey;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (sc.coop) {
+			it = next_unassembled(e, r, it, nk, owner);
+			if (it >= nk) break;
+			cur.s = window_kmer<NW>(e.batch.words, e.batch.woff[r], it, k);
+			vtx_rehash(p, cur);
+			ckey = vtx_key(p, cur);
+		} else
+#endif
+		{
+			if (it > 0) vtx_shift(p, cur, SENSE, (uint32_t)batch_base(e.batch, r, it + k - 1));
+			ckey = vtx_key(p, cur);
+			// assembledKmers.find(*it), bloom-dbg.h:842
+			uint64_t fs = wt_find(e.tab, ckey, owner);
+			if (fs != WT_EMPTY && (uint32_t)ld_coherent(&e.tab.meta[fs]) != WT_TOMB) continue;
+		}
+		if (e.dbg) w.t_seed += dbg_clock(e.dbg) - ts0;
+		const uint64_t te0 = dbg_clock(e.dbg);
 
 		w.seed = cur; w.nl = 0; w.nr = 0;
 		int ins = wt_insert(e.tab, ckey, owner, contig, sc.coop);
@@ -936,6 +988,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		uint32_t n = w.nl + 1 + w.nr;
 		total_steps += n;
 		const uint64_t tp0 = dbg_clock(e.dbg);
+		if (e.dbg) w.t_ext += tp0 - te0;
 
 		const bool tip = is_tip(n, lcode, rcode, p.trim);
 		if (tip && e.claims) {
@@ -1067,7 +1120,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 			}
 		}
 		contig++;
-		if (e.dbg) w.t_post += dbg_clock(e.dbg) - tp0;
+		if (e.dbg) { ts0 = dbg_clock(e.dbg); w.t_post += ts0 - tp0; }
 	}
 	e.first_rec[c] = first;
 	e.status[c] = abort_status ? abort_status : (uint32_t)WS_COMPLETE;
@@ -1090,6 +1143,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		d[4] = sc.dbg_nodes; d[5] = w.t_bulk; d[6] = contig; d[7] = w.t_post;
 		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
 		d[13] = sc.dbg_la; d[14] = sc.dbg_la_calls; d[15] = w.t_bp[1]; d[16] = sc.dbg_mask; d[17] = sc.dbg_mask_n; d[18] = sc.dbg_memo;
+		d[19] = w.t_seed + (dbg_clock(e.dbg) - ts0); d[20] = w.t_ext; d[21] = w.t_mat;
 	}
 }
 
