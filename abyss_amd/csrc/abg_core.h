@@ -1480,7 +1480,7 @@ struct LAFrame {        // one active call of lookAhead (ExtendPath.h:100-139)
 	Vtx<NW> v;
 	uint8_t mask, next;
 };
-constexpr uint32_t WALK_DBG_N = 24; // per-walker profiling counters (ABG_WALK_DEBUG)
+constexpr uint32_t WALK_DBG_N = 28; // per-walker profiling counters (ABG_WALK_DEBUG)
 constexpr int LA_MAX_VISITED = 1366; // 4^0 + ... + 4^5 + 1
 constexpr uint32_t LA_FAST = 96;      // ... of which this many live in a walker's fast memory
 // The trueBranch stack is two-tier: the first tbf_cap frames live in fast memory (LDS on

@@ -4477,6 +4477,8 @@ class Engine {
 		line("sum", sum);
 		fprintf(stderr, "[walkdbg]   lookAhead inside trueBranch: %.2f ms in %llu calls; bulk examine phase %.2f ms; trueBranch waiting for neighbour masks %.2f ms in %llu probe rounds; call entries %.2f ms\n", sum[13] / 1e5, (unsigned long long)sum[14], sum[15] / 1e5,
 		    sum[16] / 1e5, (unsigned long long)sum[17], sum[18] / 1e5);
+		fprintf(stderr, "[walkdbg]   bulk examine: strand hashes of the chunk %.2f ms; k-mer, identity, home slot %.2f; eight first probes %.2f; the survivors' other probes %.2f; table and checks %.2f; barrier %.2f\n",
+		    sum[22] / 1e5, sum[23] / 1e5, sum[24] / 1e5, sum[25] / 1e5, sum[26] / 1e5, sum[27] / 1e5);
 		fprintf(stderr, "[walkdbg]   the read's k-mers looked up one by one %.2f ms; inside walk_extend %.2f ms (searches and linear runs included)\n", sum[19] / 1e5, sum[20] / 1e5);
 		{
 			const uint64_t* x = &d[bi * (uint64_t)WALK_DBG_N];

@@ -192,6 +192,7 @@ struct WalkState {
 	uint32_t bulk_overflow; // the vertex table filled up during a bulk step
 	uint32_t n_bulk_calls, n_bulk_steps, n_lin_steps; // work counters of this walker
 	uint32_t n_bulk_tries;
+	uint64_t t_bx[6];               // ... the examine phase of walk_bulk piece by piece
 	uint64_t t_seed, t_ext, t_mat;  // ... the read's k-mers looked up one after the other / inside walk_extend / the path written out
 	uint64_t t_bulk, t_lin, t_post; // profiling aid (ABG_WALK_DEBUG): clock ticks in walk_bulk / walk_linear / after the extensions
 	uint64_t t_bp[4];               // ... and inside walk_bulk: verify the hint / examine the vertices / repeats / take the steps
@@ -331,6 +332,8 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		if (!same) { const uint64_t t = st_fh; st_fh = st_rh; st_rh = t; } // (the reverse complement's hashes are the strand hashes swapped)
 	}
 #endif
+	const uint64_t tx0 = dbg_clock(e.dbg);
+	uint64_t tx1 = tx0, tx2 = tx0, tx3 = tx0, tx4 = tx0;
 	for (uint32_t l = lane0; l < n; l += lstep) {
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (COOP) {
@@ -346,6 +349,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		// "new to the walker": the home slot of (key, owner) is read while the probes below are in flight -- nearly always
 		// free, which settles it (only this walker enters keys of its own, and it is not entering any now)
 		const uint64_t home = ld_coherent(&tab.hmin[wt_slot(tab, wt_key(key), owner)]);
+		tx1 = dbg_clock(e.dbg);
 		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
 		{
 			// Two stages.  Six of the eight neighbours do not exist, and nearly all of those fail the first
@@ -364,6 +368,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 #pragma unroll
 			for (unsigned q = 0; q < 8; q++) bad |= (c0[q] < p.kc ? 1u : 0u) << q;
 			unsigned surv = p.nh > 1 ? ~bad & 0xFFu : 0u;
+			tx2 = dbg_clock(e.dbg);
 			while (COOP ? wave_any(surv != 0) : surv != 0) {
 				if (surv) {
 					const unsigned q1 = (unsigned)__builtin_ctz(surv);
@@ -385,6 +390,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 				}
 			}
 		}
+		tx3 = dbg_clock(e.dbg);
 		bool ok = home == WT_EMPTY;
 		if (!ok) {
 			const uint64_t fs = wt_find(tab, wt_key(key), owner);
@@ -411,9 +417,11 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		}
 		bs.good[l] = ok ? 1 : 0;
 		bs.fbase[l] = (uint8_t)fb;
+		tx4 = dbg_clock(e.dbg);
 	}
 	wave_sync();
 	const uint64_t tq2 = dbg_clock(e.dbg);
+	if (e.dbg && lane0 == 0) { w.t_bx[0] += tx0 - tq1; w.t_bx[1] += tx1 - tx0; w.t_bx[2] += tx2 - tx1; w.t_bx[3] += tx3 - tx2; w.t_bx[4] += tx4 - tx3; w.t_bx[5] += tq2 - tx4; }
 	// ---- a vertex that repeats an earlier one of the chunk (a cycle within the read) stops the prefix
 	for (uint32_t l = lane0; l < n; l += lstep) {
 		const VKey key = bs.key[l];
@@ -845,7 +853,7 @@ ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& sc
 		sc.tbk_cap = 3 * cap;
 	}
 	w.bulk_skip = 0; w.bulk_overflow = 0; w.n_bulk_calls = 0; w.n_bulk_steps = 0; w.n_lin_steps = 0;
-	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_seed = 0; w.t_ext = 0; w.t_mat = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
+	w.n_bulk_tries = 0; w.t_bulk = 0; w.t_lin = 0; w.t_post = 0; w.t_seed = 0; w.t_ext = 0; w.t_mat = 0; for (int q = 0; q < 6; q++) w.t_bx[q] = 0; w.t_bp[0] = w.t_bp[1] = w.t_bp[2] = w.t_bp[3] = 0;
 	sc.overflow = 0;
 	sc.dbg_search = 0; sc.dbg_calls = 0; sc.dbg_nodes = 0; sc.dbg_chain = 0; sc.dbg_on = e.dbg ? 1u : 0u; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0; sc.dbg_mask = 0; sc.dbg_mask_n = 0; sc.dbg_memo = 0;
 	sc.coop = e.coop;
@@ -1144,6 +1152,7 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		d[8] = w.t_lin; d[9] = w.n_bulk_tries; d[10] = w.n_bulk_calls; d[11] = w.n_bulk_steps; d[12] = sc.dbg_chain;
 		d[13] = sc.dbg_la; d[14] = sc.dbg_la_calls; d[15] = w.t_bp[1]; d[16] = sc.dbg_mask; d[17] = sc.dbg_mask_n; d[18] = sc.dbg_memo;
 		d[19] = w.t_seed + (dbg_clock(e.dbg) - ts0); d[20] = w.t_ext; d[21] = w.t_mat;
+		for (int q = 0; q < 6; q++) d[22 + q] = w.t_bx[q];
 	}
 }
 
