@@ -16,6 +16,6 @@ for f in ("bench_default", "bench_noevents"):
     d = json.loads([l for l in open("gpurun_out/r4f/%s.json" % f) if l.startswith("{")][-1])
     print(f, round(d["value"], 1), round(d["ms_per_step"], 1), d.get("pass_ms_per_step"), d.get("parity", {}).get("ok"), d["roofline"]["kernel"], d["roofline"]["frac"], (d.get("end_to_end") or {}).get("wall_ms"))
 PY
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o r4f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_bench.json 2> $O/prof.err
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r4f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_bench.json 2> $O/prof.err
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -8 $O/kernel_stats.csv | cut -c1-150
 rm -rf $O/prof
