@@ -238,10 +238,13 @@ ABG_HD uint64_t pos_i(const Params& p, uint64_t h, unsigned i)
 // set of m/8 bytes for the walkers' and the classification's random probes (238 MB for B=2G: inside the
 // 256 MB Infinity Cache) instead of m.  Returns a value to compare with kc: the counter itself, or
 // 255 / 0 from the plane.  (Coverage sums -- solid_min_count -- keep reading the counters.)
+// (ONE load instruction whatever the mode: with a load in each arm of `if (p.solid_bits)` the compiler waits for every
+// probe before it issues the next -- a group of probes meant to be in flight together became a chain of round trips)
 ABG_HD unsigned probe_c(const Params& p, const uint8_t* __restrict__ cnt, uint64_t pos)
 {
-	if (p.solid_bits) return ((cnt[pos >> 3] >> (pos & 7)) & 1u) ? 255u : 0u;
-	return cnt[pos];
+	const bool bits = p.solid_bits != 0;
+	const unsigned byte = cnt[bits ? pos >> 3 : pos];
+	return bits ? (((byte >> (pos & 7)) & 1u) ? 255u : 0u) : byte;
 }
 
 // ------------------------------------------------------------ 2-bit k-mers
@@ -758,12 +761,21 @@ ABG_HD void stretch_hashes_wave(const uint32_t* __restrict__ words, uint64_t wof
 	const uint32_t epl = (nb + 63) >> 6; // bases per lane: element e = lane * epl + i
 	uint64_t pf[STRETCH_EPL], pr[STRETCH_EPL];
 	uint64_t af = 0, ar = 0;
+	// the lane's (at most four, consecutive) bases sit in one packed word or two: both loads go out before anything waits
+	const uint32_t t0 = lane * epl, bp0 = qlo + t0;
+	uint64_t two = 0;
+	if (t0 < nb) {
+		const uint32_t tl = t0 + epl - 1u < nb ? t0 + epl - 1u : nb - 1u; // the last base this lane takes
+		const uint64_t wi = woff + (bp0 >> 4);
+		const uint32_t lo = words[wi];
+		const uint32_t hi = ((qlo + tl) >> 4) != (bp0 >> 4) ? words[wi + 1] : 0u;
+		two = (uint64_t)lo | ((uint64_t)hi << 32);
+	}
 #pragma unroll
 	for (unsigned i = 0; i < STRETCH_EPL; i++) {
-		const uint32_t t = lane * epl + i;
+		const uint32_t t = t0 + i;
 		if (i < epl && t < nb) {
-			const uint32_t bp = qlo + t;
-			const unsigned base = (words[woff + (bp >> 4)] >> (2u * (bp & 15u))) & 3u;
+			const unsigned base = (unsigned)(two >> (2u * ((bp0 & 15u) + i))) & 3u;
 			af ^= srol_back(seed_of(base), t); ar ^= srol_fwd(seed_of(3u - base), t);
 		}
 		pf[i] = af; pr[i] = ar;

@@ -369,23 +369,29 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 			for (unsigned q = 0; q < 8; q++) bad |= (c0[q] < p.kc ? 1u : 0u) << q;
 			unsigned surv = p.nh > 1 ? ~bad & 0xFFu : 0u;
 			tx2 = dbg_clock(e.dbg);
+			// (four survivors a round: a wave goes round until its slowest lane is done, and one lane in three has a false
+			// positive among its six absent neighbours -- with two a round that was 2-3 rounds for nearly every wave.  Their
+			// hashes are computed again: eight of them kept across the first probes went to scratch)
 			while (COOP ? wave_any(surv != 0) : surv != 0) {
 				if (surv) {
-					const unsigned q1 = (unsigned)__builtin_ctz(surv);
-					surv &= surv - 1;
-					const unsigned q2 = surv ? (unsigned)__builtin_ctz(surv) : q1;
-					surv &= surv - 1;
-					const uint64_t h1 = nbr_h(q1), h2 = nbr_h(q2);
+					unsigned qs[4];
+#pragma unroll
+					for (unsigned t = 0; t < 4; t++) { qs[t] = surv ? (unsigned)__builtin_ctz(surv) : qs[0]; surv &= surv - 1; }
+					uint64_t hs[4];
+#pragma unroll
+					for (unsigned t = 0; t < 4; t++) hs[t] = nbr_h(qs[t]);
 					for (unsigned base = 1; base < p.nh; base += 3) {
-						uint8_t c1[3], c2[3];
+						uint8_t cc[4][3];
 #pragma unroll
 						for (unsigned i = 0; i < 3; i++) {
 							const unsigned hi = base + i < p.nh ? base + i : 0u;
-							c1[i] = (uint8_t)probe_c(p, cnt, pos_i(p, h1, hi));
-							c2[i] = (uint8_t)probe_c(p, cnt, pos_i(p, h2, hi));
+#pragma unroll
+							for (unsigned t = 0; t < 4; t++) cc[t][i] = (uint8_t)probe_c(p, cnt, pos_i(p, hs[t], hi)); // (a lane with fewer survivors probes its first again: a load under a lane's own condition is waited for on the spot)
 						}
 #pragma unroll
-						for (unsigned i = 0; i < 3; i++) { bad |= (c1[i] < p.kc ? 1u : 0u) << q1; bad |= (c2[i] < p.kc ? 1u : 0u) << q2; }
+						for (unsigned i = 0; i < 3; i++)
+#pragma unroll
+							for (unsigned t = 0; t < 4; t++) bad |= (cc[t][i] < p.kc ? 1u : 0u) << qs[t];
 					}
 				}
 			}
