@@ -1686,13 +1686,16 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 		bool called = false;
 		while (top >= 0 && !called) {
 			TBFrame<NW>& f = frame(top);
-			const Vtx<NW> fv = uniform_vtx(f.v);
-			const unsigned fdepth = uni32<COOP>((uint32_t)f.depth);
-			const int fdir = (int)uni32<COOP>((uint32_t)f.dir);
+			// (the frame in ONE copy: its fields read one by one are a dozen loads each waited for on the spot)
+			const TBFrame<NW> fc = f;
+			const Vtx<NW> fv = uniform_vtx(fc.v);
+			const unsigned fdepth = uni32<COOP>((uint32_t)fc.depth);
+			const int fdir = (int)uni32<COOP>((uint32_t)fc.dir);
 			const int sense = (fdir == FORWARD) ? SENSE : ANTISENSE;
-			if (uni32<COOP>((uint32_t)f.stage) == 0) {
-				unsigned nx = uni32<COOP>((uint32_t)f.next);
-				const unsigned ms = uni32<COOP>((uint32_t)f.mask_same);
+			unsigned f_next = uni32<COOP>((uint32_t)fc.next), f_mask_other = uni32<COOP>((uint32_t)fc.mask_other);
+			if (uni32<COOP>((uint32_t)fc.stage) == 0) {
+				unsigned nx = f_next;
+				const unsigned ms = uni32<COOP>((uint32_t)fc.mask_same);
 				while (nx < 4 && !((ms >> nx) & 1u)) nx++;
 				if (nx < 4) {
 					unsigned b = nx++;
@@ -1719,12 +1722,13 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				}
 				if (!flip) { top--; continue; } // visited.erase(v); return false
 				f.stage = 1;
-				f.next = 0;
-				if (!uni32<COOP>((uint32_t)f.have_other)) {
+				f.next = 0; f_next = 0;
+				if (!uni32<COOP>((uint32_t)fc.have_other)) {
 #if defined(__HIP_DEVICE_COMPILE__)
 					const uint64_t tm0 = sc.dbg_on ? wall_clock64() : 0;
 #endif
-					f.mask_other = (uint8_t)nbr_mask_cached<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE, mcache);
+					f_mask_other = nbr_mask_cached<NW, COOP>(p, tabs, cnt, fv, fdir == FORWARD ? ANTISENSE : SENSE, mcache);
+					f.mask_other = (uint8_t)f_mask_other;
 #if defined(__HIP_DEVICE_COMPILE__)
 					if (sc.dbg_on) { sc.dbg_mask += wall_clock64() - tm0; sc.dbg_mask_n++; }
 #endif
@@ -1736,8 +1740,8 @@ ABG_HDX bool true_branch_t(const Params& p_in, const uint8_t* __restrict__ cnt_i
 				const int osense = (fdir == FORWARD) ? ANTISENSE : SENSE;
 				const int odir = (fdir == FORWARD) ? REVERSE : FORWARD;
 				bool made = false;
-				unsigned nx = uni32<COOP>((uint32_t)f.next);
-				const unsigned mo = uni32<COOP>((uint32_t)f.mask_other);
+				unsigned nx = f_next;
+				const unsigned mo = f_mask_other;
 				const VKey uk = top > 0 ? keyat(top - 1) : root_uk;
 				const uint64_t ufh = uni64<COOP>(uk.fh), urh = uni64<COOP>(uk.rh);
 				while (nx < 4) {
