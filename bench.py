@@ -469,7 +469,7 @@ def main() -> int:
     # command, tools/gpu_pmc_traffic.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
     # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
     traffic = traffic_src = None
-    tsrc = os.path.join(ROOT, "profiles", "r04_b_pmc_traffic.json")
+    tsrc = os.path.join(ROOT, "profiles", "r04_d_pmc_traffic.json")
     if os.path.exists(tsrc) and a.config == 1 and a.pairs == 5_000_000 and world == 1:
         tj = json.load(open(tsrc))
         kname = {"rewalk": "FWalk", "walk": "FWalk", "presearch": "FPresearch<", "presearch_scan": "FPresearchScan", "tile_apply": "FTileApply", "tile_purity": "FTilePurity",
@@ -479,7 +479,7 @@ def main() -> int:
         t = tj.get(kname)
         if t:
             traffic = (t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024 / max(t["FETCH_SIZE"]["dispatches"], 1)
-            traffic_src = "profiles/r04_b_pmc_traffic.json (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, KB units, per launch; taken at commit %s)" % (kname, tj.get("_commit", "?"))
+            traffic_src = "profiles/r04_d_pmc_traffic.json (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, KB units, per launch; taken at commit %s)" % (kname, tj.get("_commit", "?"))
     step_bytes = (2 * per_kmer_bases + 4 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers + 12 * H * unitig_kmers
     roofline = {"bound": "hbm", "kernel": per_kernel[dom]["longest_kernel"], "family": dom,
                 "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
