@@ -73,6 +73,8 @@ struct Config {
 	bool heavy_first = true;          // ... and the candidates with the most such searches are walked first (Engine::presearch)
 	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
 	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
+	bool early_presearch = false;     // ... and those of the NEXT batch's candidates (as classified ahead) run beside this batch's commit (Engine::early_presearch;
+	                                  // measured: PASS 2 429 vs 435 ms on configs[1], inside the noise of the boxes -- left off)
 	uint32_t presearch_min_weight = 0; // ... and only for candidates with at least this many such searches on their reads (0: all)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
@@ -2537,8 +2539,11 @@ class Engine {
 		if (cend_.hmin) free_tab(cend_);
 		if (memo_tab_.hmin) free_tab(memo_tab_);
 		if (plane_) be_.free(plane_);
-		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); be_.free(pre_tags_); }
+		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); }
+		if (pre_tags_) be_.free(pre_tags_);
 		if (pre_w_) be_.free(pre_w_);
+		if (early_cand_d_) { be_.free(early_cand_d_); be_.free(pre_w2_); }
+		if (pre_req2_) { be_.free(pre_req2_); be_.free(pre_n2_d_); }
 		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
@@ -2943,6 +2948,8 @@ class Engine {
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
 		deliveries_wait(); // (the last batch's contigs are with the caller)
+		be_.wait_walkers(EARLY_CTX);
+		early_done_ = true;
 		be_.sync_side();
 		be_.wait_side_scope(); // (the guide's build, if it went to the side stream)
 		pre_n_ = 0; prefetch_ = nullptr;
@@ -4316,6 +4323,7 @@ class Engine {
 						FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_ };
 						be_.launch_slots_side(nn, f, cslots_, "classify");
 						pre_first_ = nf; pre_n_ = nn;
+						pre_batch_ = vn; pre_res_ = result_d + nf; early_done_ = false;
 					};
 				}
 				if (r.nc) {
@@ -4548,6 +4556,8 @@ class Engine {
 		if (!pre_req_) {
 			pre_req_ = be_.alloc((uint64_t)cap * (8ull * MAX_NW + 24)); // (PreReq of the widest k-mer)
 			pre_n_d_ = (uint32_t*)be_.alloc(8);
+		}
+		if (!pre_tags_) {
 			pre_tags_ = (uint64_t*)be_.alloc(8ull << PRE_TAG_LOG2);
 			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
 		}
@@ -4577,6 +4587,61 @@ class Engine {
 		uint32_t slots = wslots_;
 		if (const char* e = getenv("ABG_PRESEARCH_SLOTS")) slots = std::max(1, std::min<int>(atoi(e), (int)wslots_)); // (diagnosis)
 		be_.launch_walkers(nreq, fp, slots, "presearch", 0, false);
+	}
+	// The pre-search of the NEXT batch, started when this batch's walkers are done: the commit that follows is a string of small
+	// kernels and host round trips that leaves most of the machine idle, the next batch's verdicts are already there (classified
+	// ahead on the side stream, against an older visited filter: a superset of its candidates), and a pre-search answer is a fact
+	// about the solid filter -- whoever computes it, whenever, computes the same one.  The batch's own pre-search then finds its
+	// questions answered.  It runs on a stream of its own in half the walkers' slots and in their scratch (free by now); whoever
+	// needs that scratch next waits for it (predict_and_walk).
+	static constexpr int EARLY_CTX = 3;
+	Batch pre_batch_{}; const uint8_t* pre_res_ = nullptr; bool early_done_ = true;
+	uint32_t* early_cand_d_ = nullptr; uint32_t early_cap_ = 0;
+	void* pre_req2_ = nullptr; uint32_t* pre_n2_d_ = nullptr; uint32_t* pre_w2_ = nullptr;
+	template <int NW>
+	void early_presearch()
+	{
+		early_done_ = true;
+		if constexpr (MASKED_BUILD<NW>) return;
+		if (!cfg_.early_presearch || !cfg_.presearch || !memo_.k0 || p_.trim < 2 || !pre_n_ || dist()) return;
+		if (!be_.side_done()) return; // (the verdicts are not there yet: not worth holding the commit up)
+		be_.wait_walkers(EARLY_CTX);
+		be_.sync_side();
+		std::vector<uint8_t> res(pre_n_);
+		be_.d2h(res.data(), pre_res_, pre_n_);
+		std::vector<uint32_t> cand;
+		for (uint64_t j = 0; j < pre_n_ && cand.size() < cfg_.p2_max_candidates; j++) if (res[j] == RES_CANDIDATE) cand.push_back((uint32_t)j);
+		const uint32_t n = (uint32_t)cand.size();
+		if (!n) return;
+		if (early_cap_ < n) {
+			if (early_cand_d_) { be_.free(early_cand_d_); be_.free(pre_w2_); }
+			early_cap_ = std::max<uint32_t>(n, 1u << 16);
+			early_cand_d_ = (uint32_t*)be_.alloc(early_cap_ * 8ull); // the candidates' reads, then the list 0 .. n-1
+			pre_w2_ = (uint32_t*)be_.alloc(early_cap_ * 4ull);
+		}
+		if (!pre_req2_) {
+			pre_req2_ = be_.alloc((uint64_t)cfg_.presearch_cap * (8ull * MAX_NW + 24));
+			pre_n2_d_ = (uint32_t*)be_.alloc(8);
+		}
+		if (!pre_tags_) {
+			pre_tags_ = (uint64_t*)be_.alloc(8ull << PRE_TAG_LOG2);
+			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
+		}
+		std::vector<uint32_t> up(2ull * n);
+		for (uint32_t i = 0; i < n; i++) { up[i] = cand[i]; up[n + i] = i; }
+		be_.h2d(early_cand_d_, up.data(), up.size() * 4ull);
+		be_.memset(pre_n2_d_, 0, 8);
+		WalkEnv<NW> env = make_env<NW>(pre_batch_, early_cand_d_, nullptr, nullptr);
+		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, early_cand_d_ + n, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
+			(PreReq<NW>*)pre_req2_, pre_n2_d_, cfg_.presearch_cap, pre_w2_, cfg_.presearch_min_weight };
+		be_.launch_wave(n, fs, "presearch_scan");
+		uint32_t nreq = 0;
+		be_.d2h(&nreq, pre_n2_d_, 4);
+		nreq = std::min(nreq, cfg_.presearch_cap);
+		if (!nreq) return;
+		pre_requests_ += nreq;
+		FPresearch<NW> fp{ env, (const PreReq<NW>*)pre_req2_ };
+		be_.launch_walkers(nreq, fp, std::max<uint32_t>(64, wslots_ / 2), "presearch", EARLY_CTX, true);
 	}
 	uint32_t* pre_w_ = nullptr; uint32_t pre_w_cap_ = 0;
 	void* pre_req_ = nullptr; uint32_t* pre_n_d_ = nullptr; uint64_t* pre_tags_ = nullptr; uint64_t pre_requests_ = 0;
@@ -4610,6 +4675,7 @@ class Engine {
 		env.owner_base = r.owner_next;
 		r.owner_next += nc;
 		FWalk<NW> fw{ env, r.need_d };
+		be_.wait_walkers(EARLY_CTX); // (an early pre-search still running works in these walkers' scratch)
 		if (!async) presearch<NW>(env, r.need_d, r.nneed);
 		if (cfg_.async_guide == 2) be_.wait_side_scope(); // (the guide, if its build is still running)
 		if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
@@ -4636,6 +4702,7 @@ class Engine {
 						late_.clear();
 						use_ctx(ci);
 					}
+					if (!early_done_) early_presearch<NW>();
 					stats_.rewalked += r.nneed_all;
 					r.batch_rewalked += r.nneed_all;
 					dump_walkers(r, "rewalk", r.nneed);
@@ -4664,6 +4731,7 @@ class Engine {
 			deliver(r.cand_h, r.first, sink);
 			if (nc - r.base >= 64) needed_frac_ = std::min(1.0, (double)r.batch_rewalked / (double)(nc - r.base));
 			if (r.overflow) {
+				be_.wait_walkers(EARLY_CTX); // (the capacities below are about to be given back)
 				// the candidate at `committed` ran out of some capacity.  Results not yet committed
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.

@@ -106,6 +106,7 @@ class Session {
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
+		if (const char* e = getenv("ABG_EARLY_PRESEARCH")) cfg.early_presearch = atoi(e) != 0; // the next batch's pre-search beside this batch's commit
 		if (const char* e = getenv("ABG_HEAVY_FIRST")) cfg.heavy_first = atoi(e) != 0;
 		if (const char* e = getenv("ABG_ASYNC_LOAD")) cfg.async_load = atoi(e) != 0;
 		if (const char* e = getenv("ABG_CLS_SLOTS")) cfg.classify_slots = (uint32_t)std::max(64, atoi(e));

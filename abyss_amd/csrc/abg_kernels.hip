@@ -531,6 +531,8 @@ struct HipBackend {
 		}
 		scope_pending = false;
 	}
+	// whether what launch_slots_side queued has run (never blocks)
+	bool side_done() { return !side_pending || hipEventQuery(ev2b) == hipSuccess; }
 	void sync_side()
 	{
 		if (!side_pending) return;

@@ -77,6 +77,7 @@ struct SerialBackend {
 	template <class F> void launch_wave(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0, 1); }
 	template <class F> void launch_slots_side(uint64_t n, F f, uint32_t slots, const char* name) { launch_slots(n, f, slots, name); }
 	void sync_side() {}
+	bool side_done() { return true; }
 	// a small "fast" buffer so that the two-tier trueBranch stack crosses tiers in the tests;
 	// HC_FAST_BYTES=16384 gives the walkers what the device gives them (the chain searches and the
 	// bulk scratch then live in it as they do in LDS)
