@@ -363,10 +363,12 @@ ABG_HD Kmer<NW> window_kmer(const uint32_t* __restrict__ words, uint64_t woff, u
 		const uint32_t b0 = pos + 32u * j;
 		const uint64_t q = woff + (b0 >> 4);
 		const unsigned sh = 2u * (b0 & 15u), need = sh + 2u * nb;  // bits [sh, need) of words q, q + 1, q + 2
-		uint64_t lo = words[q];
-		if (need > 32) lo |= (uint64_t)words[q + 1] << 32;
+		// (three loads, none under a condition -- a load in a conditional arm is waited for on the spot: a word that is not
+		// needed is read again from an address that is, and left out)
+		const uint32_t w0 = words[q], w1 = words[need > 32 ? q + 1 : q], w2 = words[need > 64 ? q + 2 : q];
+		const uint64_t lo = (uint64_t)w0 | (need > 32 ? (uint64_t)w1 << 32 : 0ull);
 		uint64_t v = lo >> sh;
-		if (need > 64) v |= (uint64_t)words[q + 2] << (64u - sh);
+		if (need > 64) v |= (uint64_t)w2 << (64u - sh);
 		s.w[j] = nb < 32 ? (v & ((1ULL << (2u * nb)) - 1)) : v;
 	}
 	return s;

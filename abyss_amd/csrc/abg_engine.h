@@ -1242,13 +1242,19 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		// everything later, "visited" only counts for an entirely solid read.
 		v = first_v;
 		bool solid = true, visited = true;
+		const uint64_t rwoff = b.woff[r];
 		for (uint32_t j0 = 0; j0 < nk && solid; j0 += CLS_GROUP) {
 			uint64_t h[CLS_GROUP];
+			// the group's incoming bases sit in one packed word or two: both read here, not a load per base under a condition
+			const uint32_t i0 = j0 + k - 1, i1 = (i0 + CLS_GROUP - 1 < L ? i0 + CLS_GROUP - 1 : L - 1);
+			const uint64_t two = (uint64_t)b.words[rwoff + (i0 >> 4)] | ((uint64_t)b.words[rwoff + (i1 >> 4)] << 32);
 #pragma unroll
 			for (uint32_t q = 0; q < CLS_GROUP; q++) {
 				const uint32_t j = j0 + q;
 				if (j < nk) {
-					if (j) vtx_shift(p, v, SENSE, batch_base(b, r, j + k - 1));
+					const uint32_t bi = j + k - 1;
+					const unsigned base = (unsigned)(two >> (((bi >> 4) != (i0 >> 4) ? 32u : 0u) + 2u * (bi & 15u))) & 3u;
+					if (j) vtx_shift(p, v, SENSE, base);
 					h[q] = vtx_hash(p, v);
 				} else {
 					h[q] = h[0]; // (past the end: the group's first k-mer again)

@@ -31,12 +31,7 @@ ABG_HD unsigned batch_base(const Batch& b, uint64_t r, uint32_t i)
 template <int NW>
 ABG_HD Kmer<NW> batch_kmer(const Batch& b, uint64_t r, uint32_t pos, unsigned k)
 {
-	Kmer<NW> s;
-#pragma unroll
-	for (int j = 0; j < KW<NW>; j++) s.w[j] = 0;
-	for (unsigned i = 0; i < k; i++)
-		kmer_set(s, i, batch_base(b, r, pos + i));
-	return s;
+	return window_kmer<NW>(b.words, b.woff[r], pos, k); // (a handful of word loads in flight together, not a load per base)
 }
 // index of the sequence holding k-mer op t (koff[r] <= t < koff[r+1])
 ABG_HD uint64_t find_seq(const uint64_t* koff, uint64_t n, uint64_t t)
