@@ -298,6 +298,15 @@ struct FInsertRound {
 		uint64_t h = h0[t];
 		uint64_t v = claim_val(epoch, t);
 		bool win = true;
+		uint64_t pq[4] = { 0, 0, 0, 0 };
+		const bool four = p.nh <= 4; // (the usual case: positions computed once, the loads of a phase in flight together)
+		if (four) {
+			uint64_t cl[4];
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) { pq[j] = pos_i(p, h, j < p.nh ? j : 0u); cl[j] = claim_cur[pq[j] & cmask]; }
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) win = win & (cl[j] == v);
+		} else
 		for (unsigned j = 0; j < p.nh; j++)
 			win = win & (claim_cur[pos_i(p, h, j) & cmask] == v);
 		// losers queue for the next round: one counter bump per wavefront -- all on ONE address, which a
@@ -307,6 +316,17 @@ struct FInsertRound {
 		else slot = wave_append_slot(next_n, !win);
 		if (win && casc.bits) {
 			cascade_insert(p, casc, h, false);
+		} else if (win && four) {
+			// (the holder of all its claims is the only op of this round on its counters: what it read is what is there)
+			unsigned c[4], mn = 255;
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) c[j] = cnt[pq[j]];
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) mn = c[j] < mn ? c[j] : mn;
+			if (mn < 255) {
+#pragma unroll
+				for (unsigned j = 0; j < 4; j++) if (j < p.nh && c[j] == mn) cnt[pq[j]] = (uint8_t)(mn + 1);
+			}
 		} else if (win) {
 			unsigned mn = 255;
 			for (unsigned j = 0; j < p.nh; j++) { unsigned c = cnt[pos_i(p, h, j)]; mn = c < mn ? c : mn; }
@@ -842,7 +862,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	// a serial caller (one thread, all pairs) looks everything up again instead
 	const bool keep = nt >= TILE_PURITY_THREADS;
 	TilePair mine[TILE_PURITY_PER];
-	uint32_t slot[TILE_PURITY_PER]; // (table slot | offset within the tile << 16)
+	uint32_t slot[TILE_PURITY_PER] = {}; // (table slot | offset within the tile << 16)
 	auto off_of = [&](const TilePair& r) -> uint32_t { return (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1); };
 	auto slot_of = [&](uint32_t off) -> uint32_t {
 		uint32_t s = ((off * 0x9E3779B1u) >> 20) & (TILE_TAB - 1);
@@ -864,10 +884,17 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		}
 	};
 	if (keep) {
+		// (the loads first and none of them under a condition -- a load in a conditional arm is waited for on the spot, and
+		// these would be six round trips instead of one: a thread past the end reads pair 0 again and ignores it)
 #pragma unroll
 		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
 			const uint32_t i = tid + q * nt;
-			if (i < n) { mine[q] = bin[i]; slot[q] = slot_of(off_of(mine[q])); }
+			mine[q] = bin[i < n ? i : 0u];
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
+			const uint32_t i = tid + q * nt;
+			if (i < n) slot[q] = slot_of(off_of(mine[q]));
 		}
 	}
 	pairs([&](const TilePair& r, uint32_t i, uint32_t s, uint32_t) {
@@ -875,10 +902,24 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		atomic_add_u32(&info[s], 1);
 	});
 	sy.barrier();
+	// another k-mer on the counter -- or the earliest op a second time, through another of its hash functions
+	// (about one k-mer in 10^8: its counters then count as shared, which is always safe, and a pure counter
+	// holds exactly one pair per op of its k-mer)
+	if (keep) {
+		TilePair fst[TILE_PURITY_PER]; // (the counters' earliest pairs: again all the loads, then the comparisons)
+#pragma unroll
+		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
+			const uint32_t i = tid + q * nt;
+			fst[q] = bin[i < n ? (uint32_t)(first[slot[q] & 0xFFFFu] & 0xFFFu) : 0u];
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
+			const uint32_t i = tid + q * nt;
+			const TilePair& r = mine[q]; const TilePair& f = fst[q];
+			if (i < n && (r.hlo != f.hlo || r.hhi != f.hhi || ((r.tj ^ f.tj) != 0 && tp_t(r) == tp_t(f)))) atomic_or_u32(&info[slot[q] & 0xFFFFu], 0x80000000u);
+		}
+	} else
 	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
-		// another k-mer on the counter -- or the earliest op a second time, through another of its hash functions
-		// (about one k-mer in 10^8: its counters then count as shared, which is always safe, and a pure counter
-		// holds exactly one pair per op of its k-mer)
 		const TilePair f = bin[(uint32_t)(first[s] & 0xFFFu)];
 		if (r.hlo != f.hlo || r.hhi != f.hhi || ((r.tj ^ f.tj) != 0 && tp_t(r) == tp_t(f))) atomic_or_u32(&info[s], 0x80000000u);
 	});
@@ -925,9 +966,16 @@ ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend
 	if (!fl && !(L & LEAD_BIT)) { pend = 0; return; } // (its k-mer's leader does the raising)
 	const uint64_t h = e.h0[t];
 	unsigned mp = 256, ms = 256;
-	for (unsigned j = 0; j < e.p.nh; j++) {
-		const unsigned c = e.cnt[pos_i(e.p, h, j)];
-		if ((fl >> j) & 1u) ms = c < ms ? c : ms; else mp = c < mp ? c : mp;
+	for (unsigned j0 = 0; j0 < e.p.nh; j0 += 4) { // (four counters in flight: a load right before its use is a round trip each)
+		unsigned c[4];
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) c[q] = e.cnt[pos_i(e.p, h, j0 + q < e.p.nh ? j0 + q : 0u)];
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) {
+			const unsigned j = j0 + q;
+			if (j >= e.p.nh) continue;
+			if ((fl >> j) & 1u) ms = c[q] < ms ? c[q] : ms; else mp = c[q] < mp ? c[q] : mp;
+		}
 	}
 	const unsigned tg = mp + n > 255 ? 255u : mp + n;
 	if (fl && ms < tg) return;
@@ -956,17 +1004,35 @@ ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 	const uint32_t span = (uint32_t)(e.m - base < TILE_COUNTERS ? e.m - base : TILE_COUNTERS); // (lo and m are multiples of 8)
 	uint64_t* l8 = (uint64_t*)lds;
 	const uint64_t* g8 = (const uint64_t*)(e.cnt + base);
-	for (uint32_t i = tid; i < span / 8; i += nt) l8[i] = g8[i];
+	// (eight loads, then eight stores to the LDS: a load right before its use in a loop is a round trip per iteration)
+	{
+		const uint32_t nw = span / 8;
+		for (uint32_t i0 = tid; i0 < nw; i0 += 8 * nt) {
+			uint64_t tmp[8];
+#pragma unroll
+			for (uint32_t q = 0; q < 8; q++) { const uint32_t i = i0 + q * nt; tmp[q] = g8[i < nw ? i : i0]; }
+#pragma unroll
+			for (uint32_t q = 0; q < 8; q++) { const uint32_t i = i0 + q * nt; if (i < nw) l8[i] = tmp[q]; }
+		}
+	}
 	sy.barrier();
 	bool any = false;
-	for (uint32_t i = tid; i < n; i += nt) {
-		const TilePair r = bin[i];
-		const uint8_t tg = e.tgt[tp_t(r)];
-		if (!tg) continue;
-		// (a pure counter has one writer -- its k-mer's leader, possibly through two hash functions
-		// with the same value -- so plain byte stores do)
-		const uint32_t off = (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1);
-		if (lds[off] < tg) { lds[off] = tg; any = true; }
+	// (the same for the pairs and their ops' targets: four at a time, the loads of a phase in flight together)
+	for (uint32_t i0 = tid; i0 < n; i0 += 4 * nt) {
+		TilePair r[4]; uint8_t tg[4];
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) { const uint32_t i = i0 + q * nt; r[q] = bin[i < n ? i : i0]; }
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) tg[q] = e.tgt[tp_t(r[q])];
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			const uint32_t i = i0 + q * nt;
+			if (i >= n || !tg[q]) continue;
+			// (a pure counter has one writer -- its k-mer's leader, possibly through two hash functions
+			// with the same value -- so plain byte stores do)
+			const uint32_t off = (uint32_t)(pos_i(e.p, tp_h(r[q]), tp_j(r[q])) - e.lo) & (TILE_COUNTERS - 1);
+			if (lds[off] < tg[q]) { lds[off] = tg[q]; any = true; }
+		}
 	}
 	if (sy.any(any)) {
 		uint64_t* o8 = (uint64_t*)(e.cnt + base);
