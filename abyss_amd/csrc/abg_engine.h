@@ -746,10 +746,14 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 		uint64_t hh[PER]; uint32_t cbv[PER][MAXH];
 		if (keep) {
 #pragma unroll
+			for (uint32_t u = 0; u < PER; u++) { // (the loads first, none under a condition: PER round trips become one)
+				const uint64_t t = t0 + tid + (uint64_t)u * nt;
+				hh[u] = b.e.h0[t < t1 ? t : t0];
+			}
+#pragma unroll
 			for (uint32_t u = 0; u < PER; u++) {
 				const uint64_t t = t0 + tid + (uint64_t)u * nt;
 				if (t >= t1) continue;
-				hh[u] = b.e.h0[t];
 #pragma unroll
 				for (unsigned j = 0; j < MAXH; j++) {
 					cbv[u][j] = j < nh ? coarse_of(hh[u], j) : 0xFFFFFFFFu;
@@ -808,9 +812,14 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 		TilePair mine[PER]; uint32_t fine[PER];
 		if (keep) {
 #pragma unroll
+			for (uint32_t u = 0; u < PER; u++) { // (the loads first, none under a condition)
+				const uint32_t i = i0 + tid + u * nt;
+				mine[u] = src[i < i1 ? i : i0];
+			}
+#pragma unroll
 			for (uint32_t u = 0; u < PER; u++) {
 				const uint32_t i = i0 + tid + u * nt;
-				if (i < i1) { mine[u] = src[i]; fine[u] = fine_of(mine[u]); atomic_add_u32(&hist[fine[u]], 1); }
+				if (i < i1) { fine[u] = fine_of(mine[u]); atomic_add_u32(&hist[fine[u]], 1); }
 			}
 		} else {
 			for (uint32_t i = i0 + tid; i < i1; i += nt) atomic_add_u32(&hist[fine_of(src[i])], 1);
