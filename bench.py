@@ -526,7 +526,7 @@ def main() -> int:
         if partitioned and world > 1 and a.scaling == "strong":
             # the one-GPU point of this very job, measured in an earlier run and REPLAYED from the committed file (the driver
             # computes its own efficiency from the per-N lines; this one is for a reader of a single line)
-            one = {1: "r04_b_bench_default.json", 2: "r04_c_bench_config2_invariants.json", 3: "r04_b_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
+            one = {1: "r04_e_bench_default.json", 2: "r04_c_bench_config2_invariants.json", 3: "r04_b_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
             src = os.path.join(ROOT, "profiles", one) if one else None
             if src and os.path.exists(src) and a.pairs == preset[0] and a.k == preset[1]:
                 v1 = json.load(open(src))["value"]
