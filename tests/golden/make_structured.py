@@ -90,6 +90,11 @@ CASES = [
     ("s_plasmids_k48_K16", "plasmids", 40.0, 120, 0.004, ["-k48", "-K16", "-b2M"]),
     ("s_mixed_k192", "mixed", 60.0, 250, 0.003, ["-k192", "-b2M"]),
     ("s_mixed_k12", "mixed", 30.0, 100, 0.004, ["-k12", "-b2M"]),
+    # the number of hash functions away from the usual four: one (nothing left for the second probe stage), six (beyond the
+    # four-at-a-time paths of PASS 1), twelve (beyond the eight a cooperative probe round holds)
+    ("s_mixed_k32_H1", "mixed", 30.0, 120, 0.004, ["-k32", "-b2M", "-H1"]),
+    ("s_mixed_k40_H6", "mixed", 30.0, 120, 0.004, ["-k40", "-b2M", "-H6"]),
+    ("s_mixed_k32_H12_kc3", "mixed", 40.0, 120, 0.004, ["-k32", "-b3M", "-H12", "--kc=3"]),
 ]
 
 

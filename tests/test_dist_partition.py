@@ -26,7 +26,7 @@ def run_ranks(world, *args, timeout=900):
     return json.loads(line[7:])
 
 
-@pytest.mark.parametrize("name,world", [("k64", 2), ("k40_mixed", 3), ("k25_h3_kc3_t40", 2), ("k48_K16", 2), ("s_plasmids_k32", 3), ("s_tandem_k32", 2)])
+@pytest.mark.parametrize("name,world", [("k64", 2), ("k40_mixed", 3), ("k25_h3_kc3_t40", 2), ("k48_K16", 2), ("s_plasmids_k32", 3), ("s_tandem_k32", 2), ("s_mixed_k32_H12_kc3", 2), ("s_mixed_k40_H6", 3)])
 def test_partitioned_run_reproduces_reference_run(name, world):
     out = run_ranks(world, "golden", name)
     for key in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "ranks_agree"):

@@ -55,7 +55,7 @@ def test_reproduces_reference_run(name):
     assert st["bulk_steps"] > st["lin_steps"] and st["chain_steps"] > 0 and st["memo_hits"] > 0, (name, st)
 
 
-@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12"])
+@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12", "s_mixed_k32_H1", "s_mixed_k40_H6", "s_mixed_k32_H12_kc3"])
 def test_reproduces_reference_run_on_cycles_repeats_and_hairpins(name):
     """Graph shapes a random linear genome never makes (tests/golden/make_structured.py, from the unmodified reference at -j1):
     circular replicons, tandem repeats with units shorter and longer than k, inverted repeats and hairpins, homopolymer and
