@@ -1067,14 +1067,27 @@ ABG_HD Vtx<NW> make_neighbour(const Params& p, const Vtx<NW>& u, int sense, unsi
 // The rolling-hash tables as named scalars, for loops that must stay in registers: an array
 // held in registers that is indexed at run time -- even through a chain of selects, which the
 // optimiser folds back into an indexed load -- is demoted to per-lane scratch memory.
-struct SeedTabs { uint64_t sk0, sk1, sk2, sk3, rk0, rk1, rk2, rk3, sm0, sm1, sm2, sm3, rm0, rm1, rm2, rm3; };
+// (Round 4, late: not the sixteen rotated seeds themselves -- thirty-two scalar registers alive across a search loop whose scalars
+// already spill into vector lanes by the hundred -- but the four rotation amounts: srol^k(seed[b]) is worked out where it is
+// used, from an immediate and two shifts per half.)
+struct SeedTabs {
+	uint32_t ka, kb, ma, mb; // k % 33, k % 31, (k - 1) % 33, (k - 1) % 31: the split rotations of srol_n
+	ABG_HD static uint64_t rot(uint64_t v, unsigned a, unsigned b)
+	{
+		uint64_t lo = v & 0x1FFFFFFFFULL, hi = v >> 33; // (a == 0 / b == 0: the right shifts leave nothing, no special case)
+		lo = ((lo << a) | (lo >> (33u - a))) & 0x1FFFFFFFFULL;
+		hi = ((hi << b) | (hi >> (31u - b))) & 0x7FFFFFFFULL;
+		return (hi << 33) | lo;
+	}
+	ABG_HD uint64_t sk(unsigned b) const { return rot(seed_of(b), ka, kb); }        // p.seed_k[b]
+	ABG_HD uint64_t rk(unsigned b) const { return rot(seed_of(3u - b), ka, kb); }   // p.seedrc_k[b]
+	ABG_HD uint64_t sm(unsigned b) const { return rot(seed_of(b), ma, mb); }        // p.seed_km1[b]
+	ABG_HD uint64_t rm(unsigned b) const { return rot(seed_of(3u - b), ma, mb); }   // p.seedrc_km1[b]
+};
 ABG_HD SeedTabs seed_tabs(const Params& p)
 {
 	SeedTabs t;
-	t.sk0 = p.seed_k[0]; t.sk1 = p.seed_k[1]; t.sk2 = p.seed_k[2]; t.sk3 = p.seed_k[3];
-	t.rk0 = p.seedrc_k[0]; t.rk1 = p.seedrc_k[1]; t.rk2 = p.seedrc_k[2]; t.rk3 = p.seedrc_k[3];
-	t.sm0 = p.seed_km1[0]; t.sm1 = p.seed_km1[1]; t.sm2 = p.seed_km1[2]; t.sm3 = p.seed_km1[3];
-	t.rm0 = p.seedrc_km1[0]; t.rm1 = p.seedrc_km1[1]; t.rm2 = p.seedrc_km1[2]; t.rm3 = p.seedrc_km1[3];
+	t.ka = p.k % 33u; t.kb = p.k % 31u; t.ma = (p.k - 1u) % 33u; t.mb = (p.k - 1u) % 31u;
 	return t;
 }
 ABG_HD uint64_t pick4(unsigned i, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3)
@@ -1088,19 +1101,19 @@ ABG_HD void nbr_base(const SeedTabs& t, const Vtx<NW>& v, unsigned k, int sense,
 {
 	if (sense == SENSE) {
 		const unsigned out = kmer_get(v.s, 0);
-		fb = srol1(v.fh) ^ pick4(out, t.sk0, t.sk1, t.sk2, t.sk3);
+		fb = srol1(v.fh) ^ t.sk(out);
 		rb = sror1(v.rh ^ seed_of(3u - out));
 	} else {
 		const unsigned out = kmer_get(v.s, k - 1);
 		fb = sror1(v.fh ^ seed_of(out));
-		rb = srol1(v.rh) ^ pick4(out, t.rk0, t.rk1, t.rk2, t.rk3);
+		rb = srol1(v.rh) ^ t.rk(out);
 	}
 }
 // hashes of the neighbour with base b
 ABG_HD void nbr_hash(const SeedTabs& t, int sense, uint64_t fb, uint64_t rb, unsigned b, uint64_t& fh, uint64_t& rh)
 {
-	if (sense == SENSE) { fh = fb ^ seed_of(b); rh = rb ^ pick4(b, t.rm0, t.rm1, t.rm2, t.rm3); }
-	else { fh = fb ^ pick4(b, t.sm0, t.sm1, t.sm2, t.sm3); rh = rb ^ seed_of(3u - b); }
+	if (sense == SENSE) { fh = fb ^ seed_of(b); rh = rb ^ t.rm(b); }
+	else { fh = fb ^ t.sm(b); rh = rb ^ seed_of(3u - b); }
 }
 
 // 4-bit mask of the neighbours of `v` in direction `sense` that the solid filter contains
