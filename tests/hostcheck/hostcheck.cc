@@ -122,7 +122,13 @@ static uint64_t selftest_kmer_nw(unsigned k, const uint32_t* words, uint32_t len
 	uint64_t bad = 0;
 	for (uint32_t j = 0; j + k <= len; j++) {
 		abg::Vtx<NW> v;
-		v.s = abg::batch_kmer<NW>(b, 0, j, k);
+		// (base by base: the product's batch_kmer is window_kmer these days, so the per-base form lives here as its check)
+		for (int q = 0; q < abg::KW<NW>; q++) v.s.w[q] = 0;
+		for (unsigned i = 0; i < k; i++) abg::kmer_set(v.s, i, abg::batch_base(b, 0, j + i));
+		{
+			const abg::Kmer<NW> viaBatch = abg::batch_kmer<NW>(b, 0, j, k);
+			for (int q = 0; q < abg::KW<NW>; q++) bad += viaBatch.w[q] != v.s.w[q];
+		}
 		abg::vtx_rehash(p, v);
 		const abg::Kmer<NW> w = abg::window_kmer<NW>(words, 0, j, k);
 		uint64_t fh, rh;
@@ -130,6 +136,12 @@ static uint64_t selftest_kmer_nw(unsigned k, const uint32_t* words, uint32_t len
 		const abg::Kmer<NW> r0 = abg::kmer_revcomp(v.s, k), r1 = abg::kmer_revcomp_fast(v.s, k);
 		for (int q = 0; q < abg::KW<NW>; q++) bad += (w.w[q] != v.s.w[q]) + (r0.w[q] != r1.w[q]);
 		bad += (fh != v.fh) + (rh != v.rh);
+	}
+	// the rotated seeds worked out on the fly (SeedTabs) against the tables make_params holds
+	{
+		const abg::SeedTabs t = abg::seed_tabs(p);
+		for (unsigned bb = 0; bb < 4; bb++)
+			bad += (t.sk(bb) != p.seed_k[bb]) + (t.rk(bb) != p.seedrc_k[bb]) + (t.sm(bb) != p.seed_km1[bb]) + (t.rm(bb) != p.seedrc_km1[bb]);
 	}
 	// the prefix-XOR form of the same hashes over stretches of consecutive k-mers (stretch_hashes_serial: the
 	// arithmetic of the device's stretch_hashes_wave), from every start and for several lengths

@@ -716,7 +716,7 @@ def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
     pad = np.zeros(((L + 15) // 16) * 16, dtype=np.uint64)
     pad[:L] = rng.integers(0, 4, size=L)
     words = np.concatenate([(pad.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32), np.zeros(4, dtype=np.uint32)])
-    for k in (21, 32, 33, 64, 65, 96, 127, 128, 150, 192):
+    for k in (21, 31, 32, 33, 34, 62, 63, 64, 65, 66, 67, 93, 96, 99, 100, 127, 128, 150, 192):  # (31, 33, 34, 62, 66, 93, 99 ...: a rotation amount of SeedTabs is zero)
         assert l.hc_selftest_kmer(k, words.ctypes.data, L) == 0, k
 
 
