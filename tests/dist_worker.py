@@ -206,6 +206,34 @@ def main():
         ok, hc = case_kept(rank, world)
     elif what == "shared":
         ok, hc = case_oracle(41, 10000, 1 << 19, 25.0, 0.01, 15000, rank, world, shared=True)
+    elif what == "sliced_checkpoint":
+        # a sliced filter written out rank by rank (abg_counters_export) and read back into a fresh sliced context
+        # (abg_counters_import: each rank takes its own range of the host copy), which then runs PASS 2
+        k, counters = 41, 1 << 19
+        m1, m2 = synth.make_read_set(10000, 25.0, err=0.01, genome_seed=k, read_seed=k + 3)
+        buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+        a = DistHostCheck(k, counters, insert_batch=15000, claim_log2=12, p2_first=64)
+        a.attach()
+        a.load(buf, off)
+        saved = a.counters()
+        hc = DistHostCheck(k, counters, insert_batch=15000, claim_log2=12, p2_first=64)
+        hc.attach()
+        hc.l.hc_counters_import.argtypes = [C.c_void_p, C.c_void_p]
+        assert hc.l.hc_counters_import(hc.h, saved.ctypes.data) == 0
+        cnt = hc.counters()
+        rh, ch = hc.assemble(buf, off)
+        o = ob.Oracle(k, counters=counters)
+        o.load(buf, off)
+        ro, co = o.assemble(buf, off)
+        ok = {
+            "counting_filter": bool(np.array_equal(o.counters(), cnt)) and bool(np.array_equal(saved, cnt)),
+            "results": bool(np.array_equal(ro, rh)),
+            "contigs": [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch],
+            "visited": bool(np.array_equal(o.visited(), hc.visited())),
+            "assembly_counters": o.assembly_counters() == hc.assembly_counters(),
+            "n_contigs": len(co), "held_fraction": hc.stats()["counter_bytes_held"] / float(counters),
+        }
+        del a
     elif what == "sliced":
         # B beyond one device (ABG_SLICE_FILTER=1, set by the test): every rank holds its own range of the counters and nothing
         # else -- under tests/hostcheck the rest of the array is address space without memory, so a stray access kills the rank --

@@ -206,6 +206,10 @@ int hc_counters_export(void* h, uint8_t* out)
 {
 	try { S(h)->eng->counters_to_host(out); return 0; } catch (const abg::Failure& f) { S(h)->error = f.msg; return f.code; }
 }
+int hc_counters_import(void* h, const uint8_t* in)
+{
+	try { S(h)->eng->counters_from_host(in); return 0; } catch (const abg::Failure& f) { S(h)->error = f.msg; return f.code; }
+}
 const char* hc_last_error(void* h) { return S(h)->error.c_str(); }
 uint8_t* hc_visited(void* h) { return S(h)->eng->visited_dev(); }
 int hc_load_seqs(void* h, const char* seqs, const uint64_t* off, uint64_t n)

@@ -250,6 +250,7 @@ SLICED_CASES = [
     (3, ("bigbatch",), {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "5"}),  # one commit over thousands of contigs, hashed stamps
     (3, ("saturate_tiled",), {}),
     (2, ("kept",), {}),
+    (3, ("sliced_checkpoint",), {}),                        # the counters exported rank by rank, imported into a fresh sliced context
 ]
 
 
