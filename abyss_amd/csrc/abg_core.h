@@ -1424,7 +1424,8 @@ struct BulkScratch {
 enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide has nothing more to say
        CB_TRUE = 1,      // trueBranch answers true
        CB_NOT_CHAIN = 2, // a vertex with no or several neighbours ahead: the general search decides
-       CB_NONE = 3 };    // not examined
+       CB_NONE = 3,      // not examined
+       CB_FALSE = 4 };   // a plain dead-end tip, `depth` edges long: trueBranch answers false (see chain_true_branches)
 enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
        WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
        WSTAT_PRE_REQS, WSTAT_PRE_ADDS, // pre-search: requests made / answers it added to the memo
@@ -1534,6 +1535,7 @@ struct SearchScratch {
 	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
 	BulkScratch* bulk;
 	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
+	uint16_t chain_d[4];    // chain_true_branches: per branch proven FALSE (a plain dead-end tip), the deepest call of its search
 	uint64_t dbg_chain;    // profiling aid: clock ticks in chain_true_branches (when dbg_on)
 	uint32_t dbg_on;
 	uint64_t dbg_la; uint32_t dbg_la_calls; // ... in the lookAhead calls of trueBranch
@@ -1945,15 +1947,14 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 			bool hit = false; // visited.find(v) among the chain's vertices before this chunk
 			for (uint32_t i = 0; i < depth; i++) hit = hit | key_equal(keys[i], key);
 			const unsigned cm = ~bad & 0xFu;
-			const bool single = cm != 0 && !(cm & (cm - 1));
-			const unsigned fb = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u;
-			bool pred = true; // the one neighbour ahead is the read's next k-mer
+			const unsigned fb = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u; // (the first neighbour ahead, as the search would take them)
+			bool pred = true; // the read's next k-mer is a neighbour ahead
 			if (l + 1 < n) {
 				const uint32_t rb_pos = up ? pos + l + k : pos - l - 1u;
 				const unsigned rb = (g.words[woff + (rb_pos >> 4)] >> (2u * (rb_pos & 15u))) & 3u;
-				pred = fb == (same ? rb : 3u - rb);
+				pred = ((cm >> (same ? rb : 3u - rb)) & 1u) != 0;
 			}
-			bs.good[l] = (uint8_t)((single ? 1u : 0u) | (pred ? 2u : 0u) | (hit ? 4u : 0u));
+			bs.good[l] = (uint8_t)((cm != 0 ? 1u : 0u) | (pred ? 2u : 0u) | (hit ? 4u : 0u) | ((cm & (cm - 1)) ? 8u : 0u));
 			bs.fbase[l] = (uint8_t)fb;
 		}
 		wave_sync();
@@ -1990,8 +1991,58 @@ ABG_HDX uint32_t chain_bulk(const Params& p_in, const uint8_t* __restrict__ cnt_
 				}
 			}
 		}
-		if (T <= B && T <= C) { sc.n_chain_steps += T; return done(depth + T, CB_TRUE); }
-		if (B <= C) { sc.n_chain_steps += B; return done(depth + B, CB_NOT_CHAIN); }
+		if (T <= C) { sc.n_chain_steps += T; return done(depth + T, CB_TRUE); }
+		if (B <= C) { // (B < C cannot be: a position before C has the read's next k-mer ahead)
+			sc.n_chain_steps += B;
+			// The read runs into a dead end B edges from the branch's first vertex.  If that is a PLAIN tip -- one neighbour ahead at
+			// every vertex before the end, and one behind (the vertex the search came from) wherever trueBranch would turn round:
+			// at t_i with i >= fpTrim or, lookAhead on a plain chain, i + fpTrim <= B -- every call of the search answers false and
+			// the deepest one was B deep (chain_true_branches has the argument).  Only when the whole tip lies in this chunk.
+			if (depth != 0) return done(depth + B, CB_NOT_CHAIN);
+			bool ok = true;
+			const int osense = (sense == SENSE) ? ANTISENSE : SENSE;
+			for (uint32_t l = lane0; l <= B; l += lstep) {
+				if (l < B && (bs.good[l] & 8u)) ok = false;
+				if (!(l >= FP_TRIM || l + FP_TRIM <= B)) continue;
+#if defined(__HIP_DEVICE_COMPILE__)
+				if (!COOP)
+#endif
+				{ vertex_at(l, my_s, my_fh, my_rh); terms(); }
+				uint64_t odf = 0, odr = 0;
+				if constexpr (MASKED_BUILD<NW>) masked_terms_shifted(p, my_s, my_df, my_dr, osense, odf, odr);
+				unsigned obad = 0;
+				for (unsigned base = 0; base < p.nh; base += 4) {
+					uint8_t c[4][4];
+#pragma unroll
+					for (unsigned q = 0; q < 4; q++) {
+						// (the neighbour behind with base q: nbr() the other way round)
+						uint64_t nfh, nrh;
+						if (osense == SENSE) {
+							const unsigned out = (unsigned)my_s.w[0] & 3u;
+							nfh = srol1(my_fh) ^ pick4(out, sk0, sk1, sk2, sk3) ^ seed_of(q);
+							nrh = sror1(my_rh ^ seed_of(3u - out)) ^ pick4(q, rm0, rm1, rm2, rm3);
+						} else {
+							const unsigned out = kmer_get(my_s, k - 1);
+							nfh = sror1(my_fh ^ seed_of(out)) ^ pick4(q, sm0, sm1, sm2, sm3);
+							nrh = (srol1(my_rh) ^ pick4(out, rk0, rk1, rk2, rk3)) ^ seed_of(3u - q);
+						}
+						nfh ^= odf; nrh ^= odr;
+						const uint64_t h = nrh < nfh ? nrh : nfh;
+#pragma unroll
+						for (unsigned i = 0; i < 4; i++) c[q][i] = (uint8_t)probe_c(p, cnt, pos_i(p, h, base + i < p.nh ? base + i : 0u));
+					}
+#pragma unroll
+					for (unsigned q = 0; q < 4; q++) {
+#pragma unroll
+						for (unsigned i = 0; i < 4; i++) obad |= (c[q][i] < p.kc ? 1u : 0u) << q;
+					}
+				}
+				const unsigned om = ~obad & 0xFu;
+				if (om == 0 || (om & (om - 1))) ok = false;
+			}
+			if (COOP) ok = !wave_any(!ok);
+			return done(depth + B, ok ? CB_FALSE : CB_NOT_CHAIN);
+		}
 		sc.n_chain_steps += C + 1;
 		// positions 0..C join the chain; the descent goes on at the neighbour ahead of position C
 		for (uint32_t l = lane0; l <= C; l += lstep) {
@@ -2069,6 +2120,9 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 		}
 		VKey* const mykeys = keys + (uint64_t)grp * per_chain;
 		unsigned depth = 0;
+		// a plain tip (see below): every vertex so far has one neighbour ahead; ... and, where the search would turn round, one behind
+		bool plain = true, is_false = false, behind_ok = true, second = false;
+		unsigned behind_lo = 0; // bit i: the vertex at depth i < FP_TRIM has exactly one neighbour behind
 		if (use_guide) {
 			// read-guided descent first: one branch at a time, the whole wave on it (chain_bulk);
 			// the lock-step loop below carries on from wherever the guide leaves a branch
@@ -2101,8 +2155,17 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 #pragma unroll
 					for (int j = 0; j < KW<NW>; j++) v.s.w[j] = cs.w[j];
 					v.fh = cs.fh; v.rh = cs.rh; vtx_set_d(v, cs.df, cs.dr); depth = cs.depth;
+					if (depth) plain = false; // (the guide followed a read: nobody looked behind those vertices)
 					if (st == CB_TRUE) { is_true = true; active = false; }
-					else if (st == CB_NOT_CHAIN) active = false;
+					else if (st == CB_FALSE) { is_false = true; active = false; }
+					else if (st == CB_NOT_CHAIN) {
+						// (the read led into a dead end that is no plain tip: the walks below start over from the branch's first vertex)
+						uint64_t fb0, rb0, fh0, rh0;
+						nbr_base(tabs, u, p.k, sense, fb0, rb0);
+						nbr_hash(tabs, sense, fb0, rb0, my_b, fh0, rh0);
+						v = make_neighbour(p, u, sense, my_b, fh0, rh0);
+						depth = 0;
+					}
 				}
 			}
 			wave_sync();
@@ -2117,32 +2180,73 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 				if (hit || depth >= trim) { is_true = true; active = false; }
 				else {
 					if (sub == 0) mykeys[depth] = key;
-					// the neighbours ahead: lane (b, i) of the group probes hash i of neighbour b
-					uint64_t fb, rb, ndf, ndr;
+					// the neighbours ahead and behind: lane (b, i) of the group probes hash i of neighbour b on either side
+					const int osense = (sense == SENSE) ? ANTISENSE : SENSE;
+					uint64_t fb, rb, ndf, ndr, ofb, orb, odf, odr;
 					nbr_base(tabs, v, p.k, sense, fb, rb);
 					neighbour_mask_delta(p, v, sense, ndf, ndr); // spaced seed: the neighbours' masked-out terms
-					unsigned cm = 0;
+					nbr_base(tabs, v, p.k, osense, ofb, orb);
+					neighbour_mask_delta(p, v, osense, odf, odr);
+					unsigned cm = 0, om = 0;
 					if (COOP) {
-						const unsigned b = sub >> 2, i = sub & 3u;
-						uint64_t fh, rh;
+						const unsigned b = sub >> 2, i = sub & 3u, ii = i < p.nh ? i : 0u;
+						uint64_t fh, rh, gh, hh;
 						nbr_hash(tabs, sense, fb, rb, b, fh, rh);
 						fh ^= ndf; rh ^= ndr;
-						bool bad = false;
-						if (i < p.nh) bad = probe_c(p, cnt, pos_i(p, rh < fh ? rh : fh, i)) < p.kc;
-						const unsigned gb = (unsigned)((wave_ballot(bad) >> (16 * grp)) & 0xFFFFull);
+						nbr_hash(tabs, osense, ofb, orb, b, gh, hh);
+						gh ^= odf; hh ^= odr;
+						// (both loads unconditional and side by side: one round trip)
+						const unsigned c1 = probe_c(p, cnt, pos_i(p, rh < fh ? rh : fh, ii));
+						const unsigned c2 = probe_c(p, cnt, pos_i(p, hh < gh ? hh : gh, ii));
+						const unsigned gb = (unsigned)((wave_ballot(c1 < p.kc) >> (16 * grp)) & 0xFFFFull);
+						const unsigned ob = (unsigned)((wave_ballot(c2 < p.kc) >> (16 * grp)) & 0xFFFFull);
 #pragma unroll
-						for (unsigned q = 0; q < 4; q++) if (((gb >> (4 * q)) & 0xFu) == 0) cm |= 1u << q;
+						for (unsigned q = 0; q < 4; q++) {
+							if (((gb >> (4 * q)) & 0xFu) == 0) cm |= 1u << q;
+							if (((ob >> (4 * q)) & 0xFu) == 0) om |= 1u << q;
+						}
 					} else {
 						for (unsigned q = 0; q < 4; q++) {
 							uint64_t fh, rh;
 							nbr_hash(tabs, sense, fb, rb, q, fh, rh);
 							fh ^= ndf; rh ^= ndr;
 							if (solid_contains(p, cnt, rh < fh ? rh : fh)) cm |= 1u << q;
+							if (plain) {
+								nbr_hash(tabs, osense, ofb, orb, q, fh, rh);
+								fh ^= odf; rh ^= odr;
+								if (solid_contains(p, cnt, rh < fh ? rh : fh)) om |= 1u << q;
+							}
 						}
 					}
-					if (cm == 0 || (cm & (cm - 1))) active = false; // not a chain: the general search decides
-					else {
-						const unsigned c = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u;
+					{
+						const bool one_behind = om != 0 && !(om & (om - 1)); // (the vertex the walk came from is there: one means it and no other)
+						if (depth < FP_TRIM) behind_lo |= (one_behind ? 1u : 0u) << depth; else behind_ok = behind_ok && one_behind;
+					}
+					if (cm & (cm - 1)) plain = false;
+					if (cm == 0 && plain && behind_ok) {
+						// A plain dead-end tip t_0 .. t_depth: trueBranch (ExtendPath.h:174-244) enters every vertex once (one neighbour
+						// ahead each, none after the last) and on the way back may turn round at t_i only if i >= fpTrim or
+						// lookAhead(t_i, dir, fpTrim) -- on a plain chain: i + fpTrim <= depth -- where it finds no neighbour behind
+						// but the vertex it came from: every call answers false, the deepest one was `depth` deep.
+						bool ok = true;
+						for (unsigned i = 0; i < FP_TRIM && i + FP_TRIM <= depth; i++) ok = ok && ((behind_lo >> i) & 1u);
+						if (ok) is_false = true;
+					}
+					if (cm == 0) {
+						// this walk ends here.  One that took the first neighbour at every fork (as the search would) tries again
+						// taking the last -- in a thicket of error tips beside a trunk one of the two usually stays on the trunk;
+						// after that the general search decides
+						if (!plain && !second && !is_false) {
+							second = true;
+							uint64_t fb0, rb0, fh0, rh0;
+							nbr_base(tabs, u, p.k, sense, fb0, rb0);
+							nbr_hash(tabs, sense, fb0, rb0, my_b, fh0, rh0);
+							v = make_neighbour(p, u, sense, my_b, fh0, rh0);
+							depth = 0;
+						} else active = false;
+					} else {
+						const unsigned c = !second ? ((cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u)
+						                           : ((cm & 8u) ? 3u : (cm & 4u) ? 2u : (cm & 2u) ? 1u : 0u);
 						uint64_t fh, rh;
 						nbr_hash(tabs, sense, fb, rb, c, fh, rh);
 						v = make_neighbour(p, v, sense, c, fh, rh);
@@ -2151,19 +2255,23 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 				}
 			}
 		}
+		if (is_false && sub == 0) sc.chain_d[my_b] = (uint16_t)depth;
 		if (COOP) {
-			const uint64_t tb = wave_ballot(is_true && sub == 0);
+			const uint64_t tb = wave_ballot(is_true && sub == 0), fbm = wave_ballot(is_false && sub == 0);
 #pragma unroll
 			for (unsigned g = 0; g < 4; g++) {
-				if (!((tb >> (16 * g)) & 1ull)) continue;
+				const unsigned t = (unsigned)((tb >> (16 * g)) & 1ull), f = (unsigned)((fbm >> (16 * g)) & 1ull);
+				if (!t && !f) continue;
 				// which branch was group g's?
 				unsigned seen2 = 0;
 #pragma unroll
 				for (unsigned b = 0; b < 4; b++)
-					if ((mask >> b) & 1u) { if (seen2 == first + g) true_mask |= 1u << b; seen2++; }
+					if ((mask >> b) & 1u) { if (seen2 == first + g) true_mask |= (t << b) | (f << (4 + b)); seen2++; }
 			}
 		} else if (is_true) true_mask |= 1u << my_b;
+		else if (is_false) true_mask |= 1u << (4 + my_b);
 	}
+	wave_sync(); // (chain_d is read by the caller)
 	return true_mask;
 }
 
@@ -2229,15 +2337,18 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 #if defined(__HIP_DEVICE_COMPILE__)
 		const uint64_t tc0 = sc.dbg_on ? wall_clock64() : 0;
 #endif
-		const unsigned chain_true = (trim > 1) ? (sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
-		                                                  : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc))
-		                                       : 0u;
+		const unsigned chain_res = (trim > 1) ? (sc.coop ? chain_true_branches<NW, true>(p, cnt, u, dir, trim, mask, sc)
+		                                                 : chain_true_branches<NW, false>(p, cnt, u, dir, trim, mask, sc))
+		                                      : 0u;
+		const unsigned chain_true = chain_res & 0xFu, chain_false = (chain_res >> 4) & 0xFu;
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (sc.dbg_on) sc.dbg_chain += wall_clock64() - tc0;
 #endif
+		
 		unsigned tb = 0;
 		for (unsigned b = 0; b < 4; b++) {
 			if (!((mask >> b) & 1u)) continue;
+			if ((chain_false >> b) & 1u) { depth_of[b] = sc.chain_d[b]; continue; } // (a plain dead-end tip)
 			Vtx<NW> w = make_neighbour(p, u, sense, b, nfh[b], nrh[b]);
 			unsigned d = 0;
 			if (((chain_true >> b) & 1u) || true_branch(p, cnt, u, w, dir, trim, sc, &d)) {

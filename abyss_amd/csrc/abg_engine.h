@@ -77,6 +77,7 @@ struct Config {
 	                                  // measured: PASS 2 429 vs 435 ms on configs[1], inside the noise of the boxes -- left off)
 	uint32_t presearch_min_weight = 0; // ... and only for candidates with at least this many such searches on their reads (0: all)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
+	bool force_defer_stage = false;   // (measurement) stage 1 of a round -- everybody walks, deferring to lower-numbered walkers -- whatever the previous batch needed
 	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
 	bool pipeline_late = true;        // ... the next batch's walkers start when this batch's are done (beside its commit), not beside them
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
@@ -4583,7 +4584,7 @@ class Engine {
 		// candidates share unitigs; when most of them turned out to be needed in the previous
 		// batch they would only be walked twice, so it is skipped and everybody is walked in
 		// full by the first stage-2 launch instead.
-		const bool defer_stage = needed_frac_ < 0.5 && !dist() && !async; // (its claims are rank-local state)
+		const bool defer_stage = (needed_frac_ < 0.5 || cfg_.force_defer_stage) && !dist() && !async; // (its claims are rank-local state)
 		if (defer_stage) {
 			std::vector<uint32_t> ident(nc - base);
 			for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;

@@ -105,6 +105,7 @@ class Session {
 		if (const char* e = getenv("ABG_OVERLAP_PURITY")) cfg.overlap_purity = atoi(e) != 0; // PASS 1: the next batch's tiles judged on the side stream too
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
+		if (const char* e = getenv("ABG_DEFER_STAGE")) cfg.force_defer_stage = atoi(e) != 0;
 		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
 		if (const char* e = getenv("ABG_EARLY_PRESEARCH")) cfg.early_presearch = atoi(e) != 0; // the next batch's pre-search beside this batch's commit
 		if (const char* e = getenv("ABG_HEAVY_FIRST")) cfg.heavy_first = atoi(e) != 0;

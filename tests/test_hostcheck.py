@@ -786,3 +786,52 @@ def test_kept_reads_dropped_for_lack_of_room_leave_pass1_intact(monkeypatch):
     rh, ch = hc.assemble_chunks(chunks)
     assert np.array_equal(ro, rh) and [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch]
     assert o.assembly_counters() == hc.assembly_counters()
+
+
+def _thicket_reads(seed, unit_len, copies, flank, coverage, err, read_len=100):
+    """A genome whose middle is `copies` exact copies of one unit (spread out between unique stretches) read at
+    `coverage`: the collapsed repeat carries copies x coverage, so its sequencing errors recur and every vertex of
+    it has error tips and bubbles beside it -- the shape the walkers' search shortcuts are for."""
+    rng = np.random.default_rng(seed)
+    unit = rng.integers(0, 4, size=unit_len, dtype=np.uint8)
+    parts = []
+    for _ in range(copies):
+        parts.append(rng.integers(0, 4, size=flank, dtype=np.uint8))
+        parts.append(unit)
+    parts.append(rng.integers(0, 4, size=flank, dtype=np.uint8))
+    g = np.concatenate(parts)
+    n = int(len(g) * coverage / read_len)
+    start = rng.integers(0, len(g) - read_len, size=n)
+    reads = g[start[:, None] + np.arange(read_len)[None, :]]
+    rc = rng.random(n) < 0.5
+    reads[rc] = 3 - reads[rc][:, ::-1]
+    e = rng.random(reads.shape) < err
+    reads[e] = (reads[e] + rng.integers(1, 4, size=int(e.sum()), dtype=np.uint8)) & 3
+    return reads
+
+
+@pytest.mark.parametrize("k,trim,nh,kc", [(32, None, 4, 2), (41, 30, 3, 2), (64, None, 4, 2)])
+def test_search_shortcuts_in_a_thicket_match_the_oracle(k, trim, nh, kc, monkeypatch):
+    """successor()'s shortcuts (chain_true_branches / chain_bulk): a branch is TRUE as soon as ANY solid walk of `trim`
+    edges leaves it (ExtendPath.h:174-244 is an OR over paths: read-guided, then taking the first or the last neighbour at
+    every fork), FALSE with its exact depth when it is a plain dead-end tip.  A collapsed 12-copy repeat at 40x with 1.5 %
+    errors is nothing but forks and tips; with the device's fast memory (HC_FAST_BYTES, so that the chain searches run),
+    with and without the guide, the contigs, the read log and the visited filter are the oracle's."""
+    reads = _thicket_reads(5 + k, 700, 12, 300, 40.0, 0.015, read_len=110 if k > 41 else 100)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(reads))
+    counters = 1 << 22
+    o = ob.Oracle(k, counters=counters, num_hashes=nh, min_cov=kc, trim=trim)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    monkeypatch.setenv("HC_FAST_BYTES", "20480")
+    for stride in ("2", "0"):
+        monkeypatch.setenv("ABG_GUIDE_STRIDE", stride)
+        hc = HostCheck(k, counters, nh, kc, trim, insert_batch=50000, claim_log2=16, p2_first=256)
+        hc.load(buf, off)
+        assert np.array_equal(o.counters(), hc.counters())
+        rh, ch = hc.assemble(buf, off)
+        assert np.array_equal(ro, rh), stride
+        assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in ch], stride
+        assert np.array_equal(o.visited(), hc.visited())
+        if stride != "0":
+            assert hc.stats()["chain_steps"] > 0
