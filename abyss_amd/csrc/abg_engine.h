@@ -58,7 +58,6 @@ struct Config {
 	uint32_t rec_cap = 1u << 22;      // contig records per round
 	uint32_t wtab_log2 = 26;          // walker vertex table entries (grown per launch to fit its walkers, up to:)
 	uint32_t wtab_log2_max = 31;
-	uint32_t wclaim_log2 = 26;        // walker claim slots
 	uint32_t cend_log2 = 20;          // contigEndKmers table entries
 	uint64_t p2_first_batch = 65536;  // PASS 2 read batches grow geometrically from here (a launch is bound by its slowest walker: 8 launches of configs[1] instead of 9, 886 vs 898 ms per step)
 	uint64_t p2_max_batch = 1ull << 22;
@@ -70,27 +69,16 @@ struct Config {
 	                                  // bit plane (B beyond one GPU): 0 = when the whole filter would not fit the device, 1 = always, 2 = never
 	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
 	uint32_t classify_slots = 65536;  // lanes of the classification kernel in flight (each owns 22 KB of lookAhead scratch)
-	bool heavy_first = true;          // ... and the candidates with the most such searches are walked first (Engine::presearch)
-	bool presearch = true;            // successor() searches at the candidates' own read k-mers run ahead of the walkers (Engine::presearch)
-	uint32_t presearch_cap = 1u << 20; // ... at most this many per launch of walkers
-	bool early_presearch = false;     // ... and those of the NEXT batch's candidates (as classified ahead) run beside this batch's commit (Engine::early_presearch;
-	                                  // measured: PASS 2 429 vs 435 ms on configs[1], inside the noise of the boxes -- left off)
-	uint32_t presearch_min_weight = 0; // ... and only for candidates with at least this many such searches on their reads (0: all)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
-	bool force_defer_stage = false;   // (measurement) stage 1 of a round -- everybody walks, deferring to lower-numbered walkers -- whatever the previous batch needed
-	uint32_t pipeline_depth = 1;      // batches of PASS 2 in flight (see Engine::assemble_packed); 1: one at a time
-	bool pipeline_late = true;        // ... the next batch's walkers start when this batch's are done (beside its commit), not beside them
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
 	bool memo = true;
 	uint32_t p2_max_candidates = 1u << 18; // a batch is cut after this many candidates
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
-	uint32_t async_guide = 0;         // the guide is built on the side stream while PASS 2 starts (Engine::build_guide).  1: nobody waits for it (measured 862 vs 866 ms per step, i.e. nothing: the first launch's walkers pay for the hints they do not find yet); 2: the first launch of walkers waits, the first classification and pre-search run beside it
 	bool link_duplicates = true;      // the commit decides a contig's copies among a batch's records by their original (Engine::link_duplicates)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
-	bool stage_early = false;              // ... starting beside this batch's op_target / tile_apply instead of beside its rounds
 	bool overlap_purity = true;            // ... and its tiles judged there too (tile_purity reads nothing but the bins)
 	uint32_t dist_hash_all_ranks = 2;      // partitioned tiles: up to this many ranks, every rank hashes every op itself
 	uint32_t dist_route_min_ranks = 4;     // ... from this many ranks on, the (op, counter) pairs are routed to their owners (Engine::insert_tiles_routed); 0: never
@@ -1449,102 +1437,6 @@ struct FWalk { // one walker per item; `list` selects the candidates to walk
 	}
 };
 
-// ---- pre-search (presearch_one, abg_walk.h).  Scan: one wave per candidate about to be walked, one
-// k-mer of its read per lane: the solid masks of the vertex's neighbours behind and ahead, and for
-// every side with two or more of them -- where successor() has to search (ExtendPath.h:314-362) --
-// a request, unless the memo has the answer or another lane asked first (a lossy set of tags: a
-// lost tag costs a duplicate search, nothing else).  The vertices are taken in the READ's
-// orientation, which is the orientation its own walker meets them in.
-template <int NW>
-struct FPresearchScan {
-	Params p; Batch b; const uint8_t* cnt; const uint32_t* cand_read; const uint32_t* list;
-	SuccMemo memo; uint64_t* tags; uint64_t tag_mask, gen; // (gen: which filling of the memo the tags refer to)
-	PreReq<NW>* req; uint32_t* req_n; uint32_t req_cap;
-	uint32_t* weight; // [n] per candidate of the list: sides of its read's k-mers where successor() has to search (how heavy its walk will be)
-	uint32_t min_weight; // requests only for candidates at least this heavy (0: for all)
-	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
-	{
-		uint32_t heavy = 0;
-		const uint64_t r = cand_read[list[i]];
-		const uint32_t L = b.len[r];
-		if (L < p.k) return;
-		const uint32_t nk = L - p.k + 1;
-		const uint64_t woff = b.woff[r];
-		const SeedTabs tabs = seed_tabs(p);
-		// (min_weight > 0: a first pass counts the sides only; requests are made for the candidates with at least that many -- the
-		// ones whose walks end a launch -- and the others ask their few questions themselves)
-		for (uint32_t pass = min_weight ? 0u : 1u; pass < 2; pass++) {
-		if (pass == 1 && min_weight) {
-			uint32_t tot = 0;
-			for (unsigned bit = 0; bit < 10; bit++) tot += (uint32_t)__builtin_popcountll(wave_ballot(((heavy >> bit) & 1u) != 0)) << bit;
-			if (tot < min_weight) break;
-			heavy = 0;
-		}
-		for (uint32_t j0 = 0; j0 < nk; j0 += nlanes) {
-			const uint32_t j = j0 + lane;
-			Vtx<NW> u;
-			unsigned want[2] = { 0, 0 };
-#if defined(__HIP_DEVICE_COMPILE__)
-			uint64_t st_fh, st_rh; // (the 64 k-mers' hashes at once: stretch_hashes_wave)
-			stretch_hashes_wave<NW>(b.words, woff, j0, nk - j0 < 64u ? nk - j0 : 64u, p.k, st_fh, st_rh);
-#endif
-			if (j < nk) {
-				u.s = window_kmer<NW>(b.words, woff, j, p.k);
-#if defined(__HIP_DEVICE_COMPILE__)
-				u.fh = st_fh; u.rh = st_rh;
-#else
-				kmer_hashes(u.s, p.k, u.fh, u.rh);
-#endif
-				vtx_set_d(u, 0, 0);
-				for (int dir = 0; dir < 2; dir++) {
-					const unsigned mask = nbr_mask_lean<NW, false>(p, tabs, cnt, u, dir == FORWARD ? SENSE : ANTISENSE);
-					if (!(mask & (mask - 1))) continue;
-					heavy++;
-					if (pass == 0) continue;
-					if (memo_find(memo, u.fh, u.rh, dir) >= 0) continue;
-					uint64_t tag = (u.fh ^ (u.rh * 0x9E3779B97F4A7C15ULL)) + (uint64_t)dir + gen * 0xD1B54A32D192ED03ULL;
-					tag ^= tag >> 31; tag *= 0xD6E8FEB86659FD93ULL; tag ^= tag >> 29;
-					if (atomic_exch_u64(&tags[tag & tag_mask], tag) == tag) continue;
-					want[dir] = mask;
-				}
-			}
-			for (int dir = 0; dir < 2; dir++) {
-				const uint32_t slot = wave_append_slot(req_n, want[dir] != 0);
-				if (want[dir] && slot < req_cap) {
-					PreReq<NW>& q = req[slot];
-#pragma unroll
-					for (int w = 0; w < KW<NW>; w++) q.w[w] = u.s.w[w];
-					q.fh = u.fh; q.rh = u.rh; q.dir = (uint32_t)dir; q.mask = want[dir];
-				}
-			}
-		}
-		}
-		// (the lanes' counts summed: one ballot per bit of a count that is at most 2 x ceil(nk / lanes))
-		uint32_t total = 0;
-		for (unsigned bit = 0; bit < 10; bit++) total += (uint32_t)__builtin_popcountll(wave_ballot(((heavy >> bit) & 1u) != 0)) << bit;
-		if (lane == 0) weight[i] = total;
-	}
-};
-template <int NW>
-struct FPresearch { // one request per item, launched like the walkers (FWalk): a wave and its fast memory each
-	WalkEnv<NW> e; const PreReq<NW>* req;
-	ABG_HDN void operator()(uint64_t i, uint32_t slot, void* fast, uint32_t fast_bytes, bool coop)
-	{
-		WalkEnv<NW>* env = (WalkEnv<NW>*)fast;
-		const uint32_t a = (uint32_t)((sizeof(WalkEnv<NW>) + 15) & ~15ull);
-		*env = e;
-		env->mcache = nullptr;
-		if (fast_bytes >= WALK_FAST_WITH_CACHE) {
-			fast_bytes -= (uint32_t)sizeof(MaskCache);
-			env->mcache = (MaskCache*)((char*)fast + fast_bytes);
-		}
-		env->fast = (char*)fast + a;
-		env->fast_bytes = fast_bytes - a;
-		env->coop = coop;
-		presearch_one<NW>(*env, req[i], slot);
-	}
-};
-
 // (contig sequences hold code 4 = 'N' in columns no '1' of the spaced seed covers: never read)
 template <int NW>
 ABG_HDN uint64_t seq_kmer_hash(const Params& p, const uint8_t* seq, uint64_t j)
@@ -1640,21 +1532,6 @@ struct FDupVerify { // one wave per record: the link holds only if the two hash 
 		if (!fwd && !rev && lane == 0) d.dup_of = REC_END;
 	}
 };
-struct FDupInherit { // after FPreCommit: what was settled ahead for the original holds for its copies (one candidate per item)
-	const uint32_t* status; const uint32_t* first_rec; ContigRec* recs; uint32_t first, c_begin;
-	ABG_HD void operator()(uint64_t i, uint32_t) const
-	{
-		const uint32_t c = first + (uint32_t)i;
-		if (status[c] != WS_COMPLETE) return;
-		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
-			ContigRec& rec = recs[ri];
-			if (rec.dup_of == REC_END) continue;
-			const ContigRec& o = recs[rec.dup_of];
-			if (o.cand < c_begin) { rec.dup_of = REC_END; continue; } // (committed in an earlier call: its bits are in the filter, the ordinary tests see them)
-			if (o.pre_redundant) rec.pre_redundant = 1;
-		}
-	}
-};
 // Settles, in parallel and against the current visited snapshot, what the ordered commit
 // would otherwise test one by one: a candidate read / a contig whose k-mers are ALL visited
 // already stays so (the visited set only grows), so "read is visited" and "contig is
@@ -1680,7 +1557,6 @@ struct FPreCommit {
 	ContigRec* recs; const uint8_t* vis; const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff;
 	uint8_t* read_flag; uint32_t first;
 	uint64_t lo, span; uint8_t* part_c; uint8_t* part_r; // (whole filter: 0, ~0, NULL, NULL)
-	uint32_t skip_dups; // records linked to a lower candidate's copy (in this commit's range) inherit its verdict (FDupInherit)
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
 		uint32_t c = first + (uint32_t)i;
@@ -1700,7 +1576,6 @@ struct FPreCommit {
 			ContigRec& rec = recs[ri];
 			uint32_t cnk = rec.len - p.k + 1;
 			if (rec.len < p.k + FP_TRIM - 1 || rec.pre_redundant) continue;
-			if (skip_dups && rec.dup_of != REC_END && recs[rec.dup_of].cand >= first) continue;
 			bool red = true;
 			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains_owned(p, vis, kh[rec.seq_off + j], lo, span);
 			red = wave_all_lanes(red, nlanes);
@@ -1734,7 +1609,7 @@ template <int NW>
 struct FPredict {
 	Params p; Batch b; const uint32_t* cand_read; const uint32_t* status; const uint8_t* vis;
 	const uint64_t* rkoff; const uint64_t* rkh;
-	const uint32_t* claims; uint32_t claim_mask; uint32_t* need_list; uint32_t* need_n;
+	uint32_t* need_list; uint32_t* need_n;
 	uint32_t first; uint32_t force;
 	uint32_t rank, world; // partitioned run: need_n[1] counts every needed candidate, the list holds the ones this rank walks
 	ABG_HDN void operator()(uint64_t i, uint32_t) const
@@ -1747,8 +1622,6 @@ struct FPredict {
 		for (uint32_t j = 0; covered && j < nk; j++) {
 			uint64_t hm = rkh[rkoff[c] + j];
 			if (visited_contains(p, vis, hm)) continue;
-			uint32_t owner = claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask];
-			if (owner < c && status[owner] == WS_COMPLETE) continue;
 			covered = false;
 		}
 		if (!covered) {
@@ -1784,22 +1657,6 @@ struct FFirstFix { // first record of the candidates this rank walked in the lau
 	}
 };
 struct FAddU64 { uint64_t* a; uint64_t d; ABG_HD void operator()(uint64_t i, uint32_t) const { a[i] += d; } };
-// Several batches in flight: a batch's candidates were drawn against the visited filter as it was when the batch was classified.  Once the
-// batch before it is committed, the verdicts are brought up to date (FRefilter) and the candidates whose reads are covered by now are
-// struck from the launch that is already queued or running: a walker that has not started on one skips it (walk_read).  Nothing depends on
-// it -- the commit finds such a read visited at its turn with or without a walk -- it only saves the walk.
-struct FCancelStale {
-	const uint32_t* cand_read; const uint8_t* result; uint32_t* status; uint32_t first; uint32_t* count;
-	ABG_HD void operator()(uint64_t i, uint32_t) const
-	{
-		const uint32_t c = first + (uint32_t)i;
-		if (result[cand_read[c]] != RES_CANDIDATE) {
-			atomic_add_u32(count + 1, 1); // (covered by now, walked or not)
-			if (status[c] == WS_NONE) { status[c] = WS_CANCELLED; atomic_add_u32(count, 1); }
-		}
-	}
-};
-
 // ---- -g: outputGraph (bloom-dbg.h:1171-1242)
 // trimSeq (bloom-dbg.h:399-451) on one clean segment: the longest run of consecutive k-mers the
 // solid filter contains; the first such run wins a tie (a later one must be strictly longer).
@@ -2601,15 +2458,10 @@ class Engine {
 		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
 		free_insert();
-		for (int i = 0; i < MAX_CTX; i++) { use_ctx(i); free_walk(); }
+		free_walk();
 		if (cend_.hmin) free_tab(cend_);
 		if (memo_tab_.hmin) free_tab(memo_tab_);
 		if (plane_) be_.free(plane_);
-		if (pre_req_) { be_.free(pre_req_); be_.free(pre_n_d_); }
-		if (pre_tags_) be_.free(pre_tags_);
-		if (pre_w_) be_.free(pre_w_);
-		if (early_cand_d_) { be_.free(early_cand_d_); be_.free(pre_w2_); }
-		if (pre_req2_) { be_.free(pre_req2_); be_.free(pre_n2_d_); }
 		if (wstats_) be_.free(wstats_);
 	}
 	// Back to the state right after construction -- empty filters, zero counters, empty
@@ -2624,12 +2476,11 @@ class Engine {
 		be_.memset(cstate_, 0, sizeof(CommitState));
 		counters_ = Counters();
 		stats_ = Stats();
-		cnt_partial_ = false;
+		cnt_partial_ = false; cnt_loaded_ = false;
 		memo_valid_ = false; plane_valid_ = false;
 		last_rounds_ = 0;
 		p2_batch_ = cfg_.p2_first_batch;
 		last_candidates_ = 0;
-		needed_frac_ = 1.0;
 		if (cend_.hmin) {
 			be_.memset(cend_.hmin, 0xFF, (cend_.mask + 1) * 8);
 			be_.memset(cend_.meta, 0xFF, (cend_.mask + 1) * 8);
@@ -2661,10 +2512,15 @@ class Engine {
 	bool attach_comm(const Comm& c)
 	{
 		if (c.world < 1 || c.world > MAX_RANKS || c.rank < 0 || c.rank >= c.world || casc_.bits) return false;
-		comm_ = c;
-		free_insert(); // (PASS 1's scratch is laid out for the partition it was made under: the next load makes it anew)
 		uint64_t chunk = (m_ + c.world - 1) / c.world;
 		chunk = (chunk + 63) & ~63ull;
+		// (a sliced filter that holds counters cannot be laid out anew: this rank keeps [own_lo_, own_lo_ + own_span_) and nothing
+		// else, and another rank or world would need counters that are not here -- export and import them instead)
+		if (sliced_ && cnt_loaded_ && (c.rank != comm_.rank || c.world != comm_.world))
+			fail_now(FAIL_INVAL, "a sliced filter that holds counters cannot take a communicator with another rank or world (abg_counters_export / _import move them)");
+		const bool keep_window = sliced_ && c.rank == comm_.rank && c.world == comm_.world && own_chunk_ == chunk;
+		comm_ = c;
+		free_insert(); // (PASS 1's scratch is laid out for the partition it was made under: the next load makes it anew)
 		own_lo_ = std::min<uint64_t>(m_, (uint64_t)c.rank * chunk);
 		own_span_ = std::min<uint64_t>(m_, own_lo_ + chunk) - own_lo_;
 		own_chunk_ = chunk;
@@ -2674,12 +2530,16 @@ class Engine {
 			// probes the bit plane all ranks gather (ensure_plane), asks for coverage through an all-reduce (commit_par)
 			if (!cfg_.solid_plane || (m_ & 63) || !cfg_.par_commit)
 				fail_now(FAIL_INVAL, "a sliced filter needs the bit plane, the parallel commit and a multiple of 64 counters");
-			free_counters();
-			if (plane_) { be_.free(plane_); plane_ = nullptr; }
-			win_total_ = (uint64_t)c.world * chunk + 64;
-			win_span_ = chunk + 64;
-			cnt_ = (uint8_t*)be_.alloc_window(win_total_, own_lo_, win_span_);
-			be_.memset(cnt_ + own_lo_, 0, win_span_);
+			if (!keep_window) { // (the same rank of the same world again: the window and what it holds stay)
+				free_counters(); // (frees the window as it was made: win_lo_, not the new own_lo_)
+				if (plane_) { be_.free(plane_); plane_ = nullptr; }
+				win_total_ = (uint64_t)c.world * chunk + 64;
+				win_span_ = chunk + 64;
+				win_lo_ = own_lo_;
+				cnt_ = (uint8_t*)be_.alloc_window(win_total_, win_lo_, win_span_);
+				be_.memset(cnt_ + own_lo_, 0, win_span_);
+				cnt_loaded_ = false;
+			}
 			sliced_ = true; cnt_deferred_ = false;
 			cfg_.drain_threshold = 0; // (the drain of the last pending ops replays them on scratch copies of the other ranks' counters)
 			memo_valid_ = false; plane_valid_ = false;
@@ -2716,7 +2576,7 @@ class Engine {
 	}
 	void free_counters()
 	{
-		if (sliced_) be_.free_window(cnt_, win_total_, own_lo_, win_span_);
+		if (sliced_) be_.free_window(cnt_, win_total_, win_lo_, win_span_);
 		else if (cnt_) be_.free(cnt_);
 		cnt_ = nullptr; sliced_ = false;
 	}
@@ -2779,6 +2639,7 @@ class Engine {
 	void counters_from_host(const uint8_t* in)
 	{
 		need_counters();
+		cnt_loaded_ = true;
 		if (!sliced_) { be_.h2d(counters_dev(), in, m_); return; }
 		be_.h2d(cnt_ + own_lo_, in + own_lo_, own_span_);
 		memo_valid_ = false; plane_valid_ = false;
@@ -2891,6 +2752,7 @@ class Engine {
 	void load_packed(const Batch& b, const std::vector<OpRange>& ranges)
 	{
 		need_counters();
+		cnt_loaded_ = true;
 		{
 			// Run length of FHashOps: a lane hashes one k-mer from scratch (k rounds) and rolls the rest, so longer
 			// runs are less work -- and a run that ends where the read ends starts no second hash.  The reads'
@@ -2991,18 +2853,13 @@ class Engine {
 	// ---- PASS 2 on a device-resident packed batch of reads.  results_host (b.n bytes,
 	// may be NULL) receives a ReadResult per read; contigs are delivered in commit order.
 	//
-	// The reads go through in batches (classify -> walk the candidates -> ordered commit), and up
-	// to cfg_.pipeline_depth batches are in flight: a batch's walkers run on a stream of their own
-	// while the batch before it is committed and the batch after it is classified.  A launch of
-	// walkers ends with its slowest walker (a read in a repeat spends tens of milliseconds in
-	// trueBranch searches while the average read needs a few), so with one batch at a time most of
-	// the machine idles through every batch's tail.  The walks are pure functions of the read and
-	// the solid filter; only the commit is ordered, and it settles "visited by now" itself -- a
-	// batch classified against an older snapshot merely walks some candidates in vain.
+	// The reads go through in batches, one at a time: classify -> walk the candidates -> ordered commit; the next batch is
+	// classified on the side stream beside this batch's walkers.  (Several batches in flight, a deferral stage in which the
+	// walkers yield to lower-numbered ones, and a pre-search of the candidates' own branching k-mers were built, measured
+	// and taken out again: notes/README.md.)
 	void assemble_packed(const Batch& b, uint8_t* results_host,
 	    const std::function<void(const ContigOut&)>& sink)
 	{
-		use_ctx(0);
 		need_counters();
 		gather_counters();
 		// (PASS 1's bins and claim tables grow with the filter -- 60 GB at B=40G: PASS 2 gets that memory)
@@ -3014,12 +2871,8 @@ class Engine {
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
 		deliveries_wait(); // (the last batch's contigs are with the caller)
-		be_.wait_walkers(EARLY_CTX);
-		early_done_ = true;
 		be_.sync_side();
-		be_.wait_side_scope(); // (the guide's build, if it went to the side stream)
 		pre_n_ = 0; prefetch_ = nullptr;
-		use_ctx(0);
 		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);
 	}
@@ -3091,16 +2944,10 @@ class Engine {
 		}
 		be_.memset(guide_tab_, 0, 8ull << log2);
 		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
-		// The hints are plain 8-byte stores that the walkers check against the read they point to: a table still being
-		// filled is a table with fewer hints, nothing else.  So the build goes to the side stream and PASS 2 starts beside
-		// it (the first batch's classification, pre-search and heaviest walkers do not look at the guide much);
-		// assemble_packed waits for it before it returns.
-		if (cfg_.async_guide) be_.side_scope_begin("guide_build");
 		dispatch_nw([&](auto nw) {
 			FGuideBuild<decltype(nw)::value> f{ p2_, b, cnt2_, guide_tab_, guide_.mask, cfg_.guide_stride };
 			be_.launch_wave(sampled, f, "guide_build");
 		});
-		if (cfg_.async_guide) be_.side_scope_end();
 		guide_.tab = guide_tab_;
 		guide_slots_ = guide_.mask + 1;
 	}
@@ -3132,7 +2979,7 @@ class Engine {
 			be_.d2h(v, wstats_, sizeof v);
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
-			s.pre_requests = pre_requests_; s.pre_adds = v[WSTAT_PRE_ADDS];
+			s.pre_requests = 0; s.pre_adds = 0; // (fields of the C ABI's abg_stats kept for its layout: the pre-search is gone)
 			if (v[WSTAT_MEMO_BAD])
 				fprintf(stderr, "abyss_amd: ABG_MEMO_VERIFY: %llu memo hits differ from the recomputed answer; last: fh %016llx rh %016llx dir %llu mask %llx checked-by %s memo %03llx (written by %s) computed %03llx\n",
 				    (unsigned long long)v[WSTAT_MEMO_BAD], (unsigned long long)v[WSTAT_BAD0], (unsigned long long)v[WSTAT_BAD1], (unsigned long long)(v[WSTAT_BAD2] >> 60),
@@ -3161,7 +3008,8 @@ class Engine {
 	// switched off) the ordered single-workgroup kernel runs
 	uint64_t* Tk_ = nullptr; uint32_t* Tv_ = nullptr; uint32_t Tlog2_ = 0; // ... or per touched bit (see pc_T_slot)
 	uint64_t T_entries_ = 0; // upper bound of the keys in the table
-	bool t_hashed() const { return m_ * 4ull > cfg_.par_commit_max_bytes; }
+	bool t_hashed() const { return t_force_hashed_ || m_ * 4ull > cfg_.par_commit_max_bytes; }
+	bool t_force_hashed_ = false; // no room for a stamp per filter bit on a sliced filter, where the ordered kernel cannot run: a stamp per touched bit
 	bool use_par_commit()
 	{
 		if (!cfg_.par_commit || t_failed_) return false;
@@ -3169,6 +3017,13 @@ class Engine {
 		if (!T_) {
 			T_ = (uint32_t*)be_.try_alloc(m_ * 4ull);
 			t_tag_ = 0;
+			if (!T_ && sliced_) {
+				// (the ordered commit kernel and FContigPrep's coverage sums read counters at any position: on a sliced filter those are
+				// not there.  The stamps go to the hashed table instead -- sized to what a commit touches -- or the run fails cleanly.)
+				t_force_hashed_ = true;
+				if (cfg_.verbose) fprintf(stderr, "abyss_amd: no memory for a time stamp per filter bit, hashed stamps instead\n");
+				return true;
+			}
 			if (!T_) { t_failed_ = true; if (cfg_.verbose) fprintf(stderr, "abyss_amd: no memory for the parallel commit's time stamps, using the ordered kernel\n"); return false; }
 		}
 		return true;
@@ -3177,7 +3032,8 @@ class Engine {
 	// ---- partitioned run
 	Comm comm_;
 	bool force_dist_ = false, comm_scaled_ = false;
-	bool sliced_ = false, cnt_deferred_ = false; uint64_t win_total_ = 0, win_span_ = 0; // the sliced filter (attach_comm)
+	bool sliced_ = false, cnt_deferred_ = false; uint64_t win_total_ = 0, win_span_ = 0, win_lo_ = 0; // the sliced filter (attach_comm): the window as it was allocated
+	bool cnt_loaded_ = false; // counters were inserted or imported since the filter was last empty
 	uint64_t own_lo_ = 0, own_span_ = 0, own_chunk_ = 0;
 	uint8_t* tred_ = nullptr; // partitioned tiles: the two bytes per op of FDistPack
 	bool cnt_partial_ = false; // PASS 1 ran partitioned since the counters were last gathered
@@ -3273,7 +3129,6 @@ class Engine {
 	WalkTab wtab_{}, cend_{ nullptr, nullptr, nullptr, 0 };
 	uint32_t wtab_log2_ = 0;
 	uint64_t wtab_per_walker_ = 1536; // planning figure: vertices one walker enters (config 2 averages ~1100)
-	uint32_t* wclaims_ = nullptr;
 	void* tb_pool_ = nullptr; VKey* tbk_pool_ = nullptr; VKey* la_pool_ = nullptr; uint8_t* lbuf_ = nullptr; uint8_t* rbuf_ = nullptr;
 	uint8_t* pool_ = nullptr; uint64_t pool_cap_ = 0; uint64_t* pool_used_ = nullptr;
 	ContigRec* recs_ = nullptr; uint32_t rec_cap_ = 0; uint32_t* rec_used_ = nullptr;
@@ -3287,7 +3142,6 @@ class Engine {
 	VKey* la_pool_c2_ = nullptr; // ... and of the classification running ahead on the side stream
 	uint64_t pre_first_ = 0, pre_n_ = 0;      // range classified ahead on the side stream
 	std::function<void()> prefetch_;          // queues that classification (called right before a launch of walkers)
-	double needed_frac_ = 1.0; // share of the previous batch's candidates that had to be walked in full
 
 	// ---- -g state: the vertices seen by any search so far
 	WalkTab gtab_{ nullptr, nullptr, nullptr, 0 };
@@ -3527,8 +3381,6 @@ class Engine {
 				be_.memset(opflag_, 0, (T + 3) & ~3ull);
 			}
 			be_.memset(pend_n_, 0, 8);
-			// (the next batch's staging from the START of this batch's main-stream work, not from after tile_apply)
-			if (cfg_.stage_early && stage_next_) { stage_next_(); stage_next_ = nullptr; }
 			if (!staged) {
 				be_.memset(tcur_, 0, ntiles_ * 4);
 				dispatch_nw([&](auto nw) { FHashOps<(decltype(nw)::value & 7)> f{ p_, v, h0_, T, kbase, 0, hash_run_ }; be_.launch((T + hash_run_ - 1) / hash_run_, f, "hash_ops"); });
@@ -3828,7 +3680,6 @@ class Engine {
 		wslots_ = std::min<uint32_t>(be_.max_slots(), cfg_.walk_slots);
 		wtab_log2_ = cfg_.wtab_log2;
 		alloc_tab(wtab_, wtab_log2_);
-		wclaims_ = (uint32_t*)be_.alloc(4ull << cfg_.wclaim_log2);
 		la_pool_ = (VKey*)be_.alloc((uint64_t)wslots_ * LA_MAX_VISITED * sizeof(VKey));
 		bulk_pool_ = (BulkScratch*)be_.alloc((uint64_t)wslots_ * sizeof(BulkScratch));
 		if (!wstats_) { wstats_ = (uint64_t*)be_.alloc(WSTAT_N * 8); clear_wstats(); }
@@ -3869,7 +3720,7 @@ class Engine {
 	{
 		if (!walk_ready_) return;
 		free_tab(wtab_);
-		be_.free(wclaims_); be_.free(la_pool_); be_.free(bulk_pool_);
+		be_.free(la_pool_); be_.free(bulk_pool_);
 		free_walk_scratch();
 		be_.free(pool_); be_.free(kh_); be_.free(pool_used_); be_.free(recs_); be_.free(rec_used_);
 		be_.free(order_); be_.free(order_n_);
@@ -3905,7 +3756,7 @@ class Engine {
 	{
 		WalkEnv<NW> e;
 		e.p = p2_; e.cnt = cnt2_; e.batch = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
-		e.tab = wtab_; e.claims = nullptr; e.claim_mask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1); e.owner_base = 0;
+		e.tab = wtab_; e.owner_base = 0;
 		// scratch strides are sized for the largest TBFrame; a smaller NW fits more frames in them
 		e.tb_pool = (TBFrame<NW>*)tb_pool_;
 		e.tbk_pool = tbk_pool_;
@@ -3936,7 +3787,7 @@ class Engine {
 		cs.break_at = c_begin; cs.pad_ = 0; cs.cend_count = cend_count_;
 		be_.h2d(cstate_, &cs, sizeof cs);
 		{
-			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr, 0u };
+			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr };
 			be_.launch_wave(c_end - c_begin, f, "precommit");
 		}
 		CommitEnv<NW> e;
@@ -4293,12 +4144,8 @@ class Engine {
 	}
 
 	// ---- one batch of reads in flight -----------------------------------------------------
-	// Every candidate is walked; then the ordered commit runs as far as the results allow.  (With
-	// the deferral stage -- taken when most candidates of the previous batch turned out not to be
-	// needed -- every candidate first walks until it meets the territory of a lower-numbered read,
-	// a predictor picks the ones that will be needed after all, and those are walked privately.)
-	// Walk results are pure functions of the read and the solid filter, so they stay valid across
-	// iterations and across commits of earlier batches.
+	// Every candidate that is not entirely visited by now is walked; then the ordered commit runs as far as the results
+	// allow.  Walk results are pure functions of the read and the solid filter, so they stay valid across iterations.
 	struct BatchRun {
 		Batch v{};                  // the batch's reads
 		uint64_t first = 0, n = 0;  // ... which are reads [first, first + n) of the call
@@ -4306,112 +4153,45 @@ class Engine {
 		std::vector<uint32_t> cand_h;
 		uint32_t nc = 0;
 		uint32_t* cand_d = nullptr; uint32_t* status_d = nullptr; uint32_t* first_d = nullptr;
-		uint32_t* list_d = nullptr; uint32_t* need_d = nullptr; uint32_t* need_n = nullptr; uint64_t* rkoff_d = nullptr;
+		uint32_t* need_d = nullptr; uint32_t* need_n = nullptr; uint64_t* rkoff_d = nullptr;
 		uint32_t base = 0;          // candidates [0, base) are accounted for
 		uint32_t prepped = 0, owner_next = 0, committed = 0, force = 0xFFFFFFFFu, nneed = 0, nneed_all = 0;
-		uint64_t batch_rewalked = 0;
 		bool round_started = false; // the prologue of a round (see start_round) ran for `base`
 		bool predicted = false;     // ... including the first prediction
 		bool pending = false;       // ... and its walkers are running (or done) but not yet accounted for
 		bool overflow = false, debug = false;
 	};
-	// what a batch in flight owns besides: vertex table, walker scratch, contig pool and records
-	struct WalkRes {
-		bool ready = false;
-		WalkTab wtab{}; uint32_t wtab_log2 = 0; uint32_t* wclaims = nullptr;
-		void* tb_pool = nullptr; VKey* tbk_pool = nullptr; VKey* la_pool = nullptr; uint8_t* lbuf = nullptr; uint8_t* rbuf = nullptr;
-		BulkScratch* bulk_pool = nullptr;
-		uint8_t* pool = nullptr; uint64_t pool_cap = 0; uint64_t* pool_used = nullptr; uint64_t* kh = nullptr;
-		ContigRec* recs = nullptr; uint32_t rec_cap = 0; uint32_t* rec_used = nullptr; uint32_t* order = nullptr; uint32_t* order_n = nullptr;
-		uint32_t walk_tb_cap = 0, walk_buf_cap = 0, wslots = 0;
-		uint64_t* rkh = nullptr; uint8_t* read_flag = nullptr; uint64_t* dbg = nullptr; uint32_t g_rec = 0; uint64_t g_pool = 0;
-	};
-	std::vector<int> late_; // contexts whose first round waits for the walkers of the batch before (Config::pipeline_late)
-	static constexpr int MAX_CTX = 4;
-	WalkRes res_[MAX_CTX];
-	BatchRun run_[MAX_CTX];
-	int cur_ctx_ = 0;
-	// the engine's walker members ARE the current context: switching swaps them
-	void use_ctx(int i)
-	{
-		if (i == cur_ctx_) return;
-		WalkRes& o = res_[cur_ctx_];
-		o.ready = walk_ready_; o.wtab = wtab_; o.wtab_log2 = wtab_log2_; o.wclaims = wclaims_;
-		o.tb_pool = tb_pool_; o.tbk_pool = tbk_pool_; o.la_pool = la_pool_; o.lbuf = lbuf_; o.rbuf = rbuf_; o.bulk_pool = bulk_pool_;
-		o.pool = pool_; o.pool_cap = pool_cap_; o.pool_used = pool_used_; o.kh = kh_;
-		o.recs = recs_; o.rec_cap = rec_cap_; o.rec_used = rec_used_; o.order = order_; o.order_n = order_n_;
-		o.walk_tb_cap = walk_tb_cap_; o.walk_buf_cap = walk_buf_cap_; o.wslots = wslots_;
-		o.rkh = rkh_; o.read_flag = read_flag_; o.dbg = dbg_; o.g_rec = g_rec_; o.g_pool = g_pool_;
-		const WalkRes& n = res_[i];
-		walk_ready_ = n.ready; wtab_ = n.wtab; wtab_log2_ = n.wtab_log2; wclaims_ = n.wclaims;
-		tb_pool_ = n.tb_pool; tbk_pool_ = n.tbk_pool; la_pool_ = n.la_pool; lbuf_ = n.lbuf; rbuf_ = n.rbuf; bulk_pool_ = n.bulk_pool;
-		pool_ = n.pool; pool_cap_ = n.pool_cap; pool_used_ = n.pool_used; kh_ = n.kh;
-		recs_ = n.recs; rec_cap_ = n.rec_cap; rec_used_ = n.rec_used; order_ = n.order; order_n_ = n.order_n;
-		walk_tb_cap_ = n.walk_tb_cap; walk_buf_cap_ = n.walk_buf_cap; wslots_ = n.wslots;
-		rkh_ = n.rkh; read_flag_ = n.read_flag; dbg_ = n.dbg; g_rec_ = n.g_rec; g_pool_ = n.g_pool;
-		cur_ctx_ = i;
-	}
-	// how many batches may be in flight right now: the deferral stage and the partitioned run keep
-	// rank-local / cross-batch state and go one batch at a time
-	uint32_t depth_now() const
-	{
-		if (dist() || needed_frac_ < 0.5) return 1;
-		return std::max<uint32_t>(1, std::min<uint32_t>(cfg_.pipeline_depth, MAX_CTX));
-	}
-
 	template <int NW>
 	void assemble_nw(const Batch& b, uint8_t* result_d, uint8_t* results_host,
 	    const std::function<void(const ContigOut&)>& sink)
 	{
-		uint64_t next = 0;          // first read not yet classified
-		std::vector<int> inflight;  // contexts of the batches in flight, oldest first
-		while (next < b.n || !inflight.empty()) {
-			while (next < b.n && inflight.size() < depth_now()) {
-				int ci = 0;
-				while (std::find(inflight.begin(), inflight.end(), ci) != inflight.end()) ci++;
-				use_ctx(ci);
-				ensure_walk();
-				BatchRun& r = run_[ci];
-				classify_batch<NW>(b, next, std::min<uint64_t>(p2_batch_, b.n - next), result_d, r);
-				next += r.n;
-				counters_.reads_processed += r.n;
-				p2_batch_ = next_batch_size();
-				prefetch_ = nullptr;
-				if (next < b.n && depth_now() == 1 && !dist() && cfg_.prefetch_classify) {
-					// Classification of the NEXT batch on the side stream, queued right before this batch's
-					// walkers so that it fills the machine while they thin out (a launch ends with its
-					// slowest walker).  It sees an older snapshot; FRefilter brings it up to date.
-					const uint64_t nf = next, nn = std::min<uint64_t>(p2_batch_, b.n - next);
-					prefetch_ = [this, &b, result_d, nf, nn]() {
-						if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
-						Batch vn = b;
-						vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
-						FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_ };
-						be_.launch_slots_side(nn, f, cslots_, "classify");
-						pre_first_ = nf; pre_n_ = nn;
-						pre_batch_ = vn; pre_res_ = result_d + nf; early_done_ = false;
-					};
-				}
-				if (r.nc) {
-					setup_batch<NW>(r);
-					// the first round's walkers start right away, on the context's own stream, unless
-					// this batch goes through alone
-					if (depth_now() > 1) {
-						// (pipeline_late: not beside the walkers of the batch before -- every stale candidate would be walked before that batch's
-						// commit can strike it -- but when they are done, beside its commit: finish_batch starts it)
-						if (inflight.empty() || !cfg_.pipeline_late) start_round<NW>(r, ci, true);
-						else late_.push_back(ci);
-					}
-				}
-				inflight.push_back(ci);
+		uint64_t next = 0; // first read not yet classified
+		while (next < b.n) {
+			ensure_walk();
+			BatchRun r;
+			classify_batch<NW>(b, next, std::min<uint64_t>(p2_batch_, b.n - next), result_d, r);
+			next += r.n;
+			counters_.reads_processed += r.n;
+			p2_batch_ = next_batch_size();
+			prefetch_ = nullptr;
+			if (next < b.n && !dist() && cfg_.prefetch_classify) {
+				// Classification of the NEXT batch on the side stream, queued right before this batch's
+				// walkers so that it fills the machine while they thin out (a launch ends with its
+				// slowest walker).  It sees an older snapshot; FRefilter brings it up to date.
+				const uint64_t nf = next, nn = std::min<uint64_t>(p2_batch_, b.n - next);
+				prefetch_ = [this, &b, result_d, nf, nn]() {
+					if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
+					Batch vn = b;
+					vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
+					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_ };
+					be_.launch_slots_side(nn, f, cslots_, "classify");
+					pre_first_ = nf; pre_n_ = nn;
+				};
 			}
-			const int ci = inflight.front();
-			inflight.erase(inflight.begin());
-			use_ctx(ci);
-			BatchRun& r = run_[ci];
-			if (r.nc) finish_batch<NW>(r, ci, sink);
-			// (the batches still in flight were classified before this commit: strike what it covered from their queued walkers)
-			for (int cj : inflight) cancel_stale<NW>(run_[cj]);
+			if (r.nc) {
+				setup_batch<NW>(r);
+				finish_batch<NW>(r, sink);
+			}
 			if (results_host) {
 				be_.d2h(results_host + r.first, r.res_d, r.n);
 				if (const void* left = memchr(results_host + r.first, RES_CANDIDATE, r.n)) {
@@ -4421,20 +4201,6 @@ class Engine {
 		}
 	}
 
-	template <int NW>
-	void cancel_stale(BatchRun& r2)
-	{
-		if (!r2.nc || r2.committed >= r2.nc) return;
-		{ FRefilter<NW> f{ p_, r2.v, vis_, r2.res_d }; be_.launch(r2.n, f, "reclassify"); }
-		uint32_t* cnt = (uint32_t*)scal_;
-		be_.memset(cnt, 0, 8);
-		FCancelStale f{ r2.cand_d, r2.res_d, r2.status_d, r2.committed, cnt };
-		be_.launch(r2.nc - r2.committed, f, "reclassify");
-		uint32_t n[2] = { 0, 0 };
-		be_.d2h(n, cnt, 8);
-		stats_.cancelled += n[0];
-		if (getenv("ABG_CANCEL_DEBUG")) fprintf(stderr, "[cancel] batch of %llu reads, %u candidates: %u covered by now, %u of them not walked yet\n", (unsigned long long)r2.n, r2.nc, n[1], n[0]);
-	}
 	// Verdicts of reads [first, first + n) against the current visited snapshot, and the batch they
 	// make: the longest prefix holding at most cfg_.p2_max_candidates candidates (what the walkers'
 	// tables and the commit's positions are sized for); the rest is classified again later.
@@ -4500,7 +4266,6 @@ class Engine {
 		r.cand_d = (uint32_t*)be_.alloc(nc * 4ull);
 		r.status_d = (uint32_t*)be_.alloc(nc * 4ull);
 		r.first_d = (uint32_t*)be_.alloc(nc * 4ull);
-		r.list_d = (uint32_t*)be_.alloc(nc * 4ull);
 		r.need_d = (uint32_t*)be_.alloc(nc * 4ull);
 		r.need_n = (uint32_t*)be_.alloc(8);
 		be_.h2d(r.cand_d, r.cand_h.data(), nc * 4ull);
@@ -4564,13 +4329,11 @@ class Engine {
 	}
 
 	// Prologue of a round over the candidates [r.base, nc) -- nothing of them walked yet -- up to and
-	// including the launch of the round's first walkers.  async: those walkers go to the stream of
-	// context ci and nobody waits for them here (finish_batch does).
+	// including the launch of the round's first walkers.
 	template <int NW>
-	void start_round(BatchRun& r, int ci, bool async)
+	void start_round(BatchRun& r)
 	{
 		const uint32_t nc = r.nc, base = r.base;
-		const Batch& b = r.v;
 		stats_.rounds++;
 		be_.memset(r.status_d + base, 0, (nc - base) * 4ull);
 		be_.memset(r.first_d + base, 0xFF, (nc - base) * 4ull);
@@ -4578,150 +4341,20 @@ class Engine {
 		be_.memset(rec_used_, 0, 4);
 		be_.memset(order_n_, 0, 4);
 		g_rec_ = 0; g_pool_ = 0;
-		be_.memset(wclaims_, 0xFF, 4ull << cfg_.wclaim_log2);
 		r.prepped = 0; r.owner_next = 0;
-		// stage 1: everybody walks, deferring to lower-numbered walkers.  It pays when many
-		// candidates share unitigs; when most of them turned out to be needed in the previous
-		// batch they would only be walked twice, so it is skipped and everybody is walked in
-		// full by the first stage-2 launch instead.
-		const bool defer_stage = (needed_frac_ < 0.5 || cfg_.force_defer_stage) && !dist() && !async; // (its claims are rank-local state)
-		if (defer_stage) {
-			std::vector<uint32_t> ident(nc - base);
-			for (uint32_t i = 0; i < nc - base; i++) ident[i] = base + i;
-			be_.h2d(r.list_d, ident.data(), (nc - base) * 4ull);
-			ensure_wtab(nc - base);
-			clear_wtab();
-			WalkEnv<NW> env = make_env<NW>(b, r.cand_d, r.status_d, r.first_d);
-			env.claims = wclaims_;
-			env.owner_base = r.owner_next;
-			r.owner_next += nc;
-			FWalk<NW> fw{ env, r.list_d };
-			if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
-			be_.launch_walkers(nc - base, fw, wslots_, "walk", ci, false);
-			stats_.walked += nc - base;
-			dump_walkers(r, "walk", nc - base);
-		}
 		prep_new_records<NW>(r.prepped);
-		r.committed = base; r.force = 0xFFFFFFFFu; r.overflow = false; r.batch_rewalked = 0;
+		r.committed = base; r.force = 0xFFFFFFFFu; r.overflow = false;
 		r.round_started = true;
-		predict_and_walk<NW>(r, ci, async);
+		predict_and_walk<NW>(r);
 	}
-	// The successor() searches the walkers of `list` are about to ask for at the k-mers of their own
-	// reads, answered ahead of them, one search per wave (FPresearchScan, presearch_one).
+	// the candidates without a result whose reads are not entirely visited by now are walked
 	template <int NW>
-	void presearch(const WalkEnv<NW>& env, uint32_t* list_d, uint32_t n)
-	{
-		if constexpr (MASKED_BUILD<NW>) return;
-		if (!cfg_.presearch || !memo_.k0 || !n || p_.trim < 2) return;
-		const uint32_t cap = cfg_.presearch_cap;
-		if (pre_w_cap_ < n) {
-			if (pre_w_) be_.free(pre_w_);
-			pre_w_cap_ = std::max<uint32_t>(n, 1u << 16);
-			pre_w_ = (uint32_t*)be_.alloc(pre_w_cap_ * 4ull);
-		}
-		if (!pre_req_) {
-			pre_req_ = be_.alloc((uint64_t)cap * (8ull * MAX_NW + 24)); // (PreReq of the widest k-mer)
-			pre_n_d_ = (uint32_t*)be_.alloc(8);
-		}
-		if (!pre_tags_) {
-			pre_tags_ = (uint64_t*)be_.alloc(8ull << PRE_TAG_LOG2);
-			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
-		}
-		be_.memset(pre_n_d_, 0, 8);
-		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, list_d, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
-			(PreReq<NW>*)pre_req_, pre_n_d_, cap, pre_w_, cfg_.presearch_min_weight };
-		be_.launch_wave(n, fs, "presearch_scan");
-		uint32_t nreq = 0;
-		be_.d2h(&nreq, pre_n_d_, 4);
-		nreq = std::min(nreq, cap);
-		if (n > wslots_ && cfg_.heavy_first) {
-			// Longest first: the walkers draw their candidates from the list in order, and a launch lasts until
-			// its last walker is done -- a read in a tangle (many sides to search) that starts when the launch is
-			// half over ends half a launch after everybody else.  Results do not depend on the order.
-			std::vector<uint32_t> w(n), l(n), idx(n);
-			be_.d2h(w.data(), pre_w_, n * 4ull);
-			be_.d2h(l.data(), list_d, n * 4ull);
-			for (uint32_t i = 0; i < n; i++) idx[i] = i;
-			std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
-			std::vector<uint32_t> sorted(n);
-			for (uint32_t i = 0; i < n; i++) sorted[i] = l[idx[i]];
-			be_.h2d(list_d, sorted.data(), n * 4ull);
-		}
-		if (!nreq) return;
-		pre_requests_ += nreq;
-		FPresearch<NW> fp{ env, (const PreReq<NW>*)pre_req_ };
-		uint32_t slots = wslots_;
-		if (const char* e = getenv("ABG_PRESEARCH_SLOTS")) slots = std::max(1, std::min<int>(atoi(e), (int)wslots_)); // (diagnosis)
-		be_.launch_walkers(nreq, fp, slots, "presearch", 0, false);
-	}
-	// The pre-search of the NEXT batch, started when this batch's walkers are done: the commit that follows is a string of small
-	// kernels and host round trips that leaves most of the machine idle, the next batch's verdicts are already there (classified
-	// ahead on the side stream, against an older visited filter: a superset of its candidates), and a pre-search answer is a fact
-	// about the solid filter -- whoever computes it, whenever, computes the same one.  The batch's own pre-search then finds its
-	// questions answered.  It runs on a stream of its own in half the walkers' slots and in their scratch (free by now); whoever
-	// needs that scratch next waits for it (predict_and_walk).
-	static constexpr int EARLY_CTX = 3;
-	Batch pre_batch_{}; const uint8_t* pre_res_ = nullptr; bool early_done_ = true;
-	uint32_t* early_cand_d_ = nullptr; uint32_t early_cap_ = 0;
-	void* pre_req2_ = nullptr; uint32_t* pre_n2_d_ = nullptr; uint32_t* pre_w2_ = nullptr;
-	template <int NW>
-	void early_presearch()
-	{
-		early_done_ = true;
-		if constexpr (MASKED_BUILD<NW>) return;
-		if (!cfg_.early_presearch || !cfg_.presearch || !memo_.k0 || p_.trim < 2 || !pre_n_ || dist()) return;
-		if (!be_.side_done()) return; // (the verdicts are not there yet: not worth holding the commit up)
-		be_.wait_walkers(EARLY_CTX);
-		be_.sync_side();
-		std::vector<uint8_t> res(pre_n_);
-		be_.d2h(res.data(), pre_res_, pre_n_);
-		std::vector<uint32_t> cand;
-		for (uint64_t j = 0; j < pre_n_ && cand.size() < cfg_.p2_max_candidates; j++) if (res[j] == RES_CANDIDATE) cand.push_back((uint32_t)j);
-		const uint32_t n = (uint32_t)cand.size();
-		if (!n) return;
-		if (early_cap_ < n) {
-			if (early_cand_d_) { be_.free(early_cand_d_); be_.free(pre_w2_); }
-			early_cap_ = std::max<uint32_t>(n, 1u << 16);
-			early_cand_d_ = (uint32_t*)be_.alloc(early_cap_ * 8ull); // the candidates' reads, then the list 0 .. n-1
-			pre_w2_ = (uint32_t*)be_.alloc(early_cap_ * 4ull);
-		}
-		if (!pre_req2_) {
-			pre_req2_ = be_.alloc((uint64_t)cfg_.presearch_cap * (8ull * MAX_NW + 24));
-			pre_n2_d_ = (uint32_t*)be_.alloc(8);
-		}
-		if (!pre_tags_) {
-			pre_tags_ = (uint64_t*)be_.alloc(8ull << PRE_TAG_LOG2);
-			be_.memset(pre_tags_, 0, 8ull << PRE_TAG_LOG2);
-		}
-		std::vector<uint32_t> up(2ull * n);
-		for (uint32_t i = 0; i < n; i++) { up[i] = cand[i]; up[n + i] = i; }
-		be_.h2d(early_cand_d_, up.data(), up.size() * 4ull);
-		be_.memset(pre_n2_d_, 0, 8);
-		WalkEnv<NW> env = make_env<NW>(pre_batch_, early_cand_d_, nullptr, nullptr);
-		FPresearchScan<NW> fs{ p2_, env.batch, cnt2_, env.cand_read, early_cand_d_ + n, memo_, pre_tags_, (1ull << PRE_TAG_LOG2) - 1, memo_gen_,
-			(PreReq<NW>*)pre_req2_, pre_n2_d_, cfg_.presearch_cap, pre_w2_, cfg_.presearch_min_weight };
-		be_.launch_wave(n, fs, "presearch_scan");
-		uint32_t nreq = 0;
-		be_.d2h(&nreq, pre_n2_d_, 4);
-		nreq = std::min(nreq, cfg_.presearch_cap);
-		if (!nreq) return;
-		pre_requests_ += nreq;
-		FPresearch<NW> fp{ env, (const PreReq<NW>*)pre_req2_ };
-		be_.launch_walkers(nreq, fp, std::max<uint32_t>(64, wslots_ / 2), "presearch", EARLY_CTX, true);
-	}
-	uint32_t* pre_w_ = nullptr; uint32_t pre_w_cap_ = 0;
-	void* pre_req_ = nullptr; uint32_t* pre_n_d_ = nullptr; uint64_t* pre_tags_ = nullptr; uint64_t pre_requests_ = 0;
-	static constexpr uint32_t PRE_TAG_LOG2 = 22;
-
-	// stage 2: the candidates without a result that lower reads will not cover are walked
-	template <int NW>
-	void predict_and_walk(BatchRun& r, int ci, bool async)
+	void predict_and_walk(BatchRun& r)
 	{
 		const uint32_t nc = r.nc;
-		const uint32_t cmask = (uint32_t)((1ull << cfg_.wclaim_log2) - 1);
 		be_.memset(r.need_n, 0, 8);
 		{
-			FPredict<NW> fp{ p_, r.v, r.cand_d, r.status_d, vis_, r.rkoff_d, rkh_, wclaims_, cmask,
+			FPredict<NW> fp{ p_, r.v, r.cand_d, r.status_d, vis_, r.rkoff_d, rkh_,
 				r.need_d, r.need_n, r.committed, r.force, (uint32_t)comm_.rank, (uint32_t)comm_.world };
 			be_.launch(nc - r.committed, fp, "predict");
 		}
@@ -4737,40 +4370,27 @@ class Engine {
 		ensure_wtab(std::max<uint32_t>(r.nneed, 1));
 		clear_wtab();
 		WalkEnv<NW> env = make_env<NW>(r.v, r.cand_d, r.status_d, r.first_d);
-		env.claims = nullptr;
 		env.owner_base = r.owner_next;
 		r.owner_next += nc;
 		FWalk<NW> fw{ env, r.need_d };
-		be_.wait_walkers(EARLY_CTX); // (an early pre-search still running works in these walkers' scratch)
-		if (!async) presearch<NW>(env, r.need_d, r.nneed);
-		if (cfg_.async_guide == 2) be_.wait_side_scope(); // (the guide, if its build is still running)
 		if (prefetch_) { prefetch_(); prefetch_ = nullptr; }
-		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk", ci, async);
+		be_.launch_walkers(r.nneed, fw, wslots_, "rewalk");
 		r.pending = true;
 	}
 
 	template <int NW>
-	void finish_batch(BatchRun& r, int ci, const std::function<void(const ContigOut&)>& sink)
+	void finish_batch(BatchRun& r, const std::function<void(const ContigOut&)>& sink)
 	{
 		const uint32_t nc = r.nc;
 		while (r.base < nc) {
-			if (!r.round_started) start_round<NW>(r, ci, false);
+			if (!r.round_started) start_round<NW>(r);
 			while (r.committed < nc && !r.overflow) {
-				if (!r.predicted) predict_and_walk<NW>(r, ci, false);
+				if (!r.predicted) predict_and_walk<NW>(r);
 				r.predicted = false;
 				if (r.overflow) break;
 				if (r.pending) {
-					be_.wait_walkers(ci);
 					r.pending = false;
-					if (!late_.empty()) {
-						// the next batch's walkers start now, beside this batch's commit
-						for (int cj : late_) { use_ctx(cj); if (run_[cj].nc && !run_[cj].round_started) start_round<NW>(run_[cj], cj, true); }
-						late_.clear();
-						use_ctx(ci);
-					}
-					if (!early_done_) early_presearch<NW>();
 					stats_.rewalked += r.nneed_all;
-					r.batch_rewalked += r.nneed_all;
 					dump_walkers(r, "rewalk", r.nneed);
 					if (dist()) {
 						// (a rank prepares the records it walked; their hashes travel with the sequences)
@@ -4795,9 +4415,7 @@ class Engine {
 				r.committed = next;
 			}
 			deliver(r.cand_h, r.first, sink);
-			if (nc - r.base >= 64) needed_frac_ = std::min(1.0, (double)r.batch_rewalked / (double)(nc - r.base));
 			if (r.overflow) {
-				be_.wait_walkers(EARLY_CTX); // (the capacities below are about to be given back)
 				// the candidate at `committed` ran out of some capacity.  Results not yet committed
 				// are dropped and the walk restarts from there; if nothing was committed in this
 				// attempt the capacities themselves are too small for that read.
@@ -4844,7 +4462,7 @@ class Engine {
 		be_.free(rkh_); rkh_ = nullptr;
 		be_.free(read_flag_); read_flag_ = nullptr;
 		if (r.debug) { be_.free(dbg_); dbg_ = nullptr; }
-		be_.free(r.cand_d); be_.free(r.status_d); be_.free(r.first_d); be_.free(r.list_d);
+		be_.free(r.cand_d); be_.free(r.status_d); be_.free(r.first_d);
 		be_.free(r.need_d); be_.free(r.need_n); be_.free(r.rkoff_d);
 		r.cand_h.clear();
 	}

@@ -97,23 +97,14 @@ class Session {
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
 		if (const char* e = getenv("ABG_DIST_ROUTE_MIN")) cfg.dist_route_min_ranks = (uint32_t)atoi(e); // partitioned run: pairs routed to their owners from this many ranks on (0: never)
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
-		if (const char* e = getenv("ABG_PRESEARCH_MIN_WEIGHT")) cfg.presearch_min_weight = (uint32_t)atoi(e); // pre-search only for candidates with at least this many searches on their reads
-		if (const char* e = getenv("ABG_ASYNC_GUIDE")) cfg.async_guide = (uint32_t)atoi(e); // the walkers' guide is built beside the start of PASS 2
-		if (const char* e = getenv("ABG_PIPELINE_LATE")) cfg.pipeline_late = atoi(e) != 0; // several batches in flight: the next one's walkers start beside this one's commit (1) or beside its walkers (0)
 		if (const char* e = getenv("ABG_LINK_DUPS")) cfg.link_duplicates = atoi(e) != 0; // the commit decides a contig's copies by their original (0: every record bit by bit)
-		if (const char* e = getenv("ABG_STAGE_EARLY")) cfg.stage_early = atoi(e) != 0; // PASS 1: the next batch is staged from the start of this one
 		if (const char* e = getenv("ABG_OVERLAP_PURITY")) cfg.overlap_purity = atoi(e) != 0; // PASS 1: the next batch's tiles judged on the side stream too
 		if (const char* e = getenv("ABG_OVERLAP_BINS")) cfg.overlap_bins = atoi(e) != 0; // the next batch hashed and binned beside this one
 		if (const char* e = getenv("ABG_PREFETCH")) cfg.prefetch_classify = atoi(e) != 0;
-		if (const char* e = getenv("ABG_DEFER_STAGE")) cfg.force_defer_stage = atoi(e) != 0;
-		if (const char* e = getenv("ABG_PRESEARCH")) cfg.presearch = atoi(e) != 0;
-		if (const char* e = getenv("ABG_EARLY_PRESEARCH")) cfg.early_presearch = atoi(e) != 0; // the next batch's pre-search beside this batch's commit
-		if (const char* e = getenv("ABG_HEAVY_FIRST")) cfg.heavy_first = atoi(e) != 0;
 		if (const char* e = getenv("ABG_ASYNC_LOAD")) cfg.async_load = atoi(e) != 0;
 		if (const char* e = getenv("ABG_CLS_SLOTS")) cfg.classify_slots = (uint32_t)std::max(64, atoi(e));
 		if (const char* e = getenv("ABG_SOLID_PLANE")) cfg.solid_plane = atoi(e) != 0;
 		if (const char* e = getenv("ABG_MEMO")) cfg.memo = atoi(e) != 0; // shared answers of successor()
-		if (const char* e = getenv("ABG_PIPELINE")) cfg.pipeline_depth = (uint32_t)std::max(1, atoi(e)); // batches of PASS 2 in flight
 		if (const char* e = getenv("ABG_P2_MAX_CANDIDATES")) cfg.p2_max_candidates = (uint32_t)std::max(1, atoi(e));
 		if (const char* e = getenv("ABG_P2_STARVED_GROWTH")) cfg.p2_starved_growth = (uint32_t)std::max(2, atoi(e));
 		if (const char* e = getenv("ABG_P2_STARVED")) cfg.p2_starved = (uint32_t)atoi(e);
@@ -423,7 +414,9 @@ class Session {
 		if (!c.all_gather_v || !c.all_reduce) return fail(ABG_EINVAL, "communicator lacks a collective");
 		typename Engine<BE>::Comm ec;
 		ec.rank = c.rank; ec.world = c.world; ec.stream_ordered = c.stream_ordered != 0; ec.user = c.user;
-		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce; ec.all_to_all_v = c.all_to_all_v;
+		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce;
+		// (a caller compiled against the header without all_to_all_v passes a shorter struct: the member is read only when the caller says it is there)
+		ec.all_to_all_v = (size_t)c.struct_size >= offsetof(abg_comm, all_to_all_v) + sizeof c.all_to_all_v ? c.all_to_all_v : nullptr;
 		comm_attached_ = true;
 		if (!eng->attach_comm(ec)) return fail(ABG_EINVAL, "bad rank / world (at most " + std::to_string(MAX_RANKS) + " ranks; not available on a cascading filter)");
 		return ABG_OK;

@@ -78,7 +78,12 @@ __global__ void __launch_bounds__(64, ABG_WALK_WAVES) k_walkers(F f, uint64_t n,
 		i = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32) |
 		    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)i);
 		if (i >= n) break;
-		f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS, true);
+		// (the walker's fast memory goes down as a generic pointer whose origin the optimiser does not see: once it knew "this is
+		// LDS" in every callee -- one kernel left that calls them -- ROCm 7.2's backend emitted `v_cmp_ne_u32 0, src_shared_base`
+		// for the null tests in successor_m, which its own verifier rejects)
+		void* fast = (void*)lds;
+		asm volatile("" : "+v"(fast));
+		f(i, (uint32_t)blockIdx.x, fast, WALK_LDS, true);
 	}
 }
 
@@ -217,8 +222,6 @@ struct HipBackend {
 	{
 		if (ticket) free(ticket);
 		if (pin) hipHostFree(pin);
-		for (int i = 0; i < MAX_WCTX; i++)
-			if (wstream[i]) { hipStreamSynchronize(wstream[i]); hipFree(wticket[i]); hipEventDestroy(wev0[i]); hipEventDestroy(wev1[i]); hipStreamDestroy(wstream[i]); }
 		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
@@ -557,58 +560,16 @@ struct HipBackend {
 		hipLaunchKernelGGL(k_foreach_wave<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
 		end(name);
 	}
-	// Walkers of context `ctx`.  async: on that context's own stream, after everything queued on the
-	// main stream so far; nobody waits here -- wait_walkers(ctx) does (and books the time).
-	static constexpr int MAX_WCTX = 4;
-	hipStream_t wstream[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
-	hipEvent_t wev0[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr }, wev1[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
-	unsigned long long* wticket[MAX_WCTX] = { nullptr, nullptr, nullptr, nullptr };
-	std::string wname[MAX_WCTX];
-	bool wpending[MAX_WCTX] = { false, false, false, false };
 	template <class F>
-	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name, int ctx, bool async)
+	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name)
 	{
 		if (!n) return;
 		uint64_t blocks = n < slots ? n : slots;
-		if (!async) {
-			if (!ticket) ticket = (unsigned long long*)alloc(8);
-			check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
-			begin(name);
-			hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
-			end(name);
-			return;
-		}
-		if (!wstream[ctx]) {
-			// (lowest priority: a batch's walkers run beside the commit of the batch before, whose small kernels on the main stream
-			// must get the slots that walker waves leave, or the commit waits for the walkers it was meant to overlap)
-			int lo = 0, hi = 0;
-			hipDeviceGetStreamPriorityRange(&lo, &hi);
-			check(hipStreamCreateWithPriority(&wstream[ctx], hipStreamNonBlocking, lo), "hipStreamCreate");
-			hipEventCreate(&wev0[ctx]); hipEventCreate(&wev1[ctx]);
-			check(hipMalloc((void**)&wticket[ctx], 8), "hipMalloc");
-		}
-		hipEventRecord(wev0[ctx], stream); // order after the main stream's queue
-		hipStreamWaitEvent(wstream[ctx], wev0[ctx], 0);
-		check(hipMemsetAsync(wticket[ctx], 0, 8, wstream[ctx]), "hipMemsetAsync");
-		hipEventRecord(wev0[ctx], wstream[ctx]);
-		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, wstream[ctx], f, n, wticket[ctx]);
-		check(hipGetLastError(), name);
-		hipEventRecord(wev1[ctx], wstream[ctx]);
-		wname[ctx] = name;
-		wpending[ctx] = true;
-	}
-	void wait_walkers(int ctx)
-	{
-		if (!wpending[ctx]) return;
-		check(hipEventSynchronize(wev1[ctx]), "hipEventSynchronize");
-		if (profiling) {
-			float ms = 0;
-			hipEventElapsedTime(&ms, wev0[ctx], wev1[ctx]);
-			ProfEntry& p = prof[wname[ctx]];
-			p.ms += ms;
-			p.launches++;
-		}
-		wpending[ctx] = false;
+		if (!ticket) ticket = (unsigned long long*)alloc(8);
+		check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
+		begin(name);
+		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
+		end(name);
 	}
 	template <class F>
 	void launch_tiles(uint64_t n, F f, const char* name)
@@ -1037,7 +998,7 @@ int abg_rccl_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int
 	}
 	if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete c; return ABG_EINTERNAL; }
 	memset(out, 0, sizeof *out);
-	out->rank = rank; out->world = world; out->stream_ordered = 1; out->user = c;
+	out->rank = rank; out->world = world; out->stream_ordered = 1; out->user = c; out->struct_size = (int32_t)sizeof *out;
 	out->all_gather_v = rccl_all_gather_v;
 	out->all_reduce = rccl_all_reduce;
 	out->all_to_all_v = rccl_all_to_all_v;

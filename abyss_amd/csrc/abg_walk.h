@@ -5,9 +5,7 @@
 //
 // A "walker" owns one candidate read.  Its vertex sets (extendPath's `visited`,
 // processRead's `assembledKmers`) live in one device-wide open-addressing table keyed
-// by (k-mer identity, owner), so walkers never see each other's entries; a separate
-// lossy claim array lets a walker notice that a lower-numbered read already walks the
-// same unitig and stop early (work avoidance only: results never depend on it).
+// by (k-mer identity, owner), so walkers never see each other's entries.
 #pragma once
 #include "abg_core.h"
 
@@ -115,9 +113,7 @@ ABG_HD uint64_t wt_find(const WalkTab& t, const VKey& key, uint32_t owner)
 enum WalkStatus : uint32_t {
 	WS_NONE = 0,      // not walked yet
 	WS_COMPLETE = 1,  // all contigs of the read recorded
-	WS_DEFERRED = 2,  // ran into a unitig claimed by a lower-numbered read
-	WS_OVERFLOW = 3,  // a capacity (stack, path buffer, pool, table, records) was exceeded
-	WS_CANCELLED = 4  // not walked: an earlier batch's commit covered the read while this batch's walkers were already queued (FCancelStale)
+	WS_OVERFLOW = 3   // a capacity (stack, path buffer, pool, table, records) was exceeded
 };
 struct ContigRec {
 	uint64_t seq_off;     // offset of the sequence in the contig pool (1 byte per base, 0..3)
@@ -148,8 +144,6 @@ struct WalkEnv {
 	uint32_t* status;          // [ncand] WalkStatus
 	uint32_t* first_rec;       // [ncand]
 	WalkTab tab;
-	uint32_t* claims;          // lossy claim array (NULL: private mode, never defer)
-	uint32_t claim_mask;
 	uint32_t owner_base;       // owner ids of this launch are owner_base + candidate index
 	// per-slot scratch
 	TBFrame<NW>* tb_pool; VKey* tbk_pool; uint32_t tb_cap;
@@ -493,28 +487,25 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 // directions (ExtendPath.h:314-362) and the path grows by the one neighbour ahead.  The loop
 // keeps that state -- and wave-uniform copies of every parameter it reads -- in registers and
 // takes as many simple steps as it can; anything else (a branch, a dead end, a cycle, an entry of
-// an earlier contig, a claim of a lower-numbered walker, a full buffer) is handed back to
+// an earlier contig, a full buffer) is handed back to
 // walk_extend, which runs the step as written in the reference.  Being out of line, the loop
 // has a register allocation of its own: the searches the general code calls do not spill into it.
 // Entered with w.head pushed but not yet entered into the visited set.
 enum { LIN_GENERAL = 0, // w.head is in the visited set; its step is not simple
        LIN_INS = 1,     // inserting w.head returned w.ins (not WT_NEW); nothing else was done for it
-       LIN_DEFER = 2,   // w.head collides with the claim of a lower-numbered walker
        LIN_OVERFLOW = 3 }; // the vertex table filled up (during a bulk step)
 template <int NW, bool COOP>
 ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir_in, const uint32_t owner_in,
-    const uint32_t contig_in, const uint32_t claim_id_in, const bool may_defer_in)
+    const uint32_t contig_in)
 {
 	const Params p = uniform_params<COOP>(e.p);
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(e.cnt);
 	WalkTab tab;
 	tab.hmin = uniptr<COOP>(e.tab.hmin); tab.hmax = uniptr<COOP>(e.tab.hmax); tab.meta = uniptr<COOP>(e.tab.meta);
 	tab.mask = uni64<COOP>(e.tab.mask);
-	uint32_t* claims = uniptr<COOP>(e.claims);
-	const uint32_t claim_mask = uni32<COOP>(e.claim_mask), buf_cap = uni32<COOP>(e.buf_cap);
+	const uint32_t buf_cap = uni32<COOP>(e.buf_cap);
 	const int dir = (int)uni32<COOP>((uint32_t)dir_in);
-	const uint32_t owner = uni32<COOP>(owner_in), contig = uni32<COOP>(contig_in), claim_id = uni32<COOP>(claim_id_in);
-	const bool may_defer = uni32<COOP>(may_defer_in ? 1u : 0u) != 0;
+	const uint32_t owner = uni32<COOP>(owner_in), contig = uni32<COOP>(contig_in);
 	const int fsense = (dir == FORWARD) ? SENSE : ANTISENSE, bsense = (dir == FORWARD) ? ANTISENSE : SENSE;
 	uint8_t* buf = uniptr<COOP>(dir == FORWARD ? w.rbuf : w.lbuf);
 	uint32_t nbuf = uni32<COOP>(dir == FORWARD ? w.nr : w.nl);
@@ -539,10 +530,10 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 	const unsigned k = p.k;
 	uint32_t why;
 	int32_t ins = WT_NEW;
-	// read-guided bulk steps (walk_bulk): private walks only
+	// read-guided bulk steps (walk_bulk)
 	const uint64_t* __restrict__ gtab = uniptr<COOP>(e.guide.tab);
 	const uint64_t gmask = uni64<COOP>(e.guide.mask);
-	const bool bulk_on = gtab != nullptr && uniptr<COOP>(w.bulk) != nullptr && claims == nullptr && p.nh <= 8;
+	const bool bulk_on = gtab != nullptr && uniptr<COOP>(w.bulk) != nullptr && p.nh <= 8;
 	uint32_t bulk_skip = 0, lin_steps = 0;
 	for (;;) {
 		if (bulk_on) {
@@ -610,11 +601,6 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 		const VKey hkey = vtx_ident(p, head);
 		ins = (int32_t)uni32<COOP>((uint32_t)wt_insert(tab, wt_key(hkey), owner, contig, COOP));
 		if (ins != WT_NEW) { why = LIN_INS; break; }
-		if (claims) {
-			const uint64_t hm = hkey.fh < hkey.rh ? hkey.fh : hkey.rh; // the canonical hash: the smaller strand hash
-			uint32_t old = wu_atomic_min_u32(&claims[(uint32_t)(hm ^ (hm >> 32)) & claim_mask], claim_id, COOP);
-			if (uni32<COOP>(old) < claim_id && may_defer) { why = LIN_DEFER; break; }
-		}
 		unsigned m8 = 0xFFu;
 		if (COOP) {
 			const uint64_t bad = wave_ballot(my_active && my_c < p.kc);
@@ -658,7 +644,7 @@ ABG_HDX uint32_t walk_linear(const WalkEnv<NW>& e, WalkState<NW>& w, const int d
 // Returns the ExtCode, or -1 when the walker must stop (status written to *abort).
 template <int NW>
 ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owner, uint32_t contig,
-    uint32_t claim_id, bool may_defer, SearchScratch<NW>& sc, uint32_t* ext_out, uint32_t* abort, bool* end_earlier)
+    SearchScratch<NW>& sc, uint32_t* ext_out, uint32_t* abort, bool* end_earlier)
 {
 	const Params& p = e.p;
 	int other = (dir == FORWARD) ? REVERSE : FORWARD;
@@ -678,12 +664,11 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 		if (pending && lean) {
 			w.head = head; w.prev_key = prev_key; w.ext = ext;
 			const uint64_t tl0 = dbg_clock(e.dbg);
-			const uint32_t why = sc.coop ? walk_linear<NW, true>(e, w, dir, owner, contig, claim_id, may_defer)
-			                             : walk_linear<NW, false>(e, w, dir, owner, contig, claim_id, may_defer);
+			const uint32_t why = sc.coop ? walk_linear<NW, true>(e, w, dir, owner, contig)
+			                             : walk_linear<NW, false>(e, w, dir, owner, contig);
 			if (e.dbg) w.t_lin += dbg_clock(e.dbg) - tl0;
 			head = w.head; prev_key = w.prev_key; ext = w.ext;
 			n = w.nl + 1 + w.nr;
-			if (why == LIN_DEFER) { *abort = WS_DEFERRED; return -1; }
 			if (why == LIN_OVERFLOW) { *abort = WS_OVERFLOW; return -1; }
 			if (why == LIN_INS) {
 				ins_given = w.ins;
@@ -726,11 +711,6 @@ ABG_HDN int walk_extend(WalkEnv<NW>& e, WalkState<NW>& w, int dir, uint32_t owne
 				break;
 			}
 			*end_earlier = (ins == WT_EARLIER);
-			if (e.claims) {
-				uint64_t hm = vtx_hash(p, head);
-				uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
-				if (old < claim_id && may_defer) { *abort = WS_DEFERRED; return -1; }
-			}
 			look_behind = true; // params.lookBehind after the first extension
 			pending = false;
 		}
@@ -809,7 +789,7 @@ ABG_HDN bool ambiguous2(const Params& p, const uint8_t* cnt, const Vtx<NW>& u, c
 // functions, so they live in memory.  As locals that is per-lane scratch: 64 copies per cooperative
 // wave and a 256-byte transaction per dword touched.  They are carved out of the walker's fast
 // memory (LDS on the device) instead: one copy per wave, read by broadcast; the rest of it is the
-// fast tier of the trueBranch stack.  Shared by walk_read and presearch_one.
+// fast tier of the trueBranch stack.
 template <int NW>
 ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& scp, WalkState<NW>*& wp)
 {
@@ -861,36 +841,6 @@ ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& sc
 	sc.la_visited = e.la_pool + (uint64_t)slot * LA_MAX_VISITED;
 }
 
-// One request of the pre-search (FPresearchScan, abg_engine.h): successor(u, dir) of a vertex a
-// walker of the coming launch will most likely ask for, computed ahead and left in the memo.  The
-// walkers of a read in a tangle run dozens of these searches one after the other, and a launch lasts
-// as long as its slowest walker; run ahead, one search per wave, they take as long as ONE search.
-// successor() is a pure function of (u, dir) and the solid filter (SuccMemo), so whoever computes an
-// answer computes the same one: the pre-search changes when an answer is computed, never what it is.
-template <int NW>
-struct PreReq { uint64_t w[KW<NW>]; uint64_t fh, rh; uint32_t dir, mask; };
-template <int NW>
-ABG_HDN void presearch_one(WalkEnv<NW>& e, const PreReq<NW>& q, uint32_t slot)
-{
-	SearchScratch<NW>* scp; WalkState<NW>* wp;
-	walker_scratch(e, slot, scp, wp);
-	SearchScratch<NW>& sc = *scp;
-	Vtx<NW> u;
-#pragma unroll
-	for (int j = 0; j < KW<NW>; j++) u.s.w[j] = q.w[j];
-	u.fh = q.fh; u.rh = q.rh;
-	vtx_set_d(u, 0, 0); // (requests are only made without a spaced seed)
-	if (memo_find(e.memo, u.fh, u.rh, (int)q.dir) >= 0) return; // somebody was faster
-	sc.origin = 1;
-	Vtx<NW> vout;
-	successor_m(e.p, e.cnt, u, (int)q.dir, e.p.trim, q.mask, vout, sc);
-	if (e.wstats && ld_coherent(&e.wstats[WSTAT_VERIFY]) == 2) successor_m(e.p, e.cnt, u, (int)q.dir, e.p.trim, q.mask, vout, sc); // (diagnosis: the same search again)
-	if (e.wstats) {
-		wu_atomic_add_u64(&e.wstats[WSTAT_PRE_ADDS], sc.n_memo_adds, sc.coop);
-		wu_atomic_add_u64(&e.wstats[WSTAT_CHAIN_STEPS], sc.n_chain_steps, sc.coop);
-	}
-}
-
 #if defined(__HIP_DEVICE_COMPILE__)
 // assembledKmers.find(*it) for the read's k-mers from position `it` on, 64 of them per round (bloom-dbg.h:839-843 looks
 // them up one after the other: three dependent loads each, 87 times a read -- a sixth of the walkers' time): the first
@@ -927,8 +877,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 {
 	const Params& p = e.p;
 	const unsigned k = p.k;
-	// (several batches in flight: the commit of the batch before may have covered this read since the launch was queued)
-	if (ld_coherent(&e.status[c]) == WS_CANCELLED) return;
 	SearchScratch<NW>* scp; WalkState<NW>* wp;
 	walker_scratch(e, slot, scp, wp);
 	SearchScratch<NW>& sc = *scp;
@@ -947,7 +895,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 	const uint32_t L = e.batch.len[r];
 	const uint32_t nk = L - k + 1;
 	const uint32_t owner = e.owner_base + c;
-	const uint32_t claim_id = c;
 	uint32_t first = REC_END, last = REC_END, contig = 0;
 	uint32_t abort_status = 0;
 
@@ -981,18 +928,10 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (ins == WT_FULL) { abort_status = WS_OVERFLOW; break; }
 		bool seed_earlier = (ins == WT_EARLIER);
 		bool left_earlier = seed_earlier, right_earlier = seed_earlier;
-		if (e.claims) {
-			uint64_t hm = ckey.fh;
-			uint32_t old = wu_atomic_min_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], claim_id, sc.coop);
-			if (old < claim_id && first == REC_END) { abort_status = WS_DEFERRED; break; }
-		}
-		// A walker defers to a lower-numbered one only until it has produced a contig of its
-		// own: after that its read cannot be skipped as "visited", so its result is needed.
-		const bool may_defer = (first == REC_END);
 		uint32_t lext = 0, rext = 0;
-		int lcode = walk_extend(e, w, REVERSE, owner, contig, claim_id, may_defer, sc, &lext, &abort_status, &left_earlier);
+		int lcode = walk_extend(e, w, REVERSE, owner, contig, sc, &lext, &abort_status, &left_earlier);
 		if (lcode < 0) break;
-		int rcode = walk_extend(e, w, FORWARD, owner, contig, claim_id, may_defer, sc, &rext, &abort_status, &right_earlier);
+		int rcode = walk_extend(e, w, FORWARD, owner, contig, sc, &rext, &abort_status, &right_earlier);
 		if (rcode < 0) break;
 		uint32_t n = w.nl + 1 + w.nr;
 		total_steps += n;
@@ -1000,15 +939,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 		if (e.dbg) w.t_ext += tp0 - te0;
 
 		const bool tip = is_tip(n, lcode, rcode, p.trim);
-		if (tip && e.claims) {
-			// a tip is not output, so its k-mers stay unvisited: withdraw the claims on them, or
-			// the predictor would count reads lying on the tip as covered by this walker
-			for (uint32_t i = 0; i < n; i++) {
-				Vtx<NW> x = ws_vertex(p, w, i, sc.coop);
-				uint64_t hm = vtx_hash(p, x);
-				wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
-			}
-		}
 		if (!tip) {
 			// materialise the path: S = reverse(lbuf) + seed + rbuf, one slack base each side
 			uint64_t need = (uint64_t)n + k - 1 + 2;
@@ -1108,10 +1038,6 @@ ABG_HDN void walk_read(WalkEnv<NW>& e, uint32_t c, uint32_t slot)
 					if (hi > lo && (vtx_equal(p, popped[q], nf) || vtx_equal(p, popped[q], nb))) continue;
 					uint64_t s = wt_find(e.tab, vtx_key(p, popped[q]), owner);
 					if (s != WT_EMPTY) wu_st_coherent(&e.tab.meta[s], ((uint64_t)owner << 32) | WT_TOMB, sc.coop);
-					if (e.claims) { // trimmed off: not covered by this walker's contig after all
-						uint64_t hm = vtx_hash(p, popped[q]);
-						wu_st_u32(&e.claims[(uint32_t)(hm ^ (hm >> 32)) & e.claim_mask], 0xFFFFFFFFu, sc.coop);
-					}
 				}
 			}
 			// ---- pathToSeq (bloom-dbg.h:130-158) under a spaced seed: a column keeps its 'N' unless

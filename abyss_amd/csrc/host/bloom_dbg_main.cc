@@ -11,6 +11,7 @@
 
 #include <csignal>
 #include <sys/wait.h>
+#include <fcntl.h>
 #include <unistd.h>
 #include <sys/prctl.h>
 #include <sys/wait.h>
@@ -471,12 +472,17 @@ int main(int argc, char** argv)
 	// output is flushed and closed -- and leaves with it, so that the caller (abyss-pe's next rule) goes on while the kernel takes the
 	// worker's ~25 GB of device mappings down, a quarter of a second that neither `_exit` nor freeing the memory by hand avoids.  A child
 	// that ends without sending the byte (any failure: they all leave through exit()) is waited for and its status passed on.
-	// ABG_FOREGROUND=1 keeps everything in this process; so does --gpus, whose ranks are processes of their own already.
+	// ABG_FOREGROUND=1 keeps everything in this process; so does --gpus, whose ranks are processes of their own already.  (A pipeline
+	// that starts another GPU stage right behind this one at a large B should set ABG_FOREGROUND: until the worker is gone its device
+	// memory is not free for the next stage.)
 	int done_fd = -1;
 	if (!use_comm && !getenv("ABG_FOREGROUND")) {
 		int fd[2];
-		if (pipe(fd) == 0) {
+		// (close-on-exec: the decompressors the worker starts later must not hold the writing end open -- the parent's read below
+		// would outlast a worker that died)
+		if (pipe2(fd, O_CLOEXEC) == 0) {
 			fflush(NULL);
+			const pid_t parent = getpid();
 			const pid_t pid = fork();
 			if (pid > 0) {
 				close(fd[1]);
@@ -491,6 +497,7 @@ int main(int argc, char** argv)
 				close(fd[0]);
 				done_fd = fd[1];
 				prctl(PR_SET_PDEATHSIG, SIGTERM); // (a parent that is killed takes the worker with it)
+				if (getppid() != parent) _exit(EXIT_FAILURE); // (... also one killed between the fork and the line above)
 			} else { close(fd[0]); close(fd[1]); } // (no child: carry on here)
 		}
 	}

@@ -27,7 +27,7 @@ A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.P
 
 
 class CommStruct(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("stream_ordered", C.c_int32), ("reserved_", C.c_int32),
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("stream_ordered", C.c_int32), ("struct_size", C.c_int32),
                 ("user", C.c_void_p), ("all_gather_v", AGV_FN), ("all_reduce", AR_FN), ("all_to_all_v", A2A_FN)]
 
 
@@ -78,7 +78,7 @@ class LocalComm:
         self._agv = AGV_FN(lambda *_a: self._count("all_gather_v"))
         self._ar = AR_FN(lambda *_a: self._count("all_reduce"))
         self._a2a = A2A_FN(lambda *_a: self._count("all_to_all_v"))  # (never called: one rank's exchange is a copy inside the engine)
-        self.struct = CommStruct(0, 1, 0, 0, None, self._agv, self._ar, self._a2a)
+        self.struct = CommStruct(0, 1, 0, C.sizeof(CommStruct), None, self._agv, self._ar, self._a2a)
 
     def _count(self, what):
         self.calls[what] += 1
@@ -98,7 +98,7 @@ class StagedTorchComm:
         self._agv = AGV_FN(self._all_gather_v)
         self._ar = AR_FN(self._all_reduce)
         self._a2a = A2A_FN(self._all_to_all_v)
-        self.struct = CommStruct(self.rank, self.world, 0, 0, None, self._agv, self._ar, self._a2a)
+        self.struct = CommStruct(self.rank, self.world, 0, C.sizeof(CommStruct), None, self._agv, self._ar, self._a2a)
 
     def _all_gather_v(self, _user, buf, counts, displs, _stream):
         import torch
@@ -194,3 +194,100 @@ def device_memory_io(ctx):
         arr = np.ascontiguousarray(arr)
         assert lib.abg_dev_copy(ctx._ctx, ptr, arr.ctypes.data, arr.size, 0) == 0
     return read, write
+
+
+# ---------------------------------------------------------------------------------------------
+# A communicator checked against the host before a job trusts it with its filter: every entry of abg_comm with the
+# shapes the engine uses (uneven byte counts, empty parts, in-place all-gather, u8 / u32 / u64 reductions), the
+# expected bytes worked out locally from (source, destination, index).  bench.py runs it on the library's RCCL
+# communicator before the timed steps of every N > 1 run; tests/test_dist_partition.py runs it over gloo.
+class HostBuf:
+    """n bytes of host memory (tests/hostcheck's memory space)."""
+
+    def __init__(self, n):
+        self.a = np.zeros(max(n, 1), dtype=np.uint8)
+        self.ptr = self.a.ctypes.data
+
+    def put(self, arr):
+        self.a[:arr.size] = arr
+
+    def get(self, n):
+        return self.a[:n].copy()
+
+
+class TorchBuf:
+    """n bytes of device memory (a torch tensor: what RCCL moves)."""
+
+    def __init__(self, n, device):
+        import torch
+        self.t = torch.zeros(max(n, 1), dtype=torch.uint8, device=device)
+        self.ptr = self.t.data_ptr()
+
+    def put(self, arr):
+        import torch
+        self.t[:arr.size].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+        torch.cuda.synchronize()
+
+    def get(self, n):
+        import torch
+        torch.cuda.synchronize()
+        return self.t[:n].cpu().numpy().copy()
+
+
+def selftest(comm, make_buf, stream=None, sync=lambda: None):
+    """Run every collective of `comm` (anything with .struct / .rank / .world) once per shape and compare with what the
+    host says the result must be.  make_buf(nbytes) -> HostBuf / TorchBuf.  Returns {"ok", "checks", "failed"}."""
+    st, r, W = comm.struct, comm.rank, comm.world
+    failed, checks = [], 0
+    U64A = C.c_uint64 * W
+
+    def pat(src, dst, n, salt):
+        return ((np.arange(n, dtype=np.uint64) * 7 + np.uint64(src * 31 + dst * 17 + salt)) & np.uint64(255)).astype(np.uint8)
+
+    # ---- all_to_all_v: uneven counts, zeros among them (also a rank's own part)
+    for salt in (0, 1):
+        def cnt(a, b):
+            return 0 if (a + 2 * b + salt) % 4 == 0 else ((a * 7 + b * 3 + salt) % 5) * 1000 + 13 * (b + 1)
+        sc = [cnt(r, q) for q in range(W)]
+        rc = [cnt(q, r) for q in range(W)]
+        sd = [sum(sc[:q]) for q in range(W)]
+        rd = [sum(rc[:q]) for q in range(W)]
+        send, recv = make_buf(sum(sc)), make_buf(sum(rc))
+        if sum(sc):
+            send.put(np.concatenate([pat(r, q, sc[q], salt) for q in range(W)]))
+        rcode = st.all_to_all_v(st.user, send.ptr, U64A(*sc), U64A(*sd), recv.ptr, U64A(*rc), U64A(*rd), stream)
+        sync()
+        want = np.concatenate([pat(q, r, rc[q], salt) for q in range(W)]) if sum(rc) else np.zeros(0, dtype=np.uint8)
+        checks += 1
+        if rcode != 0 or not np.array_equal(recv.get(sum(rc)), want):
+            failed.append("all_to_all_v[%d] rc=%d" % (salt, rcode))
+    # ---- all_gather_v in place: every rank's part at its displacement, one part empty
+    cn = [0 if q == 1 % W and W > 1 else (q % 3) * 4096 + 5 * (q + 1) for q in range(W)]
+    dp = [sum(cn[:q]) for q in range(W)]
+    buf = make_buf(sum(cn))
+    whole = np.zeros(sum(cn), dtype=np.uint8)
+    whole[dp[r]:dp[r] + cn[r]] = pat(r, 0, cn[r], 5)
+    buf.put(whole)
+    rcode = st.all_gather_v(st.user, buf.ptr, U64A(*cn), U64A(*dp), stream)
+    sync()
+    want = np.concatenate([pat(q, 0, cn[q], 5) for q in range(W)])
+    checks += 1
+    if rcode != 0 or not np.array_equal(buf.get(sum(cn)), want):
+        failed.append("all_gather_v rc=%d" % rcode)
+    # ---- all_reduce: the (type, operation) pairs the engine uses
+    n = 3001
+    for dt, npdt, ops in ((U8, np.uint8, (MIN, MAX)), (U32, np.uint32, (SUM, MIN, MAX)), (U64, np.uint64, (SUM, MIN))):
+        for op in ops:
+            def vals(q):
+                x = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(q * 40503 + dt * 7 + op)) >> np.uint64(7)
+                return (x % np.uint64(251 if dt == U8 else 1 << 20)).astype(npdt)
+            b = make_buf(n * np.dtype(npdt).itemsize)
+            b.put(vals(r).view(np.uint8))
+            rcode = st.all_reduce(st.user, b.ptr, n, dt, op, stream)
+            sync()
+            allv = np.stack([vals(q).astype(np.uint64) for q in range(W)])
+            want = {SUM: allv.sum(axis=0), MAX: allv.max(axis=0), MIN: allv.min(axis=0)}[op].astype(npdt)
+            checks += 1
+            if rcode != 0 or not np.array_equal(b.get(n * np.dtype(npdt).itemsize).view(npdt), want):
+                failed.append("all_reduce dtype=%d op=%d rc=%d" % (dt, op, rcode))
+    return {"ok": not failed, "checks": checks, "failed": failed}

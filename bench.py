@@ -59,6 +59,45 @@ def gen_packed_reads(genome_len: int, n_pairs: int, read_len: int, err: float, s
     return synth.packed_reads_torch(h1, h2, n_pairs, read_len, err, read_seed, device, first=first, total_pairs=total_pairs)
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (abyss_amd/csrc/*.h, *.hip, include/abyss_amd.h): what evidence under profiles/ is
+    tied to.  (The GPU boxes get the tree without .git, so a commit id cannot be checked there; the sources can.)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "abyss_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "abyss_amd.h")]:
+        p = os.path.join(d, f)
+        if os.path.isfile(p) and (f.endswith(".h") or f.endswith(".hip")):
+            h.update(f.encode() + b"\0" + open(p, "rb").read())
+    return h.hexdigest()
+
+
+def pick_evidence(suffix: str):
+    """The file profiles/*<suffix> taken on THESE kernel sources ("_csrc_sha256" equals csrc_digest()), else the newest one by
+    name; returns (path, json, matches_head, commits_behind or None).  commits_behind: commits touching abyss_amd/csrc since the
+    file's "_commit", where git is there to ask."""
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith(suffix)) if os.path.isdir(pdir) else []
+    if not cands:
+        return None, None, False, None
+    head = csrc_digest()
+    loaded = []
+    for f in cands:
+        try:
+            loaded.append((f, json.load(open(os.path.join(pdir, f)))))
+        except Exception:  # noqa: BLE001
+            pass
+    best = [x for x in loaded if x[1].get("_csrc_sha256") == head]
+    f, j = (best or loaded)[-1]
+    behind = None
+    if not best and j.get("_commit") and os.path.isdir(os.path.join(ROOT, ".git")):
+        r = subprocess.run(["git", "-C", ROOT, "rev-list", "--count", "%s..HEAD" % j["_commit"], "--", "abyss_amd/csrc"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        if r.returncode == 0 and r.stdout.strip().isdigit():
+            behind = int(r.stdout.strip())
+    return os.path.join("profiles", f), j, bool(best), (0 if best else behind)
+
+
 def golden_for(config: int, pairs: int, k: int, K: int, bloom: str):
     """The reference's -j1 result on this very read set (tests/golden/full_size.json), or None."""
     src = os.path.join(ROOT, "tests", "golden", "full_size.json")
@@ -214,6 +253,9 @@ def main() -> int:
     ap.add_argument("--slice-filter", action="store_true",
                     help="partitioned runs: each rank keeps its own range of the counting filter only (abg_params.slice_filter = 1; "
                          "without the flag the library decides by the device's memory)")
+    ap.add_argument("--no-one-gpu-point", dest="one_gpu_point", action="store_false",
+                    help="strong-scaled N > 1 runs: do not measure the one-GPU point of the same job in this run (rank 0 alone, one warm-up "
+                         "and one timed step before the partitioned steps: about two minutes for configs[2]); the point on file is replayed instead")
     ap.add_argument("--comm", choices=["rccl", "staged"], default="rccl",
                     help="partitioned mode: the library's RCCL communicator, or torch.distributed on host copies (diagnosis)")
     a = ap.parse_args()
@@ -253,7 +295,8 @@ def main() -> int:
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm; ABG_BENCH_BACKEND=gloo lets the launch path be exercised on a
         # box with fewer GPUs than ranks (ranks then share devices)
-        dist.init_process_group(backend=backend)
+        import datetime
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=60))  # (the other ranks wait while rank 0 measures the job's one-GPU point)
     device = torch.device("cuda", local)
 
     mult = {"K": 1 << 10, "M": 1 << 20, "G": 1 << 30}
@@ -295,6 +338,61 @@ def main() -> int:
                 comm_note = comm_note or "rccl communicator failed on another rank: replicas instead"
                 a.pairs, bloom_bytes, a.bloom = single
                 genome_len = int(a.pairs * 2 * read_len / cov)
+    # The communicator checked against the host before the job trusts it with its filter (abyss_amd.dist.selftest: uneven and empty
+    # all-to-all parts, in-place all-gather, every reduction the engine uses).  A failure on any rank turns the run into replicas.
+    selftest = None
+    if partitioned and world > 1 and comm is not None:
+        t_st = time.perf_counter()
+        try:
+            selftest = adist.selftest(comm, lambda n: adist.TorchBuf(n, device), stream=None, sync=torch.cuda.synchronize)
+        except Exception as e:  # noqa: BLE001
+            selftest = {"ok": False, "checks": 0, "failed": ["exception: %r" % (e,)]}
+        selftest["seconds"] = round(time.perf_counter() - t_st, 2)
+        t = torch.tensor([1 if selftest["ok"] else 0], dtype=torch.int32, device=device if backend == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        selftest["all_ranks_ok"] = bool(int(t.item()))
+        if not selftest["all_ranks_ok"]:
+            sys.stderr.write("bench.py: rank %d: communicator self-test FAILED (%r): replicas instead\n" % (rank, selftest["failed"]))
+            comm.close()
+            comm, partitioned = None, False
+            comm_note = "rccl communicator failed its self-test: replicas instead"
+            a.pairs, bloom_bytes, a.bloom = single
+            genome_len = int(a.pairs * 2 * read_len / cov)
+    # The one-GPU point of THIS job, measured in THIS run: rank 0 alone, the whole read set, the plain (unpartitioned) engine, one
+    # warm-up and one timed step; the other ranks wait.  (A driver that divides the N-GPU value by N times ITS one-GPU line --
+    # configs[1] by default -- compares two workloads: `scaling_base` below says which job the N-GPU value belongs to.)
+    one_gpu = None
+    if partitioned and world > 1 and a.scaling == "strong" and a.one_gpu_point and bloom_bytes <= (100 << 30):
+        if rank == 0:
+            try:
+                t_g = time.perf_counter()
+                w1, o1, l1 = gen_packed_reads(genome_len, a.pairs, read_len, err, seed=42, device=device)
+                g1 = api.BloomDBG(a.k, bloom_bytes=bloom_bytes, num_hashes=4, min_cov=2, device=local,
+                                  spaced_seed=api.spaced_seed_kmer_pair(a.k, a.K) if a.K else None)
+                nr1 = 2 * a.pairs
+                ms1 = []
+                for it in range(2):
+                    if it:
+                        g1.reset()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    g1.load_packed(w1.data_ptr(), o1.data_ptr(), l1.data_ptr(), nr1)
+                    g1.assemble_packed(w1.data_ptr(), o1.data_ptr(), l1.data_ptr(), nr1, want_results=False, want_contigs=False)
+                    ms1.append((time.perf_counter() - t1) * 1e3)
+                c1 = g1.assembly_counters()
+                one_gpu = {"value": nr1 * (read_len - a.k + 1) / (ms1[-1] / 1e3) / 1e6, "ms_per_step": ms1[-1], "warmup_ms": ms1[0],
+                           "unitigs": c1["next_contig_id"], "unitig_bp": c1["bases_assembled"], "measured": True,
+                           "what": "rank 0 alone on the whole job (plain engine), one warm-up + one timed step, in this run",
+                           "seconds_spent": round(time.perf_counter() - t_g, 1)}
+                g1.close()
+                del w1, o1, l1, g1
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001  (out of memory for this job on one GPU, ...: the point on file is replayed)
+                sys.stderr.write("bench.py: one-GPU point not measured: %r\n" % (e,))
+                one_gpu = None
+                torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
     if partitioned:
         # one job: rank r holds the r-th block of the read set (same genome on every rank)
         pairs_local = a.pairs // world + (1 if rank < a.pairs % world else 0)
@@ -469,26 +567,27 @@ def main() -> int:
     # command, tools/gpu_pmc_traffic.sh; KB units, uncalibrated for narrow random accesses: MI355X_MICROARCH.md),
     # committed with the commit they were taken at; per launch of the family's longest kernel like `achieved`
     traffic = traffic_src = None
-    tsrc = os.path.join(ROOT, "profiles", "r04_d_pmc_traffic.json")
-    if os.path.exists(tsrc) and a.config == 1 and a.pairs == 5_000_000 and world == 1:
-        tj = json.load(open(tsrc))
-        kname = {"rewalk": "FWalk", "walk": "FWalk", "presearch": "FPresearch<", "presearch_scan": "FPresearchScan", "tile_apply": "FTileApply", "tile_purity": "FTilePurity",
+    traffic_head = traffic_behind = None
+    tsrc, tj, traffic_head, traffic_behind = pick_evidence("_pmc_traffic.json")
+    if tj is not None and a.config == 1 and a.pairs == 5_000_000 and world == 1:
+        kname = {"rewalk": "FWalk", "walk": "FWalk", "tile_apply": "FTileApply", "tile_purity": "FTilePurity",
                  "bin_coarse": "FBinCoarse", "bin_fine": "FBinFine", "op_target": "FOpTarget", "hash_ops": "FHashOps",
                  "insert_round": "FInsertRound", "insert_retry": "FInsertRound", "hash_claim": "FHashClaim",
                  "classify": "FClassify", "pc_timemin": "FPcTimeMin", "pc_decide": "FPcDecide"}.get(per_kernel[dom]["longest_kernel"])
         t = tj.get(kname)
         if t:
             traffic = (t["FETCH_SIZE"]["sum"] + t["WRITE_SIZE"]["sum"]) * 1024 / max(t["FETCH_SIZE"]["dispatches"], 1)
-            traffic_src = "profiles/r04_d_pmc_traffic.json (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, KB units, per launch; taken at commit %s)" % (kname, tj.get("_commit", "?"))
+            traffic_src = "%s (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this command, KB units, per launch; taken at commit %s)" % (tsrc, kname, tj.get("_commit", "?"))
     step_bytes = (2 * per_kmer_bases + 4 * H + 2 * 5 * 4 * H / (read_len - a.k + 1)) * kmers + 12 * H * unitig_kmers
     roofline = {"bound": "hbm", "kernel": per_kernel[dom]["longest_kernel"], "family": dom,
                 "achieved": per_kernel[dom]["achieved"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                # (taken on exactly these kernel sources?  else: commits to abyss_amd/csrc since -- None where git is not there to ask)
+                "traffic_kernels_are_head": traffic_head, "traffic_csrc_commits_behind": traffic_behind,
                 "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "launches": per_kernel[dom]["launches"],
                 "note": "the kernel with the largest summed duration of the step (the classification overlaps the walk on a side stream); "
                         "achieved = algorithmic bytes of its family (SURVEY.md 8d) over the summed duration of the family's kernels; "
-                        "the walk is a graph traversal of dependent random probes whose waves wait on memory 78 % of their cycles, "
-                        "not a stream (DESIGN.md section 4.2, profiles/r04_b_pmc_sq_walkers.txt)",
+                        "the walk is a graph traversal of dependent random probes, not a stream (DESIGN.md section 4.2)",
                 "whole_step": {"algorithmic_GB": step_bytes / 1e9, "achieved": step_bytes / 1e9 / (elapsed / a.steps),
                                "frac": step_bytes / 1e9 / (elapsed / a.steps) / HBM_PEAK_GBS},
                 "kernels": per_kernel}
@@ -523,15 +622,27 @@ def main() -> int:
             out["parity"] = parity
         if no_events is not None:
             out["no_events"] = no_events
+        if selftest is not None:
+            out["rccl_selftest"] = selftest
         if partitioned and world > 1 and a.scaling == "strong":
-            # the one-GPU point of this very job, measured in an earlier run and REPLAYED from the committed file (the driver
-            # computes its own efficiency from the per-N lines; this one is for a reader of a single line)
+            # the one-GPU point of this very job: measured in this run by rank 0 alone (see above), else REPLAYED from a committed
+            # earlier run (the driver computes its own efficiency from its per-N lines; this is for a reader of a single line)
             one = {1: "r04_e_bench_default.json", 2: "r04_c_bench_config2_invariants.json", 3: "r04_b_bench_config3_spaced_seed_k96_K32.json"}.get(a.config)
             src = os.path.join(ROOT, "profiles", one) if one else None
-            if src and os.path.exists(src) and a.pairs == preset[0] and a.k == preset[1]:
+            if one_gpu is not None:
+                v1 = one_gpu["value"]
+                out["strong_scaling"] = dict(one_gpu, one_gpu_value=v1, replayed=False, speedup=out["value"] / v1, efficiency=out["value"] / v1 / world,
+                                             same_unitigs=bool(one_gpu["unitigs"] == unitigs and one_gpu["unitig_bp"] == bases))
+            elif src and os.path.exists(src) and a.pairs == preset[0] and a.k == preset[1]:
                 v1 = json.load(open(src))["value"]
-                out["strong_scaling"] = {"one_gpu_value": v1, "one_gpu_source": "profiles/" + one, "replayed": True,
+                out["strong_scaling"] = {"one_gpu_value": v1, "one_gpu_source": "profiles/" + one, "replayed": True, "measured": False,
                                          "speedup": out["value"] / v1, "efficiency": out["value"] / v1 / world}
+            # which job this line's value belongs to: NOT the one a default `--gpus 1` line times (configs[1]) unless --config says so
+            out["scaling_base"] = {"config": a.config, "workload": out["config"]["workload"],
+                                   "one_gpu_value": out.get("strong_scaling", {}).get("one_gpu_value"),
+                                   "one_gpu_measured_in_this_run": one_gpu is not None,
+                                   "note": "strong scaling of ONE job over the ranks; `python bench.py --gpus 1` without --config times configs[1], a "
+                                           "different job -- divide this value by N x scaling_base.one_gpu_value, not by N x that line"}
         if partitioned:
             out["config"]["ranks_agree"] = ranks_agree
             out["config"]["counter_bytes_per_rank"] = g.stats()["counter_bytes_held"]
@@ -542,9 +653,17 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(a.k, cores=os.cpu_count() or 1, K=a.K)
             # like for like on the FULL read set: the unmodified reference at -j<all cores> is a 4-6 minute run, measured once on a
             # GPU box's host ON THE READ SET TIMED HERE (tools/gpu_cpu_reference_full.sh) and REPLAYED from the committed file
-            src = os.path.join(ROOT, "profiles", "r04_cpu_reference_config1.json")
-            if os.path.exists(src) and a.config == 1 and a.pairs == 5_000_000:
-                out["cpu_baseline"]["reference_full_config"] = dict(json.load(open(src)), replayed=True, source="profiles/r04_cpu_reference_config1.json")
+            # (two such runs are on file and they differ by box: 233 s in round 2, 362 s in round 4 -- ratios are to be quoted against
+            # the in-run sample above, or against both)
+            if a.config == 1 and a.pairs == 5_000_000:
+                full = []
+                for f in ("r02_cpu_reference_config1.json", "r04_cpu_reference_config1.json"):
+                    src = os.path.join(ROOT, "profiles", f)
+                    if os.path.exists(src):
+                        full.append(dict(json.load(open(src)), replayed=True, source="profiles/" + f))
+                if full:
+                    out["cpu_baseline"]["reference_full_config"] = full[-1]
+                    out["cpu_baseline"]["reference_full_config_all_runs"] = full
         if a.invariants and g is not None:
             import hashlib
             pc, fpc = g.counting_stats()

@@ -247,7 +247,9 @@ typedef struct abg_comm {
 	/* non-zero: the functions enqueue on `stream` (a hipStream_t) and return at once; zero: they
 	 * are called with that stream idle and return when the data is in place */
 	int32_t stream_ordered;
-	int32_t reserved_;
+	/* sizeof(abg_comm) as the caller was compiled with it.  0 (a zeroed field: what callers of the round-3 header pass, whose
+	 * struct ended after all_reduce) or anything short of the member: all_to_all_v is not read and counts as NULL. */
+	int32_t struct_size;
 	void* user;
 	/* in place: rank q's part is counts[q] bytes at buf + displs[q]; the caller's own part is
 	 * there already; on completion every rank holds every part.  Returns 0 on success. */
@@ -265,7 +267,11 @@ typedef struct abg_comm {
 #define ABG_MAX_RANKS 16
 
 /* Switch the context to the partitioned run (before any load).  The table is copied; `user`
- * must outlive the context.  world == 1 is allowed (and is the plain single-GPU path). */
+ * must outlive the context.  world == 1 is allowed (and is the plain single-GPU path).
+ * On a sliced filter (abg_params.slice_filter: a rank holds its own range of the counters only) the calls that look at the
+ * whole counting filter are COLLECTIVES -- every rank must make them, in the same order, or the run hangs:
+ * abg_counters_export, abg_counters_import, abg_counting_stats (and abg_load_* / abg_assemble_* as in every partitioned run).
+ * A sliced context that holds counters refuses a communicator with another rank or world (ABG_EINVAL). */
 int abg_attach_comm(abg_ctx* ctx, const abg_comm* comm);
 
 /* All-gather of the ranks' packed read sets, in rank order, into device buffers the context
@@ -326,8 +332,8 @@ typedef struct abg_stats {
 	uint64_t tiled_ops;     /* PASS 1: k-mer ops of batches that went through the LDS tiles ... */
 	uint64_t tiled_pending; /* ... of which this many shared a counter with another k-mer and took the reservation rounds */
 	uint64_t tile_overflows; /* ... batches whose bins overflowed (handled by the reservation rounds as a whole) */
-	uint64_t pre_requests, pre_adds; /* successor() searches requested ahead of the walkers / answers that pre-search added to the memo */
-	uint64_t cancelled;     /* candidates struck from a queued launch because an earlier batch's commit covered their reads (several batches in flight) */
+	uint64_t pre_requests, pre_adds; /* always 0 (kept for the layout: the pre-search of round 3 is gone) */
+	uint64_t cancelled;     /* always 0 (kept for the layout: several batches in flight are gone) */
 	uint64_t counter_bytes_held; /* bytes of the counting filter this context holds: all of it, or its own range of a sliced filter (abg_params.slice_filter) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);

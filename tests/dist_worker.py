@@ -28,6 +28,11 @@ from util import GoldenCase, contig_tuple, mask_of  # noqa: E402
 class DistHostCheck(HostCheck):
     def attach(self):
         self.comm = adist.StagedTorchComm(*adist.host_memory_io())
+        if os.environ.get("ABG_TEST_OLD_COMM_ABI"):
+            # a caller compiled against the header whose abg_comm ended after all_reduce: struct_size is a zeroed field there, and
+            # what lies behind the struct is not a function pointer
+            self.comm.struct.struct_size = 0
+            self.comm.struct.all_to_all_v = adist.A2A_FN(0)
         self.l.hc_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
         assert self.l.hc_attach_comm(self.h, C.byref(self.comm.struct)) == 0
         vp = C.c_void_p
@@ -167,6 +172,37 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     what = sys.argv[1]
+    if what == "selftest":
+        # abyss_amd.dist.selftest (what bench.py runs on the RCCL communicator before the timed steps of an N > 1 run) over gloo:
+        # a sound communicator passes every check on every rank; one whose all_to_all_v delivers a part to the wrong place, or
+        # whose all_reduce forgets a rank, is caught
+        comm = adist.StagedTorchComm(*adist.host_memory_io())
+        good = adist.selftest(comm, adist.HostBuf)
+        real_a2a, real_ar = comm._a2a, comm._ar  # (the thunks themselves: a field read back from the struct aliases the field)
+
+        def bad_a2a(user, send, sc, sd, recv, rc, rd, stream):
+            rc_ = real_a2a(user, send, sc, sd, recv, rc, rd, stream)
+            n = sum(int(rc[q]) for q in range(world))
+            if n > 1:
+                C.memmove(recv, recv + 1, n - 1)  # (everything one byte early)
+            return rc_
+
+        def bad_ar(user, buf, count, dtype, op, stream):
+            return 0  # (nothing combined)
+        keep = (adist.A2A_FN(bad_a2a), adist.AR_FN(bad_ar))
+        comm.struct.all_to_all_v = keep[0]
+        bad1 = adist.selftest(comm, adist.HostBuf)
+        comm.struct.all_to_all_v = real_a2a
+        comm.struct.all_reduce = keep[1]
+        bad2 = adist.selftest(comm, adist.HostBuf)
+        ok = {"good": good, "bad_a2a": bad1, "bad_all_reduce": bad2}
+        box = [None] * world
+        dist.all_gather_object(box, ok)
+        if rank == 0:
+            print("RESULT " + json.dumps({"ranks": box}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if what == "golden":
         ok, hc = case_golden(sys.argv[2], rank, world)
     elif what == "oracle":

@@ -84,12 +84,11 @@ struct SerialBackend {
 	alignas(16) unsigned char fastbuf[20480];
 	uint32_t fast_bytes = 2048;
 	SerialBackend() { if (const char* e = getenv("HC_FAST_BYTES")) fast_bytes = (uint32_t)std::min<long>(sizeof fastbuf, std::max<long>(1024, atol(e))); }
-	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*, int, bool)
+	template <class F> void launch_walkers(uint64_t n, F f, uint32_t, const char*)
 	{
 		if (fast_bytes >= sizeof(abg::MaskCache)) memset(fastbuf + fast_bytes - sizeof(abg::MaskCache), 0, sizeof(abg::MaskCache)); // (as k_walkers does)
 		for (uint64_t i = 0; i < n; i++) f(i, 0, (void*)fastbuf, fast_bytes, false);
 	}
-	void wait_walkers(int) {}
 	void launch_drain(abg::InsertDrainEnv e) { SerialSync sy; abg::insert_drain(e, sy); }
 	std::vector<unsigned char> tilebuf;
 	template <class F> void launch_tiles(uint64_t n, F f, const char*)
@@ -176,7 +175,7 @@ void* hc_create(unsigned k, unsigned nh, unsigned kc, unsigned trim, uint64_t co
 	s->cfg.insert_batch_kmers = insert_batch ? insert_batch : (1u << 16);
 	s->cfg.walk_slots = 1; s->cfg.tb_cap = 4096; s->cfg.buf_cap = 1u << 20;
 	s->cfg.pool_cap = 1ull << 26; s->cfg.rec_cap = 1u << 18; s->cfg.wtab_log2 = 22;
-	s->cfg.wclaim_log2 = 18; s->cfg.cend_log2 = 16; s->cfg.drain_threshold = 64; s->cfg.buf_cap = 1u << 20;
+	s->cfg.cend_log2 = 16; s->cfg.drain_threshold = 64; s->cfg.buf_cap = 1u << 20;
 	if (p2_first_batch) s->cfg.p2_first_batch = p2_first_batch;
 	p.insert_batch_kmers = 0; p.claim_log2 = 0; p.walk_slots = 0; p.wtab_log2 = 0;
 	if (s->create(p) != ABG_OK) { fprintf(stderr, "hostcheck: %s\n", s->error.c_str()); delete s; return nullptr; }

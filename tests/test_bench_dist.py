@@ -56,3 +56,26 @@ def test_gpus_flag_without_a_launcher_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_evidence_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py quotes TCC traffic from profiles/*_pmc_traffic.json: the file taken on exactly these kernel sources ("_csrc_sha256" ==
+    csrc_digest()) if there is one, else the newest -- and says which (roofline.traffic_kernels_are_head)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    (tmp_path / "abyss_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "abyss_amd" / "csrc" / "a.h").write_text("int a;\n")
+    (tmp_path / "include" / "abyss_amd.h").write_text("int b;\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    d1 = bench.csrc_digest()
+    (tmp_path / "profiles" / "r01_pmc_traffic.json").write_text(json.dumps({"FWalk": {}, "_csrc_sha256": d1}))
+    (tmp_path / "profiles" / "r02_pmc_traffic.json").write_text(json.dumps({"FWalk": {}, "_csrc_sha256": "somethingelse"}))
+    path, j, head, behind = bench.pick_evidence("_pmc_traffic.json")
+    assert path.endswith("r01_pmc_traffic.json") and head and behind == 0
+    (tmp_path / "abyss_amd" / "csrc" / "a.h").write_text("int a2;\n")  # a kernel changes: neither file is the head's any more
+    assert bench.csrc_digest() != d1
+    path, j, head, behind = bench.pick_evidence("_pmc_traffic.json")
+    assert path.endswith("r02_pmc_traffic.json") and not head and behind is None
+    assert bench.pick_evidence("_nothing.json") == (None, None, False, None)

@@ -318,3 +318,30 @@ def test_communicator_attached_after_a_load(sliced, monkeypatch):
     rh, ch = hc.assemble(buf, off)
     assert np.array_equal(ro, rh) and [c.seq for c in co] == [c.seq for c in ch] and [c.coverage for c in co] == [c.coverage for c in ch]
     assert comm.calls["all_reduce"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_communicator_selftest_passes_a_sound_communicator_and_catches_a_broken_one(world):
+    """abyss_amd.dist.selftest -- all_to_all_v with uneven and empty parts, in-place all_gather_v, the (type, operation) pairs of
+    all_reduce, each against what the host says must come out: bench.py runs it on the RCCL communicator before the timed steps
+    of every N > 1 run (no RCCL rank pair has ever run on this project's one-GPU boxes).  Over gloo: a sound communicator
+    passes on every rank; shifted all-to-all parts and a reduction that combines nothing are reported."""
+    out = run_ranks(world, "selftest")
+    assert len(out["ranks"]) == world
+    for r in out["ranks"]:
+        assert r["good"]["ok"] and r["good"]["checks"] == 10 and not r["good"]["failed"], r
+        assert not r["bad_all_reduce"]["ok"] and all(f.startswith("all_reduce") for f in r["bad_all_reduce"]["failed"]), r
+    # (a rank whose received parts are all empty cannot see a shifted all-to-all: at least one rank must)
+    assert any(not r["bad_a2a"]["ok"] for r in out["ranks"])
+    assert all(f.startswith("all_to_all_v") for r in out["ranks"] for f in r["bad_a2a"]["failed"])
+
+
+def test_a_communicator_of_the_older_header_is_not_asked_for_all_to_all(monkeypatch):
+    """abg_comm grew a member (all_to_all_v) in round 4; a caller compiled before that passes a shorter struct.  struct_size says how
+    much of it is there: with 0 (the field such callers zero) the engine never reads the member and keeps to all_gather_v / all_reduce
+    -- on four ranks, where the routed PASS 1 would be the default -- and stays exact."""
+    monkeypatch.setenv("ABG_TEST_OLD_COMM_ABI", "1")
+    out = run_ranks(4, "oracle")
+    for key in ("counting_filter", "results", "contigs", "visited", "assembly_counters", "ranks_agree"):
+        assert out[key], (key, out)
+    assert out["comm_calls"]["all_to_all_v"] == 0 and out["comm_calls"]["all_gather_v"] > 0

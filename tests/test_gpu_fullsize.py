@@ -93,8 +93,8 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
             assert r.returncode == 0, r.stderr.decode()
             assert r.stdout.count(b" -> ") == golden["adjlist"]["edges"]
             assert hashlib.sha256(r.stdout).hexdigest() == golden["adjlist"]["dot_sha256"]
-    # the pre-search answered ahead of the walkers, and sanely (one answer per request at most)
-    assert 0 < sa["pre_adds"] <= sa["pre_requests"]
+    # the searches went through the chain shortcuts and the memo
+    assert sa["chain_steps"] > 0 and sa["memo_hits"] > 0
     vis_a = a.visited()
     assert sa["commit_rounds"] > 0 and ca["next_contig_id"] > 50_000
 

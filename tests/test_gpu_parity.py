@@ -279,12 +279,12 @@ def test_graphviz_dump_matches_reference(name):
 
 
 @pytest.mark.parametrize("env", [{"ABG_TILED": "0"}, {"ABG_TILE_CAP": "300"}, {"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"},
-                                 {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"}, {"ABG_PIPELINE": "2"},
+                                 {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"},
                                  {"ABG_COMPACT_THRESHOLD": "1"}, {"ABG_OVERLAP_BINS": "0"}, {"ABG_OVERLAP_BINS": "1", "ABG_TILE_CAP": "300"}])
 def test_accelerators_and_fallbacks_do_not_change_results(env, monkeypatch):
     """Every accelerator has an exact slow path behind it and every table a fallback: PASS 1 without the
     LDS tiles / with bins that overflow, walkers without guide and memo / with the densest guide, the
-    commit with hashed time stamps, two batches in flight, flagged-and-compacted losers in every round,
+    commit with hashed time stamps, flagged-and-compacted losers in every round,
     PASS 1 without the next batch staged on the side stream / with a staged batch whose bins overflow.
     Same bytes as the reference, and the work counters show the path was taken."""
     for key, val in env.items():

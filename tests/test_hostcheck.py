@@ -497,12 +497,11 @@ def test_device_sized_fast_memory_runs_the_chain_searches(monkeypatch):
 
 def test_guide_and_memo_do_not_change_results(monkeypatch):
     """The guide table and the successor() memo are accelerators: with both off (ABG_GUIDE_STRIDE=0,
-    ABG_MEMO=0), with the densest guide (stride 1) and with two batches in flight (ABG_PIPELINE=2: a
-    batch classified against an older snapshot) the outputs are the reference's."""
+    ABG_MEMO=0) and with the densest guide (stride 1) the outputs are the reference's."""
     g = GoldenCase("k64")
     kw = g.kwargs()
-    for env in ({"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"}, {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PIPELINE": "2"}):
-        for key in ("ABG_GUIDE_STRIDE", "ABG_MEMO", "ABG_PIPELINE"):
+    for env in ({"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"}, {"ABG_GUIDE_STRIDE": "1"}):
+        for key in ("ABG_GUIDE_STRIDE", "ABG_MEMO"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -516,42 +515,6 @@ def test_guide_and_memo_do_not_change_results(monkeypatch):
         assert api.format_fasta(contigs, g.ids) == g.fasta
         assert api.format_read_log(results, g.ids) == g.readlog
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
-
-
-def test_presearch_answers_the_walkers_questions_ahead_and_changes_nothing(monkeypatch):
-    """Engine::presearch: successor() at the branching k-mers of the candidates' own reads, computed one
-    search per wave ahead of the walkers and left in the memo.  With it the walkers find most answers
-    there (fewer answers of their own, the same total), and with or without it the outputs are the
-    reference's -- also for odd k (oriented identities) and with a short trim."""
-    monkeypatch.setenv("HC_FAST_BYTES", "20480")
-    for name in ("k64", "k96", "k25_h3_kc3_t40"):
-        g = GoldenCase(name)
-        kw = g.kwargs()
-        adds = {}
-        for on in ("1", "0"):
-            monkeypatch.setenv("ABG_PRESEARCH", on)
-            hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000,
-                           claim_log2=16, p2_first=128)
-            hc.load(g.buf, g.off)
-            results, contigs = hc.assemble(g.buf, g.off)
-            st = hc.stats()
-            adds[on] = (st["memo_adds"], st["pre_adds"], st["pre_requests"])
-            assert api.format_fasta(contigs, g.ids) == g.fasta
-            assert api.format_read_log(results, g.ids) == g.readlog
-            assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
-        assert adds["0"][1] == 0 and adds["0"][2] == 0
-        assert adds["1"][1] > 0 and adds["1"][1] <= adds["1"][2], (name, adds)
-        # the walkers compute fewer answers themselves; serially nothing is computed twice
-        assert adds["1"][0] < adds["0"][0] and adds["1"][0] + adds["1"][1] >= adds["0"][0], (name, adds)
-    # a spaced seed switches the pre-search off (its requests carry no masked terms)
-    g = GoldenCase("k48_K16")
-    kw = g.kwargs()
-    monkeypatch.setenv("ABG_PRESEARCH", "1")
-    hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000, claim_log2=16,
-                   p2_first=128, mask=mask_of(g))
-    hc.load(g.buf, g.off)
-    results, contigs = hc.assemble(g.buf, g.off)
-    assert hc.stats()["pre_requests"] == 0 and api.format_fasta(contigs, g.ids) == g.fasta
 
 
 def test_packed_reads_get_their_prefix_sums_and_batches_on_the_device():
