@@ -1428,8 +1428,6 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
        CB_FALSE = 4 };   // a plain dead-end tip, `depth` edges long: trueBranch answers false (see chain_true_branches)
 enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
        WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
-       WSTAT_PRE_REQS, WSTAT_PRE_ADDS, // pre-search: requests made / answers it added to the memo
-       WSTAT_VERIFY, WSTAT_MEMO_BAD, WSTAT_BAD0, WSTAT_BAD1, WSTAT_BAD2, // ABG_MEMO_VERIFY: every memo hit is recomputed and compared (diagnosis)
        WSTAT_N = 16 };
 
 // ------------------------------------------------------- memo of successor()
@@ -1454,8 +1452,8 @@ ABG_HD uint64_t memo_slot(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
 	x ^= x >> 31; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 29;
 	return x & m.mask;
 }
-// -1: not there; else code << 4 | base (| origin << 16 when raw)
-ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, bool raw = false)
+// -1: not there; else code << 4 | base
+ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir)
 {
 	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return -1;
 	uint64_t s = memo_slot(m, fh, rh, dir);
@@ -1466,11 +1464,11 @@ ABG_HD int memo_find(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, bool 
 		const uint64_t v = ld_coherent(&m.val[s]);
 		if (!(v >> 63) || (int)((v >> 8) & 1u) != dir) continue; // (an entry still being written counts as absent)
 		if (ld_coherent(&m.k1[s]) != rh) continue;
-		return (int)(v & (raw ? 0x100FFu : 0xFFu));
+		return (int)(v & 0xFFu);
 	}
 	return -1;
 }
-ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsigned code, unsigned base, bool coop, unsigned origin = 0)
+ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsigned code, unsigned base, bool coop)
 {
 	if (fh == MEMO_EMPTY || rh == MEMO_EMPTY) return;
 	uint64_t s = memo_slot(m, fh, rh, dir);
@@ -1478,7 +1476,7 @@ ABG_HD void memo_add(const SuccMemo& m, uint64_t fh, uint64_t rh, int dir, unsig
 		const uint64_t cur = wu_cas_u64(&m.k0[s], MEMO_EMPTY, fh, coop);
 		if (cur == MEMO_EMPTY) {
 			wu_st_coherent(&m.k1[s], rh, coop);
-			wu_st_coherent(&m.val[s], (1ULL << 63) | ((uint64_t)(origin & 1) << 16) | ((uint64_t)(dir & 1) << 8) | ((uint64_t)code << 4) | base, coop);
+			wu_st_coherent(&m.val[s], (1ULL << 63) | ((uint64_t)(dir & 1) << 8) | ((uint64_t)code << 4) | base, coop);
 			return;
 		}
 		if (cur != fh) continue;
@@ -1530,8 +1528,7 @@ struct SearchScratch {
 	MaskCache* mcache;     // neighbour masks of the vertices the searches have looked at (NULL: none)
 	SuccMemo memo;         // answers of successor() shared by all walkers; k0 == NULL: off
 	uint32_t n_memo_hits, n_memo_adds;
-	uint64_t* wstats;      // the engine's work counters (WSTAT_VERIFY: diagnosis mode of the memo); may be NULL
-	uint32_t origin;       // 1: the pre-search (diagnosis: who wrote a memo entry)
+	uint64_t* wstats;      // the engine's work counters; may be NULL
 	Guide guide;           // read-guided chains (chain_bulk); tab == NULL: off
 	BulkScratch* bulk;
 	uint32_t n_chain_steps; // chain vertices settled by chain_bulk (work counter)
@@ -2290,12 +2287,9 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 	// vertex's two UNMASKED rolling hashes: they stand for the whole oriented k-mer, positions under
 	// a '0' included, which is what the search's later steps depend on.)
 	const bool use_memo = sc.memo.k0 != nullptr && trim == p.trim && (mask & (mask - 1));
-	int verify_hit = -1;
 	if (use_memo) {
 		const int hit = memo_find(sc.memo, u.fh, u.rh, dir);
-		const uint64_t vmode = (hit >= 0 && sc.wstats) ? ld_coherent(&sc.wstats[WSTAT_VERIFY]) : 0; // 1: walkers recompute and compare, 2: the pre-search does
-		if (vmode && vmode == 1 + sc.origin) verify_hit = memo_find(sc.memo, u.fh, u.rh, dir, true);
-		else if (hit >= 0) {
+		if (hit >= 0) {
 			sc.n_memo_hits++;
 			const int code = hit >> 4;
 			const unsigned b = (unsigned)hit & 3u;
@@ -2307,17 +2301,8 @@ ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const 
 		if (use_memo && !sc.overflow) { // (a search that ran out of stack answers anything: its walker is restarted)
 			// the successor's base: the last (SENSE) or first (ANTISENSE) base of vout
 			const unsigned b = (code == ER_LENGTH_LIMIT || code == ER_AMBI_OUT) ? kmer_get(vout.s, sense == SENSE ? p.k - 1 : 0u) : 0u;
-			if (verify_hit >= 0) {
-				sc.n_memo_hits++;
-				if (((unsigned)verify_hit & 0xFFu) != (((unsigned)code << 4) | b)) {
-					wu_atomic_add_u64(&sc.wstats[WSTAT_MEMO_BAD], 1, sc.coop);
-					wu_st_coherent(&sc.wstats[WSTAT_BAD0], u.fh, sc.coop); wu_st_coherent(&sc.wstats[WSTAT_BAD1], u.rh, sc.coop);
-					wu_st_coherent(&sc.wstats[WSTAT_BAD2], ((uint64_t)dir << 60) | ((uint64_t)mask << 52) | ((uint64_t)sc.origin << 48) | ((uint64_t)verify_hit << 20) | ((unsigned)code << 4) | b, sc.coop);
-				}
-			} else {
-				memo_add(sc.memo, u.fh, u.rh, dir, (unsigned)code, b, sc.coop, sc.origin);
-				sc.n_memo_adds++;
-			}
+			memo_add(sc.memo, u.fh, u.rh, dir, (unsigned)code, b, sc.coop);
+			sc.n_memo_adds++;
 		}
 		return code;
 	};

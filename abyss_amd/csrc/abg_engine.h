@@ -1268,7 +1268,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.tbk_cap = 0; sc.coop = false;
 		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
-		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = nullptr; sc.origin = 0; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
+		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = nullptr; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
 		// hasBluntEnd (bloom-dbg.h:489-532): lookAhead(REVERSE, 5) from the first k-mer of
@@ -2966,7 +2966,6 @@ class Engine {
 	void clear_wstats()
 	{
 		be_.memset(wstats_, 0, WSTAT_N * 8);
-		if (const char* e = getenv("ABG_MEMO_VERIFY")) { const uint64_t mode = strtoull(e, 0, 10); be_.h2d(wstats_ + WSTAT_VERIFY, &mode, 8); } // diagnosis: memo hits are recomputed
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
 	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
@@ -2980,11 +2979,6 @@ class Engine {
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
 			s.pre_requests = 0; s.pre_adds = 0; // (fields of the C ABI's abg_stats kept for its layout: the pre-search is gone)
-			if (v[WSTAT_MEMO_BAD])
-				fprintf(stderr, "abyss_amd: ABG_MEMO_VERIFY: %llu memo hits differ from the recomputed answer; last: fh %016llx rh %016llx dir %llu mask %llx checked-by %s memo %03llx (written by %s) computed %03llx\n",
-				    (unsigned long long)v[WSTAT_MEMO_BAD], (unsigned long long)v[WSTAT_BAD0], (unsigned long long)v[WSTAT_BAD1], (unsigned long long)(v[WSTAT_BAD2] >> 60),
-				    (unsigned long long)((v[WSTAT_BAD2] >> 52) & 0xF), ((v[WSTAT_BAD2] >> 48) & 1) ? "pre-search" : "walker",
-				    (unsigned long long)((v[WSTAT_BAD2] >> 20) & 0xFF), ((v[WSTAT_BAD2] >> 36) & 1) ? "pre-search" : "walker", (unsigned long long)(v[WSTAT_BAD2] & 0xFFF));
 		}
 		s.guide_slots = guide_slots_;
 		return s;

@@ -78,12 +78,7 @@ __global__ void __launch_bounds__(64, ABG_WALK_WAVES) k_walkers(F f, uint64_t n,
 		i = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(i >> 32)) << 32) |
 		    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)i);
 		if (i >= n) break;
-		// (the walker's fast memory goes down as a generic pointer whose origin the optimiser does not see: once it knew "this is
-		// LDS" in every callee -- one kernel left that calls them -- ROCm 7.2's backend emitted `v_cmp_ne_u32 0, src_shared_base`
-		// for the null tests in successor_m, which its own verifier rejects)
-		void* fast = (void*)lds;
-		asm volatile("" : "+v"(fast));
-		f(i, (uint32_t)blockIdx.x, fast, WALK_LDS, true);
+		f(i, (uint32_t)blockIdx.x, (void*)lds, WALK_LDS, true);
 	}
 }
 

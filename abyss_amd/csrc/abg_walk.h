@@ -821,7 +821,7 @@ ABG_HD void walker_scratch(WalkEnv<NW>& e, uint32_t slot, SearchScratch<NW>*& sc
 		fast += LA_FAST * sizeof(VKey); fast_bytes -= LA_FAST * (uint32_t)sizeof(VKey);
 	}
 	sc.guide = e.guide; sc.bulk = w.bulk;
-	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = e.wstats; sc.origin = 0;
+	sc.memo = e.memo; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = e.wstats;
 	sc.mcache = e.mcache;
 	if (!w.bulk) sc.guide.tab = nullptr;
 	{
