@@ -1394,7 +1394,14 @@ struct Guide {
 	uint64_t mask;
 	const uint32_t* words;  // the packed reads the hints point into
 	uint64_t nwords;
+	// What a bulk step found out about the k-mer starting at base b of `words`, kept for the next walker that comes along it
+	// (a unitig is walked by every read of the batch that lies on it, 5-6 times over): one byte per base position, 0 = nothing
+	// known yet, else SV_VALID | SV_SIMPLE (exactly one neighbour in the solid filter on either side) | the base of the one
+	// after it (bits 1-2) and of the one before it (bits 3-4), both as the READ runs.  A fact about the k-mer and the solid
+	// filter only, so whoever wrote it wrote the same; NULL: nothing is kept (no room for a byte per base).
+	uint8_t* seen;
 };
+constexpr unsigned SV_VALID = 0x80u, SV_SIMPLE = 0x01u;
 constexpr uint32_t GUIDE_MAX_NK = 256; // k-mers of a sequence that can serve as a guide
 ABG_HD uint64_t guide_slot(uint64_t hm, uint64_t mask)
 {

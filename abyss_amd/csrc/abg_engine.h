@@ -76,6 +76,7 @@ struct Config {
 	uint32_t t_tags = 1024;           // passes of the parallel commit between two clearings of its time stamps
 	uint32_t guide_stride = 4;        // every guide_stride-th read guides the walkers' bulk steps (0: no guide, see Guide).  (8 halves guide_build, 27 -> 14 ms, and gives it back: 5x the unguided steps, rewalk +13 ms; 16: +60 ms)
 	uint32_t guide_log2_max = 31;     // at most this many guide slots (8 bytes each)
+	bool guide_seen = true;           // the bulk steps keep what they found out about a read's k-mers for the next walker (Guide::seen)
 	bool link_duplicates = true;      // the commit decides a contig's copies among a batch's records by their original (Engine::link_duplicates)
 	bool par_commit = true;           // parallel fixed-point commit (4 bytes of time stamp per filter bit) ...
 	bool overlap_bins = true;              // PASS 1: the next batch is hashed and binned on the side stream while this one is applied
@@ -1267,7 +1268,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		SearchScratch<NW> sc;
 		sc.tb = nullptr; sc.tb_keys = nullptr; sc.tb_cap = 0; sc.overflow = 0; sc.dbg_nodes = 0;
 		sc.tbf = nullptr; sc.tbf_keys = nullptr; sc.tbf_cap = 0; sc.tbk_cap = 0; sc.coop = false;
-		sc.guide = Guide{ nullptr, 0, nullptr, 0 }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
+		sc.guide = Guide{ nullptr, 0, nullptr, 0, nullptr }; sc.bulk = nullptr; sc.dbg_chain = 0; sc.dbg_on = 0; sc.n_chain_steps = 0; sc.dbg_la = 0; sc.dbg_la_calls = 0;
 		sc.memo = SuccMemo{ nullptr, nullptr, nullptr, 0 }; sc.n_memo_hits = 0; sc.n_memo_adds = 0; sc.wstats = nullptr; sc.mcache = nullptr; sc.la_fast = nullptr; sc.la_fast_cap = 0;
 		sc.la = sc.la_local;
 		sc.la_visited = la_pool + (uint64_t)slot * LA_MAX_VISITED;
@@ -2455,6 +2456,7 @@ class Engine {
 		if (la_pool_c_) be_.free(la_pool_c_);
 		if (la_pool_c2_) be_.free(la_pool_c2_);
 		if (guide_tab_) be_.free(guide_tab_);
+		if (guide_seen_) be_.free(guide_seen_);
 		if (gtab_.hmin) free_tab(gtab_);
 		free_shared();
 		free_insert();
@@ -2925,7 +2927,7 @@ class Engine {
 	// sized to the sampled reads' k-mers, of which the solid ones -- a genome's worth -- stay.
 	void build_guide(const Batch& b)
 	{
-		guide_.tab = nullptr; guide_slots_ = 0;
+		guide_.tab = nullptr; guide_.seen = nullptr; guide_slots_ = 0;
 		if (!cfg_.guide_stride || p_.nh > 8 || !b.n) return;
 		const uint64_t sampled = (b.n + cfg_.guide_stride - 1) / cfg_.guide_stride;
 		uint64_t nwords = 0;
@@ -2950,6 +2952,14 @@ class Engine {
 		});
 		guide_.tab = guide_tab_;
 		guide_slots_ = guide_.mask + 1;
+		// what the bulk steps find out about a read's k-mers, for the walkers that come along them later (Guide::seen): a byte per
+		// base of the call's reads -- 1.5 GB for configs[1] -- when the device has that to spare
+		if (cfg_.guide_seen) {
+			const uint64_t need = nwords * 16, total = be_.device_mem_bytes();
+			if (guide_seen_ && guide_seen_bytes_ < need) { be_.free(guide_seen_); guide_seen_ = nullptr; }
+			if (!guide_seen_ && (!total || need <= total / 24)) { guide_seen_ = (uint8_t*)be_.try_alloc(need); guide_seen_bytes_ = need; }
+			if (guide_seen_) { be_.memset(guide_seen_, 0, need); guide_.seen = guide_seen_; }
+		}
 	}
 	// Batches grow geometrically up to p2_max_batch (larger ones walk too many reads of the same
 	// unitigs side by side).  A batch with few candidates, though, is bound by its slowest walker,
@@ -3116,7 +3126,8 @@ class Engine {
 	uint32_t* lead_alt_ = nullptr; uint8_t* opflag_alt_ = nullptr; // ... and, when its tiles are judged there as well, of what tile_purity leaves per op
 	bool staged_purity_ = false;
 	// PASS 2 resources
-	Guide guide_{ nullptr, 0, nullptr, 0 }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
+	Guide guide_{ nullptr, 0, nullptr, 0, nullptr }; uint64_t* guide_tab_ = nullptr; uint32_t guide_log2_ = 0;
+	uint8_t* guide_seen_ = nullptr; uint64_t guide_seen_bytes_ = 0;
 	BulkScratch* bulk_pool_ = nullptr; uint64_t* wstats_ = nullptr; uint64_t guide_slots_ = 0;
 	SuccMemo memo_{ nullptr, nullptr, nullptr, 0 }; WalkTab memo_tab_{ nullptr, nullptr, nullptr, 0 }; bool memo_valid_ = false; uint64_t memo_gen_ = 0; // (valid: filled against the solid filter as it is now)
 	bool walk_ready_ = false;

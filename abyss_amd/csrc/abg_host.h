@@ -111,6 +111,7 @@ class Session {
 		if (const char* e = getenv("ABG_P2_GROWTH")) cfg.p2_growth = (uint32_t)std::max(2, atoi(e));
 		if (const char* e = getenv("ABG_DRAIN_THRESHOLD")) cfg.drain_threshold = (uint32_t)strtoul(e, 0, 10);
 		if (const char* e = getenv("ABG_GUIDE_STRIDE")) cfg.guide_stride = (uint32_t)strtoul(e, 0, 10); // 0: walk step by step
+		if (const char* e = getenv("ABG_GUIDE_SEEN")) cfg.guide_seen = atoi(e) != 0; // the bulk steps' findings kept per read k-mer (0: every walker probes again)
 		if (const char* e = getenv("ABG_GUIDE_LOG2_MAX")) cfg.guide_log2_max = (uint32_t)std::min(36, std::max(10, atoi(e)));
 		if (!be.ok()) return fail(ABG_ENODEV, be.why());
 		eng = new Engine<BE>(be, cfg);

@@ -217,6 +217,7 @@ struct HipBackend {
 	{
 		if (ticket) free(ticket);
 		if (pin) hipHostFree(pin);
+		for (int i = 0; i < 2; i++) { if (big_pin[i]) hipHostFree(big_pin[i]); if (big_ev[i]) hipEventDestroy(big_ev[i]); }
 		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
 		if (ev0) hipEventDestroy(ev0);
@@ -357,8 +358,39 @@ struct HipBackend {
 			check(hipStreamSynchronize(stream), "hipStreamSynchronize"); // (the buffer is reused right away)
 			return;
 		}
+		// Large uploads (a chunk's packed reads, their offsets and lengths) come from pageable memory, which the runtime stages
+		// at 5-50 ms per 64 MB: through two pinned buffers of our own instead, a piece copied in while the one before it is on
+		// its way -- the rate of a memcpy.
+		if (n >= (1u << 20) && big_pin_ok()) {
+			const char* src = (const char*)s;
+			size_t done = 0;
+			for (int i = 0; done < n; i ^= 1) {
+				const size_t m = n - done < BIG_PIN ? n - done : BIG_PIN;
+				check(hipEventSynchronize(big_ev[i]), "hipEventSynchronize"); // (the buffer's last copy has left)
+				memcpy(big_pin[i], src + done, m);
+				check(hipMemcpyAsync((char*)d + done, big_pin[i], m, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
+				check(hipEventRecord(big_ev[i], stream), "hipEventRecord");
+				done += m;
+			}
+			check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+			return;
+		}
 		check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	static constexpr size_t BIG_PIN = 8u << 20;
+	void* big_pin[2] = { nullptr, nullptr }; hipEvent_t big_ev[2] = { nullptr, nullptr }; int big_state = 0; // 0 untried, 1 ready, -1 unavailable
+	bool big_pin_ok()
+	{
+		if (big_state == 0) {
+			big_state = -1;
+			if (!getenv("ABG_NO_PINNED_UPLOAD") &&
+			    hipHostMalloc(&big_pin[0], BIG_PIN, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&big_pin[1], BIG_PIN, hipHostMallocDefault) == hipSuccess &&
+			    hipEventCreateWithFlags(&big_ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&big_ev[1], hipEventDisableTiming) == hipSuccess)
+				big_state = 1;
+			else (void)hipGetLastError();
+		}
+		return big_state == 1;
 	}
 	void d2h(void* d, const void* s, size_t n)
 	{

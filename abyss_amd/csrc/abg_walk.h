@@ -235,6 +235,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 	const uint8_t* __restrict__ cnt = uniptr<COOP>(e.cnt);
 	const uint32_t* __restrict__ gwords = uniptr<COOP>(e.guide.words);
 	const uint64_t gnwords = uni64<COOP>(e.guide.nwords);
+	uint8_t* const seen = uniptr<COOP>(e.guide.seen);
 	WalkTab tab;
 	tab.hmin = uniptr<COOP>(e.tab.hmin); tab.hmax = uniptr<COOP>(e.tab.hmax); tab.meta = uniptr<COOP>(e.tab.meta);
 	tab.mask = uni64<COOP>(e.tab.mask);
@@ -338,9 +339,26 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		// "new to the walker": the home slot of (key, owner) is read while the probes below are in flight -- nearly always
 		// free, which settles it (only this walker enters keys of its own, and it is not entering any now)
 		const uint64_t home = ld_coherent(&tab.hmin[wt_slot(tab, wt_key(key), owner)]);
+		// what an earlier walker left about this k-mer (Guide::seen), and the base the read goes on with: both loads beside the one above
+		const uint32_t rpos = up ? pos + l : pos - l; // the vertex's k-mer in the read
+		const uint64_t seen_at = woff * 16u + rpos;
+		const unsigned known = seen ? (unsigned)seen[seen_at] : 0u;
+		const uint32_t rb_pos = (l + 1 < n) ? (up ? pos + l + k : pos - l - 1u) : (up ? pos + l : pos - l); // (always inside the read)
+		const uint32_t rb_word = gwords[woff + (rb_pos >> 4)];
 		tx1 = dbg_clock(e.dbg);
 		unsigned bad = 0; // bit q: neighbour q (q < 4 behind, q >= 4 ahead) is not in the solid filter
-		{
+		// A cooperative caller skips the probes when EVERY vertex of the chunk is known (a wave goes round for its slowest lane
+		// anyway); a serial one vertex by vertex.
+		const bool skip_probes = COOP ? !wave_any(l < n && !(known & SV_VALID)) : (known & SV_VALID) != 0;
+		if (skip_probes) {
+			if (known & SV_SIMPLE) {
+				// the bases as the walker holds the k-mer: its reverse complement swaps the sides and complements the bases
+				const unsigned nx = (known >> 1) & 3u, pv = (known >> 3) & 3u;
+				const unsigned sense_b = same ? nx : 3u - pv, anti_b = same ? pv : 3u - nx; // neighbour added at the end / at the front
+				const unsigned fbk = fsense == SENSE ? sense_b : anti_b, bbk = fsense == SENSE ? anti_b : sense_b;
+				bad = 0xFFu & ~((1u << bbk) | (1u << (4u + fbk)));
+			} else bad = 0xFFu; // (not a simple vertex: no step through it)
+		} else {
 			// Two stages.  Six of the eight neighbours do not exist, and nearly all of those fail the first
 			// hash function already: that one is probed for all eight, the other nh - 1 only for the neighbours
 			// that passed it, two of them per round (the usual survivors: the one behind and the one ahead).
@@ -384,6 +402,18 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 					}
 				}
 			}
+			if (seen && !(known & SV_VALID)) {
+				// for whoever comes next: simple or not, and the two neighbours as the read runs
+				const unsigned bm = ~bad & 0xFu, fm = (~bad >> 4) & 0xFu;
+				unsigned v = SV_VALID;
+				if (bm != 0 && !(bm & (bm - 1)) && fm != 0 && !(fm & (fm - 1))) {
+					const unsigned bbx = (bm & 1u) ? 0u : (bm & 2u) ? 1u : (bm & 4u) ? 2u : 3u, fbx = (fm & 1u) ? 0u : (fm & 2u) ? 1u : (fm & 4u) ? 2u : 3u;
+					const unsigned sense_b = fsense == SENSE ? fbx : bbx, anti_b = fsense == SENSE ? bbx : fbx;
+					const unsigned nx = same ? sense_b : 3u - anti_b, pv = same ? anti_b : 3u - sense_b;
+					v |= SV_SIMPLE | (nx << 1) | (pv << 3);
+				}
+				seen[seen_at] = (uint8_t)v;
+			}
 		}
 		tx3 = dbg_clock(e.dbg);
 		bool ok = home == WT_EMPTY;
@@ -406,8 +436,7 @@ ABG_HDX uint32_t walk_bulk(const WalkEnv<NW>& e, WalkState<NW>& w, const int dir
 		}
 		if (l + 1 < n) {
 			// the read's next k-mer adds this base at the walking end
-			const uint32_t rb_pos = up ? pos + l + k : pos - l - 1u;
-			const unsigned rb = (gwords[woff + (rb_pos >> 4)] >> (2u * (rb_pos & 15u))) & 3u;
+			const unsigned rb = (rb_word >> (2u * (rb_pos & 15u))) & 3u;
 			ok = ok && fb == (same ? rb : 3u - rb);
 		}
 		bs.good[l] = ok ? 1 : 0;

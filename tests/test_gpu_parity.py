@@ -279,7 +279,7 @@ def test_graphviz_dump_matches_reference(name):
 
 
 @pytest.mark.parametrize("env", [{"ABG_TILED": "0"}, {"ABG_TILE_CAP": "300"}, {"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"},
-                                 {"ABG_GUIDE_STRIDE": "1"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"},
+                                 {"ABG_GUIDE_STRIDE": "1"}, {"ABG_GUIDE_SEEN": "0"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"},
                                  {"ABG_COMPACT_THRESHOLD": "1"}, {"ABG_OVERLAP_BINS": "0"}, {"ABG_OVERLAP_BINS": "1", "ABG_TILE_CAP": "300"}])
 def test_accelerators_and_fallbacks_do_not_change_results(env, monkeypatch):
     """Every accelerator has an exact slow path behind it and every table a fallback: PASS 1 without the

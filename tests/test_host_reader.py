@@ -102,10 +102,13 @@ def test_sam_qseq_export_match_reference_live(tmp_path):
             assert run_mine(opts, path) == ref, (path, opts)
 
 
+@pytest.mark.parametrize("mapped", ["1", "0"])
 @pytest.mark.parametrize("i", range(len(OPTS)))
-def test_parallel_reader_matches_golden(i, monkeypatch):
+def test_parallel_reader_matches_golden(i, mapped, monkeypatch):
     """SequenceReader: the file cut into blocks at record boundaries, each parsed by the same FastaReader
-    logic on its own thread (-j 4), here with windows of 600 bytes so that records straddle windows."""
+    logic on its own thread (-j 4), here with windows of 600 bytes so that records straddle windows --
+    windows of the mapped file (the default) and windows filled by pread (ABG_READER_MMAP=0)."""
+    monkeypatch.setenv("ABG_READER_MMAP", mapped)
     inp = os.path.join(GOLDEN, "reader_input.fq")
     want = open(os.path.join(GOLDEN, "reader_%d.tsv" % i), "rb").read()
     assert run_mine(OPTS[i] + ["-j", "4"], inp) == want

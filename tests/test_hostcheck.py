@@ -497,11 +497,12 @@ def test_device_sized_fast_memory_runs_the_chain_searches(monkeypatch):
 
 def test_guide_and_memo_do_not_change_results(monkeypatch):
     """The guide table and the successor() memo are accelerators: with both off (ABG_GUIDE_STRIDE=0,
-    ABG_MEMO=0) and with the densest guide (stride 1) the outputs are the reference's."""
+    ABG_MEMO=0), with the densest guide (stride 1), and with that guide but nothing kept of what the bulk steps find out about
+    a read's k-mers (ABG_GUIDE_SEEN=0: every walker probes again) the outputs are the reference's."""
     g = GoldenCase("k64")
     kw = g.kwargs()
-    for env in ({"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"}, {"ABG_GUIDE_STRIDE": "1"}):
-        for key in ("ABG_GUIDE_STRIDE", "ABG_MEMO"):
+    for env in ({"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"}, {"ABG_GUIDE_STRIDE": "1"}, {"ABG_GUIDE_STRIDE": "1", "ABG_GUIDE_SEEN": "0"}):
+        for key in ("ABG_GUIDE_STRIDE", "ABG_MEMO", "ABG_GUIDE_SEEN"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
