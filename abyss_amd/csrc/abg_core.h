@@ -2125,8 +2125,17 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 		VKey* const mykeys = keys + (uint64_t)grp * per_chain;
 		unsigned depth = 0;
 		// a plain tip (see below): every vertex so far has one neighbour ahead; ... and, where the search would turn round, one behind
-		bool plain = true, is_false = false, behind_ok = true, second = false;
+		bool plain = true, is_false = false, behind_ok = true;
 		unsigned behind_lo = 0; // bit i: the vertex at depth i < FP_TRIM has exactly one neighbour behind
+		// The walk below is a depth-first search over the neighbours AHEAD only (no turning round, no lookAhead): at a fork it takes
+		// the first neighbour, as trueBranch would, and remembers the others; at a dead end it goes back to the last fork that has
+		// one left.  Any walk of `trim` edges it finds answers true (trueBranch is an OR over such walks); when it runs out of
+		// forks or of its budget of steps nothing is known and the general search decides.  The forks live behind the chain's keys.
+		struct Fork { Vtx<NW> v; uint32_t depth, mask; };
+		Fork* const forks = (Fork*)(mykeys + trim);
+		const unsigned fork_cap = (unsigned)(((uint64_t)(per_chain - trim) * sizeof(VKey)) / sizeof(Fork)) < 8u ? (unsigned)(((uint64_t)(per_chain - trim) * sizeof(VKey)) / sizeof(Fork)) : 8u;
+		unsigned nforks = 0, steps = 0;
+		const unsigned budget = 4u * trim + 64u;
 		if (use_guide) {
 			// read-guided descent first: one branch at a time, the whole wave on it (chain_bulk);
 			// the lock-step loop below carries on from wherever the guide leaves a branch
@@ -2174,6 +2183,7 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 			}
 			wave_sync();
 		}
+		unsigned from_depth = depth; // where the guide left the walk
 		while (COOP ? wave_any(active) : active) {
 			if (active) {
 				const VKey key = vtx_ident(p, v);
@@ -2236,21 +2246,37 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 						for (unsigned i = 0; i < FP_TRIM && i + FP_TRIM <= depth; i++) ok = ok && ((behind_lo >> i) & 1u);
 						if (ok) is_false = true;
 					}
+					steps++;
 					if (cm == 0) {
-						// this walk ends here.  One that took the first neighbour at every fork (as the search would) tries again
-						// taking the last -- in a thicket of error tips beside a trunk one of the two usually stays on the trunk;
-						// after that the general search decides
-						if (!plain && !second && !is_false) {
-							second = true;
+						// this walk ends here: back to the last fork with a neighbour left, if there is one
+						if (!is_false && nforks > 0 && steps < budget) {
+							wave_sync(); // (the fork was written by the group's first lane)
+							const Fork f = forks[nforks - 1];
+							unsigned m = f.mask;
+							const unsigned c = (m & 1u) ? 0u : (m & 2u) ? 1u : (m & 4u) ? 2u : 3u;
+							m &= m - 1;
+							if (m) { if (sub == 0) forks[nforks - 1].mask = m; } else nforks--;
+							uint64_t fb2, rb2, fh2, rh2;
+							nbr_base(tabs, f.v, p.k, sense, fb2, rb2);
+							nbr_hash(tabs, sense, fb2, rb2, c, fh2, rh2);
+							v = make_neighbour(p, f.v, sense, c, fh2, rh2);
+							depth = f.depth + 1u;
+						} else if (!is_false && from_depth > 0 && steps < budget) {
+							// (the guide handed the walk over some way down a read that led nowhere: once more from the branch's first vertex)
+							from_depth = 0;
 							uint64_t fb0, rb0, fh0, rh0;
 							nbr_base(tabs, u, p.k, sense, fb0, rb0);
 							nbr_hash(tabs, sense, fb0, rb0, my_b, fh0, rh0);
 							v = make_neighbour(p, u, sense, my_b, fh0, rh0);
-							depth = 0;
+							depth = 0; nforks = 0;
 						} else active = false;
 					} else {
-						const unsigned c = !second ? ((cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u)
-						                           : ((cm & 8u) ? 3u : (cm & 4u) ? 2u : (cm & 2u) ? 1u : 0u);
+						const unsigned c = (cm & 1u) ? 0u : (cm & 2u) ? 1u : (cm & 4u) ? 2u : 3u;
+						const unsigned rest = cm & (cm - 1);
+						if (rest && nforks < fork_cap) {
+							if (sub == 0) { forks[nforks].v = v; forks[nforks].depth = depth; forks[nforks].mask = rest; }
+							nforks++;
+						}
 						uint64_t fh, rh;
 						nbr_hash(tabs, sense, fb, rb, c, fh, rh);
 						v = make_neighbour(p, v, sense, c, fh, rh);
