@@ -571,7 +571,11 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // touches, and keep their order among themselves in the reservation rounds.
 constexpr int MAX_RANKS = 16;
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
-constexpr uint32_t TILE_SORT_MAX = 3072;                            // pairs of one tile per batch, at most
+#ifndef ABG_TILE_PAIRS_LOG2
+#define ABG_TILE_PAIRS_LOG2 11 // a batch is sized so that a tile sees 2^this pairs of it on average (12: half as many batches, twice the LDS table; see notes/README.md)
+#endif
+constexpr uint32_t TILE_PAIRS_MEAN = 1u << ABG_TILE_PAIRS_LOG2;
+constexpr uint32_t TILE_SORT_MAX = 3u * TILE_PAIRS_MEAN / 2;        // pairs of one tile per batch, at most (3072)
 // An (op, counter) pair as the bins hold it: the op's canonical hash and "op id | hash function << 28" -- 12 bytes.
 // The counter is not stored: it is pos_i(h, j), some twenty integer instructions wherever a pair is looked at,
 // against four bytes written twice and read three times per pair and batch (the bins are what PASS 1 moves most of).
@@ -839,10 +843,10 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 // memory (TILE_TAB slots: the counter's offset; the earliest pair on it as op id << 12 | pair
 // index; how many pairs).  A counter all of whose pairs carry the hash of its earliest pair's
 // k-mer is pure, and that pair's op leads the k-mer's ops.
-constexpr uint32_t TILE_TAB = 4096; // (TILE_SORT_MAX = 3072 pairs at most: the table is never full)
+constexpr uint32_t TILE_TAB = 2u * TILE_PAIRS_MEAN, TILE_IDX_BITS = ABG_TILE_PAIRS_LOG2 + 1; // (4096 slots for at most 3072 pairs: the table is never full; a pair's index in its bin fits TILE_IDX_BITS)
 constexpr uint32_t PUR_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t TILE_PURITY_FAST = TILE_TAB * (4 + 8 + 4);
-constexpr uint32_t TILE_PURITY_THREADS = 512, TILE_PURITY_PER = (TILE_SORT_MAX + TILE_PURITY_THREADS - 1) / TILE_PURITY_THREADS;
+constexpr uint32_t TILE_PURITY_THREADS = ABG_TILE_PAIRS_LOG2 > 11 ? 1024 : 512, TILE_PURITY_PER = (TILE_SORT_MAX + TILE_PURITY_THREADS - 1) / TILE_PURITY_THREADS;
 template <class Sync>
 ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 {
@@ -897,7 +901,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		}
 	}
 	pairs([&](const TilePair& r, uint32_t i, uint32_t s, uint32_t) {
-		atomic_min_u64(&first[s], ((uint64_t)tp_t(r) << 12) | i);
+		atomic_min_u64(&first[s], ((uint64_t)tp_t(r) << TILE_IDX_BITS) | i);
 		atomic_add_u32(&info[s], 1);
 	});
 	sy.barrier();
@@ -909,7 +913,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 #pragma unroll
 		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
 			const uint32_t i = tid + q * nt;
-			fst[q] = bin[i < n ? (uint32_t)(first[slot[q] & 0xFFFFu] & 0xFFFu) : 0u];
+			fst[q] = bin[i < n ? (uint32_t)(first[slot[q] & 0xFFFFu] & ((1u << TILE_IDX_BITS) - 1u)) : 0u];
 		}
 #pragma unroll
 		for (uint32_t q = 0; q < TILE_PURITY_PER; q++) {
@@ -919,7 +923,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		}
 	} else
 	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
-		const TilePair f = bin[(uint32_t)(first[s] & 0xFFFu)];
+		const TilePair f = bin[(uint32_t)(first[s] & ((1u << TILE_IDX_BITS) - 1u))];
 		if (r.hlo != f.hlo || r.hhi != f.hhi || ((r.tj ^ f.tj) != 0 && tp_t(r) == tp_t(f))) atomic_or_u32(&info[s], 0x80000000u);
 	});
 	sy.barrier();
@@ -938,7 +942,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 		// 32-byte write transaction to a random place: the first two hash functions speak for all (an op whose first
 		// two counters are BOTH shared learns nothing and goes to the rounds -- op_verdict reads n == 0 as that)
 		if (tp_j(r) >= e.lead_js) return;
-		const bool first_op = (uint32_t)(first[s] >> 12) == t;
+		const bool first_op = (uint32_t)(first[s] >> TILE_IDX_BITS) == t;
 		e.lead[t] = (inf & 0x7FFFFFFFu) | (first_op ? LEAD_BIT : 0u);
 	});
 }
@@ -3228,8 +3232,8 @@ class Engine {
 		const uint64_t R = dist() ? (uint64_t)comm_.world : 1;
 		ntiles_ = ((dist() ? own_chunk_ : m_) + TILE_COUNTERS - 1) >> TILE_BITS;
 		if (cfg_.tiled_insert && !casc_.bits && p_.nh <= 16) {
-			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114));
-			T = std::min<uint64_t>(T, 2048ull * ntiles_ * R / p_.nh);
+			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114 * (TILE_PAIRS_MEAN / 2048u)));
+			T = std::min<uint64_t>(T, (uint64_t)TILE_PAIRS_MEAN * ntiles_ * R / p_.nh);
 			T = std::min<uint64_t>(T, 1ull << TP_T_BITS); // (a pair holds its op in 28 bits)
 			if (T >= 1024) {
 				tiled_ = true;

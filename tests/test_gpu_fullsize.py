@@ -172,3 +172,34 @@ def test_full_size_spaced_seed_run_is_the_reference_fasta():
     assert (n, bp) == (golden["unitigs"], golden["unitig_bp"])
     assert fasta.hexdigest() == golden["fasta_sha256"]
     g.close()
+
+
+def test_full_size_run_in_configs2_regime_is_the_reference_fasta():
+    """configs[2] gives its counting filter 35.8 bytes per genome base (B=40G for 1.2 Gbp), half of configs[1]'s: the false-positive
+    branches, the crowded counters of PASS 1 and the commit's redundancy tests all run at another rate.  Its reference run at size
+    is beyond a round of this build (14-15 h at -j1, 46 GB), so the regime is pinned at configs[1]'s size: the 5 M pairs with -b1G
+    (1 GiB / 30 Mbp), the unmodified reference at -j1 (tests/golden/make_full_size.py --only ref_c2regime).  Same bytes."""
+    import torch
+    import bench
+    device = torch.device("cuda:0")
+    genome_len = int(PAIRS * 2 * READ_LEN / 50.0)
+    words, woff, lens = bench.gen_packed_reads(genome_len, PAIRS, READ_LEN, 0.005, seed=42, device=device)
+    torch.cuda.synchronize()
+    golden = bench.golden_for(2, PAIRS, K, 0, "1G")
+    assert golden is not None, "tests/golden/full_size.json has no run in configs[2]'s regime"
+    g = api.BloomDBG(K, bloom_bytes=1 << 30, num_hashes=4, min_cov=2)
+    g.load_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), 2 * PAIRS)
+    assert g.counting_stats()[1] == golden["filtered_popcount"]
+    _, contigs = g.assemble_packed(words.data_ptr(), woff.data_ptr(), lens.data_ptr(), 2 * PAIRS, want_results=False, want_contigs=True)
+    fasta = hashlib.sha256()
+    n = bp = 0
+    for c in contigs:
+        if not c.redundant:
+            fasta.update(b">%d %d %d read:r%d/%d\n%s\n" % (c.contig_id, len(c.seq), c.coverage, c.read_index % PAIRS, 1 if c.read_index < PAIRS else 2, c.seq))
+            n += 1
+            bp += len(c.seq)
+    assert (n, bp) == (golden["unitigs"], golden["unitig_bp"])
+    assert fasta.hexdigest() == golden["fasta_sha256"]
+    ca = g.assembly_counters()
+    assert "solid reads: %d" % ca["solid_reads"] in golden["last_progress_line"] and "visited reads: %d" % ca["visited_reads"] in golden["last_progress_line"]
+    g.close()
