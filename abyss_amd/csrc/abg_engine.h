@@ -51,6 +51,9 @@ struct Config {
 	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	bool benign_sharers = true;       // ... and k-mers that share a counter they cannot write are settled by the tiles as well (op_verdict)
+	bool cosettle = true;             // ... and k-mers that may write shared counters, when every k-mer on those is settled too (op_verdict, FCoSettle)
+	uint32_t cosettle_passes = 6;     // passes of that fixed point before the candidates left over go to the rounds after all (1 .. CO_MAX_PASSES)
+	uint32_t cosettle_log2 = 24;      // bits of the table of counters the rounds' k-mers touch
 	uint32_t walk_slots = 4096;       // concurrent walkers (one per wavefront; 2048 are resident)
 	uint32_t tb_cap = 512;            // trueBranch frames per walker beyond the ones that fit in LDS
 	uint32_t buf_cap = 1u << 16;      // extension bases per side per walker
@@ -571,6 +574,13 @@ struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219
 // touches, and keep their order among themselves in the reservation rounds.
 constexpr int MAX_RANKS = 16;
 constexpr uint32_t TILE_BITS = 16, TILE_COUNTERS = 1u << TILE_BITS; // 64 KB of counters in LDS
+// The pairs are binned, and judged by tile_purity, in units of a tile or of a half / quarter of one (BIN_COUNTERS); tile_apply takes the
+// TILE_SPLIT bins of its tile together.  A batch is sized by the pairs a BIN sees (what tile_purity's table in LDS holds): with two
+// bins to the tile a batch is twice as large and the counter array is streamed through tile_apply half as often.
+#ifndef ABG_TILE_SPLIT_LOG2
+#define ABG_TILE_SPLIT_LOG2 1 // (measured on configs[1]: 0 -> 653 ms a step, 1 -> 634, 2 -> 675-681: notes/README.md)
+#endif
+constexpr uint32_t BIN_BITS = TILE_BITS - ABG_TILE_SPLIT_LOG2, BIN_COUNTERS = 1u << BIN_BITS, TILE_SPLIT = 1u << ABG_TILE_SPLIT_LOG2;
 #ifndef ABG_TILE_PAIRS_LOG2
 #define ABG_TILE_PAIRS_LOG2 11 // a batch is sized so that a tile sees 2^this pairs of it on average (12: half as many batches, twice the LDS table; see notes/README.md)
 #endif
@@ -598,7 +608,14 @@ struct TileEnv {
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
 	uint32_t benign = 1;              // op_verdict: k-mers that cannot write their shared counters are settled by the tiles too
 	uint32_t lead_js = 2;             // tile_purity: pairs of the first lead_js hash functions write `lead` (a partitioned run: all -- every rank must know)
+	// the settling of k-mers that DO write shared counters (op_verdict, FCoSettle); all null / 0 when that is off
+	uint32_t* bad = nullptr;          // [(bad_mask + 1) / 32] bit "some k-mer on this counter goes through the rounds", by hashed counter position
+	uint32_t bad_mask = 0;
+	uint8_t* wmask = nullptr;         // [T] candidates: bit j = the k-mer may raise its shared counter j
+	uint32_t* chg = nullptr;          // [CO_MAX_PASSES + 1] chg[i] != 0: pass i took a candidate back
 };
+constexpr uint32_t CO_MAX_PASSES = 15;
+constexpr uint8_t PEND_NO = 0, PEND_ROUNDS = 1, PEND_CANDIDATE = 2; // TileEnv::pendf
 // canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
 // rolled (NTC64, nthash.hpp:242-257,275-279).  Under a spaced seed the rolled state is the UNMASKED
 // pair plus the XOR of the masked positions' terms (what maskHash takes out again,
@@ -724,7 +741,7 @@ struct FBinCoarse { // item: a chunk of BIN_CHUNK_OPS ops; fast memory: 2 x ncoa
 		// the coarse bin of counter j of hash h, or ~0 when the counter is another rank's
 		auto coarse_of = [&](uint64_t h, unsigned j) -> uint32_t {
 			const uint64_t pos = pos_i(b.e.p, h, j) - b.e.lo; // (a counter outside [lo, m) is another rank's)
-			return pos < span ? (uint32_t)((pos >> TILE_BITS) >> b.cshift) : 0xFFFFFFFFu;
+			return pos < span ? (uint32_t)((pos >> BIN_BITS) >> b.cshift) : 0xFFFFFFFFu;
 		};
 		auto put = [&](uint64_t h, uint64_t t, unsigned j, uint32_t cb) {
 			const uint32_t slot = atomic_add_u32(&cur[cb], 1);
@@ -796,7 +813,7 @@ struct FBinFine { // item: chunk q of coarse bin cb (item = cb * chunks_per_bin 
 		const TilePair* src = b.coarse + (uint64_t)cb * b.ccap;
 		// the tile (within the coarse bin) a pair belongs to
 		auto fine_of = [&](const TilePair& r) -> uint32_t {
-			return (uint32_t)((pos_i(b.e.p, tp_h(r), tp_j(r)) - b.e.lo) >> TILE_BITS) & (nfine - 1);
+			return (uint32_t)((pos_i(b.e.p, tp_h(r), tp_j(r)) - b.e.lo) >> BIN_BITS) & (nfine - 1);
 		};
 		for (uint32_t i = tid; i < nfine; i += nt) hist[i] = 0;
 		sy.barrier();
@@ -866,7 +883,7 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	const bool keep = nt >= TILE_PURITY_THREADS;
 	TilePair mine[TILE_PURITY_PER];
 	uint32_t slot[TILE_PURITY_PER] = {}; // (table slot | offset within the tile << 16)
-	auto off_of = [&](const TilePair& r) -> uint32_t { return (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1); };
+	auto off_of = [&](const TilePair& r) -> uint32_t { return (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (BIN_COUNTERS - 1); };
 	auto slot_of = [&](uint32_t off) -> uint32_t {
 		uint32_t s = ((off * 0x9E3779B1u) >> 20) & (TILE_TAB - 1);
 		for (;;) {
@@ -960,15 +977,46 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 //  * Anything else -- and every op when a bin overflowed -- goes through the reservation rounds.
 // Every op of K reads the same flags, the same n and the same counters (nothing writes them between
 // the previous batch's rounds and tile_apply), so all of K's ops get the same verdict.
+ABG_HD uint32_t bad_slot(const TileEnv& e, uint64_t pos) { return (uint32_t)(pos ^ (pos >> 27)) & e.bad_mask; }
+ABG_HD void mark_bad(const TileEnv& e, uint64_t h, unsigned js)
+{
+	for (unsigned j = 0; j < e.p.nh && j < 8; j++)
+		if ((js >> j) & 1u) { const uint32_t s = bad_slot(e, pos_i(e.p, h, j)); atomic_or_u32(&e.bad[s >> 5], 1u << (s & 31u)); }
+}
+ABG_HD bool any_bad(const TileEnv& e, uint64_t h, unsigned js)
+{
+	bool b = false;
+	for (unsigned j = 0; j < e.p.nh && j < 8; j++)
+		if ((js >> j) & 1u) { const uint32_t s = bad_slot(e, pos_i(e.p, h, j)); b |= ((ld_coherent(&e.bad[s >> 5]) >> (s & 31u)) & 1u) != 0; }
+	return b;
+}
+// ... and (round 5) the k-mers that DO write a shared counter, as long as nothing about it depends on the order:
+//  * K's shared counters all hold at least m_P, the minimum of its own counters P.  Then a shared counter c never falls
+//    below K's running minimum over P (an op of K that finds c AT the minimum raises it along with the others, and the
+//    other k-mers only ever raise it): K's n ops take P to tg exactly as if S were not there, and each of them raises c
+//    only when c equals the running minimum, by one, never past tg.
+//  * If EVERY k-mer on c is of that kind (or cannot write c at all: the case above), c ends at the maximum of its old value
+//    and the targets of the k-mers on it, in whatever order their ops run: it is at least each target (see above), and no
+//    op takes it past the target of its own k-mer.  None of them reads anything an op outside the group writes.
+//  * If some k-mer on c goes through the rounds, it reads c at its place in the order: every k-mer that may raise c has to
+//    go through the rounds with it.  That is a fixed point over the k-mers and the counters they share: op_verdict marks
+//    the counters of the k-mers the rounds get (`bad`, a bit per hashed counter position: a collision sends a k-mer
+//    to the rounds that need not go, never the reverse) and leaves the others as CANDIDATES; FCoSettle takes a candidate
+//    back that may raise a marked counter and marks its counters, pass after pass until a pass changes nothing (chains
+//    of k-mers sharing counters are short: a batch touches ~3 % of the counters); FCoFinal settles what is left, or
+//    sends every candidate to the rounds when the last pass still found something.
+// (tests/hostcheck; the rule and its closure were first checked against the sequential filter in a simulation of 59
+// batches at configs[1]'s and configs[2]'s occupancy, and with counters driven into saturation: notes/README.md.)
 ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend)
 {
-	tgt = 0; pend = 1;
+	tgt = 0; pend = PEND_ROUNDS;
 	if (e.flags[0]) return;
 	const uint32_t fl = e.opflag[t], L = e.lead[t], n = L & ~LEAD_BIT;
-	if (fl && (!n || e.p.nh > 8 || !e.benign)) return;
-	if (!fl && !(L & LEAD_BIT)) { pend = 0; return; } // (its k-mer's leader does the raising)
+	if (fl && (!n || e.p.nh > 8 || !e.benign)) { if (e.bad && e.p.nh <= 8) mark_bad(e, e.h0[t], fl); return; }
+	if (!fl && !(L & LEAD_BIT)) { pend = PEND_NO; return; } // (its k-mer's leader does the raising)
 	const uint64_t h = e.h0[t];
 	unsigned mp = 256, ms = 256;
+	unsigned cs[8];
 	for (unsigned j0 = 0; j0 < e.p.nh; j0 += 4) { // (four counters in flight: a load right before its use is a round trip each)
 		unsigned c[4];
 #pragma unroll
@@ -977,12 +1025,23 @@ ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend
 		for (unsigned q = 0; q < 4; q++) {
 			const unsigned j = j0 + q;
 			if (j >= e.p.nh) continue;
+			if (j < 8) cs[j] = c[q];
 			if ((fl >> j) & 1u) ms = c[q] < ms ? c[q] : ms; else mp = c[q] < mp ? c[q] : mp;
 		}
 	}
 	const unsigned tg = mp + n > 255 ? 255u : mp + n;
-	if (fl && ms < tg) return;
-	pend = 0;
+	if (fl && ms < tg) {
+		if (!e.bad) return;
+		if (ms < mp) { mark_bad(e, h, fl); return; }
+		// a candidate: the shared counters it may raise
+		unsigned w = 0;
+		for (unsigned j = 0; j < e.p.nh && j < 8; j++) if (((fl >> j) & 1u) && cs[j] < tg) w |= 1u << j;
+		e.wmask[t] = (uint8_t)w;
+		pend = PEND_CANDIDATE;
+		if (L & LEAD_BIT) tgt = (uint8_t)tg; // (mp < 255: ms < tg <= 255 and ms >= mp)
+		return;
+	}
+	pend = PEND_NO;
 	if ((L & LEAD_BIT) && mp < 255) tgt = (uint8_t)tg;
 }
 struct FOpTarget { // one op per item: its target (leaders) and whether it is left to the reservation rounds
@@ -994,14 +1053,60 @@ struct FOpTarget { // one op per item: its target (leaders) and whether it is le
 		e.tgt[t] = tg; e.pendf[t] = pd;
 	}
 };
+ABG_HD bool has_candidate(uint64_t w) // some byte of w is PEND_CANDIDATE
+{
+	const uint64_t x = w ^ (0x0101010101010101ull * PEND_CANDIDATE);
+	return ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0;
+}
+struct FCoSettle { // eight ops per item, pass `pass` >= 1 of the fixed point (op_verdict): a candidate that may raise a marked counter goes to the rounds
+	TileEnv e; uint64_t T; uint32_t pass;
+	ABG_HD void operator()(uint64_t g, uint32_t) const
+	{
+		if (pass > 1 && !e.chg[pass - 1]) return; // (the pass before changed nothing: done)
+		const uint64_t w = ((const uint64_t*)e.pendf)[g];
+		if (!has_candidate(w)) return;
+		for (unsigned q = 0; q < 8; q++) {
+			const uint64_t t = g * 8 + q;
+			if (((w >> (8 * q)) & 0xFFu) != PEND_CANDIDATE || t >= T) continue;
+			const uint64_t h = e.h0[t];
+			if (!any_bad(e, h, e.wmask[t])) continue;
+			e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0;
+			mark_bad(e, h, e.opflag[t]);
+			e.chg[pass] = 1;
+		}
+	}
+};
+struct FCoFinal { // eight ops per item: the candidates left are settled -- or all go to the rounds, when the last pass still took one back
+	TileEnv e; uint64_t T; uint32_t last;
+	ABG_HD void operator()(uint64_t g, uint32_t) const
+	{
+		const uint64_t w = ((const uint64_t*)e.pendf)[g];
+		if (!has_candidate(w)) return;
+		const bool all_back = e.chg[last] != 0;
+		for (unsigned q = 0; q < 8; q++) {
+			const uint64_t t = g * 8 + q;
+			if (((w >> (8 * q)) & 0xFFu) != PEND_CANDIDATE || t >= T) continue;
+			if (all_back) { e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0; }
+			else e.pendf[t] = PEND_NO;
+		}
+	}
+};
 // `lds`: TILE_COUNTERS bytes
 template <class Sync>
 ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 {
 	if (ld_coherent(&e.flags[0])) return;
-	const uint32_t n = ld_coherent(&e.tcur[tile]) < e.cap ? ld_coherent(&e.tcur[tile]) : e.cap;
+	// the tile's bins (TILE_SPLIT of them; the last tile of the range may have fewer)
+	const uint64_t nbins = (e.m - e.lo + BIN_COUNTERS - 1) >> BIN_BITS;
+	uint32_t nb[TILE_SPLIT], n = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < TILE_SPLIT; q++) {
+		const uint64_t bi = tile * TILE_SPLIT + q;
+		const uint32_t f = bi < nbins ? ld_coherent(&e.tcur[bi]) : 0u;
+		nb[q] = f < e.cap ? f : e.cap;
+		n += nb[q];
+	}
 	if (!n) return;
-	const TilePair* bin = e.bins + tile * e.cap;
 	const uint32_t tid = sy.tid(), nt = sy.nthreads();
 	const uint64_t base = e.lo + (tile << TILE_BITS);
 	const uint32_t span = (uint32_t)(e.m - base < TILE_COUNTERS ? e.m - base : TILE_COUNTERS); // (lo and m are multiples of 8)
@@ -1012,14 +1117,42 @@ ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 	bool any = false;
 	// (measured: fetching several pairs and their targets ahead, or the tile in batches of eight loads, does not help here --
 	// 1.56 against 1.50 ms a launch: the kernel streams the array in and out and lives on its many workgroups in flight)
-	for (uint32_t i = tid; i < n; i += nt) {
-		const TilePair r = bin[i];
+	constexpr uint32_t PER = TILE_SPLIT * ((TILE_SORT_MAX + 1023) / 1024);
+	uint32_t mine[PER]; // (a thread's raises as offset | target << 16, for the passes below)
+	uint32_t kept = 0;
+	const bool keep = e.bad && nt >= 1024;
+	// body(pair): its target, when there is one, against the counter
+	auto raise = [&](const TilePair& r, bool first) -> bool {
 		const uint8_t tg = e.tgt[tp_t(r)];
-		if (!tg) continue;
+		if (!tg) return false;
 		// (a pure counter has one writer -- its k-mer's leader, possibly through two hash functions
 		// with the same value -- so plain byte stores do)
 		const uint32_t off = (uint32_t)(pos_i(e.p, tp_h(r), tp_j(r)) - e.lo) & (TILE_COUNTERS - 1);
-		if (lds[off] < tg) { lds[off] = tg; any = true; }
+		if (first && keep && kept < PER) mine[kept++] = off | ((uint32_t)tg << 16);
+		if (lds[off] < tg) { lds[off] = tg; return true; }
+		return false;
+	};
+#pragma unroll
+	for (uint32_t q = 0; q < TILE_SPLIT; q++) {
+		const TilePair* bin = e.bins + (tile * TILE_SPLIT + q) * e.cap;
+		for (uint32_t i = tid; i < nb[q]; i += nt) any |= raise(bin[i], true);
+	}
+	if (e.bad) {
+		// a shared counter may have several writers now (op_verdict: k-mers settled together), and it ends at the largest
+		// of their targets: plain byte stores again, and passes until every raise finds its counter at or above its target
+		for (bool again = any; sy.any(again);) {
+			again = false;
+			if (keep) {
+#pragma unroll
+				for (uint32_t q = 0; q < PER; q++)
+					if (q < kept) { const uint32_t off = mine[q] & 0xFFFFu; const uint8_t tg = (uint8_t)(mine[q] >> 16); if (lds[off] < tg) { lds[off] = tg; again = true; } }
+			} else {
+				for (uint32_t q = 0; q < TILE_SPLIT; q++) {
+					const TilePair* bin = e.bins + (tile * TILE_SPLIT + q) * e.cap;
+					for (uint32_t i = tid; i < nb[q]; i += nt) again |= raise(bin[i], false);
+				}
+			}
+		}
 	}
 	if (sy.any(any)) {
 		uint64_t* o8 = (uint64_t*)(e.cnt + base);
@@ -1162,7 +1295,7 @@ struct FBinCoarseRec { // FBinCoarse over received records: item = a chunk of BI
 		const uint64_t span = b.e.m - b.e.lo;
 		auto coarse_of = [&](const TilePair& r) -> uint32_t {
 			const uint64_t pos = pos_i(b.e.p, tp_h(r), tp_j(r)) - b.e.lo;
-			return pos < span ? (uint32_t)((pos >> TILE_BITS) >> b.cshift) : 0xFFFFFFFFu; // (never: the sender computed the same owner)
+			return pos < span ? (uint32_t)((pos >> BIN_BITS) >> b.cshift) : 0xFFFFFFFFu; // (never: the sender computed the same owner)
 		};
 		for (uint32_t i = tid; i < b.ncoarse; i += nt) hist[i] = 0;
 		sy.barrier();
@@ -3122,11 +3255,12 @@ class Engine {
 	uint32_t hash_run_ = 8;    // FHashOps: consecutive ops per lane
 	uint64_t insert_scratch_bytes_ = 0; // what ensure_insert holds
 	uint32_t claim_log2_ = 0;  // slots per claim table
-	bool tiled_ = false; uint64_t ntiles_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
+	bool tiled_ = false; uint64_t ntiles_ = 0, napply_ = 0; uint32_t tile_cap_ = 0; // PASS 1 through tiles (TileEnv)
 	TilePair* coarse_ = nullptr; uint32_t* ccur_ = nullptr; uint32_t coarse_cap_ = 0, cshift_ = 0, ncoarse_ = 0;
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr; uint8_t* pendf_ = nullptr;
 	// a second set of hashes, bins and bin cursors: the batch being staged on the side stream (stage_bins)
 	uint64_t* h0_alt_ = nullptr; TilePair* bins_alt_ = nullptr; uint32_t* tcur_alt_ = nullptr;
+	uint8_t* wmask_ = nullptr; uint32_t* bad_ = nullptr; uint32_t* cochg_ = nullptr; // what settles k-mers writing shared counters (op_verdict)
 	uint32_t* lead_alt_ = nullptr; uint8_t* opflag_alt_ = nullptr; // ... and, when its tiles are judged there as well, of what tile_purity leaves per op
 	bool staged_purity_ = false;
 	// PASS 2 resources
@@ -3230,9 +3364,10 @@ class Engine {
 		tiled_ = false;
 		// (partitioned run: a rank tiles its own range, and sees 1/R of a batch's pairs)
 		const uint64_t R = dist() ? (uint64_t)comm_.world : 1;
-		ntiles_ = ((dist() ? own_chunk_ : m_) + TILE_COUNTERS - 1) >> TILE_BITS;
+		ntiles_ = ((dist() ? own_chunk_ : m_) + BIN_COUNTERS - 1) >> BIN_BITS; // (bins: what the pairs are sorted into and tile_purity judges)
+		napply_ = (ntiles_ + TILE_SPLIT - 1) / TILE_SPLIT;                     // (tiles: what tile_apply holds in LDS)
 		if (cfg_.tiled_insert && !casc_.bits && p_.nh <= 16) {
-			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114 * (TILE_PAIRS_MEAN / 2048u)));
+			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114 * (TILE_PAIRS_MEAN / 2048u) * TILE_SPLIT));
 			T = std::min<uint64_t>(T, (uint64_t)TILE_PAIRS_MEAN * ntiles_ * R / p_.nh);
 			T = std::min<uint64_t>(T, 1ull << TP_T_BITS); // (a pair holds its op in 28 bits)
 			if (T >= 1024) {
@@ -3275,7 +3410,12 @@ class Engine {
 			lead_ = (uint32_t*)be_.alloc(nb * 4);
 			opflag_ = (uint8_t*)be_.alloc(nb + 8); // (flagged with word-wide ORs)
 			tgt_ = (uint8_t*)be_.alloc(nb);
-			pendf_ = (uint8_t*)be_.alloc(nb);
+			pendf_ = (uint8_t*)be_.alloc(nb + 8); // (FCoSettle reads it a word at a time)
+			if (!dist() && cfg_.cosettle && cfg_.benign_sharers && p_.nh <= 8) {
+				wmask_ = (uint8_t*)be_.alloc(nb);
+				bad_ = (uint32_t*)be_.alloc((1ull << cfg_.cosettle_log2) / 8);
+				cochg_ = (uint32_t*)be_.alloc((CO_MAX_PASSES + 1) * 4);
+			}
 			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
 			if (routed()) {
 				// a rank hashes a slice of at most rown_ ops and sends nh records each; a destination gets 1 / R of them on average
@@ -3328,6 +3468,7 @@ class Engine {
 	{
 		if (!h0_) return;
 		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); be_.free(pendf_); tiled_ = false; }
+		if (bad_) { be_.free(wmask_); be_.free(bad_); be_.free(cochg_); wmask_ = nullptr; bad_ = nullptr; cochg_ = nullptr; }
 		if (tred_) { be_.free(tred_); tred_ = nullptr; }
 		if (rsend_) {
 			be_.free(rsend_); be_.free(rrecv_); be_.free(rslot_); be_.free(rcur_); be_.free(rrep_out_); be_.free(rrep_in_); be_.free(rtgt_out_); be_.free(rtgt_in_); be_.free(rpendf_);
@@ -3402,9 +3543,20 @@ class Engine {
 				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 			}
 			// (the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
+			if (bad_) {
+				te.bad = bad_; te.bad_mask = (uint32_t)((1ull << cfg_.cosettle_log2) - 1); te.wmask = wmask_; te.chg = cochg_;
+				be_.memset(bad_, 0, (1ull << cfg_.cosettle_log2) / 8);
+				be_.memset(cochg_, 0, (CO_MAX_PASSES + 1) * 4);
+			}
 			if (!judged) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
-			{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+			if (bad_) {
+				// the k-mers that may raise shared counters: settled together, or sent to the rounds together (op_verdict)
+				const uint32_t np = std::max(1u, std::min(cfg_.cosettle_passes, CO_MAX_PASSES));
+				for (uint32_t q = 1; q <= np; q++) { FCoSettle f{ te, T, q }; be_.launch((T + 7) / 8, f, "co_settle"); }
+				FCoFinal f{ te, T, np }; be_.launch((T + 7) / 8, f, "co_settle");
+			}
+			{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
 			be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_); // the ops for the rounds, in op order
 			// the next batch's hashing and binning starts here, beside the rounds (queued before tile_apply it
 			// slows that down by as much as it gains: 453-463 vs 446-452 ms per configs[1] step)
@@ -3508,7 +3660,7 @@ class Engine {
 		{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
 		c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
 		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
-		{ FTileApply f{ te }; be_.launch_tiles(ntiles_, f, "tile_apply"); }
+		{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
 		be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_);
 		if (stage_next_) { stage_next_(); stage_next_ = nullptr; } // (the next batch, beside this one's rounds)
 		uint32_t nn[4] = { 0, 0, 0, 0 };
@@ -3603,7 +3755,7 @@ class Engine {
 			FRouteTgt f{ rrecv_, rtgt_in_, tgt_ };
 			be_.launch(nrec, f, "route_tgt");
 			FTileApply fa{ te };
-			be_.launch_tiles(ntiles_, fa, "tile_apply");
+			be_.launch_tiles(napply_, fa, "tile_apply");
 		}
 		// the ops left over: each rank's own (in op order), made known to all
 		be_.memset(pend_n_, 0, 8);

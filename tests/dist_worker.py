@@ -231,8 +231,8 @@ def main():
         # the same through the ranks' tiles: one k-mer hundreds of times in a batch, counters driven to 255
         reads = [b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAGCTTGGCATTCGGATACCGGTAAGCTAGCTAACGGT"] * 400 + [b"A" * 150] * 12 + [b"AC" * 75] * 8
         buf, off = api.concat_seqs(reads)
-        o = ob.Oracle(40, counters=1 << 20)
-        hc = DistHostCheck(40, 1 << 20, insert_batch=30000, claim_log2=16)
+        o = ob.Oracle(40, counters=1 << 22)
+        hc = DistHostCheck(40, 1 << 22, insert_batch=30000, claim_log2=16)
         hc.attach()
         o.load(buf, off)
         hc.load(buf, off)

@@ -35,7 +35,9 @@ def test_partitioned_run_reproduces_reference_run(name, world):
     # PASS 1 went through each rank's own tiles (Engine::insert_tiles_dist), the k-mers that share a
     # counter with another one through the partitioned reservation rounds
     st = out["stats"]
-    assert st["tile_overflows"] == 0 and 0 < st["tiled_pending"] < st["tiled_ops"], st
+    # (the tandem repeats put hundreds of ops of one k-mer into a batch of a few thousand: a bin of this small filter may run
+    # over, and that batch then takes the rounds as a whole -- tested on its own in test_hostcheck.py)
+    assert (st["tile_overflows"] == 0 or "tandem" in name) and 0 < st["tiled_pending"] < st["tiled_ops"], st
 
 
 def test_partitioned_run_on_eight_ranks():

@@ -15,7 +15,7 @@ from util import GOLDEN, GoldenCase, contig_tuple, mask_of, random_reads
 
 class HostCheck:
     def __init__(self, k, counters, num_hashes=4, min_cov=2, trim=None, insert_batch=0, claim_log2=0, p2_first=0, mask=None):
-        l = C.CDLL(build.build_hostcheck())
+        l = C.CDLL(os.environ.get("ABG_HOSTCHECK_LIB") or build.build_hostcheck())
         l.hc_create.restype = C.c_void_p
         l.hc_create.argtypes = [C.c_uint] * 4 + [C.c_uint64, C.c_uint64, C.c_uint, C.c_uint64, C.c_char_p]
         l.hc_destroy.argtypes = [C.c_void_p]
@@ -658,14 +658,55 @@ def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
     assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
     # homopolymer runs: one k-mer hundreds of times in a batch (a counter with 254 pairs or more
     # is left to the reservation rounds, which then see every op of that k-mer)
-    buf, off = api.concat_seqs([b"A" * 150] * 30 + [bytes(r) for r in rep[:50]] + [b"AC" * 75] * 20)
-    o = ob.Oracle(k, counters=1 << 18)
-    hc = HostCheck(k, 1 << 18, insert_batch=30000, claim_log2=16)
+    buf, off = api.concat_seqs([b"A" * 150] * 15 + [bytes(r) for r in rep[:50]] + [b"AC" * 75] * 20)  # (1,665 ops of one k-mer: a bin holds them)
+    o = ob.Oracle(k, counters=1 << 20)
+    hc = HostCheck(k, 1 << 20, insert_batch=30000, claim_log2=16)
     o.load(buf, off)
     hc.load(buf, off)
     st = hc.stats()
     assert st["tiled_ops"] > 0 and st["tiled_pending"] > 254
     assert np.array_equal(o.counters(), hc.counters())
+
+
+def test_kmers_writing_shared_counters_are_settled_together_or_go_to_the_rounds_together(monkeypatch):
+    """op_verdict's round-5 rule (abg_engine.h): a k-mer that may raise a counter it shares is settled by the tiles when every
+    k-mer on that counter is (FCoSettle's fixed point, FCoFinal), the shared counter ending at the largest target -- the
+    counter array stays the oracle's sequential incrementMin (CountingBloomFilter.hpp:135-162) at three occupancies, with
+    the rule off, with too few passes for the fixed point (every candidate then takes the rounds), and with a table of
+    marked counters so small that nearly every candidate meets a marked bit; and it sends an order of magnitude fewer
+    ops to the reservation rounds."""
+    k = 40
+    m1, m2 = synth.make_read_set(30000, 30.0)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    keys = ("ABG_COSETTLE", "ABG_COSETTLE_PASSES", "ABG_COSETTLE_LOG2")
+    for counters in (1 << 21, 1 << 19, 1 << 18):
+        o = ob.Oracle(k, counters=counters)
+        o.load(buf, off)
+        pending = {}
+        for name, env in (("off", {"ABG_COSETTLE": "0"}), ("on", {}), ("one_pass", {"ABG_COSETTLE_PASSES": "1"}),
+                          ("two_passes", {"ABG_COSETTLE_PASSES": "2"}), ("tiny_table", {"ABG_COSETTLE_LOG2": "10"})):
+            for key in keys:
+                monkeypatch.delenv(key, raising=False)
+            for key, val in env.items():
+                monkeypatch.setenv(key, val)
+            hc = HostCheck(k, counters, insert_batch=30000, claim_log2=16)
+            hc.load(buf, off)
+            st = hc.stats()
+            assert st["tiled_ops"] > 0 and st["tile_overflows"] == 0, (counters, name, st)
+            assert np.array_equal(o.counters(), hc.counters()), (counters, name)
+            pending[name] = st["tiled_pending"]
+        assert pending["on"] * 10 < pending["off"], pending
+        assert pending["on"] <= pending["two_passes"] <= pending["one_pass"] <= pending["off"], pending
+        assert pending["on"] <= pending["tiny_table"] <= pending["off"], pending
+    # counters driven into saturation while k-mers share them: 40 copies of a small read set, a dense filter
+    m1, m2 = synth.make_read_set(3000, 30.0)
+    reads = synth.codes_to_ascii(np.concatenate([m1, m2]))
+    buf, off = api.matrix_to_seqs(np.tile(reads, (12, 1)))
+    o = ob.Oracle(k, counters=1 << 16)
+    hc = HostCheck(k, 1 << 16, insert_batch=30000, claim_log2=16)
+    o.load(buf, off)
+    hc.load(buf, off)
+    assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
 
 
 def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
