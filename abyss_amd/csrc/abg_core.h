@@ -1324,6 +1324,19 @@ ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
 }
 #endif
 
+// A lane's rank among the lanes of its wavefront that `want`, and how many do.  Must be reached by all active lanes together.
+// (A serial caller is a wave of one lane.)
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD uint32_t wave_rank(bool want, uint32_t& count)
+{
+	const uint64_t m = __ballot(want ? 1 : 0);
+	count = (uint32_t)__popcll(m);
+	return (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1));
+}
+#else
+ABG_HD uint32_t wave_rank(bool want, uint32_t& count) { count = want ? 1u : 0u; return 0; }
+#endif
+
 // Atomics issued by a cooperative caller (a whole wavefront in lock step, see
 // abg_core.h): lane 0 performs the operation, every lane receives its result.
 #if defined(__HIP_DEVICE_COMPILE__)

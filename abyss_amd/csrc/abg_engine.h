@@ -613,9 +613,15 @@ struct TileEnv {
 	uint32_t bad_mask = 0;
 	uint8_t* wmask = nullptr;         // [T] candidates: bit j = the k-mer may raise its shared counter j
 	uint32_t* chg = nullptr;          // [CO_MAX_PASSES + 1] chg[i] != 0: pass i took a candidate back
+	uint32_t* colist = nullptr;       // [T] the candidates, those of a group of 2^glog2 consecutive ops packed at the start of the group's stretch (CO_* below)
+	uint8_t* cocnt = nullptr;         // [T >> glog2] how many of a group's ops are candidates
+	uint32_t glog2 = 0;               // 6 where a wavefront runs 64 consecutive ops (FOpTarget), 0 for a serial caller
 };
 constexpr uint32_t CO_MAX_PASSES = 15;
 constexpr uint8_t PEND_NO = 0, PEND_ROUNDS = 1, PEND_CANDIDATE = 2; // TileEnv::pendf
+// an entry of TileEnv::colist: the op's place in its group << 26 | CO_MORE | the `bad` slot of the one shared counter it may raise
+// (CO_MORE: it may raise several -- TileEnv::wmask says which, the slot field is 0); CO_DEAD once it went to the rounds
+constexpr uint32_t CO_LANE_SHIFT = 26, CO_MORE = 1u << 25, CO_SLOT_MASK = CO_MORE - 1, CO_DEAD = 0xFFFFFFFFu;
 // canonical hashes of the k-mers [j0, j1) of one sequence: the first from scratch, the rest
 // rolled (NTC64, nthash.hpp:242-257,275-279).  Under a spaced seed the rolled state is the UNMASKED
 // pair plus the XOR of the masked positions' terms (what maskHash takes out again,
@@ -983,11 +989,13 @@ ABG_HD void mark_bad(const TileEnv& e, uint64_t h, unsigned js)
 	for (unsigned j = 0; j < e.p.nh && j < 8; j++)
 		if ((js >> j) & 1u) { const uint32_t s = bad_slot(e, pos_i(e.p, h, j)); atomic_or_u32(&e.bad[s >> 5], 1u << (s & 31u)); }
 }
+// (plain loads: a mark set by another workgroup during this very pass may be missed -- the pass that set it has changed something,
+// so another pass follows and sees it; a device-coherent load goes past the L2 of its XCD, at several times the latency)
 ABG_HD bool any_bad(const TileEnv& e, uint64_t h, unsigned js)
 {
 	bool b = false;
 	for (unsigned j = 0; j < e.p.nh && j < 8; j++)
-		if ((js >> j) & 1u) { const uint32_t s = bad_slot(e, pos_i(e.p, h, j)); b |= ((ld_coherent(&e.bad[s >> 5]) >> (s & 31u)) & 1u) != 0; }
+		if ((js >> j) & 1u) { const uint32_t s = bad_slot(e, pos_i(e.p, h, j)); b |= ((e.bad[s >> 5] >> (s & 31u)) & 1u) != 0; }
 	return b;
 }
 // ... and (round 5) the k-mers that DO write a shared counter, as long as nothing about it depends on the order:
@@ -1007,9 +1015,9 @@ ABG_HD bool any_bad(const TileEnv& e, uint64_t h, unsigned js)
 //    sends every candidate to the rounds when the last pass still found something.
 // (tests/hostcheck; the rule and its closure were first checked against the sequential filter in a simulation of 59
 // batches at configs[1]'s and configs[2]'s occupancy, and with counters driven into saturation: notes/README.md.)
-ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend)
+ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend, uint32_t& centry)
 {
-	tgt = 0; pend = PEND_ROUNDS;
+	tgt = 0; pend = PEND_ROUNDS; centry = 0;
 	if (e.flags[0]) return;
 	const uint32_t fl = e.opflag[t], L = e.lead[t], n = L & ~LEAD_BIT;
 	if (fl && (!n || e.p.nh > 8 || !e.benign)) { if (e.bad && e.p.nh <= 8) mark_bad(e, e.h0[t], fl); return; }
@@ -1038,6 +1046,8 @@ ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend
 		for (unsigned j = 0; j < e.p.nh && j < 8; j++) if (((fl >> j) & 1u) && cs[j] < tg) w |= 1u << j;
 		e.wmask[t] = (uint8_t)w;
 		pend = PEND_CANDIDATE;
+		if (w & (w - 1)) centry = CO_MORE;
+		else for (unsigned j = 0; j < e.p.nh && j < 8; j++) if ((w >> j) & 1u) centry = bad_slot(e, pos_i(e.p, h, j));
 		if (L & LEAD_BIT) tgt = (uint8_t)tg; // (mp < 255: ms < tg <= 255 and ms >= mp)
 		return;
 	}
@@ -1049,45 +1059,65 @@ struct FOpTarget { // one op per item: its target (leaders) and whether it is le
 	ABG_HD void operator()(uint64_t t, uint32_t) const
 	{
 		uint8_t tg, pd;
-		op_verdict(e, t, tg, pd);
+		uint32_t ce;
+		op_verdict(e, t, tg, pd, ce);
 		e.tgt[t] = tg; e.pendf[t] = pd;
+		if (!e.bad) return;
+		// the candidates of this group of ops, packed: what FCoSettle's passes read instead of every op's flags and hashes
+		uint32_t cnt;
+		const uint32_t r = wave_rank(pd == PEND_CANDIDATE, cnt);
+		const uint64_t g0 = (t >> e.glog2) << e.glog2;
+		if (pd == PEND_CANDIDATE) e.colist[g0 + r] = (uint32_t)(t - g0) << CO_LANE_SHIFT | ce;
+		e.cocnt[t >> e.glog2] = (uint8_t)cnt; // (every lane of the group the same value)
 	}
 };
-ABG_HD bool has_candidate(uint64_t w) // some byte of w is PEND_CANDIDATE
-{
-	const uint64_t x = w ^ (0x0101010101010101ull * PEND_CANDIDATE);
-	return ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0;
-}
-struct FCoSettle { // eight ops per item, pass `pass` >= 1 of the fixed point (op_verdict): a candidate that may raise a marked counter goes to the rounds
-	TileEnv e; uint64_t T; uint32_t pass;
+struct FCoSettle { // one group of the candidate list per item, pass `pass` >= 1 of the fixed point (op_verdict): a candidate that may raise a marked counter goes to the rounds
+	TileEnv e; uint32_t pass;
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
 		if (pass > 1 && !e.chg[pass - 1]) return; // (the pass before changed nothing: done)
-		const uint64_t w = ((const uint64_t*)e.pendf)[g];
-		if (!has_candidate(w)) return;
-		for (unsigned q = 0; q < 8; q++) {
-			const uint64_t t = g * 8 + q;
-			if (((w >> (8 * q)) & 0xFFu) != PEND_CANDIDATE || t >= T) continue;
-			const uint64_t h = e.h0[t];
-			if (!any_bad(e, h, e.wmask[t])) continue;
-			e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0;
-			mark_bad(e, h, e.opflag[t]);
-			e.chg[pass] = 1;
+		const uint32_t cnt = e.cocnt[g];
+		const uint64_t base = g << e.glog2;
+		// four entries a turn, and their probes in flight together (a lane's entries are 4 .. 40 bytes in a row: read one at a time
+		// they are a chain of round trips, ~100 us a pass of a 30 M-op batch)
+		for (uint32_t r0 = 0; r0 < cnt; r0 += 4) {
+			uint32_t en[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+			{ const uint4 v = *(const uint4*)(e.colist + base + r0); en[0] = v.x; en[1] = v.y; en[2] = v.z; en[3] = v.w; } // (the list has 64 entries of slack, a group starts at a multiple of 64)
+#else
+			for (uint32_t q = 0; q < 4; q++) en[q] = r0 + q < cnt ? e.colist[base + r0 + q] : CO_DEAD;
+#endif
+			uint32_t word[4];
+#pragma unroll
+			for (uint32_t q = 0; q < 4; q++) {
+				if (r0 + q >= cnt) en[q] = CO_DEAD;
+				word[q] = e.bad[((en[q] & CO_MORE) ? 0u : (en[q] & CO_SLOT_MASK)) >> 5]; // (plain loads: see any_bad)
+			}
+#pragma unroll
+			for (uint32_t q = 0; q < 4; q++) {
+				if (en[q] == CO_DEAD) continue;
+				const uint64_t t = base + (en[q] >> CO_LANE_SHIFT);
+				const bool bad = (en[q] & CO_MORE) ? any_bad(e, e.h0[t], e.wmask[t]) : ((word[q] >> (en[q] & 31u)) & 1u) != 0;
+				if (!bad) continue;
+				e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0;
+				mark_bad(e, e.h0[t], e.opflag[t]);
+				e.colist[base + r0 + q] = CO_DEAD;
+				e.chg[pass] = 1;
+			}
 		}
 	}
 };
-struct FCoFinal { // eight ops per item: the candidates left are settled -- or all go to the rounds, when the last pass still took one back
-	TileEnv e; uint64_t T; uint32_t last;
+struct FCoFinal { // one group of the candidate list per item, when the last pass still took a candidate back: every candidate left goes to the rounds
+	TileEnv e; uint32_t last; // (otherwise they stay PEND_CANDIDATE, which the compaction of the rounds' ops reads as settled)
 	ABG_HD void operator()(uint64_t g, uint32_t) const
 	{
-		const uint64_t w = ((const uint64_t*)e.pendf)[g];
-		if (!has_candidate(w)) return;
-		const bool all_back = e.chg[last] != 0;
-		for (unsigned q = 0; q < 8; q++) {
-			const uint64_t t = g * 8 + q;
-			if (((w >> (8 * q)) & 0xFFu) != PEND_CANDIDATE || t >= T) continue;
-			if (all_back) { e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0; }
-			else e.pendf[t] = PEND_NO;
+		if (!e.chg[last]) return;
+		const uint32_t cnt = e.cocnt[g];
+		for (uint32_t r = 0; r < cnt; r++) {
+			const uint32_t en = e.colist[(g << e.glog2) + r];
+			if (en == CO_DEAD) continue;
+			const uint64_t t = (g << e.glog2) + (en >> CO_LANE_SHIFT);
+			e.pendf[t] = PEND_ROUNDS; e.tgt[t] = 0;
 		}
 	}
 };
@@ -2535,7 +2565,7 @@ struct FPcWrite { // commit order of the records and the contig ids (off = recor
 //   void* alloc(size_t); void free(void*); void memset(void*, int, size_t);
 //   void h2d(void*, const void*, size_t); void d2h(void*, const void*, size_t);
 //   uint32_t max_slots();                       // upper bound on concurrent items of launch()
-//   template<class F> void launch(uint64_t n, F f, const char* name);               // f(i, slot)
+//   template<class F> void launch(uint64_t n, F f, const char* name);               // f(i, slot); 2^ITEM_GROUP_LOG2 consecutive items run as one wavefront (wave_rank)
 //   template<class F> void launch_slots(uint64_t n, F f, uint32_t slots, const char* name);
 //   template<class F> void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name); // one item per wave, lane 0
 //   template<class F> void launch_wave(uint64_t n, F f, const char* name);   // f(item, lane, nlanes): one item per wave
@@ -3260,6 +3290,7 @@ class Engine {
 	TilePair* bins_ = nullptr; uint32_t* tcur_ = nullptr; uint32_t* lead_ = nullptr; uint8_t* opflag_ = nullptr; uint8_t* tgt_ = nullptr; uint8_t* pendf_ = nullptr;
 	// a second set of hashes, bins and bin cursors: the batch being staged on the side stream (stage_bins)
 	uint64_t* h0_alt_ = nullptr; TilePair* bins_alt_ = nullptr; uint32_t* tcur_alt_ = nullptr;
+	uint32_t* colist_ = nullptr; uint8_t* cocnt_ = nullptr;
 	uint8_t* wmask_ = nullptr; uint32_t* bad_ = nullptr; uint32_t* cochg_ = nullptr; // what settles k-mers writing shared counters (op_verdict)
 	uint32_t* lead_alt_ = nullptr; uint8_t* opflag_alt_ = nullptr; // ... and, when its tiles are judged there as well, of what tile_purity leaves per op
 	bool staged_purity_ = false;
@@ -3415,6 +3446,8 @@ class Engine {
 				wmask_ = (uint8_t*)be_.alloc(nb);
 				bad_ = (uint32_t*)be_.alloc((1ull << cfg_.cosettle_log2) / 8);
 				cochg_ = (uint32_t*)be_.alloc((CO_MAX_PASSES + 1) * 4);
+				colist_ = (uint32_t*)be_.alloc((nb + 64) * 4);
+				cocnt_ = (uint8_t*)be_.alloc((nb >> BE::ITEM_GROUP_LOG2) + 64);
 			}
 			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
 			if (routed()) {
@@ -3468,7 +3501,7 @@ class Engine {
 	{
 		if (!h0_) return;
 		if (tiled_) { be_.free(coarse_); be_.free(ccur_); be_.free(bins_); be_.free(tcur_); be_.free(lead_); be_.free(opflag_); be_.free(tgt_); be_.free(pendf_); tiled_ = false; }
-		if (bad_) { be_.free(wmask_); be_.free(bad_); be_.free(cochg_); wmask_ = nullptr; bad_ = nullptr; cochg_ = nullptr; }
+		if (bad_) { be_.free(wmask_); be_.free(bad_); be_.free(cochg_); be_.free(colist_); be_.free(cocnt_); wmask_ = nullptr; bad_ = nullptr; cochg_ = nullptr; colist_ = nullptr; cocnt_ = nullptr; }
 		if (tred_) { be_.free(tred_); tred_ = nullptr; }
 		if (rsend_) {
 			be_.free(rsend_); be_.free(rrecv_); be_.free(rslot_); be_.free(rcur_); be_.free(rrep_out_); be_.free(rrep_in_); be_.free(rtgt_out_); be_.free(rtgt_in_); be_.free(rpendf_);
@@ -3544,7 +3577,8 @@ class Engine {
 			}
 			// (the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
 			if (bad_) {
-				te.bad = bad_; te.bad_mask = (uint32_t)((1ull << cfg_.cosettle_log2) - 1); te.wmask = wmask_; te.chg = cochg_;
+				te.bad = bad_; te.bad_mask = (uint32_t)((1ull << cfg_.cosettle_log2) - 1); te.wmask = wmask_; te.chg = cochg_; // (cosettle_log2 <= 25: CO_SLOT_MASK)
+				te.colist = colist_; te.cocnt = cocnt_; te.glog2 = BE::ITEM_GROUP_LOG2;
 				be_.memset(bad_, 0, (1ull << cfg_.cosettle_log2) / 8);
 				be_.memset(cochg_, 0, (CO_MAX_PASSES + 1) * 4);
 			}
@@ -3553,8 +3587,9 @@ class Engine {
 			if (bad_) {
 				// the k-mers that may raise shared counters: settled together, or sent to the rounds together (op_verdict)
 				const uint32_t np = std::max(1u, std::min(cfg_.cosettle_passes, CO_MAX_PASSES));
-				for (uint32_t q = 1; q <= np; q++) { FCoSettle f{ te, T, q }; be_.launch((T + 7) / 8, f, "co_settle"); }
-				FCoFinal f{ te, T, np }; be_.launch((T + 7) / 8, f, "co_settle");
+				const uint64_t ngroups = (T + (1ull << te.glog2) - 1) >> te.glog2;
+				for (uint32_t q = 1; q <= np; q++) { FCoSettle f{ te, q }; be_.launch(ngroups, f, "co_settle"); }
+				FCoFinal f{ te, np }; be_.launch(ngroups, f, "co_settle");
 			}
 			{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
 			be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_); // the ops for the rounds, in op order

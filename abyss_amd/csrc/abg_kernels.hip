@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(1024) k_insert_drain(abg::InsertDrainEnv e)
 struct ProfEntry { double ms = 0; uint64_t launches = 0; };
 
 struct HipBackend {
+	static constexpr uint32_t ITEM_GROUP_LOG2 = 6; // launch(): a wavefront runs 64 consecutive items (k_foreach)
 	int device = 0;
 	bool good = false;
 	std::string reason;
@@ -414,21 +415,24 @@ struct HipBackend {
 	// order (the same list on every rank of a partitioned run); *count_dev = how many
 	void* cub_tmp = nullptr;
 	size_t cub_tmp_bytes = 0;
+	// the items whose flag byte is 1 (exactly: PASS 1 leaves a 2 on the ops its tiles have settled, abg::PEND_CANDIDATE), in order
+	struct IsOne { __host__ __device__ bool operator()(uint8_t f) const { return f == 1; } };
 	void compact_flagged(const uint32_t* in, const uint8_t* flags, uint64_t n, uint32_t* out, uint32_t* count_dev)
 	{
 		begin("compact");
 		size_t need = 0;
 		hipcub::CountingInputIterator<uint32_t> iota(0);
-		if (in) check(hipcub::DeviceSelect::Flagged(nullptr, need, in, flags, out, count_dev, (int)n, stream), "DeviceSelect");
-		else check(hipcub::DeviceSelect::Flagged(nullptr, need, iota, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		hipcub::TransformInputIterator<bool, IsOne, const uint8_t*> fl(flags, IsOne());
+		if (in) check(hipcub::DeviceSelect::Flagged(nullptr, need, in, fl, out, count_dev, (int)n, stream), "DeviceSelect");
+		else check(hipcub::DeviceSelect::Flagged(nullptr, need, iota, fl, out, count_dev, (int)n, stream), "DeviceSelect");
 		if (need > cub_tmp_bytes) {
 			if (cub_tmp) { hipStreamSynchronize(stream); hipFree(cub_tmp); }
 			cub_tmp_bytes = need * 2;
 			check(hipMalloc(&cub_tmp, cub_tmp_bytes), "hipMalloc");
 		}
 		size_t bytes = cub_tmp_bytes;
-		if (in) check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, in, flags, out, count_dev, (int)n, stream), "DeviceSelect");
-		else check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, iota, flags, out, count_dev, (int)n, stream), "DeviceSelect");
+		if (in) check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, in, fl, out, count_dev, (int)n, stream), "DeviceSelect");
+		else check(hipcub::DeviceSelect::Flagged(cub_tmp, bytes, iota, fl, out, count_dev, (int)n, stream), "DeviceSelect");
 		end("compact");
 	}
 	// in-place inclusive prefix sum over n 64-bit values

@@ -27,6 +27,7 @@ struct SerialSync {
 };
 
 struct SerialBackend {
+	static constexpr uint32_t ITEM_GROUP_LOG2 = 0; // launch() runs its items one at a time
 	bool ok() const { return true; }
 	std::string why() const { return ""; }
 	void bind_thread() {}
@@ -69,7 +70,7 @@ struct SerialBackend {
 	void compact_flagged(const uint32_t* in, const uint8_t* flags, uint64_t n, uint32_t* out, uint32_t* count)
 	{
 		uint32_t m = 0;
-		for (uint64_t i = 0; i < n; i++) if (flags[i]) out[m++] = in ? in[i] : (uint32_t)i;
+		for (uint64_t i = 0; i < n; i++) if (flags[i] == 1) out[m++] = in ? in[i] : (uint32_t)i; // (1 exactly: abg::PEND_ROUNDS)
 		*count = m;
 	}
 	template <class F> void launch(uint64_t n, F f, const char*) { for (uint64_t i = 0; i < n; i++) f(i, 0); }

@@ -10,6 +10,17 @@ run() {
   name=$1; shift
   cd /tmp && env "$@" timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$name -o ks -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-events > $O/$name.log 2>&1
   f=$(find /tmp/ks_$name -name '*kernel_stats.csv' | head -1)
+  t=$(find /tmp/ks_$name -name '*kernel_trace.csv' | head -1)
+  if [ -n "${TRACE_OF:-}" ]; then python - "$t" "$TRACE_OF" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in sys.argv[2].split(","))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+mid = len(rows) // 2
+print("dispatches of", sys.argv[2], "from the middle of the run: name, us")
+for r in rows[mid:mid + 40]:
+    print("   %-40s %8.1f" % (r["Kernel_Name"].split("abg::")[-1][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+PY
+  fi
   cp "$f" $O/${name}_kernel_stats.csv
   python - "$f" $name <<'PY'
 import csv, re, sys
