@@ -185,7 +185,6 @@ struct HipBackend {
 	bool side_pending = false;
 	bool profiling = false;
 	std::map<std::string, ProfEntry> prof;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	uint32_t cus = 256;
 	unsigned long long* ticket = nullptr;
 
@@ -210,8 +209,6 @@ struct HipBackend {
 		}
 		hipEventCreate(&ev2a);
 		hipEventCreate(&ev2b);
-		hipEventCreate(&ev0);
-		hipEventCreate(&ev1);
 		good = true;
 	}
 	~HipBackend()
@@ -221,8 +218,8 @@ struct HipBackend {
 		for (int i = 0; i < 2; i++) { if (big_pin[i]) hipHostFree(big_pin[i]); if (big_ev[i]) hipEventDestroy(big_ev[i]); }
 		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
-		if (ev0) hipEventDestroy(ev0);
-		if (ev1) hipEventDestroy(ev1);
+		prof_drain(true);
+		for (auto& q : prof_free) { hipEventDestroy(q.first); hipEventDestroy(q.second); }
 		if (ev2a) hipEventDestroy(ev2a);
 		if (ev2b) hipEventDestroy(ev2b);
 		if (stream2) hipStreamDestroy(stream2);
@@ -400,12 +397,14 @@ struct HipBackend {
 			check(hipMemcpyAsync(pin, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
 			check(hipStreamSynchronize(stream), "hipStreamSynchronize");
 			memcpy(d, pin, n);
+			prof_drain();
 			return;
 		}
 		check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+		prof_drain(); // (the stream is idle: the launches' events have their times)
 	}
-	void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+	void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); prof_drain(); }
 	void d2d(void* d, const void* s, size_t n)
 	{
 		if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D");
@@ -475,18 +474,39 @@ struct HipBackend {
 		return mem_limit && mem_limit < tot ? (uint64_t)mem_limit : (uint64_t)tot; // (ABG_MEM_LIMIT_MB: a smaller device, for the tests)
 	}
 
-	void begin(const char*) { if (profiling) hipEventRecord(ev0, stream); }
+	// Per-launch timing (abg_profile_enable): an event before and one behind every launch on the main stream, read when the host
+	// waits for the stream anyway (d2h, sync) -- waiting for each launch's second event on the spot kept the host from queueing
+	// ahead, ~1.5 % of a configs[1] step.
+	struct ProfPending { hipEvent_t a, b; ProfEntry* p; };
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+	std::vector<ProfPending> prof_pending;
+	std::pair<hipEvent_t, hipEvent_t> prof_cur{ nullptr, nullptr };
+	void begin(const char*)
+	{
+		if (!profiling) return;
+		if (prof_free.empty()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); prof_free.push_back({ a, b }); }
+		prof_cur = prof_free.back(); prof_free.pop_back();
+		hipEventRecord(prof_cur.first, stream);
+	}
 	void end(const char* name)
 	{
 		check(hipGetLastError(), name);
-		if (!profiling) return;
-		hipEventRecord(ev1, stream);
-		hipEventSynchronize(ev1);
-		float ms = 0;
-		hipEventElapsedTime(&ms, ev0, ev1);
-		ProfEntry& p = prof[name];
-		p.ms += ms;
-		p.launches++;
+		if (!profiling || !prof_cur.first) return;
+		hipEventRecord(prof_cur.second, stream);
+		prof_pending.push_back({ prof_cur.first, prof_cur.second, &prof[name] });
+		prof_cur = { nullptr, nullptr };
+		if (prof_pending.size() >= 8192) prof_drain();
+	}
+	void prof_drain(bool discard = false)
+	{
+		for (ProfPending& q : prof_pending) {
+			if (!discard && hipEventSynchronize(q.b) == hipSuccess) {
+				float ms = 0;
+				if (hipEventElapsedTime(&ms, q.a, q.b) == hipSuccess) { q.p->ms += ms; q.p->launches++; }
+			}
+			prof_free.push_back({ q.a, q.b });
+		}
+		prof_pending.clear();
 	}
 	template <class F>
 	void launch(uint64_t n, F f, const char* name)
@@ -1083,6 +1103,7 @@ int abg_profile_enable(abg_ctx* ctx, int on)
 {
 	if (!ctx) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
+		ctx->s.be.prof_drain();
 		ctx->s.be.profiling = on != 0;
 		return ABG_OK;
 	});
@@ -1091,6 +1112,7 @@ int abg_profile_reset(abg_ctx* ctx)
 {
 	if (!ctx) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
+		ctx->s.be.prof_drain(true);
 		ctx->s.be.prof.clear();
 		return ABG_OK;
 	});
@@ -1099,6 +1121,7 @@ int abg_profile_get(abg_ctx* ctx, const char* name, double* total_ms, uint64_t* 
 {
 	if (!ctx || !name) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
+		ctx->s.be.prof_drain();
 		auto it = ctx->s.be.prof.find(name);
 		double ms = 0;
 		uint64_t n = 0;
@@ -1200,12 +1223,14 @@ int abg_overlap_edges(abg_overlap* o, uint64_t* offsets, uint32_t* targets)
 int abg_overlap_profile(abg_overlap* o, int on)
 {
 	if (!o) return ABG_EINVAL;
+	o->be.prof_drain();
 	o->be.profiling = on != 0;
 	return ABG_OK;
 }
 int abg_overlap_profile_get(abg_overlap* o, const char* name, double* total_ms, uint64_t* launches)
 {
 	if (!o || !name) return ABG_EINVAL;
+	o->be.prof_drain();
 	auto it = o->be.prof.find(name);
 	if (total_ms) *total_ms = it != o->be.prof.end() ? it->second.ms : 0;
 	if (launches) *launches = it != o->be.prof.end() ? it->second.launches : 0;
