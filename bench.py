@@ -125,9 +125,23 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
         args = [build.build_cli(), "-k%d" % a.k, "-b%s" % a.bloom, "-H4", "-q3", "-j%d" % (os.cpu_count() or 1)]
         if a.K:
             args.append("-K%d" % a.K)
-        t0 = time.time()
-        r = subprocess.run(args + ["r1.fq", "r2.fq"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        wall = time.time() - t0
+        # the files just written are 3 GB of dirty pages: let the kernel write them back before anything is timed (they stay in the
+        # page cache), and take the fastest of three runs -- on a box whose host is busy a single run has measured anything between
+        # 1.3 and 4.7 s for the same 0.63 s of device work; every run's wall time is in wall_ms_runs
+        try:
+            os.sync()
+        except Exception:
+            pass
+        walls, r = [], None
+        for _ in range(3):
+            t0 = time.time()
+            ri = subprocess.run(args + ["r1.fq", "r2.fq"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            walls.append(time.time() - t0)
+            if r is None or ri.returncode != 0 or walls[-1] == min(walls):
+                r = ri
+            if ri.returncode != 0:
+                break
+        wall = min(walls)
         adj = None
         if r.returncode == 0 and golden and "adjlist" in golden:
             # abyss-pe's next step on the unitigs just written (AdjList $(alopt) --dot, bin/abyss-pe:575-577)
@@ -143,7 +157,8 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
     kmers = 2 * a.pairs * (read_len - a.k + 1)
     out = {"what": "abyss_amd/bin/abyss-bloom-dbg on the FASTQ files of this read set (two %.2f GB files, page cache warm), process "
                    "start to last unitig written" % (a.pairs * (2 * read_len + 12) / 1e9),
-           "rc": r.returncode, "wall_ms": round(wall * 1e3), "value": kmers / wall / 1e6, "unit": "Mk-mers/s",
+           "rc": r.returncode, "wall_ms": round(wall * 1e3), "wall_ms_runs": [round(w * 1e3) for w in walls],
+           "wall_ms_is": "the fastest of the runs listed", "value": kmers / wall / 1e6, "unit": "Mk-mers/s",
            "threads": os.cpu_count() or 1, "unitigs": r.stdout.count(b">"), "fasta_sha256": hashlib.sha256(r.stdout).hexdigest(),
            "files_written_in_s": round(prep, 1), "measured": "in this run"}
     if golden:
