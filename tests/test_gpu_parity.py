@@ -145,6 +145,36 @@ def test_small_claim_table_and_batches_still_exact():
     assert g.stats()["insert_rounds"] > 20
 
 
+@pytest.mark.parametrize("counters", [1 << 22, 1 << 20, 1 << 19])
+def test_kmers_raising_shared_counters_settled_by_the_tiles_leave_the_oracles_counters(counters, monkeypatch):
+    """PASS 1's round-5 rule on the device (op_verdict / FCoSettle / FCoFinal, tile_apply's repeated raises; the candidates packed per
+    wavefront by a ballot): the counter array is the oracle's sequential incrementMin (CountingBloomFilter.hpp:135-162) with the
+    rule on, off, cut short after one and two passes (every candidate left then takes the rounds) and with a 1,024-bit table of
+    marked counters, at three occupancies; with the rule on an order of magnitude fewer ops take the reservation rounds."""
+    m1, m2 = synth.make_read_set(60000, 40.0, err=0.006, genome_seed=11, read_seed=12)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    o = ob.Oracle(48, counters=counters)
+    o.load(buf, off)
+    want = o.counters()
+    pending = {}
+    for name, env in (("off", {"ABG_COSETTLE": "0"}), ("on", {}), ("one_pass", {"ABG_COSETTLE_PASSES": "1"}),
+                      ("two_passes", {"ABG_COSETTLE_PASSES": "2"}), ("tiny_table", {"ABG_COSETTLE_LOG2": "10"})):
+        for key in ("ABG_COSETTLE", "ABG_COSETTLE_PASSES", "ABG_COSETTLE_LOG2"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        g = api.BloomDBG(48, counters=counters, insert_batch_kmers=1 << 17)
+        g.load(buf, off)
+        st = g.stats()
+        assert st["tiled_ops"] > 0 and st["tile_overflows"] == 0, (name, st)
+        assert np.array_equal(want, g.counters()), name
+        pending[name] = st["tiled_pending"]
+        g.close()
+    assert pending["on"] * 8 < pending["off"], pending
+    assert pending["on"] <= pending["two_passes"] <= pending["one_pass"] <= pending["off"], pending
+    assert pending["on"] <= pending["tiny_table"] <= pending["off"], pending
+
+
 def test_saturating_counters_and_duplicate_kmers():
     reads = [b"ACGTTGCATGCCGATAGCTAGGATCCATGCAAATTTGGCC"] * 300 + [b"A" * 60, b"T" * 60, b"ACAC" * 20]
     buf, off = api.concat_seqs(reads)
