@@ -23,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row['Counter_Name'] != c: continue
             name = row['Kernel_Name']
             for key in ("FHashOps", "FBinCoarse", "FBinFine", "FTilePurity", "FOpTarget", "FTileApply", "FClaimList", "FHashClaim", "FInsertRound", "FClassify", "FWalk", "FGuideBuild", "k_commit", "k_insert_drain", "FContigPrep",
-                        "FPcTimeMin", "FPcDecide", "FPcApply"):
+                        "FPcTimeMin", "FPcDecide", "FPcApply", "FCoSettle", "FCoFinal", "FPendCount", "FPendWrite", "FPreCommit", "FPcShort", "FRefilter", "FSolidPlane"):
                 if key in name:
                     agg[key][0] += float(row['Counter_Value']); agg[key][1] += 1
         for k, (v, n) in agg.items():
