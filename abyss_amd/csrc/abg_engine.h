@@ -72,6 +72,7 @@ struct Config {
 	                                  // bit plane (B beyond one GPU): 0 = when the whole filter would not fit the device, 1 = always, 2 = never
 	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
 	uint32_t classify_slots = 65536;  // lanes of the classification kernel in flight (each owns 22 KB of lookAhead scratch)
+	bool cls_both = true;             // the classification probes the solid plane and the visited filter in one array of two bits a position (FBothBuild)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
 	bool memo = true;
@@ -537,6 +538,24 @@ struct FSolidPlane { // bit i of the plane = counter i >= kc; one item per 64 co
 		plane[i] = bits;
 	}
 };
+// The classification asks every k-mer's H positions two things, "solid?" and "visited?": two sectors a position while the answers live
+// in two arrays.  `both` holds them side by side -- bit 2i the solid plane's, bit 2i + 1 the visited filter's -- so the pair is one load
+// (FClassify); built from the two at the start of an assemble call, kept up by the commits (both_set) while it runs.
+ABG_HD uint64_t spread_bits(uint32_t x) // bit i of x to bit 2i
+{
+	uint64_t v = x;
+	v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+	v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+	v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	v = (v | (v << 2)) & 0x3333333333333333ull;
+	v = (v | (v << 1)) & 0x5555555555555555ull;
+	return v;
+}
+struct FBothBuild { // one item per 32 positions
+	const uint32_t* plane32; const uint32_t* vis32; uint64_t* both;
+	ABG_HD void operator()(uint64_t i, uint32_t) const { both[i] = spread_bits(plane32[i]) | (spread_bits(vis32[i]) << 1); }
+};
+ABG_HD void both_set(uint32_t* both32, uint64_t pos) { if (both32) atomic_or_u32(&both32[pos >> 4], 2u << (2u * (uint32_t)(pos & 15u))); }
 struct FPopcount { // CountingBloomFilter::popCount / filtered_popcount (hpp:219-242), 8 counters per item
 	const uint64_t* cnt8; uint32_t kc; uint64_t* out; // out[0] non-zero, out[1] >= kc
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -1467,13 +1486,14 @@ constexpr uint8_t RES_CANDIDATE = 0x80;
 // the 6 G probes of a step are what bounds the kernel.  One read per lane it stays; the next
 // batch's classification is queued on a side stream ahead of the current batch's walkers.)
 #ifndef ABG_CLS_GROUP
-#define ABG_CLS_GROUP 4
+#define ABG_CLS_GROUP 8 // (8 with the two-bit array -- one load a position, 32 in flight a round -- 602.7 vs 607.3 ms a step for 4)
 #endif
 constexpr uint32_t CLS_GROUP = ABG_CLS_GROUP; // k-mers of a read probed per round of FClassify / FRefilter
 template <int NW>
 struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), one read per item
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
 	VKey* la_pool; // [slots][LA_MAX_VISITED]
+	const uint8_t* both = nullptr; // the solid plane's and the visited filter's bits side by side (FBothBuild), or NULL
 	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
 	{
 		uint64_t r = first + i;
@@ -1532,8 +1552,14 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 #pragma unroll
 					for (unsigned t = 0; t < 4; t++) {
 						const uint64_t pos = pos_i(p, h[q], base + t < p.nh ? base + t : 0u);
-						c[q][t] = (uint8_t)probe_c(p, cnt, pos);
-						w[q][t] = (uint8_t)((vis[pos >> 3] >> (pos & 7)) & 1u);
+						if (both) {
+							const unsigned two = (unsigned)(both[pos >> 2] >> (2u * (unsigned)(pos & 3u))) & 3u;
+							c[q][t] = (two & 1u) ? 255 : 0;
+							w[q][t] = (uint8_t)(two >> 1);
+						} else {
+							c[q][t] = (uint8_t)probe_c(p, cnt, pos);
+							w[q][t] = (uint8_t)((vis[pos >> 3] >> (pos & 7)) & 1u);
+						}
 					}
 				}
 #pragma unroll
@@ -1988,7 +2014,7 @@ struct FRehash { // move every entry of one vertex table into another (owner 0)
 };
 template <int NW>
 struct CommitEnv {
-	Params p; Batch b; uint32_t* vis32;
+	Params p; Batch b; uint32_t* vis32; uint32_t* both32 = nullptr; // (both32: the classification's copy of the visited bits, or NULL)
 	const uint32_t* cand_read; const uint32_t* status; const uint32_t* first_rec;
 	ContigRec* recs; const uint8_t* pool; uint8_t* result;
 	const uint64_t* kh;      // hash of the k-mer starting at each pool offset (FContigPrep)
@@ -2122,6 +2148,7 @@ ABG_HDN void commit_candidates(CommitEnv<NW>& e, uint32_t c_begin, uint32_t c_en
 						for (unsigned q = 0; q < p.nh; q++) {
 							uint64_t pos = pos_i(p, h, q);
 							atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
+							both_set(e.both32, pos);
 						}
 					}
 				}
@@ -2179,6 +2206,7 @@ struct ParCommit {
 	const uint64_t* kh; const uint64_t* rkh; const uint64_t* rkoff; const uint8_t* read_flag;
 	const uint8_t* cnt8;   // the counting filter (FPcApply: coverage of the inserted contigs)
 	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
+	uint32_t* both32 = nullptr; // the classification's copy of the visited bits (FBothBuild), or NULL
 	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp;
 	                       // or NULL: the stamps live in the hash table below, keyed by bit position
 	uint64_t* Tk;          // [Tmask + 1] bit positions (T_KEY_EMPTY: free)
@@ -2554,6 +2582,7 @@ struct FPcApply { // one wave per candidate before the break: results, visited b
 					for (unsigned q = 0; q < e.p.nh; q++) {
 						uint64_t pos = pos_i(e.p, h, q);
 						atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
+						both_set(e.both32, pos);
 						if (e.cnt8) { const unsigned c = e.cnt8[pos]; mn = c < mn ? c : mn; }
 					}
 					if (e.cnt8) cov += mn;
@@ -2663,7 +2692,7 @@ class Engine {
 	}
 	~Engine()
 	{
-		free_counters(); be_.free(vis_); be_.free(cstate_); be_.free(scal_);
+		free_counters(); be_.free(vis_); if (both_) be_.free(both_); be_.free(cstate_); be_.free(scal_);
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
@@ -3083,6 +3112,7 @@ class Engine {
 		if (insert_scratch_bytes_ > cfg_.keep_insert_scratch_bytes) free_insert();
 		ensure_walk();
 		ensure_plane();
+		ensure_both();
 		build_guide(b);
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
@@ -3134,6 +3164,18 @@ class Engine {
 		}
 		p2_.solid_bits = 1; cnt2_ = plane_;
 	}
+	// the classification's two bits per position (FBothBuild): single-GPU runs that probe the plane, rebuilt for every assemble call
+	// (nothing but this call's commits writes the visited filter while it runs)
+	void ensure_both()
+	{
+		const bool want = cfg_.cls_both && p2_.solid_bits && !dist() && !sliced_ && !(m_ & 63);
+		if (!want) { if (both_) { be_.free(both_); both_ = nullptr; } return; }
+		if (!both_) both_ = (uint8_t*)be_.try_alloc(m_ / 4 + 64);
+		if (!both_) return;
+		FBothBuild f{ (const uint32_t*)plane_, (const uint32_t*)vis_, (uint64_t*)both_ };
+		be_.launch(m_ / 32, f, "both_build");
+	}
+	uint8_t* both_ = nullptr;
 	uint64_t ovf_seen_[2] = { 0, 0 }; // partitioned run: the walkers' pool / record overflow counters as last read
 	uint8_t* plane_ = nullptr; bool plane_valid_ = false;
 	Params p2_; const uint8_t* cnt2_ = nullptr; // what the probing kernels of PASS 2 get: p_ / cnt_, or the plane
@@ -4044,7 +4086,7 @@ class Engine {
 		}
 		CommitEnv<NW> e;
 		e.read_flag = read_flag_;
-		e.p = p_; e.b = b; e.vis32 = (uint32_t*)vis_;
+		e.p = p_; e.b = b; e.vis32 = (uint32_t*)vis_; e.both32 = (uint32_t*)both_;
 		e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d;
 		e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
@@ -4093,7 +4135,7 @@ class Engine {
 		e.own_lo = part ? own_lo_ : 0; e.own_span = part ? own_span_ : ~0ULL; e.part_c = part_c; e.part_r = part_r;
 		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
-		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.T = T_; e.cend = cend_; e.cnt8 = cnt_;
+		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.both32 = (uint32_t*)both_; e.T = T_; e.cend = cend_; e.cnt8 = cnt_;
 		e.Tk = nullptr; e.Tv = nullptr; e.Tmask = 0;
 		if (t_hashed()) {
 			// the bits this commit can stamp: (k-mers of the contigs in the pool) x H
@@ -4435,7 +4477,7 @@ class Engine {
 					if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
 					Batch vn = b;
 					vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
-					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_ };
+					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_, both_ };
 					be_.launch_slots_side(nn, f, cslots_, "classify");
 					pre_first_ = nf; pre_n_ = nn;
 				};
@@ -4480,7 +4522,7 @@ class Engine {
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			be_.sync_side();
-			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_ };
+			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_, both_ };
 			be_.launch_slots(n, f, cslots_, "classify");
 		}
 		pre_n_ = 0;
