@@ -1614,12 +1614,22 @@ struct FRefilter {
 // that may be solid (the first of its H counters says so: one probe drops nearly all k-mers with a
 // sequencing error) leaves a hint "this k-mer is k-mer j of the read at word offset woff" in the
 // slot of its canonical hash.  Plain stores: whichever read wrote last serves as the guide.
+constexpr uint32_t GUIDE_READS_PER_ITEM = 4; // FGuideBuild: sampled reads a wavefront takes side by side, 16 lanes each (a 150 bp read keeps 11 lanes busy with runs of 8 k-mers)
 template <int NW>
 struct FGuideBuild {
-	Params p; Batch b; const uint8_t* cnt; uint64_t* tab; uint64_t mask; uint32_t stride;
+	Params p; Batch b; const uint8_t* cnt; uint64_t* tab; uint64_t mask; uint32_t stride; uint64_t nsampled;
 	ABG_HDN void operator()(uint64_t i, uint32_t lane, uint32_t nlanes) const
 	{
-		const uint64_t r = i * stride;
+		const uint32_t per = nlanes >= GUIDE_READS_PER_ITEM ? nlanes / GUIDE_READS_PER_ITEM : nlanes; // lanes per read
+		const uint32_t sub = lane / per, nsub = nlanes / per, sl = lane - sub * per;
+		for (uint32_t q = sub; q < GUIDE_READS_PER_ITEM; q += nsub) {
+			const uint64_t si = i * GUIDE_READS_PER_ITEM + q;
+			if (si >= nsampled) break;
+			one_read(si * stride, sl, per);
+		}
+	}
+	ABG_HDN void one_read(uint64_t r, uint32_t lane, uint32_t nlanes) const
+	{
 		const uint32_t L = b.len[r];
 		if (L < p.k) return;
 		const uint32_t nk = L - p.k + 1;
@@ -1627,14 +1637,21 @@ struct FGuideBuild {
 		if (nk > GUIDE_MAX_NK || woff > GUIDE_MAX_WOFF) return;
 		if (!p.mask) {
 			// (without a spaced seed the key is the canonical hash itself: a lane rolls along a run of
-			// consecutive k-mers instead of hashing every one of them from scratch -- 24 -> 7 ms per configs[1] step)
+			// consecutive k-mers instead of hashing every one of them from scratch -- 24 -> 7 ms per configs[1] step;
+			// the run's probes go out together, then the hints of the k-mers that passed)
 			constexpr uint32_t RUN = 8;
-			for (uint32_t j0 = lane * RUN; j0 < nk; j0 += nlanes * RUN)
-				kmer_hash_run(p, [&](unsigned q) { return batch_base(b, r, q); }, j0, j0 + RUN < nk ? j0 + RUN : nk,
-				    [&](uint32_t j, uint64_t hm) {
-					    if (probe_c(p, cnt, pos_i(p, hm, 0)) < p.kc) return;
-					    tab[guide_slot(hm, mask)] = guide_pack(woff, j, nk, guide_tag(hm));
-				    });
+			for (uint32_t j0 = lane * RUN; j0 < nk; j0 += nlanes * RUN) {
+				const uint32_t j1 = j0 + RUN < nk ? j0 + RUN : nk;
+				uint64_t hm[RUN];
+				for (uint32_t q = 0; q < RUN; q++) hm[q] = 0;
+				kmer_hash_run(p, [&](unsigned q) { return batch_base(b, r, q); }, j0, j1, [&](uint32_t j, uint64_t h) { hm[j - j0] = h; });
+				unsigned c[RUN];
+#pragma unroll
+				for (uint32_t q = 0; q < RUN; q++) c[q] = probe_c(p, cnt, pos_i(p, hm[j0 + q < j1 ? q : 0u], 0));
+#pragma unroll
+				for (uint32_t q = 0; q < RUN; q++)
+					if (j0 + q < j1 && c[q] >= p.kc) tab[guide_slot(hm[q], mask)] = guide_pack(woff, j0 + q, nk, guide_tag(hm[q]));
+			}
 			return;
 		}
 		for (uint32_t j = lane; j < nk; j += nlanes) {
@@ -3204,8 +3221,8 @@ class Engine {
 		be_.memset(guide_tab_, 0, 8ull << log2);
 		guide_.mask = (1ull << log2) - 1; guide_.words = b.words; guide_.nwords = nwords;
 		dispatch_nw([&](auto nw) {
-			FGuideBuild<decltype(nw)::value> f{ p2_, b, cnt2_, guide_tab_, guide_.mask, cfg_.guide_stride };
-			be_.launch_wave(sampled, f, "guide_build");
+			FGuideBuild<decltype(nw)::value> f{ p2_, b, cnt2_, guide_tab_, guide_.mask, cfg_.guide_stride, sampled };
+			be_.launch_wave((sampled + GUIDE_READS_PER_ITEM - 1) / GUIDE_READS_PER_ITEM, f, "guide_build");
 		});
 		guide_.tab = guide_tab_;
 		guide_slots_ = guide_.mask + 1;
