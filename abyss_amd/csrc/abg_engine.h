@@ -72,6 +72,7 @@ struct Config {
 	                                  // bit plane (B beyond one GPU): 0 = when the whole filter would not fit the device, 1 = always, 2 = never
 	bool solid_plane = true;          // PASS 2 probes the bit plane "counter >= kc" instead of the counters (Engine::ensure_plane)
 	uint32_t classify_slots = 65536;  // lanes of the classification kernel in flight (each owns 22 KB of lookAhead scratch)
+	uint32_t cls_both_max_mb = 1024;  // ... for filters whose two-bit array is at most this large
 	bool cls_both = true;             // the classification probes the solid plane and the visited filter in one array of two bits a position (FBothBuild)
 	bool prefetch_classify = true;    // classify batch i + 1 on a side stream while batch i's walkers thin out
 	uint32_t memo_log2 = 0;           // entries of the successor() memo (0: sized to the filter; see SuccMemo)
@@ -3185,7 +3186,8 @@ class Engine {
 	// (nothing but this call's commits writes the visited filter while it runs)
 	void ensure_both()
 	{
-		const bool want = cfg_.cls_both && p2_.solid_bits && !dist() && !sliced_ && !(m_ & 63);
+		// (filters up to cls_both_max_mb of it: on configs[2]'s 40 G counters the 10 GB array gains 1 % a pass and costs the first pass 6 s)
+		const bool want = cfg_.cls_both && p2_.solid_bits && !dist() && !sliced_ && !(m_ & 63) && m_ / 4 <= ((uint64_t)cfg_.cls_both_max_mb << 20);
 		if (!want) { if (both_) { be_.free(both_); both_ = nullptr; } return; }
 		if (!both_) both_ = (uint8_t*)be_.try_alloc(m_ / 4 + 64);
 		if (!both_) return;

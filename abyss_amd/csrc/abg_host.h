@@ -99,6 +99,7 @@ class Session {
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
 		if (const char* e = getenv("ABG_COSETTLE")) cfg.cosettle = atoi(e) != 0; // (0: round 4's rule -- a k-mer that may write a shared counter takes the rounds)
 		if (const char* e = getenv("ABG_CLS_BOTH")) cfg.cls_both = atoi(e) != 0; // (0: the classification reads the plane and the visited filter where they are)
+		if (const char* e = getenv("ABG_CLS_BOTH_MAX_MB")) cfg.cls_both_max_mb = (uint32_t)std::max(0, atoi(e));
 		if (const char* e = getenv("ABG_COSETTLE_PASSES")) cfg.cosettle_passes = (uint32_t)std::max(1, atoi(e));
 		if (const char* e = getenv("ABG_COSETTLE_LOG2")) cfg.cosettle_log2 = (uint32_t)std::min(25, std::max(5, atoi(e))); // (tests: a table in which nearly every counter looks marked)
 		if (const char* e = getenv("ABG_LINK_DUPS")) cfg.link_duplicates = atoi(e) != 0; // the commit decides a contig's copies by their original (0: every record bit by bit)
