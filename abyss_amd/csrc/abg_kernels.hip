@@ -10,6 +10,7 @@
 //
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -508,6 +509,23 @@ struct HipBackend {
 		}
 		prof_pending.clear();
 	}
+	// A kernel launch on the main stream, timed when profiling is on: the two events ride on the dispatch itself
+	// (hipExtLaunchKernelGGL) -- no event packets of their own on the stream, and what they bracket is the kernel alone.
+	template <class K, class... A>
+	void launch_kernel(const char* name, K kernel, dim3 grid, dim3 block, A... args)
+	{
+		if (!profiling) {
+			hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+			check(hipGetLastError(), name);
+			return;
+		}
+		if (prof_free.empty()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); prof_free.push_back({ a, b }); }
+		const std::pair<hipEvent_t, hipEvent_t> ev = prof_free.back(); prof_free.pop_back();
+		hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev.first, ev.second, 0, args...);
+		check(hipGetLastError(), name);
+		prof_pending.push_back({ ev.first, ev.second, &prof[name] });
+		if (prof_pending.size() >= 8192) prof_drain();
+	}
 	template <class F>
 	void launch(uint64_t n, F f, const char* name)
 	{
@@ -515,9 +533,7 @@ struct HipBackend {
 		uint64_t blocks = (n + 255) / 256;
 		uint64_t cap = (uint64_t)cus * 8;
 		if (blocks > cap) blocks = cap;
-		begin(name);
-		hipLaunchKernelGGL(k_foreach<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
-		end(name);
+		launch_kernel(name, k_foreach<F>, dim3((uint32_t)blocks), dim3(256), f, n);
 	}
 	template <class F>
 	void launch_slots(uint64_t n, F f, uint32_t slots, const char* name)
@@ -526,9 +542,7 @@ struct HipBackend {
 		uint64_t blocks = (n + 63) / 64;
 		uint64_t cap = slots / 64 ? slots / 64 : 1;
 		if (blocks > cap) blocks = cap;
-		begin(name);
-		hipLaunchKernelGGL(k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n);
-		end(name);
+		launch_kernel(name, k_foreach_w<F>, dim3((uint32_t)blocks), dim3(64), f, n);
 	}
 	// The same on the side stream: it starts after everything queued on the main stream SO FAR
 	// and runs next to whatever the main stream queues afterwards (queue it BEFORE the kernel it
@@ -607,9 +621,7 @@ struct HipBackend {
 		uint64_t blocks = (n + 3) / 4;
 		uint64_t cap = (uint64_t)cus * 8;
 		if (blocks > cap) blocks = cap;
-		begin(name);
-		hipLaunchKernelGGL(k_foreach_wave<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, f, n);
-		end(name);
+		launch_kernel(name, k_foreach_wave<F>, dim3((uint32_t)blocks), dim3(256), f, n);
 	}
 	template <class F>
 	void launch_walkers(uint64_t n, F f, uint32_t slots, const char* name)
@@ -618,9 +630,7 @@ struct HipBackend {
 		uint64_t blocks = n < slots ? n : slots;
 		if (!ticket) ticket = (unsigned long long*)alloc(8);
 		check(hipMemsetAsync(ticket, 0, 8, stream), "hipMemsetAsync");
-		begin(name);
-		hipLaunchKernelGGL(k_walkers<F>, dim3((uint32_t)blocks), dim3(64), 0, stream, f, n, ticket);
-		end(name);
+		launch_kernel(name, k_walkers<F>, dim3((uint32_t)blocks), dim3(64), f, n, ticket);
 	}
 	template <class F>
 	void launch_tiles(uint64_t n, F f, const char* name)
@@ -629,9 +639,7 @@ struct HipBackend {
 		uint64_t blocks = n;
 		const uint64_t cap = (uint64_t)cus * (F::FAST > 32768 ? 2 : 8);
 		if (blocks > cap) blocks = cap;
-		begin(name);
-		hipLaunchKernelGGL(k_tiles<F>, dim3((uint32_t)blocks), dim3(F::THREADS), 0, stream, f, n);
-		end(name);
+		launch_kernel(name, k_tiles<F>, dim3((uint32_t)blocks), dim3(F::THREADS), f, n);
 	}
 	void launch_drain(abg::InsertDrainEnv e)
 	{
