@@ -602,6 +602,8 @@ def main() -> int:
                 "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 # (taken on exactly these kernel sources?  else: commits to abyss_amd/csrc since -- None where git is not there to ask)
                 "traffic_kernels_are_head": traffic_head, "traffic_csrc_commits_behind": traffic_behind,
+                # (the rocprofv3 --kernel-trace --stats summary taken in the same gpurun call as the traffic file: tools/gpu_r5_final.sh counters)
+                "kernel_stats": (lambda f: f if tsrc and os.path.exists(os.path.join(ROOT, f)) else None)((tsrc or "").replace("_pmc_traffic.json", "_kernel_stats_config1.csv")),
                 "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "launches": per_kernel[dom]["launches"],
                 "note": "the main stream's kernel with the largest summed duration of the step (the classification overlaps the walk on a side stream: its family is in `kernels`); "
                         "achieved = algorithmic bytes of its family (SURVEY.md 8d) over the summed duration of the family's kernels; "
