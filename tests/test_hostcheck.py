@@ -709,6 +709,24 @@ def test_kmers_writing_shared_counters_are_settled_together_or_go_to_the_rounds_
     assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
 
 
+@pytest.mark.parametrize("nh", [1, 2, 3, 5, 8, 9])
+def test_the_settling_rule_with_few_and_many_hash_functions(nh):
+    """op_verdict's rules read an op's flags per hash function (a byte: up to 8) and learn the k-mer's op count from its first two
+    counters: one hash function (no second counter to learn from), two, an odd number, the most a flag byte holds, and one more
+    (every flagged k-mer then takes the rounds) -- the counter array stays the oracle's on a filter dense enough for chains."""
+    k = 33
+    m1, m2 = synth.make_read_set(20000, 30.0, genome_seed=nh, read_seed=nh + 50)
+    buf, off = api.matrix_to_seqs(synth.codes_to_ascii(np.concatenate([m1, m2])))
+    counters = 1 << 19
+    o = ob.Oracle(k, counters=counters, num_hashes=nh)
+    hc = HostCheck(k, counters, num_hashes=nh, insert_batch=30000, claim_log2=16)
+    o.load(buf, off)
+    hc.load(buf, off)
+    st = hc.stats()
+    assert st["tiled_ops"] > 0, st
+    assert np.array_equal(o.counters(), hc.counters())
+
+
 def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
     """hc_selftest_kmer: window_kmer vs batch_kmer, kmer_revcomp_fast vs kmer_revcomp, kmer_hashes vs vtx_rehash,
     and the prefix-XOR hashes of stretches of consecutive k-mers (stretch_hashes_serial: the arithmetic of the
