@@ -566,7 +566,22 @@ class SequenceReader {
 				// (no second record start in sight yet: look further)
 			}
 #ifdef MADV_POPULATE_READ
-			madvise((void*)((uintptr_t)(m_map + m_pos) & ~(uintptr_t)4095), end + ((uintptr_t)(m_map + m_pos) & 4095), MADV_POPULATE_READ); // (one pass over the page tables instead of a fault per parser thread and page)
+			{
+				// one pass over the page tables instead of a fault per parser thread and page -- by a few threads, a part of the
+				// window each: a single call takes 20 ms for 256 MB of page cache, four side by side 11 (and it stands in front of
+				// every window's parse)
+				const uintptr_t a0 = (uintptr_t)(m_map + m_pos) & ~(uintptr_t)4095, a1 = (uintptr_t)(m_map + m_pos) + end;
+				static const unsigned max_parts = []() { const char* e = getenv("ABG_READER_POPULATE_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 8u; }();
+				const unsigned parts = (unsigned)std::min<size_t>(std::min(m_threads, max_parts), (a1 - a0) / ((size_t)8 << 20) + 1);
+				const uintptr_t step = (((a1 - a0) / parts) + 4095) & ~(uintptr_t)4095;
+				std::vector<std::thread> pop;
+				for (unsigned q = 1; q < parts; q++) {
+					const uintptr_t b0 = a0 + q * step, b1 = std::min(a1, b0 + step);
+					if (b0 < b1) pop.emplace_back([b0, b1]() { madvise((void*)b0, b1 - b0, MADV_POPULATE_READ); });
+				}
+				madvise((void*)a0, std::min(a1, a0 + step) - a0, MADV_POPULATE_READ);
+				for (auto& t : pop) t.join();
+			}
 #endif
 		} else
 		for (;;) {
