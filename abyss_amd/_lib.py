@@ -59,6 +59,8 @@ def symbols():
         "abg_profile_enable", "abg_profile_reset", "abg_profile_get", "abg_get_stats",
         "abg_overlap_create", "abg_overlap_destroy", "abg_overlap_last_error", "abg_overlap_join", "abg_overlap_edges",
         "abg_overlap_profile", "abg_overlap_profile_get",
+        "abg_rr_create", "abg_rr_destroy", "abg_rr_last_error", "abg_rr_bytes", "abg_rr_clear", "abg_rr_insert_seqs",
+        "abg_rr_contains_seqs", "abg_rr_popcount", "abg_rr_export", "abg_rr_sync", "abg_rr_profile", "abg_rr_profile_get",
     ]
 
 
@@ -122,5 +124,19 @@ def load(path: str | None = None):
     lib.abg_overlap_edges.argtypes = [vp, vp, vp]
     lib.abg_overlap_profile.argtypes = [vp, C.c_int]
     lib.abg_overlap_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
+    lib.abg_rr_create.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    lib.abg_rr_destroy.argtypes = [vp]
+    lib.abg_rr_destroy.restype = None
+    lib.abg_rr_last_error.argtypes = [vp]
+    lib.abg_rr_last_error.restype = C.c_char_p
+    lib.abg_rr_bytes.argtypes = [vp, u64p]
+    lib.abg_rr_clear.argtypes = [vp]
+    lib.abg_rr_insert_seqs.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, u64p]
+    lib.abg_rr_contains_seqs.argtypes = [vp, vp, vp, C.c_uint64, vp]
+    lib.abg_rr_popcount.argtypes = [vp, u64p]
+    lib.abg_rr_export.argtypes = [vp, vp]
+    lib.abg_rr_sync.argtypes = [vp]
+    lib.abg_rr_profile.argtypes = [vp, C.c_int]
+    lib.abg_rr_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
     _lib = lib
     return lib

@@ -441,3 +441,79 @@ def format_read_log(results: np.ndarray, read_ids: Sequence[bytes]) -> bytes:
     for rid, r in zip(read_ids, results):
         rows.append(rid + b"\t" + READ_RESULT_NAMES[int(r)].encode() + b"\n")
     return b"".join(rows)
+
+
+class ReadFilter:
+    """The Bloom filter of the reads' r-mers that abyss-rresolver-short keeps per r value, on one GPU
+    (btllib::KmerBloomFilter as RResolver/BloomFilters.cpp:139-264 uses it; include/abyss_amd.h abg_rr_*)."""
+
+    def __init__(self, nbytes: int, r: int, hash_num: int = 7, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.abg_rr_create(device, nbytes, hash_num, r, C.byref(self._h))
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_rr_last_error(None)
+            self._h = None
+            raise AbyssAmdError("abg_rr_create failed (%d): %s" % (rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.abg_rr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _lib.ABG_OK:
+            msg = self._lib.abg_rr_last_error(self._h)
+            raise AbyssAmdError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    @property
+    def nbytes(self) -> int:
+        b = C.c_uint64()
+        self._check(self._lib.abg_rr_bytes(self._h, C.byref(b)), "abg_rr_bytes")
+        return b.value
+
+    def clear(self) -> None:
+        self._check(self._lib.abg_rr_clear(self._h), "abg_rr_clear")
+
+    def insert(self, buf: bytes, off: np.ndarray, max_bases: int, lengths: Sequence[int] = ()) -> int:
+        """insert(seq[:max_bases]) for every sequence of one of `lengths` (all when empty); returns how many were of a wanted length."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n = C.c_uint64(0)
+        keep = C.c_char_p(buf)
+        self._check(self._lib.abg_rr_insert_seqs(self._h, C.cast(keep, C.c_void_p), off.ctypes.data, len(off) - 1, max_bases,
+                                                 ln.ctypes.data if len(ln) else None, len(ln), C.byref(n)), "abg_rr_insert_seqs")
+        return n.value
+
+    def contains(self, buf: bytes, off: np.ndarray) -> np.ndarray:
+        """How many r-mers of every sequence the filter holds."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        out = np.zeros(len(off) - 1, dtype=np.uint32)
+        keep = C.c_char_p(buf)
+        self._check(self._lib.abg_rr_contains_seqs(self._h, C.cast(keep, C.c_void_p), off.ctypes.data, len(off) - 1, out.ctypes.data if len(out) else None),
+                    "abg_rr_contains_seqs")
+        return out
+
+    def popcount(self) -> int:
+        c = C.c_uint64()
+        self._check(self._lib.abg_rr_popcount(self._h, C.byref(c)), "abg_rr_popcount")
+        return c.value
+
+    def export(self) -> np.ndarray:
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        self._check(self._lib.abg_rr_export(self._h, out.ctypes.data), "abg_rr_export")
+        return out
+
+    def profile(self, on: bool = True) -> None:
+        self._lib.abg_rr_profile(self._h, int(on))
+
+    def profile_get(self, name: str) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        self._lib.abg_rr_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value

@@ -49,12 +49,32 @@ def csrc_files():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "abyss_amd.h")]
 
 
+OBJ_DIR = os.path.join(ROOT, "abyss_amd", "lib", "obj")
+# translation units of the library and what each is rebuilt for (the big one takes minutes; the others seconds)
+UNITS = {
+    "abg_kernels": ["abg_kernels.hip", "abg_core.h", "abg_engine.h", "abg_walk.h", "abg_host.h", "abg_overlap.h"],
+    "abg_rr": ["abg_rr.hip", "abg_rr.h", "abg_core.h"],
+}
+
+
 def build_lib(force: bool = False) -> str:
-    """libabyss_amd.so: the gfx950 kernels + C ABI."""
-    if force or _newer(LIB, csrc_files()):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-              "-o", LIB, os.path.join(CSRC, "abg_kernels.hip")])
+    """libabyss_amd.so: the gfx950 kernels + C ABI, one object per translation unit."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    header = os.path.join(ROOT, "include", "abyss_amd.h")
+    objs, procs = [], []
+    for unit, deps in UNITS.items():
+        obj = os.path.join(OBJ_DIR, unit + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, d) for d in deps] + [header]):
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", obj, os.path.join(CSRC, unit + ".hip")]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("build step failed: %s" % " ".join(cmd))
+    if force or procs or _newer(LIB, objs):
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 
@@ -76,6 +96,9 @@ def build_cli(force: bool = False) -> str:
         _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o",
               os.path.join(BIN_DIR, "AdjList"), os.path.join(CSRC, "host", "adjlist_main.cc"),
               "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
+        _run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-o",
+              os.path.join(BIN_DIR, "abyss-rresolver-short"), os.path.join(CSRC, "host", "rresolver_main.cc"),
+              "-L" + os.path.dirname(LIB), "-labyss_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
     return out
 
 
@@ -91,6 +114,7 @@ def build_oracle(force: bool = False) -> None:
 
 READER_CHECK = os.path.join(ROOT, "tests", "hostcheck", "reader_check")
 ADJLIST_CHECK = os.path.join(ROOT, "tests", "hostcheck", "adjlist_check")
+RRESOLVER_CHECK = os.path.join(ROOT, "tests", "hostcheck", "rresolver_check")
 
 
 def build_hostcheck(force: bool = False) -> str:
@@ -105,6 +129,10 @@ def build_hostcheck(force: bool = False) -> str:
                                        os.path.join(CSRC, "host", "fasta_reader.h")]):
         _run(["g++", "-std=c++17", "-O2", "-o", ADJLIST_CHECK, asrc, "-L" + os.path.dirname(HOSTCHECK), "-lhostcheck",
               "-Wl,-rpath,$ORIGIN"])
+    hsrc = [os.path.join(CSRC, "host", f) for f in ("rresolver_core.h", "graph_writers.h", "fasta_reader.h", "si_bytes.h")]
+    csrc = os.path.join(ROOT, "tests", "hostcheck", "rresolver_check.cc")
+    if force or _newer(RRESOLVER_CHECK, [csrc, os.path.join(CSRC, "abg_rr.h"), os.path.join(CSRC, "abg_core.h")] + hsrc):
+        _run(["g++", "-std=c++17", "-O2", "-Wno-unknown-pragmas", "-o", RRESOLVER_CHECK, csrc, "-lpthread"])
     return HOSTCHECK
 
 

@@ -16,6 +16,7 @@
 #pragma once
 
 #include "fasta_reader.h"
+#include "graph_writers.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -35,9 +36,9 @@
 namespace abgadj {
 
 #define ABG_ADJ_PROGRAM "AdjList"
-#define ABG_ADJ_VERSION "2.3.10"
+#define ABG_ADJ_VERSION ABG_IO_VERSION
 
-enum Format { ADJ = 0, ASQG, DOT, GFA1, GFA2, SAM }; // Graph/Options.h (the ones AdjList offers)
+using abgio::ADJ; using abgio::ASQG; using abgio::DOT; using abgio::GFA1; using abgio::GFA2; using abgio::SAM; // Graph/Options.h (the ones AdjList offers)
 
 struct Options {
 	unsigned k = 0, singleKmer = 0, minOverlap = 50;
@@ -81,7 +82,11 @@ struct Graph {
 		for (auto& x : extra) e += x.size();
 		return e;
 	}
-	std::string vname(uint64_t u) const { return name[u >> 1] + ((u & 1) ? '-' : '+'); }
+	// (what abgio's writers ask of a graph)
+	bool removed(uint64_t) const { return false; }
+	const std::string& cname(uint64_t u) const { return name[u >> 1]; }
+	unsigned len(uint64_t u) const { return length[u >> 1]; }
+	unsigned cov(uint64_t u) const { return coverage[u >> 1]; }
 };
 
 static const char USAGE_MESSAGE[] =
@@ -259,50 +264,12 @@ inline void read_contigs(const std::string& path, const Options& o, Graph& g, st
 	}
 }
 
-// Histogram::bin + barplot (Common/Histogram.cpp:45-95) over the out-degrees; printGraphStats (Graph/GraphUtil.h:43-64)
+// printGraphStats (Graph/GraphUtil.h:43-64) over the out-degrees
 inline void print_graph_stats(FILE* out, const Graph& g)
 {
 	std::map<int, uint64_t> h;
 	for (uint64_t u = 0; u < g.nv(); u++) h[(int)g.degree(u)]++;
-	const unsigned v = (unsigned)g.nv(), e = (unsigned)g.edges();
-	auto sig = [](float x, int prec) { // operator<<(float) under setprecision(prec): %g
-		char b[64];
-		snprintf(b, sizeof b, "%.*g", prec, x);
-		return std::string(b);
-	};
-	fprintf(out, "V=%u E=%u E/V=%s\n", v, e, sig((float)e / v, 3).c_str());
-	if (h.empty()) return;
-	const int mn = h.begin()->first, mx = h.rbegin()->first;
-	std::vector<uint64_t> bins;
-	{
-		const unsigned nb = (unsigned)mx + 1;
-		const int per = (int)ceilf((float)(mx - mn) / nb);
-		int next = mn + per;
-		uint64_t count = 0;
-		for (auto& kv : h) {
-			if (kv.first >= next) { bins.push_back(count); count = 0; next += per; }
-			count += kv.second;
-		}
-		if (count > 0) bins.push_back(count);
-	}
-	static const char* bars[10] = { " ", "_", "\342\226\201", "\342\226\202", "\342\226\203", "\342\226\204", "\342\226\205", "\342\226\206", "\342\226\207", "\342\226\210" };
-	std::vector<std::string> cells;
-	const uint64_t top = 1 + *std::max_element(bins.begin(), bins.end());
-	for (uint64_t b : bins) cells.push_back(bars[10 * b / top]);
-	while (!cells.empty() && cells.back() == " ") cells.pop_back();
-	std::string plot;
-	for (auto& c : cells) plot += c;
-	uint64_t n = 0, n0 = 0, n1 = 0, n234 = 0;
-	for (auto& kv : h) {
-		n += kv.second;
-		if (kv.first == 0) n0 += kv.second;
-		else if (kv.first == 1) n1 += kv.second;
-		else if (kv.first <= 4) n234 += kv.second;
-	}
-	const uint64_t n5 = n - (n0 + n1 + n234);
-	fprintf(out, "Degree: %s\n        01234\n0: %s%% 1: %s%% 2-4: %s%% 5+: %s%% max: %d\n", plot.c_str(),
-	    sig((float)100 * n0 / n, 2).c_str(), sig((float)100 * n1 / n, 2).c_str(), sig((float)100 * n234 / n, 2).c_str(),
-	    sig((float)100 * n5 / n, 2).c_str(), mx);
+	abgio::print_graph_stats(out, (unsigned)g.nv(), (unsigned)g.edges(), h);
 }
 
 // addOverlapsSA, AdjList.cpp:137-189: overlaps of [m, k-1) bases between the vertices without a k-1 overlap
@@ -347,129 +314,6 @@ inline void add_short_overlaps(const Options& o, Graph& g)
 	}
 }
 
-// ---- writers ----
-struct Out {
-	std::string buf;
-	FILE* f;
-	explicit Out(FILE* f) : f(f) { buf.reserve(1u << 20); }
-	~Out() { flush(); }
-	void flush() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
-	Out& operator<<(const std::string& s) { buf += s; if (buf.size() > (1u << 20) - 4096) flush(); return *this; }
-	Out& operator<<(const char* s) { buf += s; return *this; }
-	Out& operator<<(char c) { buf += c; return *this; }
-	Out& operator<<(unsigned long long x) { buf += std::to_string(x); return *this; }
-	Out& operator<<(unsigned long x) { buf += std::to_string(x); return *this; }
-	Out& operator<<(unsigned x) { buf += std::to_string(x); return *this; }
-	Out& operator<<(int x) { buf += std::to_string(x); return *this; }
-};
-
-inline void write_adj(Out& out, const Graph& g) // Graph/AdjIO.h:32-66
-{
-	const int def = -(int)(g.k - 1);
-	for (uint64_t i = 0; i < g.n(); i++) {
-		out << g.name[i] << ' ' << g.length[i] << ' ' << g.coverage[i];
-		for (unsigned sense = 0; sense < 2; sense++) {
-			out << "\t;";
-			g.for_out(2 * i + sense, [&](uint32_t v, int d) {
-				out << ' ' << g.vname(v ^ sense);
-				if (d != def) out << " [d=" << d << ']';
-			});
-		}
-		out << '\n';
-	}
-}
-inline void write_dot(Out& out, const Graph& g) // Graph/DotIO.h:14-101
-{
-	const int def = -(int)(g.k - 1);
-	out << "digraph adj {\n";
-	out << "graph [k=" << g.k << "]\nedge [d=" << def << "]\n";
-	for (uint64_t u = 0; u < g.nv(); u++)
-		out << '"' << g.vname(u) << "\" [l=" << g.length[u >> 1] << " C=" << g.coverage[u >> 1] << "]\n";
-	for (uint64_t u = 0; u < g.nv(); u++)
-		g.for_out(u, [&](uint32_t v, int d) {
-			out << '"' << g.vname(u) << "\" -> \"" << g.vname(v) << '"';
-			if (d != def) out << " [d=" << d << ']';
-			out << '\n';
-		});
-	out << "}\n";
-}
-inline void write_gfa1(Out& out, const Graph& g) // Graph/GfaIO.h:15-66
-{
-	out << "H\tVN:Z:1.0\n";
-	for (uint64_t i = 0; i < g.n(); i++) {
-		out << "S\t" << g.name[i] << "\t*\tLN:i:" << g.length[i];
-		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
-		out << '\n';
-	}
-	for (uint64_t u = 0; u < g.nv(); u++)
-		g.for_out(u, [&](uint32_t v, int d) {
-			if (u > (uint64_t)(v ^ 1u)) return; // only the canonical edge
-			out << "L\t" << g.name[u >> 1] << '\t' << ((u & 1) ? '-' : '+') << '\t' << g.name[v >> 1] << '\t' << ((v & 1) ? '-' : '+');
-			if (d <= 0) out << '\t' << -d << "M\n"; else out << "\t*\n";
-		});
-}
-inline void write_gfa2(Out& out, const Graph& g) // Graph/GfaIO.h:69-118,129-155,191-211
-{
-	out << "H\tVN:Z:2.0\n";
-	for (uint64_t i = 0; i < g.n(); i++) {
-		out << "S\t" << g.name[i] << '\t' << g.length[i] << "\t*";
-		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
-		out << '\n';
-	}
-	for (uint64_t u = 0; u < g.nv(); u++)
-		g.for_out(u, [&](uint32_t v, int d) {
-			if (u > (uint64_t)(v ^ 1u)) return;
-			const unsigned overlap = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
-			const bool us = u & 1, vs = v & 1;
-			const unsigned ustart = us ? 0 : ulen - overlap, uend = us ? overlap : ulen;
-			const unsigned vstart = !vs ? 0 : vlen - overlap, vend = !vs ? overlap : vlen;
-			out << "E\t*\t" << g.vname(u) << '\t' << g.vname(v);
-			out << '\t' << ustart; if (ustart == ulen) out << '$';
-			out << '\t' << uend; if (uend == ulen) out << '$';
-			out << '\t' << vstart; if (vstart == vlen) out << '$';
-			out << '\t' << vend; if (vend == vlen) out << '$';
-			out << '\t' << overlap << "M\n";
-		});
-}
-inline void write_asqg(Out& out, const Graph& g) // Graph/AsqgIO.h:13-70
-{
-	out << "HT\tVN:i:1\n";
-	for (uint64_t i = 0; i < g.n(); i++) {
-		out << "VT\t" << g.name[i] << "\t*\tLN:i:" << g.length[i];
-		if (g.coverage[i] > 0) out << "\tKC:i:" << g.coverage[i];
-		out << '\n';
-	}
-	for (uint64_t u = 0; u < g.nv(); u++)
-		g.for_out(u, [&](uint32_t v, int d) {
-			if (u > (uint64_t)(v ^ 1u)) return;
-			const unsigned overlap = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
-			const bool us = u & 1, vs = v & 1;
-			out << "ED\t" << g.name[u >> 1] << ' ' << g.name[v >> 1]
-			    << ' ' << (us ? 0u : ulen - overlap) << ' ' << (int)((us ? overlap : ulen) - 1) << ' ' << ulen
-			    << ' ' << (!vs ? 0u : vlen - overlap) << ' ' << (int)((!vs ? overlap : vlen) - 1) << ' ' << vlen
-			    << ' ' << (us != vs ? 1 : 0) << " -1\n";
-		});
-}
-inline void write_sam(Out& out, const Graph& g, const std::string& commandLine) // Graph/SAMIO.h:18-70
-{
-	out << "@HD\tVN:1.0\n@PG\tID:" ABG_ADJ_PROGRAM "\tVN:" ABG_ADJ_VERSION "\tCL:" << commandLine << '\n';
-	for (uint64_t i = 0; i < g.n(); i++) {
-		out << "@SQ\tSN:" << g.name[i] << "\tLN:" << g.length[i];
-		if (g.coverage[i] > 0) out << "\tXC:" << g.coverage[i];
-		out << '\n';
-	}
-	for (uint64_t u = 0; u < g.nv(); u++)
-		g.for_out(u, [&](uint32_t v, int d) {
-			if (d > 0) return;
-			const bool us = u & 1, vs = v & 1;
-			const unsigned alen = (unsigned)-d, ulen = g.length[u >> 1], vlen = g.length[v >> 1];
-			const unsigned pos = 1 + (us ? 0 : ulen - alen), clip = vlen - alen;
-			out << g.name[v >> 1] << '\t' << (us == vs ? 0 : 0x10) << '\t' << g.name[u >> 1] << '\t' << pos << "\t255\t";
-			if (us) out << clip << 'H' << alen << "M\t"; else out << alen << 'M' << clip << "H\t";
-			out << "*\t0\t0\t*\t*\n";
-		});
-}
-
 // main(), AdjList.cpp:307-420, after option parsing
 inline int run(const Options& o, const Join& join, FILE* fout)
 {
@@ -493,15 +337,8 @@ inline int run(const Options& o, const Join& join, FILE* fout)
 		if (o.verbose > 0) print_graph_stats(stderr, g);
 	}
 	{
-		Out out(fout);
-		switch (o.format) {
-		case ADJ: write_adj(out, g); break;
-		case DOT: write_dot(out, g); break;
-		case GFA1: write_gfa1(out, g); break;
-		case GFA2: write_gfa2(out, g); break;
-		case ASQG: write_asqg(out, g); break;
-		case SAM: write_sam(out, g, o.commandLine); break;
-		}
+		abgio::Out out(fout);
+		abgio::write_graph(out, g, o.format, ABG_ADJ_PROGRAM, o.commandLine);
 	}
 	if (fflush(fout) != 0 || ferror(fout)) { fprintf(stderr, ABG_ADJ_PROGRAM ": error writing the output\n"); return EXIT_FAILURE; }
 	return EXIT_SUCCESS;

@@ -36,6 +36,7 @@ struct ReaderOptions {         // DataLayer/FastaReader.cpp:15-38 (namespace opt
 	int qualityThreshold = 0;  // -q
 	int qualityOffset = 0;     // --standard-quality 33 / --illumina-quality 64
 	int internalQThreshold = 0;// -Q
+	int foldCase = 1;          // 0: FastaReader::NO_FOLD_CASE (RResolver/Contigs.cpp:128)
 };
 
 class FastaReader {
@@ -158,7 +159,7 @@ class FastaReader {
 				s.erase(back); s.erase(0, front);
 				if (!q.empty()) { q.erase(back); q.erase(0, front); }
 			}
-			for (auto& ch : s) ch = (char)toupper((unsigned char)ch); // FOLD_CASE
+			if (m_opt.foldCase) for (auto& ch : s) ch = (char)toupper((unsigned char)ch); // FOLD_CASE
 			return finish(s, q, qoff_default);
 		}
 	}

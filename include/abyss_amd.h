@@ -366,6 +366,37 @@ int abg_overlap_edges(abg_overlap* o, uint64_t* offsets, uint32_t* targets);
 int abg_overlap_profile(abg_overlap* o, int on);
 int abg_overlap_profile_get(abg_overlap* o, const char* name, double* total_ms, uint64_t* launches);
 
+/* ---- the stage after AdjList: the read filter of abyss-rresolver-short (RResolver/BloomFilters.cpp) ------------
+ * RResolver keeps ONE plain Bloom filter of the reads' r-mers per r value: g_vanillaBloom = btllib::KmerBloomFilter(bytes,
+ * HASH_NUM = 7, r) (BloomFilters.h:12, BloomFilters.cpp:246), filled by loadReads (:139-209: for every read of the current
+ * read size, insert(seq.substr(0, r + extract - 1))) and asked by testSequence (RAlgorithmsShort.cpp:310-366: found =
+ * contains(sequence)).  btllib is not part of the reference tree (configure.ac:268-276 wants it installed); the hash is its
+ * published ntHash2 -- forward + reverse strand value, multiply-shift extras, r-mers with a character other than ACGT (either
+ * case) skipped -- and the array is btllib's BloomFilter: `bytes` rounded up to a multiple of 8, bit (h % bits) % 8 of byte
+ * (h % bits) / 8.  An abg_rr owns a HIP stream, the filter in device memory and its staging buffers; one abg_rr is not
+ * thread-safe.  Sequences are ASCII with n + 1 offsets as in abg_load_seqs.  A maintainer replaces the three btllib calls by
+ * these (INTEGRATION.md shows the stub). */
+typedef struct abg_rr abg_rr;
+int abg_rr_create(int device, uint64_t bytes, uint32_t hash_num, uint32_t r, abg_rr** out);
+void abg_rr_destroy(abg_rr* f);
+const char* abg_rr_last_error(const abg_rr* f); /* f may be NULL: the last failed abg_rr_create */
+int abg_rr_bytes(const abg_rr* f, uint64_t* bytes); /* KmerBloomFilter::get_bytes(): the size after rounding */
+int abg_rr_clear(abg_rr* f);
+/* KmerBloomFilter::insert(seq.substr(0, max_bases)) for every sequence whose length is one of lengths[0 .. n_lengths) (every
+ * sequence when n_lengths is 0: the test of BloomFilters.cpp:182) and at least r.  max_bases: 1..4096.  *n_inserted (may be
+ * NULL) is incremented by the number of sequences of a wanted length (currentReadCount, :185).  Returns once the caller's buffers
+ * have been read; the kernels may still be running (every other call orders itself behind them). */
+int abg_rr_insert_seqs(abg_rr* f, const char* seqs, const uint64_t* offsets, uint64_t n, uint32_t max_bases,
+    const uint32_t* lengths, uint32_t n_lengths, uint64_t* n_inserted);
+/* found[i] = KmerBloomFilter::contains(sequence i): how many of its r-mers the filter holds */
+int abg_rr_contains_seqs(abg_rr* f, const char* seqs, const uint64_t* offsets, uint64_t n, uint32_t* found);
+int abg_rr_popcount(abg_rr* f, uint64_t* bits_set);  /* get_pop_cnt(): occupancy = bits_set / (8 * bytes), FPR = occupancy ^ hash_num */
+int abg_rr_export(abg_rr* f, uint8_t* host_out);      /* the array, abg_rr_bytes() bytes (parity tests) */
+int abg_rr_sync(abg_rr* f);                           /* waits for everything queued */
+/* kernel timing as abg_profile_enable / abg_profile_get: "rr_insert", "rr_contains", "rr_popcount" */
+int abg_rr_profile(abg_rr* f, int on);
+int abg_rr_profile_get(abg_rr* f, const char* name, double* total_ms, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,8 @@
 //   btllib_check hash K H SEQ       one line per ACGT-only k-mer of SEQ: position, then its H hash values
 //   btllib_check bloom BYTES H K    sequences on stdin, one per line: inserts the lines before an empty line, then prints for
 //                                   every later line how many of its k-mers the filter holds; last line: the filter's popcount
+//   btllib_check bloomdump BYTES H K SPAN OUT   sequences on stdin, one per line: inserts the first SPAN characters of every line
+//                                   that long at least K (RResolver/BloomFilters.cpp:191-193), writes the filter's array to OUT
 #include "btllib/bloom_filter.hpp"
 
 #include <cinttypes>
@@ -34,6 +36,21 @@ int main(int argc, char** argv)
 		printf("%" PRIu64 " %zu\n", bf.get_pop_cnt(), bf.get_bytes());
 		return 0;
 	}
-	fprintf(stderr, "usage: btllib_check hash K H SEQ | bloom BYTES H K\n");
+	if (argc == 7 && !strcmp(argv[1], "bloomdump")) {
+		btllib::KmerBloomFilter bf((size_t)strtoull(argv[2], 0, 10), (unsigned)atoi(argv[3]), (unsigned)atoi(argv[4]));
+		const size_t span = (size_t)strtoull(argv[5], 0, 10);
+		std::string line;
+		while (std::getline(std::cin, line)) {
+			const std::string seq = line.substr(0, span);
+			if (seq.size() >= bf.get_k()) bf.insert(seq);
+		}
+		FILE* o = fopen(argv[6], "wb");
+		if (!o) return 1;
+		for (size_t i = 0; i < bf.get_bytes(); i++) fputc(bf.get_bloom_filter().data()[i].load(), o);
+		fclose(o);
+		printf("%" PRIu64 " %zu\n", bf.get_pop_cnt(), bf.get_bytes());
+		return 0;
+	}
+	fprintf(stderr, "usage: btllib_check hash K H SEQ | bloom BYTES H K | bloomdump BYTES H K SPAN OUT\n");
 	return 2;
 }

@@ -9,6 +9,7 @@ Per case: the reads (npz), the unitigs and their graph (the stage's inputs), and
 contigs, the resolved graph and the histograms of -h.  Run in the build container (needs /root/reference):
     python tests/golden/make_rresolver.py
 """
+import hashlib
 import json
 import os
 import subprocess
@@ -26,6 +27,8 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(HERE, "rresolver")
 
 # name, genome length, k, read length, coverage, error rate, repeats (count, shortest, longest, most copies), -b, extra options
+# (a fourth entry with TWO read lengths -- 100 and 125 bases, a few N and lower-case bases -- is made by mixed_case() below:
+# two read sizes, so two Bloom filters and two rounds of resolution, and reads that the filter must skip over)
 CASES = [
     ("rr_k64", 80000, 64, 150, 40.0, 0.003, (40, 66, 116, 4), "16M", []),
     ("rr_k32", 60000, 32, 100, 40.0, 0.003, (40, 34, 70, 3), "8M", []),
@@ -76,6 +79,97 @@ def run_case(name, G, k, L, cov, err, reps, b, extra, td):
             "files": files, "options": " ".join(os.path.basename(c) for c in cmd[1:])}
 
 
+# name of the case whose inputs are used, option changes, output format: the same stage with other parameters.  Only the
+# sha256 of every output is kept (the SAM header's @PG line names the binary and is left out of the digest).
+#   -n1 / -n2   few branching paths: more than branching^2 combinations, so the heads and tails are shuffled (std::random_shuffle,
+#               RAlgorithmsShort.cpp:488-505) -- pins the order in which the reference at -j1 works through the repeats
+#   --adj input the graph read in ADJ format (the other format this stage's drop-in reads)
+VARIANTS = [
+    ("rr_k32", ["-n1"], "dot", "dot"),
+    ("rr_k32", ["-n2", "-t3"], "adj", "adj"),
+    ("rr_k32", ["-x2"], "gfa2", "dot"),
+    ("rr_k32", ["-r62"], "sam", "dot"),
+    ("rr_k64", ["-n1"], "dot", "adj"),
+    ("rr_k64", ["-m10", "-M20"], "gfa1", "dot"),
+    ("rr_k64", ["-a2.5", "-t3"], "asqg", "dot"),
+    ("rr_k48_t3_x6", ["-n2"], "dot", "dot"),
+    ("rr_mixed", ["-n3"], "adj", "adj"),
+    ("rr_mixed", ["-r70", "-r75"], "dot", "dot"),
+]
+
+
+def digest(data):
+    return hashlib.sha256(b"".join(l for l in data.splitlines(True) if not l.startswith(b"@PG"))).hexdigest()
+
+
+def write_reads(td, name, info):
+    """The reads of a case as the tests write them: one FASTA file, or (read_files == 'fq+fa') the first half as FASTQ
+    and the second half as FASTA with the sequence over two lines."""
+    d = np.load(os.path.join(OUT, name + ".reads.npz"))
+    buf, off = d["buf"].tobytes(), d["off"]
+    seqs = [buf[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+    if info.get("read_files") != "fq+fa":
+        with open(os.path.join(td, "reads.fa"), "wb") as f:
+            for i, s in enumerate(seqs):
+                f.write(b">r%d\n%s\n" % (i, s))
+        return ["reads.fa"]
+    h = len(seqs) // 2
+    with open(os.path.join(td, "reads_1.fq"), "wb") as f:
+        for i, s in enumerate(seqs[:h]):
+            f.write(b"@r%d 1:N:0:x\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+    with open(os.path.join(td, "reads_2.fa"), "wb") as f:
+        for i, s in enumerate(seqs[h:]):
+            f.write(b">r%d\n%s\n%s\n" % (h + i, s[:60], s[60:]))
+    return ["reads_1.fq", "reads_2.fa"]
+
+
+def run_variant(base, info, extra, fmt, gin, td):
+    for fn in (base + "-1.fa", base + "-1.dot", base + "-1.adj"):
+        open(os.path.join(td, fn), "wb").write(open(os.path.join(OUT, fn), "rb").read())
+    reads = write_reads(td, base, info)
+    cmd = [os.path.join(REF, "abyss-rresolver-short"), "-b" + info["bloom"], "-f0.8", "-j1", "-k%d" % info["k"]] + info["extra"] + extra + [
+        "-h", "o", "--" + fmt, "-c", "o.fa", "-g", "o.g", "-S", "o.S", "-U", "o.U", base + "-1.fa", base + "-1." + gin] + reads
+    subprocess.run(cmd, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    return {f: digest(open(os.path.join(td, f), "rb").read()) for f in sorted(os.listdir(td)) if f.startswith("o")}
+
+
+def mixed_case(td):
+    """60 kbp, k=40, reads of 100 and of 125 bases (two read sizes: two filters, two rounds), some with an N or lower case."""
+    name, G, k, b = "rr_mixed", 60000, 40, "8M"
+    g = genome(G, (40, 42, 90, 3), 77)
+    sets = []
+    for L, cov, seed in ((100, 28.0, 3), (125, 24.0, 4)):
+        m1, m2 = synth.sample_pairs(g, g, int(G * cov / (2 * L)), read_len=L, err=0.003, seed=seed, frag_lo=260, frag_hi=360)
+        sets += [bytearray(bytes(r)) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
+    rng = np.random.default_rng(9)
+    rng.shuffle(sets)
+    for i in rng.choice(len(sets), len(sets) // 50, replace=False):
+        sets[i][int(rng.integers(0, len(sets[i])))] = ord("N")
+    for i in rng.choice(len(sets), len(sets) // 50, replace=False):
+        a = int(rng.integers(0, 80))
+        sets[i][a:a + 7] = bytes(sets[i][a:a + 7]).lower()
+    seqs = [bytes(s) for s in sets]
+    np.savez_compressed(os.path.join(OUT, name + ".reads.npz"), buf=np.frombuffer(b"".join(seqs), dtype=np.uint8),
+                        off=np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64))
+    info = {"k": k, "bloom": b, "extra": [], "read_len": 0, "reads": len(seqs), "read_files": "fq+fa"}
+    reads = write_reads(td, name, info)
+    fa = subprocess.run([os.path.join(REF, "abyss-bloom-dbg"), "-k%d" % k, "-b" + b, "-j1"] + reads, cwd=td,
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    open(os.path.join(td, name + "-1.fa"), "wb").write(fa)
+    dot = subprocess.run([os.path.join(REF, "AdjList"), "-k%d" % k, "-m0", "--dot", name + "-1.fa"], cwd=td, stdout=subprocess.PIPE, check=True).stdout
+    open(os.path.join(td, name + "-1.dot"), "wb").write(dot)
+    cmd = [os.path.join(REF, "abyss-rresolver-short"), "-b" + b, "-f0.8", "-j1", "-k%d" % k, "-h", name + "-1-rr", "--dot", "-c", name + "-1-rr.fa",
+           "-g", name + "-1-rr.dot", name + "-1.fa", name + "-1.dot"] + reads
+    subprocess.run(cmd, cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    files = sorted(f for f in os.listdir(td) if f.startswith(name + "-1"))
+    for f in files:
+        open(os.path.join(OUT, f), "wb").write(open(os.path.join(td, f), "rb").read())
+    nin, nout = fa.count(b">"), open(os.path.join(td, name + "-1-rr.fa"), "rb").read().count(b">")
+    print(name, "unitigs", nin, "-> contigs", nout, "files", len(files))
+    info.update(unitigs=nin, contigs=nout, files=files, options=" ".join(os.path.basename(c) for c in cmd[1:]))
+    return info
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "abyss-rresolver-short")):
         sys.exit("build the reference first: make -C oracle ref")
@@ -84,6 +178,20 @@ def main():
     for name, G, k, L, cov, err, reps, b, extra in CASES:
         with tempfile.TemporaryDirectory() as td:
             index[name] = run_case(name, G, k, L, cov, err, reps, b, extra, td)
+    with tempfile.TemporaryDirectory() as td:
+        index["rr_mixed"] = mixed_case(td)
+    for name, info in index.items():  # the graph in ADJ format as well (the same AdjList run, other writer)
+        k = info["k"]
+        adj = subprocess.run([os.path.join(REF, "AdjList"), "-k%d" % k, "-m%d" % (50 if k > 50 else 0), "--adj", name + "-1.fa"], cwd=OUT,
+                             stdout=subprocess.PIPE, check=True).stdout
+        open(os.path.join(OUT, name + "-1.adj"), "wb").write(adj)
+    variants = []
+    for base, extra, fmt, gin in VARIANTS:
+        with tempfile.TemporaryDirectory() as td:
+            sha = run_variant(base, index[base], extra, fmt, gin, td)
+        variants.append({"base": base, "extra": extra, "format": fmt, "graph_in": gin, "sha256": sha})
+        print("variant", base, extra, fmt, gin, len(sha), "files")
+    index["_variants"] = variants
     json.dump(index, open(os.path.join(OUT, "index.json"), "w"), indent=1, sort_keys=True)
 
 

@@ -70,3 +70,18 @@ def test_host_binary_multi_gpu_launch_fails_cleanly_without_devices(tmp_path):
     r = subprocess.run([exe, "-k32", "-b1M", "--gpus=2", "--checkpoint=100", "r.fa"], cwd=tmp_path, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and b"--checkpoint is not available with --gpus" in r.stderr
+
+
+@pytest.mark.skipif(_have_gpu(), reason="a GPU is present")
+def test_rresolver_has_no_cpu_fallback(tmp_path):
+    """abg_rr_create -> ABG_ENODEV without a GPU, and the drop-in abyss-rresolver-short says so and exits 1 once it needs the filter."""
+    import subprocess
+    import rr_util
+    with pytest.raises(api.AbyssAmdError) as e:
+        api.ReadFilter(1 << 20, 64)
+    assert "no HIP device" in str(e.value)
+    build.build_cli()
+    reads = rr_util.write_inputs(str(tmp_path), "rr_k32")
+    r = subprocess.run([os.path.join(build.BIN_DIR, "abyss-rresolver-short"), "-b8M", "-k32", "-c", "o.fa", "-g", "o.dot", "--dot", "rr_k32-1.fa", "rr_k32-1.dot"] + reads,
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1 and b"no HIP device" in r.stderr and not os.path.exists(tmp_path / "o.fa")

@@ -12,6 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import rr_util
 from util import GOLDEN
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -91,27 +92,19 @@ def test_shim_bloom_filter_layout_and_membership():
 
 
 @needs_ref
-@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(RRG, "index.json")))))
+@pytest.mark.parametrize("name", rr_util.CASES)
 def test_oracle_build_reproduces_the_rresolver_goldens(name, tmp_path):
     """make -C oracle ref && the rule of bin/abyss-pe:581-585 on the committed inputs: the resolved contigs, the resolved
     graph and every histogram are the committed ones, with one thread and with four."""
-    info = json.load(open(os.path.join(RRG, "index.json")))[name]
-    d = np.load(os.path.join(RRG, name + ".reads.npz"))
-    buf, off = d["buf"].tobytes(), d["off"]
-    with open(tmp_path / "reads.fa", "wb") as f:
-        for i in range(len(off) - 1):
-            f.write(b">r%d\n%s\n" % (i, buf[int(off[i]):int(off[i + 1])]))
-    for fn in (name + "-1.fa", name + "-1.dot"):
-        (tmp_path / fn).write_bytes(open(os.path.join(RRG, fn), "rb").read())
-    outs = [f for f in info["files"] if "-1-rr" in f]
-    assert any(f.endswith("-1-rr.fa") for f in outs) and any(f.endswith("-1-rr.dot") for f in outs) and len(outs) >= 4
+    info = rr_util.INDEX[name]
+    want = rr_util.golden_outputs(name)
+    assert any(f.endswith("-1-rr.fa") for f in want) and any(f.endswith("-1-rr.dot") for f in want) and len(want) >= 4
     for j in (1, 4):
-        for f in outs:
-            if (tmp_path / f).exists():
-                os.remove(tmp_path / f)
-        cmd = [RR, "-b" + info["bloom"], "-f0.8", "-j%d" % j, "-k%d" % info["k"]] + info["extra"] + [
-            "-h", name + "-1-rr", "--dot", "-c", name + "-1-rr.fa", "-g", name + "-1-rr.dot", name + "-1.fa", name + "-1.dot", "reads.fa"]
-        subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-        for f in outs:
-            assert (tmp_path / f).read_bytes() == open(os.path.join(RRG, f), "rb").read(), (f, j)
+        assert rr_util.run_case(RR, str(tmp_path), name, threads=j) == want, j
     assert info["contigs"] < info["unitigs"]  # (the stage did resolve repeats on this input)
+
+
+@needs_ref
+@pytest.mark.parametrize("v", rr_util.VARIANTS[::3], ids=rr_util.variant_id)
+def test_oracle_build_reproduces_the_variant_digests(v, tmp_path):
+    assert rr_util.run_variant(RR, str(tmp_path), v) == v["sha256"]
