@@ -1134,13 +1134,42 @@ class Resolver {
 		std::vector<uint32_t> found;
 		size_t size() const { return off.size() - 1; }
 	};
-	// libstdc++'s std::random_shuffle (bits/stl_algo.h): the reference calls it on the heads and tails of a path with more
-	// than branching^2 combinations, and its rand() stream is part of the -j1 behaviour
-	template <class T> static void random_shuffle(std::vector<T>& v)
+	// libstdc++'s std::random_shuffle (bits/stl_algo.h: for i = 1 .. n-1 swap v[i] with v[rand() % (i + 1)]): the reference calls it
+	// on the heads and tails of a path with more than branching^2 combinations, and its rand() stream is part of the -j1
+	// behaviour.  The reference never calls srand and nothing else in it draws from rand(), so the stream is glibc's from seed 1 --
+	// kept here as a generator of our own (glibc's TYPE_3 additive feedback: r[i] = r[i-3] + r[i-31], output r[i] >> 1), because
+	// in this process other libraries (the HIP runtime) may draw from rand() as well.
+	struct GlibcRand {
+		uint32_t r[34];
+		int at = 0;
+		GlibcRand()
+		{
+			int32_t x[344 + 34];
+			x[0] = 1;
+			for (int i = 1; i < 31; i++) {
+				const int64_t hi = x[i - 1] / 127773, lo = x[i - 1] % 127773;
+				int64_t w = 16807 * lo - 2836 * hi;
+				if (w < 0) w += 2147483647;
+				x[i] = (int32_t)w;
+			}
+			for (int i = 31; i < 34; i++) x[i] = x[i - 31];
+			for (int i = 34; i < 344; i++) x[i] = (int32_t)((uint32_t)x[i - 31] + (uint32_t)x[i - 3]);
+			for (int i = 0; i < 34; i++) r[i] = (uint32_t)x[344 - 34 + i];
+		}
+		int next()
+		{
+			// r holds the last 34 values as a ring; the new one is r[-31] + r[-3]
+			const uint32_t v = r[(at + 34 - 31) % 34] + r[(at + 34 - 3) % 34];
+			r[at] = v;
+			at = (at + 1) % 34;
+			return (int)(v >> 1);
+		}
+	};
+	mutable GlibcRand rng;
+	template <class T> void random_shuffle(std::vector<T>& v) const
 	{
-		if (v.empty()) return;
 		for (size_t i = 1; i < v.size(); i++) {
-			const size_t j = (size_t)(std::rand() % (long)(i + 1));
+			const size_t j = (size_t)(rng.next() % (long)(i + 1));
 			if (i != j) std::swap(v[i], v[j]);
 		}
 	}

@@ -140,3 +140,63 @@ def test_the_two_rules_in_a_row_write_the_reference_overlap_graph(tmp_path):
     if os.path.exists(ao.REF_ADJLIST):
         r = subprocess.run([ao.REF_ADJLIST, "-k40", "-m0", "--dot", "asm-1.fa"], cwd=tmp_path, stdout=subprocess.PIPE)
         assert r.returncode == 0 and r.stdout == (tmp_path / "asm-1.dot").read_bytes()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PE), reason="the reference tree is not on this machine")
+def test_abyss_pe_issues_the_rresolver_command_line_our_binary_accepts(tmp_path):
+    """The rule after `-1.dot` in Bloom mode (bin/abyss-pe:581-585): `abyss-rresolver-short -b$B -f0.8 -j$j -k$k -h asm-1-rr --dot
+    -c asm-1-rr.fa -g asm-1-rr.dot asm-1.fa asm-1.dot $(in)`."""
+    import rr_util
+    build.build_cli()
+    real = os.path.join(build.BIN_DIR, "abyss-rresolver-short")
+    d = tmp_path / "shim"
+    d.mkdir()
+    rec = tmp_path / "argv.txt"
+    sh = d / "abyss-rresolver-short"
+    sh.write_text("#!/bin/sh\nprintf '%%s\\n' \"$@\" > %s\nexec %s \"$@\"\n" % (rec, real))
+    sh.chmod(sh.stat().st_mode | stat.S_IXUSR)
+    reads = rr_util.write_inputs(str(tmp_path), "rr_k32")
+    os.rename(tmp_path / "rr_k32-1.fa", tmp_path / "asm-1.fa")
+    os.rename(tmp_path / "rr_k32-1.dot", tmp_path / "asm-1.dot")
+    env = dict(os.environ, PATH="%s:%s" % (d, os.environ["PATH"]))
+    r = subprocess.run(["make", "-rRf", REF_PE, "name=asm", "k=32", "B=8M", "j=2", "in=%s" % " ".join(reads), "asm-1-rr.fa"],
+                       cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    out = (r.stdout + r.stderr).decode()
+    assert rec.exists(), out
+    assert rec.read_text().split("\n")[:-1] == ["-b8M", "-f0.8", "-j2", "-k32", "-h", "asm-1-rr", "--dot", "-c", "asm-1-rr.fa", "-g", "asm-1-rr.dot",
+                                                 "asm-1.fa", "asm-1.dot"] + reads
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        assert r.returncode == 0, out
+        assert (tmp_path / "asm-1-rr.fa").read_bytes() == rr_util.golden_outputs("rr_k32")["rr_k32-1-rr.fa"]
+    else:
+        assert r.returncode != 0 and "no HIP device" in out and "invalid option" not in out and "missing" not in out, out
+
+
+@pytest.mark.gpu
+def test_the_three_rules_in_a_row_write_what_the_reference_binaries_write(tmp_path):
+    """`%-1.fa`, `%-1.dot`, `%-1-rr.fa %-1-rr.dot` as abyss-pe issues them in Bloom mode (bin/abyss-pe:553-555,575-577,581-585), the
+    three drop-ins from PATH on a read set with short repeats; every file equals what the unmodified reference binaries
+    (oracle/_ref, -j1) write on the same reads."""
+    import numpy as np
+    import rr_util
+    cli = build.build_cli()
+    name = "rr_k64"
+    reads = rr_util.write_inputs(str(tmp_path), name)
+    env = dict(os.environ, PATH="%s:%s" % (os.path.dirname(cli), os.environ["PATH"]))
+    rules = ["abyss-bloom-dbg -k64 -b16M -j2 %s > asm-1.fa" % " ".join(reads),
+             "AdjList -k64 -m50 --dot asm-1.fa > asm-1.dot",
+             "abyss-rresolver-short -b16M -f0.8 -j2 -k64 -h asm-1-rr --dot -c asm-1-rr.fa -g asm-1-rr.dot asm-1.fa asm-1.dot %s" % " ".join(reads)]
+    for rule in rules:
+        r = subprocess.run(["sh", "-c", rule], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+    # the golden case was made by the same three rules with the reference's binaries (tests/golden/make_rresolver.py)
+    assert (tmp_path / "asm-1.fa").read_bytes() == open(os.path.join(rr_util.RRG, name + "-1.fa"), "rb").read()
+    assert (tmp_path / "asm-1.dot").read_bytes() == open(os.path.join(rr_util.RRG, name + "-1.dot"), "rb").read()
+    want = rr_util.golden_outputs(name)
+    for f, data in want.items():
+        assert (tmp_path / f.replace(name, "asm")).read_bytes() == data, f
