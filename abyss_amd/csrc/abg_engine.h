@@ -51,6 +51,7 @@ struct Config {
 	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	bool benign_sharers = true;       // ... and k-mers that share a counter they cannot write are settled by the tiles as well (op_verdict)
+	bool sorted_overflow = true;      // a batch whose pairs run a bin over is judged and applied through a sort of its pairs (Engine::sorted_judge) instead of taking the reservation rounds as a whole
 	bool cosettle = true;             // ... and k-mers that may write shared counters, when every k-mer on those is settled too (op_verdict, FCoSettle)
 	uint32_t cosettle_passes = 6;     // passes of that fixed point before the candidates left over go to the rounds after all (1 .. CO_MAX_PASSES)
 	uint32_t cosettle_log2 = 24;      // bits of the table of counters the rounds' k-mers touch
@@ -628,6 +629,7 @@ struct TileEnv {
 	uint32_t* flags;                  // [0] a bin overflowed: the batch goes through the reservation rounds instead
 	uint32_t benign = 1;              // op_verdict: k-mers that cannot write their shared counters are settled by the tiles too
 	uint32_t lead_js = 2;             // tile_purity: pairs of the first lead_js hash functions write `lead` (a partitioned run: all -- every rank must know)
+	uint32_t count_max = 0x7FFFFFFFu; // a counter with this many pairs or more is treated like a shared one (a partitioned run: 254 -- the ranks pass a leader's op count in a byte)
 	// the settling of k-mers that DO write shared counters (op_verdict, FCoSettle); all null / 0 when that is off
 	uint32_t* bad = nullptr;          // [(bad_mask + 1) / 32] bit "some k-mer on this counter goes through the rounds", by hashed counter position
 	uint32_t bad_mask = 0;
@@ -972,9 +974,9 @@ ABG_HDN void tile_purity(const TileEnv& e, uint64_t tile, void* fast, Sync& sy)
 	sy.barrier();
 	pairs([&](const TilePair& r, uint32_t, uint32_t s, uint32_t) {
 		const uint32_t inf = info[s], t = tp_t(r);
-		// (a counter with 254 pairs or more is treated like a shared one: the partitioned run passes
-		// the leaders' op counts between the ranks in a byte)
-		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= 254) {
+		// (a partitioned run treats a counter with 254 pairs or more like a shared one: it passes the leaders' op counts
+		// between the ranks in a byte.  Elsewhere n ops of a k-mer are n ops however many: min(m + n, 255))
+		if ((inf >> 31) || (inf & 0x7FFFFFFFu) >= e.count_max) {
 			// shared: bit j of the op's flag byte (several tiles may flag one op at once: a word-wide OR)
 			const uint32_t bit = e.p.nh <= 8 ? (1u << tp_j(r)) : 0xFFu;
 			atomic_or_u32((uint32_t*)e.opflag + (t >> 2), bit << (8 * (t & 3u)));
@@ -1257,6 +1259,84 @@ ABG_HDN void tile_apply(const TileEnv& e, uint64_t tile, uint8_t* lds, Sync& sy)
 		for (uint32_t i = tid; i < span / 8; i += nt) o8[i] = l8[i];
 	}
 }
+// ---- a batch whose pairs do not fit its bins (Engine::insert_sorted) ----
+// A bin holds what a tile sees of a batch of random k-mers, with room to spare; a k-mer that recurs thousands of times in a
+// batch -- a homopolymer run, a satellite, a collapsed repeat at high coverage -- puts all its pairs on H counters and runs
+// the bins of those over.  Such a batch is judged and applied without the tiles: every (op, counter) pair, sorted by counter
+// position (a stable radix sort: a counter's pairs stay in op order), the segments of equal positions judged as tile_purity
+// judges a counter's pairs -- same flags, same `lead` -- and the leaders' targets raised with a byte-wide atomic maximum.
+// What op_verdict, the fixed point and the reservation rounds do in between is the tile path's, unchanged.
+struct SortEnv {
+	TileEnv e; uint64_t T, np;        // np = T * nh pairs
+	uint64_t* key; uint32_t* val;     // [np] counter position; op << 4 | hash function -- sorted by position
+	uint64_t* sid;                    // [np] 1 on the first pair of a position, then (inclusive sum) the pair's segment, from 1
+	uint32_t* start;                  // [segments + 1] first pair of every segment; np after the last
+	uint8_t* impure;                  // [segments] another k-mer on the counter (or the earliest op twice)
+};
+struct FSortKeys { // one pair per item, op-major: pair q belongs to op q / nh
+	SortEnv s;
+	ABG_HD void operator()(uint64_t q, uint32_t) const
+	{
+		const uint64_t t = q / s.e.p.nh; const unsigned j = (unsigned)(q - t * s.e.p.nh);
+		s.key[q] = pos_i(s.e.p, s.e.h0[t], j);
+		s.val[q] = (uint32_t)t << 4 | j;
+	}
+};
+struct FSegHeads {
+	SortEnv s;
+	ABG_HD void operator()(uint64_t i, uint32_t) const { s.sid[i] = (i == 0 || s.key[i] != s.key[i - 1]) ? 1u : 0u; }
+};
+struct FSegStarts { // after the inclusive sum
+	SortEnv s;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		if (i == 0 || s.key[i] != s.key[i - 1]) { s.start[s.sid[i] - 1] = (uint32_t)i; s.impure[s.sid[i] - 1] = 0; }
+		if (i + 1 == s.np) s.start[s.sid[i]] = (uint32_t)s.np;
+	}
+};
+struct FSegImpure { // tile_purity's test of a pair against the counter's earliest pair
+	SortEnv s;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint64_t g = s.sid[i] - 1, f = s.start[g];
+		if (i == f) return;
+		const uint32_t v = s.val[i], vf = s.val[f];
+		if (s.e.h0[v >> 4] != s.e.h0[vf >> 4] || (v >> 4) == (vf >> 4)) s.impure[g] = 1;
+	}
+};
+struct FSegJudge { // ... and what it then does for the pair's op
+	SortEnv s;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint64_t g = s.sid[i] - 1;
+		const uint32_t f = s.start[g], cnt = s.start[g + 1] - f, v = s.val[i], t = v >> 4, j = v & 15u;
+		if (s.impure[g] || cnt >= s.e.count_max) {
+			const uint32_t bit = s.e.p.nh <= 8 ? (1u << j) : 0xFFu;
+			atomic_or_u32((uint32_t*)s.e.opflag + (t >> 2), bit << (8 * (t & 3u)));
+			return;
+		}
+		if (j >= s.e.lead_js) return;
+		s.e.lead[t] = cnt | ((s.val[f] >> 4) == t ? LEAD_BIT : 0u);
+	}
+};
+struct FSegApply { // tile_apply's raise: the counter to the maximum of what it holds and its leaders' targets
+	SortEnv s;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint8_t tg = s.e.tgt[s.val[i] >> 4];
+		if (!tg) return;
+		const uint64_t pos = s.key[i];
+		uint32_t* w = (uint32_t*)(s.e.cnt + (pos & ~3ull));
+		const unsigned sh = 8u * (unsigned)(pos & 3u);
+		for (uint32_t old = *w;;) {
+			if (((old >> sh) & 0xFFu) >= tg) return;
+			const uint32_t want = (old & ~(0xFFu << sh)) | ((uint32_t)tg << sh);
+			const uint32_t got = cas_u32(w, old, want);
+			if (got == old) return;
+			old = got;
+		}
+	}
+};
 struct FClaimList { // FClaim over a list of ops
 	Params p; const uint64_t* h0; const uint32_t* pend; uint64_t* claim; uint64_t cmask; uint32_t epoch;
 	ABG_HD void operator()(uint64_t i, uint32_t) const
@@ -3066,7 +3146,7 @@ class Engine {
 		uint64_t* h0 = h0_alt_;
 		const bool part = dist();
 		TileEnv te{ p_, cnt_, part ? own_lo_ : 0, part ? own_lo_ + own_span_ : m_, h0_alt_, bins_alt_, tile_cap_, tcur_alt_, lead_alt_ ? lead_alt_ : lead_,
-			opflag_alt_ ? opflag_alt_ : opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u, part ? 16u : 2u };
+			opflag_alt_ ? opflag_alt_ : opflag_, tgt_, pendf_, flag, cfg_.benign_sharers ? 1u : 0u, part ? 16u : 2u, part ? 254u : 0x7FFFFFFFu };
 		const uint64_t R = part ? (uint64_t)comm_.world : 1, me = part ? (uint64_t)comm_.rank : 0;
 		if (part && R > cfg_.dist_hash_all_ranks) {
 			// partitioned run: this rank's slice of the hashes on the side stream, the all-gather on the main
@@ -3686,14 +3766,28 @@ class Engine {
 				FBinFine f2{ bn, cpb };
 				be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 			}
-			// (the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
+			// A bin that ran over (a k-mer recurring thousands of times in the batch): the pairs are judged and applied through a
+			// sort instead of the tiles (sorted_judge).  Staged batches wrote their flag word while the batch before took its rounds.
+			SortBufs sb;
+			bool sorted = false;
+			if (cfg_.sorted_overflow) {
+				uint32_t over = 0;
+				be_.d2h(&over, pend_n_ + flag_word, 4);
+				if (over) {
+					be_.memset(lead_, 0, T * 4);
+					be_.memset(opflag_, 0, (T + 3) & ~3ull);
+					sorted = sorted_judge(te, T, sb);
+					if (sorted) { be_.memset(pend_n_ + flag_word, 0, 4); stats_.tile_overflows++; }
+				}
+			}
+			// (otherwise the tile kernels do nothing once a bin has overflowed: one read-back tells both the pending count and that)
 			if (bad_) {
 				te.bad = bad_; te.bad_mask = (uint32_t)((1ull << cfg_.cosettle_log2) - 1); te.wmask = wmask_; te.chg = cochg_; // (cosettle_log2 <= 25: CO_SLOT_MASK)
 				te.colist = colist_; te.cocnt = cocnt_; te.glog2 = BE::ITEM_GROUP_LOG2;
 				be_.memset(bad_, 0, (1ull << cfg_.cosettle_log2) / 8);
 				be_.memset(cochg_, 0, (CO_MAX_PASSES + 1) * 4);
 			}
-			if (!judged) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
+			if (!judged && !sorted) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
 			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
 			if (bad_) {
 				// the k-mers that may raise shared counters: settled together, or sent to the rounds together (op_verdict)
@@ -3702,7 +3796,8 @@ class Engine {
 				for (uint32_t q = 1; q <= np; q++) { FCoSettle f{ te, q }; be_.launch(ngroups, f, "co_settle"); }
 				FCoFinal f{ te, np }; be_.launch(ngroups, f, "co_settle");
 			}
-			{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
+			if (sorted) { SortEnv se = sb.env(te, T); FSegApply f{ se }; be_.launch(se.np, f, "tile_apply"); sorted_free(sb); }
+			else { FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
 			{
 				// the ops for the rounds, in op order (FPendCount)
 				const uint64_t ng = (T + PEND_GROUP - 1) / PEND_GROUP;
@@ -3764,6 +3859,41 @@ class Engine {
 		epoch_++;
 	}
 
+	// The pairs of a batch sorted by counter and judged segment by segment (SortEnv): `lead` and `opflag` come out as
+	// tile_purity would leave them with bins of any size.  false: no memory for it (the batch then takes the rounds as a whole).
+	struct SortBufs {
+		uint64_t* key = nullptr; uint32_t* val = nullptr; uint64_t* sid = nullptr; uint32_t* start = nullptr; uint8_t* impure = nullptr; uint64_t np = 0;
+		SortEnv env(const TileEnv& te, uint64_t T) const { return SortEnv{ te, T, np, key + np, val + np, sid, start, impure }; }
+	};
+	void sorted_free(SortBufs& sb)
+	{
+		be_.sync(); // (blocks of this size are not recycled: they go back to the device once nothing queued reads them)
+		be_.free(sb.key); be_.free(sb.val); be_.free(sb.sid); be_.free(sb.start); be_.free(sb.impure);
+		sb = SortBufs();
+	}
+	bool sorted_judge(const TileEnv& te, uint64_t T, SortBufs& sb)
+	{
+		const uint64_t np = T * p_.nh;
+		if (p_.nh > 16 || np >= 0x7FFFFFFFull) return false;
+		sb.np = np;
+		sb.key = (uint64_t*)be_.try_alloc(2 * np * 8); sb.val = (uint32_t*)be_.try_alloc(2 * np * 4);
+		sb.sid = (uint64_t*)be_.try_alloc(np * 8); sb.start = (uint32_t*)be_.try_alloc((np + 1) * 4); sb.impure = (uint8_t*)be_.try_alloc(np);
+		if (!sb.key || !sb.val || !sb.sid || !sb.start || !sb.impure) {
+			if (sb.key) be_.free(sb.key); if (sb.val) be_.free(sb.val); if (sb.sid) be_.free(sb.sid); if (sb.start) be_.free(sb.start); if (sb.impure) be_.free(sb.impure);
+			sb = SortBufs();
+			return false;
+		}
+		{ SortEnv in{ te, T, np, sb.key, sb.val, sb.sid, sb.start, sb.impure }; FSortKeys f{ in }; be_.launch(np, f, "sort_judge"); }
+		be_.sort_pairs_u64_u32(sb.key, sb.key + np, sb.val, sb.val + np, np);
+		const SortEnv se = sb.env(te, T);
+		{ FSegHeads f{ se }; be_.launch(np, f, "sort_judge"); }
+		be_.inclusive_sum_u64(sb.sid, np);
+		{ FSegStarts f{ se }; be_.launch(np, f, "sort_judge"); }
+		{ FSegImpure f{ se }; be_.launch(np, f, "sort_judge"); }
+		{ FSegJudge f{ se }; be_.launch(np, f, "sort_judge"); }
+		return true;
+	}
+
 	// The tiles of insert_range over a range-partitioned filter.  Each rank hashes a slice of the
 	// batch's ops and the slices are all-gathered (8 bytes per op instead of every rank hashing
 	// every op); each rank then bins the pairs on the counters it owns into its own tiles and
@@ -3775,7 +3905,7 @@ class Engine {
 	{
 		cnt_partial_ = true;
 		const uint64_t R = (uint64_t)comm_.world, me = (uint64_t)comm_.rank;
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u, 16u };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, pend_n_ + flag_word, cfg_.benign_sharers ? 1u : 0u, 16u, 254u };
 		const bool judged = staged && purity_done_;
 		if (!judged) {
 			be_.memset(lead_, 0, T * 4);
@@ -3845,7 +3975,7 @@ class Engine {
 		const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
 		const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk), nown = b - a;
 		uint32_t* rflag = rcur_ + MAX_RANKS; // [0] some room ran out on this rank
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u, 16u };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u, 16u, 254u };
 		be_.memset(lead_, 0, T * 4);
 		be_.memset(opflag_, 0, (T + 3) & ~3ull);
 		be_.memset(tcur_, 0, ntiles_ * 4);

@@ -331,7 +331,7 @@ typedef struct abg_stats {
 	uint64_t memo_hits, memo_adds; /* successor() answers taken from / added to the shared memo */
 	uint64_t tiled_ops;     /* PASS 1: k-mer ops of batches that went through the LDS tiles ... */
 	uint64_t tiled_pending; /* ... of which this many shared a counter with another k-mer and took the reservation rounds */
-	uint64_t tile_overflows; /* ... batches whose bins overflowed (handled by the reservation rounds as a whole) */
+	uint64_t tile_overflows; /* ... batches whose bins overflowed (judged through a sort of their pairs instead of the tiles; without memory for that, by the reservation rounds as a whole) */
 	uint64_t pre_requests, pre_adds; /* always 0 (kept for the layout: the pre-search of round 3 is gone) */
 	uint64_t cancelled;     /* always 0 (kept for the layout: several batches in flight are gone) */
 	uint64_t counter_bytes_held; /* bytes of the counting filter this context holds: all of it, or its own range of a sliced filter (abg_params.slice_filter) */

@@ -54,6 +54,11 @@ def replicons(kind, rng):
         g = [rnd(rng, 1200), b"A" * 80, rnd(rng, 700), b"AC" * 50, rnd(rng, 700), b"T" * 45 + b"G" + b"T" * 45, rnd(rng, 900),
              b"AAG" * 30, rnd(rng, 600), b"C" * 30, rnd(rng, 1200)]
         return [(b"".join(g), False)]
+    if kind == "satellite":
+        # a 10 kbp homopolymer and a 10 kbp dinucleotide satellite at 500-fold coverage beside an ordinary 8 kbp sequence at 40-fold
+        # (third field: a coverage multiplier): their k-mers recur tens of thousands of times in a batch of PASS 1 -- more pairs
+        # on one counter than a tile's bin holds -- and everything about them saturates (counters at 255)
+        return [(rnd(rng, 8000), False), (rnd(rng, 400) + b"A" * 10000 + rnd(rng, 400), False, 12.5), (rnd(rng, 400) + b"AC" * 5000 + rnd(rng, 400), False, 12.5)]
     if kind == "mixed":
         # (the k-mer size at its limits: MAX_KMER = 192 wants long reads; a small k makes a crowded graph)
         return [(rnd(rng, 9000), False), (rnd(rng, 1400), True), (rnd(rng, 60) * 12, False)]
@@ -62,8 +67,9 @@ def replicons(kind, rng):
 
 def sample(reps, rng, cov, L, err):
     reads = []
-    for seq, circ in reps:
-        n = max(4, int(len(seq) * cov / L))
+    for rep in reps:
+        seq, circ = rep[0], rep[1]
+        n = max(4, int(len(seq) * cov * (rep[2] if len(rep) > 2 else 1.0) / L))
         if circ:
             ext = seq * (L // len(seq) + 2)
             starts = rng.integers(0, len(seq), size=n)
@@ -95,6 +101,7 @@ CASES = [
     ("s_mixed_k32_H1", "mixed", 30.0, 120, 0.004, ["-k32", "-b2M", "-H1"]),
     ("s_mixed_k40_H6", "mixed", 30.0, 120, 0.004, ["-k40", "-b2M", "-H6"]),
     ("s_mixed_k32_H12_kc3", "mixed", 40.0, 120, 0.004, ["-k32", "-b3M", "-H12", "--kc=3"]),
+    ("s_satellite_k40", "satellite", 40.0, 120, 0.004, ["-k40", "-b4M"]),
 ]
 
 

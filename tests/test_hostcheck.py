@@ -197,7 +197,7 @@ def test_device_logic_reproduces_reference_run(name):
         g.meta["reads"], g.meta["solid_reads"], g.meta["visited_reads"])
 
 
-@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12", "s_mixed_k32_H1", "s_mixed_k40_H6", "s_mixed_k32_H12_kc3"])
+@pytest.mark.parametrize("name", ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12", "s_mixed_k32_H1", "s_mixed_k40_H6", "s_mixed_k32_H12_kc3", "s_satellite_k40"])
 def test_device_logic_reproduces_reference_run_on_cycles_repeats_and_hairpins(name):
     """Graph shapes a random linear genome never makes (tests/golden/make_structured.py, from the unmodified reference at -j1):
     circular replicons, tandem repeats with units shorter and longer than k, inverted repeats and hairpins, homopolymer and
@@ -656,16 +656,54 @@ def test_tiled_insert_matches_oracle_and_survives_bin_overflow(monkeypatch):
     o.load(buf, off)
     hc.load(buf, off)
     assert hc.counters().max() == 255 and np.array_equal(o.counters(), hc.counters())
-    # homopolymer runs: one k-mer hundreds of times in a batch (a counter with 254 pairs or more
-    # is left to the reservation rounds, which then see every op of that k-mer)
+    # homopolymer runs: one k-mer hundreds of times in a batch.  n ops of a k-mer nobody shares a counter with are n ops however
+    # many: its leader raises the counters by n (until round 6 a counter with 254 pairs or more was left to the rounds, one round per op)
     buf, off = api.concat_seqs([b"A" * 150] * 15 + [bytes(r) for r in rep[:50]] + [b"AC" * 75] * 20)  # (1,665 ops of one k-mer: a bin holds them)
     o = ob.Oracle(k, counters=1 << 20)
     hc = HostCheck(k, 1 << 20, insert_batch=30000, claim_log2=16)
     o.load(buf, off)
     hc.load(buf, off)
     st = hc.stats()
-    assert st["tiled_ops"] > 0 and st["tiled_pending"] > 254
+    assert st["tiled_ops"] > 0 and st["tiled_pending"] == 0 and st["tile_overflows"] == 0 and st["insert_rounds"] == 0
     assert np.array_equal(o.counters(), hc.counters())
+
+
+def test_a_kmer_that_recurs_thousands_of_times_in_a_batch_does_not_serialise_it(monkeypatch):
+    """A homopolymer run, a two-base and a five-base satellite at several hundred-fold coverage among ordinary reads: their k-mers'
+    pairs run the bins of their counters over (no ABG_TILE_CAP here).  The batch is then judged and applied through a sort of its
+    pairs (Engine::sorted_judge) -- same counters as the sequential filter, and about as many reservation rounds as the same reads
+    take without the repeats; with that switched off the whole batch takes the rounds, one round per copy (the old behaviour,
+    still exact)."""
+    k = 40
+    m1, m2 = synth.make_read_set(30000, 30.0)
+    plain = [bytes(r) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
+    rng = np.random.default_rng(4)
+    hot = [b"A" * 150] * 400 + [b"AC" * 75] * 300 + [b"CA" * 75] * 100 + [(b"GATTA" * 30)[i % 5:][:140] for i in range(300)]
+    hot += [b"T" * 150] * 100  # (the homopolymer's reverse complement: the same canonical k-mer)
+    mixed = plain + hot
+    order = rng.permutation(len(mixed))
+    reads = [mixed[i] for i in order]
+    buf, off = api.concat_seqs(reads)
+    pbuf, poff = api.concat_seqs(plain)
+    counters = 1 << 21
+    base = HostCheck(k, counters, insert_batch=1 << 20, claim_log2=16)
+    base.load(pbuf, poff)
+    base_rounds = base.stats()["insert_rounds"]
+    o = ob.Oracle(k, counters=counters)
+    o.load(buf, off)
+    hc = HostCheck(k, counters, insert_batch=1 << 20, claim_log2=16)
+    hc.load(buf, off)
+    st = hc.stats()
+    assert st["tile_overflows"] > 0 and st["tiled_ops"] > 0
+    assert np.array_equal(o.counters(), hc.counters())
+    assert st["insert_rounds"] <= 3 * max(base_rounds, 8), (st["insert_rounds"], base_rounds)
+    assert o.counters().max() == 255
+    # the fall-back of old: exact, and a chain of rounds as long as the hottest k-mer's copies
+    monkeypatch.setenv("ABG_SORTED_OVERFLOW", "0")
+    old = HostCheck(k, counters, insert_batch=1 << 20, claim_log2=16)
+    old.load(buf, off)
+    assert np.array_equal(o.counters(), old.counters())
+    assert old.stats()["insert_rounds"] > 20 * st["insert_rounds"]
 
 
 def test_kmers_writing_shared_counters_are_settled_together_or_go_to_the_rounds_together(monkeypatch):

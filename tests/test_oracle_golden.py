@@ -120,7 +120,7 @@ def test_iterator_skips_non_acgt():
 GRAPH_GOLDEN = json.load(open(os.path.join(GOLDEN, "graph_golden.json")))
 
 
-STRUCTURED = ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12", "s_mixed_k32_H1", "s_mixed_k40_H6", "s_mixed_k32_H12_kc3"]
+STRUCTURED = ["s_plasmids_k32", "s_tandem_k32", "s_tandem_k64_t20", "s_inverted_k40", "s_lowcomplex_k25", "s_plasmids_k48_K16", "s_mixed_k192", "s_mixed_k12", "s_mixed_k32_H1", "s_mixed_k40_H6", "s_mixed_k32_H12_kc3", "s_satellite_k40"]
 
 
 @pytest.mark.parametrize("name", STRUCTURED)

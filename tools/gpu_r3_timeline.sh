@@ -2,11 +2,11 @@
 # kernel timeline of one configs[1] step (rocprofv3 --kernel-trace): where PASS 2's time goes between the launches
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3t; mkdir -p $O
+O=$R/gpurun_out/${OUT:-r3t}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in ${1:-1}; do
 rm -rf /tmp/tl_$v
-ABG_PRESEARCH=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tl_$v -o tl -- python $R/bench.py --warmup 1 --steps 1 --no-cpu-baseline --no-events > /tmp/tl_$v.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tl_$v -o tl -- python $R/bench.py --warmup 1 --steps 1 --no-cpu-baseline --no-events > /tmp/tl_$v.log 2>&1
 tail -1 /tmp/tl_$v.log | cut -c1-300
 find /tmp/tl_$v -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_ps$v.csv \;
 python - $v <<'PY' > $O/timeline_ps$1.txt
