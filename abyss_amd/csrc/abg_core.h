@@ -1324,6 +1324,17 @@ ABG_HD uint32_t wave_append_slot(uint32_t* counter, bool want)
 }
 #endif
 
+// *counter += the lanes of the wavefront that `want`, with one atomic per wavefront.
+#if defined(__HIP_DEVICE_COMPILE__)
+ABG_HD void wave_count_add(uint64_t* counter, bool want)
+{
+	const uint64_t m = __ballot(want ? 1 : 0);
+	if (m && (int)__lane_id() == __ffsll((unsigned long long)m) - 1) atomicAdd((unsigned long long*)counter, (unsigned long long)__popcll(m));
+}
+#else
+ABG_HD void wave_count_add(uint64_t* counter, bool want) { if (want) *counter += 1; }
+#endif
+
 // A lane's rank among the lanes of its wavefront that `want`, and how many do.  Must be reached by all active lanes together.
 // (A serial caller is a wave of one lane.)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1448,6 +1459,7 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
        CB_FALSE = 4 };   // a plain dead-end tip, `depth` edges long: trueBranch answers false (see chain_true_branches)
 enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
        WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
+       WSTAT_CLS_COVERED,              // reads whose classification took k-mers from the archive of committed contigs (ContigArchive)
        WSTAT_N = 16 };
 
 // ------------------------------------------------------- memo of successor()
@@ -1629,6 +1641,91 @@ ABG_HD bool look_ahead(const Params& p, const uint8_t* __restrict__ cnt, const V
 {
 	return sc.coop ? look_ahead_t<NW, true>(p, cnt, start, dir, limit, sc)
 	               : look_ahead_t<NW, false>(p, cnt, start, dir, limit, sc);
+}
+
+// lookAhead for a caller that is one lane among 64 doing the same for other vertices (the classification's two blunt-end tests
+// per read, bloom-dbg.h:489-532): the same search as look_ahead_t -- depth first, bases in A, C, G, T order, one visited set for
+// the whole search -- with nothing in memory.  look_ahead_t keeps its frames, its visited set and the caller's SearchScratch in
+// scratch / global memory and asks the filter one probe at a time (solid_contains stops at the first miss): some seventy
+// dependent round trips per search, which is what a wave of classifications spent most of its time waiting for.  Here the
+// vertex is rolled forwards and BACK (a level keeps the base that left, not the vertex), the five levels' {mask, next
+// neighbour, base that left} sit in one word, the visited set in LA_REG_KEYS register pairs, and the 4 x H probes of a vertex's
+// neighbours go out together: one round trip per vertex entered.  Returns 0 / 1, or 2 when the visited set outgrew the
+// registers (the caller then runs look_ahead_t, which gives the same answer from the start).  Plain builds only (no spaced seed).
+constexpr unsigned LA_REG_KEYS = 8;
+template <int NW>
+ABG_HD unsigned nbr_mask_wide(const Params& p, const SeedTabs& t, const uint8_t* __restrict__ cnt, const Vtx<NW>& v, int sense)
+{
+	uint64_t fb, rb, h[4];
+	nbr_base(t, v, p.k, sense, fb, rb);
+#pragma unroll
+	for (unsigned q = 0; q < 4; q++) {
+		uint64_t fh, rh;
+		nbr_hash(t, sense, fb, rb, q, fh, rh);
+		h[q] = rh < fh ? rh : fh;
+	}
+	unsigned ok = 0xFu;
+	for (unsigned base = 0; base < p.nh; base += 4) {
+		unsigned c[4][4];
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) {
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) c[q][j] = probe_c(p, cnt, pos_i(p, h[q], base + j < p.nh ? base + j : 0u));
+		}
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) {
+#pragma unroll
+			for (unsigned j = 0; j < 4; j++) if (c[q][j] < p.kc) ok &= ~(1u << q);
+		}
+	}
+	return ok;
+}
+template <int NW>
+ABG_HD unsigned look_ahead_reg(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& start, int dir)
+{
+	static_assert(!MASKED_BUILD<NW>, "plain builds only");
+	const SeedTabs tabs = seed_tabs(p);
+	const int sense = dir == FORWARD ? SENSE : ANTISENSE, back = dir == FORWARD ? ANTISENSE : SENSE;
+	const unsigned limit = FP_TRIM;
+	VKey keys[LA_REG_KEYS];
+	unsigned nv = 1;
+	keys[0] = vtx_ident(p, start);
+#pragma unroll
+	for (unsigned i = 1; i < LA_REG_KEYS; i++) keys[i] = keys[0];
+	Vtx<NW> cur = start;
+	// level d of the search in bits [9 d, 9 d + 9) of `st`: neighbour mask (4), next neighbour to try (3), the base that left when the level was entered (2)
+	uint64_t st = nbr_mask_wide(p, tabs, cnt, cur, sense);
+	int depth = 0;
+	while (depth >= 0) {
+		const unsigned sh = 9u * (unsigned)depth;
+		const unsigned fm = (unsigned)(st >> sh) & 0xFu;
+		unsigned nx = (unsigned)(st >> (sh + 4)) & 7u;
+		while (nx < 4 && !((fm >> nx) & 1u)) nx++;
+		if (nx >= 4) {
+			// back to the level above: the vertex rolled back by the base that left
+			if (depth > 0) vtx_shift(p, cur, back, (unsigned)(st >> (sh + 7)) & 3u);
+			depth--;
+			continue;
+		}
+		st = (st & ~(7ULL << (sh + 4))) | ((uint64_t)(nx + 1) << (sh + 4));
+		const unsigned left = sense == SENSE ? kmer_get(cur.s, 0) : kmer_get(cur.s, p.k - 1);
+		const Vtx<NW> w = nbr_vertex_lean(p, tabs, cur, sense, nx);
+		const VKey wk = vtx_ident(p, w);
+		bool seen = false;
+#pragma unroll
+		for (unsigned i = 0; i < LA_REG_KEYS; i++) seen = seen | (i < nv && key_equal(keys[i], wk));
+		if (seen) continue;
+		if (nv >= LA_REG_KEYS) return 2;
+#pragma unroll
+		for (unsigned i = 0; i < LA_REG_KEYS; i++) if (i == nv) keys[i] = wk;
+		nv++;
+		if ((unsigned)(depth + 1) >= limit) return 1;
+		depth++;
+		cur = w;
+		const uint64_t lvl = (uint64_t)nbr_mask_wide(p, tabs, cnt, cur, sense) | ((uint64_t)left << 7);
+		st = (st & ~(0x1FFULL << (9u * (unsigned)depth))) | (lvl << (9u * (unsigned)depth));
+	}
+	return 0;
 }
 
 // trueBranch (ExtendPath.h:174-261).  Edge (u -> v) walked in direction `dir`.  Every

@@ -51,6 +51,8 @@ struct Config {
 	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	bool benign_sharers = true;       // ... and k-mers that share a counter they cannot write are settled by the tiles as well (op_verdict)
+	bool cls_archive = true;          // PASS 2: the classification takes the k-mers of a read that lie on a contig committed by an earlier batch from an archive of those contigs instead of probing the filters (ContigArchive)
+	uint32_t cls_archive_max_mb = 16384; // ... whose bases and table together stay below this
 	bool sorted_overflow = true;      // a batch whose pairs run a bin over is judged and applied through a sort of its pairs (Engine::sorted_judge) instead of taking the reservation rounds as a whole
 	bool cosettle = true;             // ... and k-mers that may write shared counters, when every k-mer on those is settled too (op_verdict, FCoSettle)
 	uint32_t cosettle_passes = 6;     // passes of that fixed point before the candidates left over go to the rounds after all (1 .. CO_MAX_PASSES)
@@ -1561,6 +1563,86 @@ struct FTileApply {
 // provisional per-read result of the classify step
 constexpr uint8_t RES_CANDIDATE = 0x80;
 
+// ---- the committed contigs as the classification reads them (round 6) ----
+// allKmersInBloom(seq, solidKmerSet) and allKmersInBloom(seq, assembledKmerSet) (bloom-dbg.h:58-77,816-828) ask 2 x H bits of
+// every k-mer of every read: 87 k-mers x 4 sectors of a 2 GB array for a 150 bp read, nine tenths of them for reads that lie on
+// sequence some earlier read has assembled.  Every k-mer of an inserted contig is solid (the walk's vertices are: successor()
+// follows solid neighbours, the seed read is entirely solid) and visited (addKmersToBloom, bloom-dbg.h:79-90, FPcApply), and a
+// filter's answer depends on a k-mer's canonical hash only.  So the commit copies every contig it inserts into an archive -- a
+// byte per base, contigs separated by ARC_SEP bytes, which no base equals -- and leaves "the k-mer with this hash starts at
+// archive position P" in a direct-mapped table; the classification looks its current k-mer up, compares the read with the
+// archive base by base (either strand), and every k-mer of the read inside the run that matched needs no probe: both answers
+// are yes.  A wrong or stale table entry, a run cut short by a separator, an archive half written by a commit running beside
+// the classification of the next batch: the comparison fails or ends early and the k-mers are probed as before.  The archive
+// only ever holds contigs of batches before the one being classified, so a verdict drawn from it is one the visited filter
+// gives at the read's turn (visited bits are never cleared while it lives: Engine::reset and visited_dev drop it).
+constexpr uint8_t ARC_SEP = 0xFF;
+constexpr uint64_t ARC_HEAD = 8, ARC_PAD = 16; // separators before the first contig / readable bytes after the last position
+constexpr uint32_t ARC_POS_BITS = 40;
+struct ContigArchive {
+	uint8_t* seq = nullptr;   // [cap + ARC_PAD] 0..3 a base (4: the 'N' of a contig column under a spaced seed), ARC_SEP everywhere else
+	uint64_t cap = 0;
+	uint64_t* used = nullptr; // [1] bytes handed out (from ARC_HEAD; beyond cap: contigs that found no room and are not there)
+	uint64_t* tab = nullptr;  // [mask + 1] bits 40..63 of the k-mer's hash << 40 | archive position of its first base; 0: empty
+	uint64_t mask = 0;
+	uint64_t* nreads = nullptr; // [1] statistics: reads the archive answered for at least one k-mer
+};
+ABG_HD uint64_t arc_slot(uint64_t h, uint64_t mask) { return ((h * 0x9E3779B97F4A7C15ULL) >> 22) & mask; }
+ABG_HD uint64_t arc_entry(uint64_t h, uint64_t pos) { return (h & ~((1ULL << ARC_POS_BITS) - 1)) | pos; }
+ABG_HD uint64_t arc_load8(const uint8_t* q) { uint64_t x; __builtin_memcpy(&x, q, 8); return x; }
+// bases i .. i + 7 of a packed read of L bases, a byte each (past the end: whatever the read's last word holds)
+ABG_HD uint64_t arc_read8(const uint32_t* words, uint64_t woff, uint32_t L, uint32_t i)
+{
+	const uint32_t a = i >> 4, last = (L - 1) >> 4, b = a < last ? a + 1 : last;
+	const uint64_t w = (uint64_t)words[woff + a] | ((uint64_t)words[woff + b] << 32);
+	uint64_t t = (w >> (2u * (i & 15u))) & 0xFFFFu;
+	t = (t | (t << 24)) & 0x000000FF000000FFULL;
+	t = (t | (t << 12)) & 0x000F000F000F000FULL;
+	t = (t | (t << 6)) & 0x0303030303030303ULL;
+	return t;
+}
+// How many k-mers of the read, from k-mer j on, are consecutive k-mers of ONE archived contig, the first of them the k-mer at
+// archive position P read forwards or backwards (0: the k-mer at P is another one).  The loads of a stretch of ARC_CHUNK x 8
+// bases go out together, none under a condition (a comparison that stops at its first difference is a round trip per word):
+// the way the contig reads is settled by the first eight bases, then two or three stretches cover a 150 bp read.  An address
+// past the end of a run is clamped into the archive -- what it yields is only looked at when every base before it matched, and
+// then (a separator ends every run, the first of them at ARC_HEAD - 1) it was not clamped.
+constexpr uint32_t ARC_CHUNK = 8;
+ABG_HD uint32_t arc_cover(const ContigArchive& a, uint64_t P, const uint32_t* words, uint64_t woff, uint32_t L, uint32_t j, unsigned k)
+{
+	if (P < ARC_HEAD || P + k > a.cap) return 0;
+	const uint32_t n = L - j;
+	const uint64_t E = P + k - 1, top = a.cap + ARC_PAD - 8, C3 = 0x0303030303030303ULL;
+	// read base j + t against seq[P + t], or against the complement of seq[E - t]: eight bytes ending there, turned round
+	const uint64_t r0 = arc_read8(words, woff, L, j);
+	const uint64_t f0 = arc_load8(a.seq + P) ^ r0, b0 = (__builtin_bswap64(arc_load8(a.seq + E - 7)) ^ C3) ^ r0;
+	const uint32_t first = n < 8 ? n : 8u;
+	const bool fwd = (f0 ? (uint32_t)__builtin_ctzll(f0) >> 3 : 8u) >= first;
+	if (!fwd && (b0 ? (uint32_t)__builtin_ctzll(b0) >> 3 : 8u) < first) return 0;
+	uint32_t t = first;
+	while (t < n) {
+		uint64_t d[ARC_CHUNK];
+#pragma unroll
+		for (uint32_t c = 0; c < ARC_CHUNK; c++) {
+			const uint32_t tt = t + 8 * c, jj = j + tt < L ? j + tt : L - 1;
+			uint64_t av;
+			if (fwd) { const uint64_t q = P + tt; av = arc_load8(a.seq + (q < top ? q : top)); }
+			else { const uint64_t q = E - 7 - (tt < E - 7 ? tt : E - 7); av = __builtin_bswap64(arc_load8(a.seq + q)) ^ C3; }
+			d[c] = av ^ arc_read8(words, woff, L, jj);
+		}
+		bool done = false;
+#pragma unroll
+		for (uint32_t c = 0; c < ARC_CHUNK; c++) {
+			if (done || t >= n) continue;
+			const uint32_t m = d[c] ? (uint32_t)__builtin_ctzll(d[c]) >> 3 : 8u;
+			t += m < n - t ? m : n - t;
+			done = m < 8;
+		}
+		if (done) break;
+	}
+	return t >= k ? t - k + 1 : 0u;
+}
+
 // (A wave-per-read form of this kernel -- k-mers over the lanes, hashed from scratch, the two
 // blunt-end searches in lock step -- was measured at 375 ms per config-1 step against 155 ms for
 // this one: hashing every k-mer from scratch costs more ALU than the probes cost memory time, and
@@ -1575,6 +1657,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 	Params p; Batch b; uint64_t first; const uint8_t* cnt; const uint8_t* vis; uint8_t* result;
 	VKey* la_pool; // [slots][LA_MAX_VISITED]
 	const uint8_t* both = nullptr; // the solid plane's and the visited filter's bits side by side (FBothBuild), or NULL
+	ContigArchive arc{};           // the contigs committed so far (seq == NULL: none kept)
 	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
 	{
 		uint64_t r = first + i;
@@ -1594,36 +1677,61 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		v.s = batch_kmer<NW>(b, r, 0, k);
 		vtx_rehash(p, v);
 		Vtx<NW> first_v = v;
-		if (!look_ahead(p, cnt, v, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		// (the search in registers, look_ahead_reg; look_ahead_t under a spaced seed and for the rare search whose visited set outgrows them)
+		auto la = [&](const Vtx<NW>& s) -> bool {
+			if constexpr (!MASKED_BUILD<NW>) { const unsigned a = look_ahead_reg(p, cnt, s, REVERSE); if (a != 2) return a != 0; }
+			return look_ahead(p, cnt, s, REVERSE, FP_TRIM, sc);
+		};
+		if (!la(v)) { result[r] = RR_BLUNT_END; return; }
 		Vtx<NW> lastv;
 		lastv.s = batch_kmer<NW>(b, r, nk - 1, k);
 		vtx_rehash(p, lastv);
 		vtx_revcomp(p, lastv);
-		if (!look_ahead(p, cnt, lastv, REVERSE, FP_TRIM, sc)) { result[r] = RR_BLUNT_END; return; }
+		if (!la(lastv)) { result[r] = RR_BLUNT_END; return; }
 		// allKmersInBloom(seq, solidKmerSet), then allKmersInBloom(seq, assembledKmerSet) against the
 		// snapshot (bloom-dbg.h:58-77,816-828).  One sweep over the k-mers, CLS_GROUP of them per
 		// round: their 2 x H probes go out together, so a round costs one memory latency instead of
 		// 2 x CLS_GROUP.  The verdicts are those of the two separate loops: not solid wins over
 		// everything later, "visited" only counts for an entirely solid read.
 		v = first_v;
-		bool solid = true, visited = true;
+		bool solid = true, visited = true, covered = false;
 		const uint64_t rwoff = b.woff[r];
-		for (uint32_t j0 = 0; j0 < nk && solid; j0 += CLS_GROUP) {
+		uint32_t at = 0; // v is the vertex of k-mer `at` of the read
+		// the archive's entry for the k-mer the sweep stands at (ContigArchive): fetched a round ahead, with the probes of the group before
+		uint64_t en = arc.seq ? arc.tab[arc_slot(vtx_hash(p, v), arc.mask)] : 0;
+		for (uint32_t j0 = 0; j0 < nk && solid;) {
+			if (at != j0) { // (after a run the archive answered for: the hashes start over)
+				v.s = batch_kmer<NW>(b, r, j0, k); vtx_rehash(p, v);
+				at = j0;
+				en = arc.tab[arc_slot(vtx_hash(p, v), arc.mask)];
+			}
+			if (en && !((en ^ vtx_hash(p, v)) >> ARC_POS_BITS)) {
+				// the k-mers from here on that lie on a contig some earlier batch committed: solid and visited, no probe
+				const uint32_t nc = arc_cover(arc, en & ((1ULL << ARC_POS_BITS) - 1), b.words, rwoff, L, j0, k);
+				if (nc) { j0 += nc; covered = true; continue; }
+			}
 			uint64_t h[CLS_GROUP];
 			// the group's incoming bases sit in one packed word or two: both read here, not a load per base under a condition
-			const uint32_t i0 = j0 + k - 1, i1 = (i0 + CLS_GROUP - 1 < L ? i0 + CLS_GROUP - 1 : L - 1);
+			// (one base more than the group's: the k-mer after it is hashed for the archive's next entry)
+			const uint32_t i0 = j0 + k - 1, i1 = (i0 + CLS_GROUP < L ? i0 + CLS_GROUP : L - 1);
 			const uint64_t two = (uint64_t)b.words[rwoff + (i0 >> 4)] | ((uint64_t)b.words[rwoff + (i1 >> 4)] << 32);
+			auto base_at = [&](uint32_t bi) -> unsigned { return (unsigned)(two >> (((bi >> 4) != (i0 >> 4) ? 32u : 0u) + 2u * (bi & 15u))) & 3u; };
 #pragma unroll
 			for (uint32_t q = 0; q < CLS_GROUP; q++) {
 				const uint32_t j = j0 + q;
 				if (j < nk) {
-					const uint32_t bi = j + k - 1;
-					const unsigned base = (unsigned)(two >> (((bi >> 4) != (i0 >> 4) ? 32u : 0u) + 2u * (bi & 15u))) & 3u;
-					if (j) vtx_shift(p, v, SENSE, base);
+					if (q) vtx_shift(p, v, SENSE, base_at(j + k - 1));
 					h[q] = vtx_hash(p, v);
+					at = j;
 				} else {
 					h[q] = h[0]; // (past the end: the group's first k-mer again)
 				}
+			}
+			en = 0;
+			if (j0 + CLS_GROUP < nk) {
+				vtx_shift(p, v, SENSE, base_at(j0 + CLS_GROUP + k - 1));
+				at = j0 + CLS_GROUP;
+				if (arc.seq) en = arc.tab[arc_slot(vtx_hash(p, v), arc.mask)];
 			}
 			bool so = true, vi = true;
 			for (unsigned base = 0; base < p.nh; base += 4) {
@@ -1650,7 +1758,9 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 				}
 			}
 			solid = solid & so; visited = visited & vi;
+			j0 += CLS_GROUP;
 		}
+		if (arc.nreads) wave_count_add(arc.nreads, covered);
 		if (!solid) { result[r] = RR_NOT_SOLID; return; }
 		result[r] = visited ? (uint8_t)RR_ALL_KMERS_VISITED : RES_CANDIDATE;
 	}
@@ -2305,6 +2415,7 @@ struct ParCommit {
 	const uint8_t* cnt8;   // the counting filter (FPcApply: coverage of the inserted contigs)
 	uint32_t* vis32;       // the visited filter: its state before the range until FPcApply runs
 	uint32_t* both32 = nullptr; // the classification's copy of the visited bits (FBothBuild), or NULL
+	ContigArchive arc{};   // where FPcApply leaves a copy of every contig it inserts, for the classification of later batches (seq == NULL: nowhere)
 	uint32_t* T;           // [filter bits] time stamps: (tag << T_TIME_BITS) | position, see t_stamp;
 	                       // or NULL: the stamps live in the hash table below, keyed by bit position
 	uint64_t* Tk;          // [Tmask + 1] bit positions (T_KEY_EMPTY: free)
@@ -2674,8 +2785,21 @@ struct FPcApply { // one wave per candidate before the break: results, visited b
 				const uint64_t* ch = e.kh + rec.seq_off;
 				const uint32_t cnk = rec.len - e.p.k + 1;
 				uint32_t cov = 0;
+				// ... and the contig into the archive the classification of later batches reads (ContigArchive): the bases, then
+				// every k-mer's position under its hash (plain stores, the last writer of a slot stays)
+				uint64_t apos = 0;
+				if (e.arc.seq) {
+					if (lane == 0) apos = atomic_add_u64(e.arc.used, (uint64_t)rec.len + 1);
+					apos = uni64<true>(apos);
+					if (apos + rec.len + 1 > e.arc.cap) apos = 0; // (no room: the contig is not archived)
+					else {
+						const uint8_t* src = e.pool + rec.seq_off;
+						for (uint32_t q = lane; q < rec.len; q += nlanes) e.arc.seq[apos + q] = src[q];
+					}
+				}
 				for (uint32_t j = lane; j < cnk; j += nlanes) {
 					uint64_t h = ch[j];
+					if (apos) e.arc.tab[arc_slot(h, e.arc.mask)] = arc_entry(h, apos + j);
 					unsigned mn = 255;
 					for (unsigned q = 0; q < e.p.nh; q++) {
 						uint64_t pos = pos_i(e.p, h, q);
@@ -2791,6 +2915,7 @@ class Engine {
 	~Engine()
 	{
 		free_counters(); be_.free(vis_); if (both_) be_.free(both_); be_.free(cstate_); be_.free(scal_);
+		free_archive();
 		if (casc_.bits) be_.free(casc_.bits);
 		if (mask_d_) be_.free(mask_d_);
 		if (T_) be_.free(T_);
@@ -2817,6 +2942,7 @@ class Engine {
 		else if (sliced_) be_.memset(cnt_ + own_lo_, 0, own_span_);
 		else if (cnt_) be_.memset(cnt_, 0, m_);
 		be_.memset(vis_, 0, vis_bytes_);
+		arc_valid_ = false; loaded_ops_ = 0;
 		be_.memset(cstate_, 0, sizeof(CommitState));
 		counters_ = Counters();
 		stats_ = Stats();
@@ -2989,7 +3115,7 @@ class Engine {
 		memo_valid_ = false; plane_valid_ = false;
 	}
 	uint8_t* cascade_level_dev(uint32_t l) { return (uint8_t*)(casc_.bits + (uint64_t)l * casc_.level_words); }
-	uint8_t* visited_dev() { return vis_; }
+	uint8_t* visited_dev() { arc_valid_ = false; /* (the caller may write: what the archive of committed contigs says may no longer hold) */ return vis_; }
 	uint64_t visited_bytes() const { return m_ / 8; }
 	Counters counters() const { return counters_; }
 	void set_counters(const Counters& c) { counters_ = c; }
@@ -3211,6 +3337,7 @@ class Engine {
 		ensure_walk();
 		ensure_plane();
 		ensure_both();
+		ensure_archive(b);
 		build_guide(b);
 		ensure_memo();
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
@@ -3275,6 +3402,51 @@ class Engine {
 		be_.launch(m_ / 32, f, "both_build");
 	}
 	uint8_t* both_ = nullptr;
+	// The archive of committed contigs the classification reads (ContigArchive): single-GPU runs with the parallel commit (FPcApply
+	// fills it).  Sized by the call's reads -- a byte for every fourth read k-mer, a table slot for every eighth: a genome sequenced
+	// four-fold or deeper fits, and what does not fit is simply not archived -- and kept from call to call as long as the visited
+	// filter is (reset, visited_dev: emptied).
+	void free_archive()
+	{
+		if (arc_.seq) { be_.free(arc_.seq); be_.free(arc_.used); be_.free(arc_.tab); }
+		arc_ = ContigArchive(); arc_valid_ = false;
+	}
+	void ensure_archive(const Batch& b)
+	{
+		const bool want = cfg_.cls_archive && !dist() && !sliced_ && !casc_.bits && b.n && use_par_commit();
+		if (!want) { free_archive(); return; }
+		// (the k-mers PASS 1 loaded, wherever they came from -- the caller may assemble its reads in several calls; a filter that
+		// was imported: a sixteenth of its counters)
+		const uint64_t nk = loaded_ops_ ? loaded_ops_ : m_ / 4;
+		uint64_t cap = std::max<uint64_t>(nk / 4, 1ull << 16) + ARC_HEAD, slots = 1ull << 12;
+		while (slots < cap / 2) slots <<= 1;
+		const uint64_t budget = (uint64_t)cfg_.cls_archive_max_mb << 20;
+		while (slots > (1ull << 12) && slots * 8 + cap > budget) { slots >>= 1; cap = std::min(cap, slots * 2); }
+		if (cap >= (1ULL << ARC_POS_BITS)) cap = (1ULL << ARC_POS_BITS) - 1;
+		if (arc_.seq && (arc_.cap < cap || arc_.mask + 1 < slots)) free_archive(); // (a larger read set than the one it was made for)
+		if (!arc_.seq) {
+			arc_.seq = (uint8_t*)be_.try_alloc(cap + ARC_PAD);
+			arc_.tab = (uint64_t*)be_.try_alloc(slots * 8);
+			arc_.used = (uint64_t*)be_.try_alloc(8);
+			if (!arc_.seq || !arc_.tab || !arc_.used) {
+				if (arc_.seq) be_.free(arc_.seq); if (arc_.tab) be_.free(arc_.tab); if (arc_.used) be_.free(arc_.used);
+				arc_ = ContigArchive();
+				return;
+			}
+			arc_.cap = cap; arc_.mask = slots - 1;
+			arc_valid_ = false;
+		}
+		arc_.nreads = wstats_ ? wstats_ + WSTAT_CLS_COVERED : nullptr;
+		if (!arc_valid_) {
+			be_.memset(arc_.seq, ARC_SEP, arc_.cap + ARC_PAD);
+			be_.memset(arc_.tab, 0, (arc_.mask + 1) * 8);
+			const uint64_t head = ARC_HEAD;
+			be_.h2d(arc_.used, &head, 8);
+			arc_valid_ = true;
+		}
+	}
+	ContigArchive arc_{}; bool arc_valid_ = false;
+	uint64_t loaded_ops_ = 0; // k-mers inserted since the filter was last empty (ensure_archive)
 	uint64_t ovf_seen_[2] = { 0, 0 }; // partitioned run: the walkers' pool / record overflow counters as last read
 	uint8_t* plane_ = nullptr; bool plane_valid_ = false;
 	Params p2_; const uint8_t* cnt2_ = nullptr; // what the probing kernels of PASS 2 get: p_ / cnt_, or the plane
@@ -3335,7 +3507,7 @@ class Engine {
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
 	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
-	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, pre_requests = 0, pre_adds = 0, cancelled = 0; };
+	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, cls_covered_reads = 0, archive_bases = 0, cancelled = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -3344,8 +3516,9 @@ class Engine {
 			be_.d2h(v, wstats_, sizeof v);
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
-			s.pre_requests = 0; s.pre_adds = 0; // (fields of the C ABI's abg_stats kept for its layout: the pre-search is gone)
+			s.cls_covered_reads = v[WSTAT_CLS_COVERED];
 		}
+		if (arc_.seq && arc_valid_) { uint64_t u = 0; be_.d2h(&u, arc_.used, 8); s.archive_bases = std::min(u, arc_.cap) - ARC_HEAD; }
 		s.guide_slots = guide_slots_;
 		return s;
 	}
@@ -3714,6 +3887,7 @@ class Engine {
 		const uint64_t s = rg.s, e = rg.e;
 		uint64_t T = rg.k1 - rg.k0;
 		if (T == 0) return;
+		loaded_ops_ += T;
 		if (T > batch_ops_ || T >= 0xFFFFFFFFull) {
 			fail_now(FAIL_INTERNAL, strf("a single sequence has more k-mers (%llu) than insert_batch_kmers", T));
 		}
@@ -4285,6 +4459,7 @@ class Engine {
 		e.p = p_; e.b = b; e.cand_read = cand_d; e.status = status_d; e.first_rec = first_d;
 		e.recs = recs_; e.pool = pool_; e.result = result_d; e.kh = kh_; e.rkh = rkh_; e.rkoff = rkoff_d;
 		e.read_flag = read_flag_; e.vis32 = (uint32_t*)vis_; e.both32 = (uint32_t*)both_; e.T = T_; e.cend = cend_; e.cnt8 = cnt_;
+		if (!part) e.arc = arc_;
 		e.Tk = nullptr; e.Tv = nullptr; e.Tmask = 0;
 		if (t_hashed()) {
 			// the bits this commit can stamp: (k-mers of the contigs in the pool) x H
@@ -4626,7 +4801,7 @@ class Engine {
 					if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
 					Batch vn = b;
 					vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
-					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_, both_ };
+					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_, both_, arc_ };
 					be_.launch_slots_side(nn, f, cslots_, "classify");
 					pre_first_ = nf; pre_n_ = nn;
 				};
@@ -4671,7 +4846,7 @@ class Engine {
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			be_.sync_side();
-			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_, both_ };
+			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_, both_, arc_ };
 			be_.launch_slots(n, f, cslots_, "classify");
 		}
 		pre_n_ = 0;

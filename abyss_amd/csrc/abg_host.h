@@ -97,6 +97,8 @@ class Session {
 		if (const char* e = getenv("ABG_TILED")) cfg.tiled_insert = atoi(e) != 0; // PASS 1 through LDS tiles
 		if (const char* e = getenv("ABG_DIST_ROUTE_MIN")) cfg.dist_route_min_ranks = (uint32_t)atoi(e); // partitioned run: pairs routed to their owners from this many ranks on (0: never)
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
+		if (const char* e = getenv("ABG_CLS_ARCHIVE")) cfg.cls_archive = atoi(e) != 0; // (0: the classification probes the filters for every k-mer)
+		if (const char* e = getenv("ABG_CLS_ARCHIVE_MAX_MB")) cfg.cls_archive_max_mb = (uint32_t)std::max(0, atoi(e));
 		if (const char* e = getenv("ABG_SORTED_OVERFLOW")) cfg.sorted_overflow = atoi(e) != 0; // (0: a batch that runs a bin over takes the reservation rounds as a whole)
 		if (const char* e = getenv("ABG_COSETTLE")) cfg.cosettle = atoi(e) != 0; // (0: round 4's rule -- a k-mer that may write a shared counter takes the rounds)
 		if (const char* e = getenv("ABG_CLS_BOTH")) cfg.cls_both = atoi(e) != 0; // (0: the classification reads the plane and the visited filter where they are)

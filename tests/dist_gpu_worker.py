@@ -60,7 +60,7 @@ def staged():
     comm = adist.StagedTorchComm(*adist.device_memory_io(g))
     g.attach_comm(comm)
     ok = against_oracle(g, k, counters, buf, off)
-    ok["stats"] = {k: v for k, v in g.stats().items() if k not in ("bulk_calls", "bulk_steps", "lin_steps", "chain_steps", "memo_hits", "memo_adds", "pre_requests", "pre_adds")}  # (per-rank work)
+    ok["stats"] = {k: v for k, v in g.stats().items() if k not in ("bulk_calls", "bulk_steps", "lin_steps", "chain_steps", "memo_hits", "memo_adds", "cls_covered_reads", "archive_bases")}  # (per-rank work)
     box = [None] * world
     dist.all_gather_object(box, json.dumps(ok, sort_keys=True))
     ok["ranks_agree"] = all(b == box[0] for b in box)

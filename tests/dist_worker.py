@@ -281,7 +281,7 @@ def main():
     else:
         raise SystemExit("unknown case")
     # (the walkers' own work counters are per rank: each rank walks its share of the candidates)
-    ok["stats"] = {k: v for k, v in hc.stats().items() if k not in ("bulk_calls", "bulk_steps", "lin_steps", "chain_steps", "memo_hits", "memo_adds", "pre_requests", "pre_adds")}
+    ok["stats"] = {k: v for k, v in hc.stats().items() if k not in ("bulk_calls", "bulk_steps", "lin_steps", "chain_steps", "memo_hits", "memo_adds", "cls_covered_reads", "archive_bases")}
     ok["comm_calls"] = hc.comm.calls
     # every rank must have reached the same verdicts
     flat = json.dumps({k: v for k, v in ok.items() if k not in ("comm_calls", "comm_pass1")}, sort_keys=True)  # (what a rank sent is its own business)

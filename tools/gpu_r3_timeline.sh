@@ -9,7 +9,7 @@ rm -rf /tmp/tl_$v
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tl_$v -o tl -- python $R/bench.py --warmup 1 --steps 1 --no-cpu-baseline --no-events > /tmp/tl_$v.log 2>&1
 tail -1 /tmp/tl_$v.log | cut -c1-300
 find /tmp/tl_$v -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_ps$v.csv \;
-python - $v <<'PY' > $O/timeline_ps$1.txt
+python - $v <<'PY' > $O/timeline_ps$v.txt
 import csv, glob, sys, re
 f = glob.glob('/tmp/tl_%s/**/*kernel_trace.csv' % sys.argv[1], recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
