@@ -2418,6 +2418,11 @@ ABG_HDX unsigned chain_true_branches(const Params& p_in, const uint8_t* __restri
 // (The neighbour hashes are recomputed here rather than passed in: an array handed to this
 // out-of-line function would have to live in memory at every call site, i.e. in the per-lane
 // scratch of the unbranched walking loop.)
+// PRECONDITION: u is in the solid filter.  The plain-tip shortcut of the branch tests (CB_FALSE in chain_bulk, is_false in
+// chain_true_branches) reads "exactly one solid neighbour behind the branch's first vertex" as "that neighbour is u, where the
+// search came from" -- true only when u itself is solid.  Every caller passes a vertex of a path being extended: a k-mer of an
+// entirely solid read or a vertex successor() returned (walk_extend, walk_linear, walk_bulk); extendPath in the reference has
+// the same property (ExtendPath.h:405-459 extends paths of graph vertices, and a vertex of RollingBloomDBG is a solid k-mer).
 template <int NW>
 ABG_HDX int successor_m(const Params& p, const uint8_t* __restrict__ cnt, const Vtx<NW>& u, int dir,
     unsigned trim, unsigned mask, Vtx<NW>& vout, SearchScratch<NW>& sc)

@@ -51,6 +51,7 @@ struct Config {
 	bool async_load = true;           // abg_load_seqs*: the device's share of a call runs beside the caller's next packing (Session::load_seqs_v)
 	bool tiled_insert = true;         // PASS 1 through LDS-sized tiles of the counter array (see TileEnv); else reservation rounds only
 	bool benign_sharers = true;       // ... and k-mers that share a counter they cannot write are settled by the tiles as well (op_verdict)
+	uint32_t cls_debug_skip = 0;      // FClassify::dbg_skip
 	bool cls_archive = true;          // PASS 2: the classification takes the k-mers of a read that lie on a contig committed by an earlier batch from an archive of those contigs instead of probing the filters (ContigArchive)
 	uint32_t cls_archive_max_mb = 16384; // ... whose bases and table together stay below this
 	bool sorted_overflow = true;      // a batch whose pairs run a bin over is judged and applied through a sort of its pairs (Engine::sorted_judge) instead of taking the reservation rounds as a whole
@@ -1658,6 +1659,7 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 	VKey* la_pool; // [slots][LA_MAX_VISITED]
 	const uint8_t* both = nullptr; // the solid plane's and the visited filter's bits side by side (FBothBuild), or NULL
 	ContigArchive arc{};           // the contigs committed so far (seq == NULL: none kept)
+	uint32_t dbg_skip = 0;         // diagnosis only, WRONG verdicts (ABG_CLS_DEBUG_SKIP): 1 no look-aheads, 2 no sweep -- what each part of the kernel costs
 	ABG_HDN void operator()(uint64_t i, uint32_t slot) const
 	{
 		uint64_t r = first + i;
@@ -1682,12 +1684,15 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 			if constexpr (!MASKED_BUILD<NW>) { const unsigned a = look_ahead_reg(p, cnt, s, REVERSE); if (a != 2) return a != 0; }
 			return look_ahead(p, cnt, s, REVERSE, FP_TRIM, sc);
 		};
+		if (!(dbg_skip & 1u)) {
 		if (!la(v)) { result[r] = RR_BLUNT_END; return; }
 		Vtx<NW> lastv;
 		lastv.s = batch_kmer<NW>(b, r, nk - 1, k);
 		vtx_rehash(p, lastv);
 		vtx_revcomp(p, lastv);
 		if (!la(lastv)) { result[r] = RR_BLUNT_END; return; }
+		}
+		if (dbg_skip & 2u) { result[r] = RR_NOT_SOLID; return; }
 		// allKmersInBloom(seq, solidKmerSet), then allKmersInBloom(seq, assembledKmerSet) against the
 		// snapshot (bloom-dbg.h:58-77,816-828).  One sweep over the k-mers, CLS_GROUP of them per
 		// round: their 2 x H probes go out together, so a round costs one memory latency instead of
@@ -4801,7 +4806,7 @@ class Engine {
 					if (!la_pool_c2_) la_pool_c2_ = (VKey*)be_.alloc((uint64_t)cslots_ * LA_MAX_VISITED * sizeof(VKey));
 					Batch vn = b;
 					vn.woff = b.woff + nf; vn.len = b.len + nf; vn.koff = b.koff + nf; vn.n = nn;
-					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_, both_, arc_ };
+					FClassify<NW> f{ p2_, vn, 0, cnt2_, vis_, result_d + nf, la_pool_c2_, both_, arc_, cfg_.cls_debug_skip };
 					be_.launch_slots_side(nn, f, cslots_, "classify");
 					pre_first_ = nf; pre_n_ = nn;
 				};
@@ -4846,7 +4851,7 @@ class Engine {
 			c_all_gather_v(res_d, c.data(), d.data());
 		} else {
 			be_.sync_side();
-			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_, both_, arc_ };
+			FClassify<NW> f{ p2_, v, 0, cnt2_, vis_, res_d, la_pool_c_, both_, arc_, cfg_.cls_debug_skip };
 			be_.launch_slots(n, f, cslots_, "classify");
 		}
 		pre_n_ = 0;

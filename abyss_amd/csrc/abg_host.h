@@ -98,6 +98,7 @@ class Session {
 		if (const char* e = getenv("ABG_DIST_ROUTE_MIN")) cfg.dist_route_min_ranks = (uint32_t)atoi(e); // partitioned run: pairs routed to their owners from this many ranks on (0: never)
 		if (const char* e = getenv("ABG_BENIGN")) cfg.benign_sharers = atoi(e) != 0; // (diagnosis: 0 sends every k-mer with a shared counter to the rounds)
 		if (const char* e = getenv("ABG_CLS_ARCHIVE")) cfg.cls_archive = atoi(e) != 0; // (0: the classification probes the filters for every k-mer)
+		if (const char* e = getenv("ABG_CLS_DEBUG_SKIP")) cfg.cls_debug_skip = (uint32_t)atoi(e); // (diagnosis: WRONG verdicts -- FClassify without its look-aheads (1) / its sweep (2))
 		if (const char* e = getenv("ABG_CLS_ARCHIVE_MAX_MB")) cfg.cls_archive_max_mb = (uint32_t)std::max(0, atoi(e));
 		if (const char* e = getenv("ABG_SORTED_OVERFLOW")) cfg.sorted_overflow = atoi(e) != 0; // (0: a batch that runs a bin over takes the reservation rounds as a whole)
 		if (const char* e = getenv("ABG_COSETTLE")) cfg.cosettle = atoi(e) != 0; // (0: round 4's rule -- a k-mer that may write a shared counter takes the rounds)
@@ -425,7 +426,13 @@ class Session {
 		ec.rank = c.rank; ec.world = c.world; ec.stream_ordered = c.stream_ordered != 0; ec.user = c.user;
 		ec.all_gather_v = c.all_gather_v; ec.all_reduce = c.all_reduce;
 		// (a caller compiled against the header without all_to_all_v passes a shorter struct: the member is read only when the caller says it is there)
+		// struct_size is 0 (a caller of the round-4 header: the field was reserved there) or the size of a struct that reaches at
+		// least to all_to_all_v; anything else is a struct this library does not know -- refused, not guessed at
+		if (c.struct_size != 0 && (size_t)c.struct_size < offsetof(abg_comm, all_to_all_v))
+			return fail(ABG_EINVAL, "abg_comm.struct_size is neither 0 nor the size of a struct this library knows (set it to sizeof(abg_comm))");
 		ec.all_to_all_v = (size_t)c.struct_size >= offsetof(abg_comm, all_to_all_v) + sizeof c.all_to_all_v ? c.all_to_all_v : nullptr;
+		if (c.struct_size == 0 && cfg.verbose && c.world >= 4)
+			fprintf(stderr, "abyss_amd: abg_comm.struct_size is 0 (a caller built against the older header): all_to_all_v is not read, the partitioned PASS 1 runs without routed pairs\n");
 		comm_attached_ = true;
 		if (!eng->attach_comm(ec)) return fail(ABG_EINVAL, "bad rank / world (at most " + std::to_string(MAX_RANKS) + " ranks; not available on a cascading filter)");
 		return ABG_OK;

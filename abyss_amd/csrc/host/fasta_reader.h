@@ -437,6 +437,10 @@ class SequenceReader {
 					// The file mapped: the parser threads read the page cache where it lies (no copy into a window buffer first --
 					// 256 MB of pread by 16 threads was the longest serial stretch of a window, ~4 of the reader's ~4 GB/s).
 					// ABG_READER_MMAP=0, or a mapping that fails, falls back to windows filled by pread.
+					// What the mapping asks of the file: it keeps the size it had when it was opened -- bytes appended later are not
+					// read (the pread path reads to the end of the file as it is then), and a file truncated or rewritten under the
+					// run takes the process down with SIGBUS where pread sees a short read.  Reads being written by another process
+					// go through ABG_READER_MMAP=0 or a pipe.  Windows already parsed are given back (MADV_DONTNEED, next_window).
 					const char* e = getenv("ABG_READER_MMAP");
 					if (st.st_size > 0 && !(e && atoi(e) == 0)) {
 						void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(m_f), 0);
@@ -571,19 +575,36 @@ class SequenceReader {
 				// one pass over the page tables instead of a fault per parser thread and page -- by a few threads, a part of the
 				// window each: a single call takes 20 ms for 256 MB of page cache, four side by side 11 (and it stands in front of
 				// every window's parse)
-				const uintptr_t a0 = (uintptr_t)(m_map + m_pos) & ~(uintptr_t)4095, a1 = (uintptr_t)(m_map + m_pos) + end;
+				// (the kernel's page size, not 4096: madvise wants page-aligned addresses; a kernel before 5.14 knows no
+				// MADV_POPULATE_READ and says EINVAL -- the first call's answer switches the whole thing off, threads included)
+				static const uintptr_t page = []() { const long v = sysconf(_SC_PAGESIZE); return (uintptr_t)(v > 0 ? v : 4096); }();
+				static std::atomic<bool> populate_ok{ true };
+				const uintptr_t a0 = (uintptr_t)(m_map + m_pos) & ~(page - 1), a1 = (uintptr_t)(m_map + m_pos) + end;
 				static const unsigned max_parts = []() { const char* e = getenv("ABG_READER_POPULATE_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 8u; }();
 				const unsigned parts = (unsigned)std::min<size_t>(std::min(m_threads, max_parts), (a1 - a0) / ((size_t)8 << 20) + 1);
-				const uintptr_t step = (((a1 - a0) / parts) + 4095) & ~(uintptr_t)4095;
-				std::vector<std::thread> pop;
-				for (unsigned q = 1; q < parts; q++) {
-					const uintptr_t b0 = a0 + q * step, b1 = std::min(a1, b0 + step);
-					if (b0 < b1) pop.emplace_back([b0, b1]() { madvise((void*)b0, b1 - b0, MADV_POPULATE_READ); });
+				const uintptr_t step = (((a1 - a0) / parts) + page - 1) & ~(page - 1);
+				if (populate_ok.load(std::memory_order_relaxed)) {
+					if (madvise((void*)a0, std::min(a1, a0 + step) - a0, MADV_POPULATE_READ) != 0 && (errno == EINVAL || errno == ENOSYS))
+						populate_ok.store(false, std::memory_order_relaxed);
+					else {
+						std::vector<std::thread> pop;
+						for (unsigned q = 1; q < parts; q++) {
+							const uintptr_t b0 = a0 + q * step, b1 = std::min(a1, b0 + step);
+							if (b0 < b1) pop.emplace_back([b0, b1]() { madvise((void*)b0, b1 - b0, MADV_POPULATE_READ); });
+						}
+						for (auto& t : pop) t.join();
+					}
 				}
-				madvise((void*)a0, std::min(a1, a0 + step) - a0, MADV_POPULATE_READ);
-				for (auto& t : pop) t.join();
 			}
 #endif
+			// the pages before the PREVIOUS window's start are not needed again (that window may still be with its parser threads:
+			// dropping a page under a reader would only cost a fault, but there is no reason to)
+			{
+				static const uintptr_t pg = []() { const long v = sysconf(_SC_PAGESIZE); return (uintptr_t)(v > 0 ? v : 4096); }();
+				const uintptr_t lo = (uintptr_t)m_map + m_released, hi = ((uintptr_t)(m_map + m_prev_start)) & ~(pg - 1);
+				if (hi > lo) { madvise((void*)lo, hi - lo, MADV_DONTNEED); m_released = hi - (uintptr_t)m_map; }
+				m_prev_start = m_pos;
+			}
 		} else
 		for (;;) {
 			if (!m_eof) { // the unparsed tail of the previous window, then fresh bytes
@@ -675,6 +696,7 @@ class SequenceReader {
 	} m_raw;
 	size_t m_pos = 0; // file offset of the next byte to read into m_raw
 	const char* m_map = nullptr; size_t m_map_size = 0; // the file mapped (m_pos: where the next window starts)
+	size_t m_released = 0, m_prev_start = 0;            // ... its pages below m_released given back; where the window before this one started
 	const char* buf_data() const { return m_map ? m_map + m_pos : m_mem ? m_buf.data() : m_raw.p; }
 	size_t buf_size() const { return m_map ? m_map_size - m_pos : m_mem ? m_buf.size() : m_raw.n; }
 	size_t read_parallel(char* dst, size_t want)
