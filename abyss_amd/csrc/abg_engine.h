@@ -633,6 +633,7 @@ struct TileEnv {
 	uint32_t benign = 1;              // op_verdict: k-mers that cannot write their shared counters are settled by the tiles too
 	uint32_t lead_js = 2;             // tile_purity: pairs of the first lead_js hash functions write `lead` (a partitioned run: all -- every rank must know)
 	uint32_t count_max = 0x7FFFFFFFu; // a counter with this many pairs or more is treated like a shared one (a partitioned run: 254 -- the ranks pass a leader's op count in a byte)
+	const uint8_t* cval = nullptr;    // partitioned run: [T x nh] 255 - (counter j of op t), combined from the ranks that own them (FDistPack2); NULL: op_verdict reads e.cnt
 	// the settling of k-mers that DO write shared counters (op_verdict, FCoSettle); all null / 0 when that is off
 	uint32_t* bad = nullptr;          // [(bad_mask + 1) / 32] bit "some k-mer on this counter goes through the rounds", by hashed counter position
 	uint32_t bad_mask = 0;
@@ -1053,7 +1054,10 @@ ABG_HD void op_verdict(const TileEnv& e, uint64_t t, uint8_t& tgt, uint8_t& pend
 	for (unsigned j0 = 0; j0 < e.p.nh; j0 += 4) { // (four counters in flight: a load right before its use is a round trip each)
 		unsigned c[4];
 #pragma unroll
-		for (unsigned q = 0; q < 4; q++) c[q] = e.cnt[pos_i(e.p, h, j0 + q < e.p.nh ? j0 + q : 0u)];
+		for (unsigned q = 0; q < 4; q++) {
+			const unsigned jq = j0 + q < e.p.nh ? j0 + q : 0u;
+			c[q] = e.cval ? 255u - e.cval[t * e.p.nh + jq] : e.cnt[pos_i(e.p, h, jq)];
+		}
 #pragma unroll
 		for (unsigned q = 0; q < 4; q++) {
 			const unsigned j = j0 + q;
@@ -1392,6 +1396,50 @@ struct FDistTarget { // FOpTarget from the combined bytes
 		uint8_t tg = 0;
 		if (!flag && !buf[2 * T] && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
 		e.tgt[t] = tg;
+	}
+};
+// ... and with the rules of rounds 4 and 5 (op_verdict: k-mers that cannot write their shared counters, k-mers that raise shared
+// counters settled together), which ask more of the other ranks: every counter of the op, and WHICH of them are shared.
+//   mx (all_reduce MAX): [t] n, the ops of the k-mer in the batch (0: this rank owns no pure counter of it; < 254, tile_purity)
+//                        [T + t] 1: the op is the earliest of them
+//                        [2T + t nh + j] 255 - counter j of the op, from the rank that owns it (the others: 0 -- and 0 from the
+//                        owner is a counter at 255, which is what the maximum then says)
+//                        [(2 + nh) T] 1: a bin overflowed somewhere
+//   sm (all_reduce SUM): [t] bit j: counter j is shared with another k-mer of the batch (one rank owns a counter: the bits of the
+//                        ranks are disjoint and their sum is their union)
+// Every rank then holds what op_verdict reads on one GPU -- for EVERY op: verdicts, the table of marked counters and the passes
+// of the fixed point come out the same on every rank, and nothing else has to travel.
+struct FDistPack2 {
+	TileEnv e; uint64_t T; uint8_t* mx; uint8_t* sm;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		const uint32_t L = e.lead[t];
+		mx[t] = (uint8_t)(L & 0xFFu);
+		mx[T + t] = (L & LEAD_BIT) ? 1 : 0;
+		sm[t] = e.opflag[t];
+		const uint64_t h = e.h0[t];
+		uint8_t* cv = mx + 2 * T + t * e.p.nh;
+		for (unsigned j0 = 0; j0 < e.p.nh; j0 += 4) { // (the loads of four counters together, none under a condition)
+			unsigned c[4]; bool own[4];
+#pragma unroll
+			for (unsigned q = 0; q < 4; q++) {
+				const uint64_t pos = pos_i(e.p, h, j0 + q < e.p.nh ? j0 + q : 0u);
+				own[q] = pos - e.lo < e.m - e.lo;
+				c[q] = e.cnt[own[q] ? pos : e.lo];
+			}
+#pragma unroll
+			for (unsigned q = 0; q < 4; q++) if (j0 + q < e.p.nh) cv[j0 + q] = own[q] ? (uint8_t)(255u - c[q]) : (uint8_t)0;
+		}
+		if (t == 0) mx[(2 + e.p.nh) * T] = e.flags[0] ? 1 : 0;
+	}
+};
+struct FDistUnpack2 { // the combined bytes back where op_verdict reads them
+	TileEnv e; uint64_t T; const uint8_t* mx; const uint8_t* sm;
+	ABG_HD void operator()(uint64_t t, uint32_t) const
+	{
+		e.lead[t] = (uint32_t)mx[t] | (mx[T + t] ? LEAD_BIT : 0u);
+		e.opflag[t] = sm[t];
+		if (t == 0 && mx[(2 + e.p.nh) * T]) e.flags[0] = 1;
 	}
 };
 struct FClaimOwned { // FClaim / FClaimList on the counters of [lo, lo + span) only (pend == NULL: all ops)
@@ -3768,6 +3816,9 @@ class Engine {
 		if (cfg_.tiled_insert && !casc_.bits && p_.nh <= 16) {
 			uint64_t T = std::max<uint64_t>(batch_ops_, std::min<uint64_t>(1ull << 28, m_ / 114 * (TILE_PAIRS_MEAN / 2048u) * TILE_SPLIT));
 			T = std::min<uint64_t>(T, (uint64_t)TILE_PAIRS_MEAN * ntiles_ * R / p_.nh);
+			// (the routed path still settles by round 2's rule -- a k-mer with a shared counter takes the rounds -- and the share of such
+			// k-mers grows with the batch: it keeps the batch of the rounds before the bins were halved, half of everybody else's)
+			if (routed() && T / TILE_SPLIT >= (1u << 20)) T /= TILE_SPLIT; // (small filters: the batch is what their few tiles hold anyway)
 			T = std::min<uint64_t>(T, 1ull << TP_T_BITS); // (a pair holds its op in 28 bits)
 			if (T >= 1024) {
 				tiled_ = true;
@@ -3811,14 +3862,14 @@ class Engine {
 			tgt_ = (uint8_t*)be_.alloc(nb);
 			pendf_ = (uint8_t*)be_.alloc(nb + 8); // (read a word at a time: FPendWrite)
 			pgrp_ = (uint64_t*)be_.alloc((nb / PEND_GROUP + 2) * 8);
-			if (!dist() && cfg_.cosettle && cfg_.benign_sharers && p_.nh <= 8) {
+			if (!routed() && cfg_.cosettle && cfg_.benign_sharers && p_.nh <= 8) {
 				wmask_ = (uint8_t*)be_.alloc(nb);
 				bad_ = (uint32_t*)be_.alloc((1ull << cfg_.cosettle_log2) / 8);
 				cochg_ = (uint32_t*)be_.alloc((CO_MAX_PASSES + 1) * 4);
 				colist_ = (uint32_t*)be_.alloc((nb + 64) * 4);
 				cocnt_ = (uint8_t*)be_.alloc((nb >> BE::ITEM_GROUP_LOG2) + 64);
 			}
-			if (dist()) tred_ = (uint8_t*)be_.alloc(2 * nb + 64);
+			if (dist()) tred_ = (uint8_t*)be_.alloc((bad_ ? 3 + p_.nh : 2) * nb + 256); // (FDistPack: 2 bytes an op; FDistPack2: 2 + nh and 1)
 			if (routed()) {
 				// a rank hashes a slice of at most rown_ ops and sends nh records each; a destination gets 1 / R of them on average
 				rown_ = (((nb + R - 1) / R + 7) & ~7ull);
@@ -4118,11 +4169,35 @@ class Engine {
 			be_.launch_tiles((uint64_t)ncoarse_ * cpb, f2, "bin_fine");
 		}
 		if (!judged) { FTilePurity f{ te }; be_.launch_tiles(ntiles_, f, "tile_purity"); }
-		{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
-		c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
-		{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
-		{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
-		be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_);
+		if (bad_) {
+			// the single-GPU rules (op_verdict, FCoSettle) on what the ranks know together: FDistPack2
+			uint8_t* mx = tred_; uint8_t* sm = tred_ + (((2 + p_.nh) * T + 1 + 63) & ~63ull);
+			{ FDistPack2 f{ te, T, mx, sm }; be_.launch(T, f, "dist_pack"); }
+			c_all_reduce(mx, (2 + p_.nh) * T + 1, DT_U8, OP_MAX);
+			c_all_reduce(sm, T, DT_U8, OP_SUM);
+			{ FDistUnpack2 f{ te, T, mx, sm }; be_.launch(T, f, "dist_pack"); }
+			te.cval = mx + 2 * T;
+			te.bad = bad_; te.bad_mask = (uint32_t)((1ull << cfg_.cosettle_log2) - 1); te.wmask = wmask_; te.chg = cochg_;
+			te.colist = colist_; te.cocnt = cocnt_; te.glog2 = BE::ITEM_GROUP_LOG2;
+			be_.memset(bad_, 0, (1ull << cfg_.cosettle_log2) / 8);
+			be_.memset(cochg_, 0, (CO_MAX_PASSES + 1) * 4);
+			{ FOpTarget f{ te }; be_.launch(T, f, "op_target"); }
+			const uint32_t np = std::max(1u, std::min(cfg_.cosettle_passes, CO_MAX_PASSES));
+			const uint64_t ngroups = (T + (1ull << te.glog2) - 1) >> te.glog2;
+			for (uint32_t q = 1; q <= np; q++) { FCoSettle f{ te, q }; be_.launch(ngroups, f, "co_settle"); }
+			{ FCoFinal f{ te, np }; be_.launch(ngroups, f, "co_settle"); }
+			{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
+			const uint64_t ng = (T + PEND_GROUP - 1) / PEND_GROUP;
+			FPendCount fc{ pendf_, T, pgrp_ }; be_.launch(ng, fc, "compact");
+			be_.inclusive_sum_u64(pgrp_, ng);
+			FPendWrite fw{ pendf_, T, pgrp_, pend_[1], pend_n_ }; be_.launch(ng, fw, "compact");
+		} else {
+			{ FDistPack f{ te, T, tred_ }; be_.launch(T, f, "dist_pack"); }
+			c_all_reduce(tred_, 2 * T + 1, DT_U8, OP_MAX);
+			{ FDistTarget f{ te, T, tred_ }; be_.launch(T, f, "op_target"); }
+			{ FTileApply f{ te }; be_.launch_tiles(napply_, f, "tile_apply"); }
+			be_.compact_flagged(nullptr, pendf_, T, pend_[1], pend_n_);
+		}
 		if (stage_next_) { stage_next_(); stage_next_ = nullptr; } // (the next batch, beside this one's rounds)
 		uint32_t nn[4] = { 0, 0, 0, 0 };
 		be_.d2h(nn, pend_n_, 16);
