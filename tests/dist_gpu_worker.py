@@ -110,7 +110,7 @@ def rccl1():
     gw, go, gl, nt = g.share_reads(dw, do, dl, n)
     ok["share_total"] = nt == n
     ok.update(against_oracle(g, k, counters, buf, off, packed=(gw, go, gl, nt)))
-    ok["launches"] = {nm: g.profile_get(nm)[1] for nm in ("comm_all_reduce", "comm_all_gather", "compact", "insert_apply", "merge_fix")}
+    ok["launches"] = {nm: g.profile_get(nm)[1] for nm in ("comm_all_reduce", "comm_all_gather", "compact", "insert_apply", "merge_fix", "dist_pack", "co_settle")}
     if os.environ.get("ABG_SLICE_FILTER") == "1":
         ok["launches"].update({nm: g.profile_get(nm)[1] for nm in ("pc_cover", "solid_plane")})
         ok["held"] = g.stats()["counter_bytes_held"]

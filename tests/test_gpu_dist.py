@@ -33,7 +33,16 @@ def test_rccl_single_rank_partitioned_path_reproduces_reference_runs_and_oracle(
                 "assembly_counters"):
         assert out[key], (key, out)
     assert out["n_contigs"] > 10
-    assert all(v > 0 for v in out["launches"].values()), out["launches"]
+    # (round 6: the single-GPU rules on the partitioned path leave this small run's rounds nothing -- the partitioned reservation
+    # rounds are exercised by the same run under round 2's rule below)
+    assert all(v > 0 for nm, v in out["launches"].items() if nm != "insert_apply"), out["launches"]
+    assert out["launches"]["dist_pack"] > 0 and out["launches"]["co_settle"] > 0, out["launches"]
+    env["ABG_COSETTLE"] = "0"
+    r = subprocess.run([sys.executable, WORKER, "rccl1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    out = result_of(r)
+    for key in ("k64", "k40_mixed", "k48_K16", "counting_filter", "results", "contigs", "visited", "assembly_counters"):
+        assert out[key], (key, out)
+    assert out["launches"]["insert_apply"] > 0 and out["launches"]["co_settle"] == 0, out["launches"]
 
 
 def test_rccl_single_rank_routed_path_reproduces_reference_runs_and_oracle():
