@@ -2079,11 +2079,29 @@ struct FPreCommit {
 			ContigRec& rec = recs[ri];
 			uint32_t cnk = rec.len - p.k + 1;
 			if (rec.len < p.k + FP_TRIM - 1 || rec.pre_redundant) continue;
+			// (a verified copy of a record this very call tests -- a lower candidate's, same k-mers, same snapshot -- takes that
+			// one's answer afterwards, FPreCommitCopies: four fifths of a batch's record k-mers are such copies)
+			if (rec.dup_of != REC_END && recs[rec.dup_of].cand >= first) continue;
 			bool red = true;
 			for (uint32_t j = lane; j < cnk; j += nlanes) red = red & visited_contains_owned(p, vis, kh[rec.seq_off + j], lo, span);
 			red = wave_all_lanes(red, nlanes);
 			if (part_r) { if (lane == 0) part_r[ri] = red ? 1 : 0; }
 			else if (lane == 0 && red) rec.pre_redundant = 1;
+		}
+	}
+};
+struct FPreCommitCopies { // one candidate per item, after FPreCommit: the copies take their original's answer ("entirely visited" is a fact about the k-mer set)
+	const uint32_t* status; const uint32_t* first_rec; ContigRec* recs; const uint8_t* read_flag; uint32_t first; uint32_t k;
+	ABG_HD void operator()(uint64_t i, uint32_t) const
+	{
+		const uint32_t c = first + (uint32_t)i;
+		if (read_flag[c] || status[c] != WS_COMPLETE) return;
+		for (uint32_t ri = first_rec[c]; ri != REC_END; ri = recs[ri].next) {
+			ContigRec& rec = recs[ri];
+			if (rec.len < k + FP_TRIM - 1 || rec.pre_redundant || rec.dup_of == REC_END) continue;
+			const ContigRec& o = recs[rec.dup_of];
+			// (an original whose read turned out visited was not tested: its copy then stays "not settled" and is decided bit by bit)
+			if (o.cand >= first && o.pre_redundant) rec.pre_redundant = 1;
 		}
 	}
 };
@@ -4486,6 +4504,8 @@ class Engine {
 		{
 			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin, 0, ~0ULL, nullptr, nullptr };
 			be_.launch_wave(c_end - c_begin, f, "precommit");
+			FPreCommitCopies fc{ status_d, first_d, recs_, read_flag_, c_begin, p_.k };
+			be_.launch(c_end - c_begin, fc, "precommit");
 		}
 		CommitEnv<NW> e;
 		e.read_flag = read_flag_;
@@ -4528,6 +4548,7 @@ class Engine {
 			FPreCommit<NW> f{ p_, b, cand_d, status_d, first_d, recs_, vis_, kh_, rkh_, rkoff_d, read_flag_, c_begin,
 				part ? own_lo_ : 0, part ? own_span_ : ~0ULL, part_c, part_r };
 			be_.launch_wave(n, f, "precommit");
+			if (!part) { FPreCommitCopies fc{ status_d, first_d, recs_, read_flag_, c_begin, p_.k }; be_.launch(n, fc, "precommit"); }
 			if (part) {
 				c_all_reduce(part_buf, (uint64_t)n + nrec, DT_U8, OP_MIN);
 				FPreCommitFin ff{ status_d, first_d, recs_, read_flag_, c_begin, p_.k, part_c, part_r };
