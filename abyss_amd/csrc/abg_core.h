@@ -620,6 +620,14 @@ ABG_HD unsigned solid_min_count(const Params& p, const uint8_t* __restrict__ cnt
 ABG_HD bool visited_contains(const Params& p, const uint8_t* __restrict__ vis, uint64_t h)
 {
 	bool ok = true;
+	if (p.nh <= 4) { // (up to four hash functions: the loads together, none under a condition -- in the loop below each is a round trip of its own)
+		uint8_t b4[4]; uint64_t q4[4];
+#pragma unroll
+		for (unsigned i = 0; i < 4; i++) { q4[i] = pos_i(p, h, i < p.nh ? i : 0u); b4[i] = vis[q4[i] >> 3]; }
+#pragma unroll
+		for (unsigned i = 0; i < 4; i++) ok = ok & (((b4[i] >> (q4[i] & 7)) & 1u) != 0); // (i >= nh: position 0 again)
+		return ok;
+	}
 	for (unsigned i = 0; i < p.nh; i++) {
 		uint64_t q = pos_i(p, h, i);
 		ok = ok & (((vis[q >> 3] >> (q & 7)) & 1u) != 0);

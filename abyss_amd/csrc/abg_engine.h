@@ -2048,6 +2048,14 @@ struct FDupVerify { // one wave per record: the link holds only if the two hash 
 ABG_HD bool visited_contains_owned(const Params& p, const uint8_t* __restrict__ vis, uint64_t h, uint64_t lo, uint64_t span)
 {
 	bool ok = true;
+	if (p.nh <= 4) { // (the four loads together: see pc_bit_before)
+		uint64_t q4[4]; uint8_t b4[4];
+#pragma unroll
+		for (unsigned i = 0; i < 4; i++) { q4[i] = pos_i(p, h, i < p.nh ? i : 0u); b4[i] = vis[q4[i] >> 3]; }
+#pragma unroll
+		for (unsigned i = 0; i < 4; i++) if (i < p.nh && q4[i] - lo < span) ok = ok & (((b4[i] >> (q4[i] & 7)) & 1u) != 0);
+		return ok;
+	}
 	for (unsigned i = 0; i < p.nh; i++) {
 		const uint64_t q = pos_i(p, h, i);
 		if (q - lo < span) ok = ok & (((vis[q >> 3] >> (q & 7)) & 1u) != 0);
@@ -2543,6 +2551,19 @@ ABG_HD uint32_t pc_T_get(const ParCommit& e, uint64_t pos) // the raw stamp, or 
 ABG_HD bool pc_bit_before(const ParCommit& e, uint64_t h, uint32_t time)
 {
 	bool ok = true;
+	if (e.T && e.p.nh <= 4) {
+		// (a stamp per filter bit, up to four hash functions: the eight loads together, none under a condition -- in the loop below
+		// each is a round trip of its own)
+		uint64_t pos[4]; uint32_t vw[4], tw[4];
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) { pos[q] = pos_i(e.p, h, q < e.p.nh ? q : 0u); vw[q] = e.vis32[pos[q] >> 5]; tw[q] = e.T[pos[q]]; }
+#pragma unroll
+		for (unsigned q = 0; q < 4; q++) {
+			if (q >= e.p.nh || pos[q] - e.own_lo >= e.own_span) continue;
+			ok = ok & ((((vw[q] >> (pos[q] & 31)) & 1u) != 0) | (t_read(tw[q], e.tag) < time));
+		}
+		return ok;
+	}
 	for (unsigned q = 0; q < e.p.nh; q++) {
 		uint64_t pos = pos_i(e.p, h, q);
 		if (pos - e.own_lo >= e.own_span) continue;
@@ -2872,6 +2893,21 @@ struct FPcApply { // one wave per candidate before the break: results, visited b
 					uint64_t h = ch[j];
 					if (apos) e.arc.tab[arc_slot(h, e.arc.mask)] = arc_entry(h, apos + j);
 					unsigned mn = 255;
+					if (e.cnt8 && e.p.nh <= 4) {
+						// (the counters' loads together, then the bits: in the loop below a load waits behind the atomics before it)
+						uint64_t pos[4]; unsigned c[4];
+#pragma unroll
+						for (unsigned q = 0; q < 4; q++) { pos[q] = pos_i(e.p, h, q < e.p.nh ? q : 0u); c[q] = e.cnt8[pos[q]]; }
+#pragma unroll
+						for (unsigned q = 0; q < 4; q++) {
+							if (q >= e.p.nh) continue;
+							atomic_or_u32(&e.vis32[pos[q] >> 5], 1u << (pos[q] & 31));
+							both_set(e.both32, pos[q]);
+							mn = c[q] < mn ? c[q] : mn;
+						}
+						cov += mn;
+						continue;
+					}
 					for (unsigned q = 0; q < e.p.nh; q++) {
 						uint64_t pos = pos_i(e.p, h, q);
 						atomic_or_u32(&e.vis32[pos >> 5], 1u << (pos & 31));
