@@ -349,13 +349,16 @@ def test_graphviz_dump_matches_reference(name):
 
 @pytest.mark.parametrize("env", [{"ABG_TILED": "0"}, {"ABG_TILE_CAP": "300"}, {"ABG_GUIDE_STRIDE": "0", "ABG_MEMO": "0"},
                                  {"ABG_GUIDE_STRIDE": "1"}, {"ABG_GUIDE_SEEN": "0"}, {"ABG_PAR_COMMIT_MAX_GB": "0", "ABG_T_TAGS": "4"},
-                                 {"ABG_COMPACT_THRESHOLD": "1"}, {"ABG_OVERLAP_BINS": "0"}, {"ABG_OVERLAP_BINS": "1", "ABG_TILE_CAP": "300"}])
+                                 {"ABG_COMPACT_THRESHOLD": "1"}, {"ABG_OVERLAP_BINS": "0"}, {"ABG_OVERLAP_BINS": "1", "ABG_TILE_CAP": "300"},
+                                 {"ABG_P2_FIRST_BATCH": "256"}, {"ABG_P2_FIRST_BATCH": "256", "ABG_CLS_ARCHIVE": "0"},
+                                 {"ABG_P2_FIRST_BATCH": "256", "ABG_CLS_ARCHIVE_MAX_MB": "0"}])
 def test_accelerators_and_fallbacks_do_not_change_results(env, monkeypatch):
     """Every accelerator has an exact slow path behind it and every table a fallback: PASS 1 without the
     LDS tiles / with bins that overflow, walkers without guide and memo / with the densest guide, the
     commit with hashed time stamps, flagged-and-compacted losers in every round,
-    PASS 1 without the next batch staged on the side stream / with a staged batch whose bins overflow.
-    Same bytes as the reference, and the work counters show the path was taken."""
+    PASS 1 without the next batch staged on the side stream / with a staged batch whose bins overflow, the classification with
+    the archive of committed contigs over many small batches / without it / with an archive too small for the contigs (what does
+    not fit is not archived).  Same bytes as the reference, and the work counters show the path was taken."""
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     gc = GoldenCase("k64")
@@ -374,6 +377,13 @@ def test_accelerators_and_fallbacks_do_not_change_results(env, monkeypatch):
         assert st["bulk_steps"] == 0 and st["memo_hits"] == 0
     else:
         assert st["bulk_steps"] > st["lin_steps"] and st["memo_hits"] > 0
+    if "ABG_P2_FIRST_BATCH" in env:
+        if env.get("ABG_CLS_ARCHIVE") == "0":
+            assert st["cls_covered_reads"] == 0 and st["archive_bases"] == 0, st
+        elif "ABG_CLS_ARCHIVE_MAX_MB" in env:
+            assert 0 < st["archive_bases"] < 20000 and st["walk_rounds"] > 3, st
+        else:
+            assert st["cls_covered_reads"] > 100 and st["archive_bases"] > 15000 and st["walk_rounds"] > 3, st
     assert api.format_fasta(contigs, gc.ids) == gc.fasta
     assert api.format_read_log(results, gc.ids) == gc.readlog
     assert api.format_trace(contigs, gc.ids, gc.reads, gc.opts["k"], with_length=False) == gc.trace

@@ -518,6 +518,34 @@ def test_guide_and_memo_do_not_change_results(monkeypatch):
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace
 
 
+@pytest.mark.parametrize("name", ["k64", "k40_mixed", "s_tandem_k32", "s_inverted_k40", "s_lowcomplex_k25", "s_satellite_k40", "k48_K16"])
+def test_archive_of_committed_contigs_does_not_change_verdicts(name, monkeypatch):
+    """Round 6: the classification takes the k-mers of a read that lie on a contig an earlier batch committed from an archive of those
+    contigs (ContigArchive: a byte per base, a k-mer -> position table filled by FPcApply) instead of probing the two filters for
+    each (bloom-dbg.h:58-77,816-828).  Many small batches, so that most reads meet the archive: the reference's read log (every
+    verdict), FASTA and trace with the archive on, off, and with one far too small for the contigs (what does not fit is not
+    archived, the table's slots collide) -- on random genomes and on the shapes where a read matches a contig on either strand,
+    on several contigs or on itself (tandem and inverted repeats, homopolymer runs, satellites), and under a spaced seed."""
+    g = GoldenCase(name)
+    kw = g.kwargs()
+    covered = {}
+    for tag, env in (("on", {}), ("off", {"ABG_CLS_ARCHIVE": "0"}), ("tiny", {"ABG_CLS_ARCHIVE_MAX_MB": "0"})):
+        for key in ("ABG_CLS_ARCHIVE", "ABG_CLS_ARCHIVE_MAX_MB"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        hc = HostCheck(kw["k"], g.meta["counters"], kw["num_hashes"], kw["min_cov"], kw["trim"], insert_batch=50000, claim_log2=16,
+                       p2_first=64, mask=mask_of(g))
+        hc.load(g.buf, g.off)
+        results, contigs = hc.assemble(g.buf, g.off)
+        st = hc.stats()
+        covered[tag] = (st["cls_covered_reads"], st["archive_bases"])
+        assert api.format_fasta(contigs, g.ids) == g.fasta, tag
+        assert api.format_read_log(results, g.ids) == g.readlog, tag
+        assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace, tag
+    assert covered["off"] == (0, 0) and covered["on"][0] > 0 and covered["on"][1] >= covered["tiny"][1] > 0, covered
+
+
 def test_packed_reads_get_their_prefix_sums_and_batches_on_the_device():
     """abg_load_packed: the k-mer prefix sums (FKmerCounts + scan) and the batches' op ranges
     (FCutRanges) are made where the reads are.  Ragged lengths, batches of a few hundred ops (many
