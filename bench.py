@@ -15,7 +15,7 @@ configs[2], the configuration BASELINE.json lists for the partitioned filter, st
 ("scaling": "strong"; its one-GPU point is replayed from profiles/ in `strong_scaling`): every rank
 holds 1/N of the reads, the counting filter is range-partitioned by position over the ranks' HBM
 during PASS 1 (RCCL), gathered for PASS 2, whose walks are split over the ranks and merged before the
-ordered commit (DESIGN.md section 7); the unitigs are bit-identical to a 1-GPU run of that job.
+ordered commit (DESIGN.md section 6); the unitigs are bit-identical to a 1-GPU run of that job.
 --scaling weak makes the job N times --pairs / --bloom instead; --mode replicas runs N independent
 copies of the job (no collective on the data path).  --config 4 is configs[4] (1.2 G pairs, k=96, B=500G
 on eight GPUs): a filter beyond one GPU -- each rank keeps its own range of the counters, PASS 2 probes

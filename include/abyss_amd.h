@@ -233,7 +233,7 @@ int abg_contains_seq(abg_ctx* ctx, const char* seq, uint64_t len, uint32_t* pos_
  * shards are all-gathered before PASS 2, whose classification and walks are split over the
  * ranks, whose contigs are gathered, and whose ordered commit tests and stamps each rank's own
  * bits (a byte per candidate and per contig through all_reduce).  Results are bit-identical to
- * a single-GPU run over the concatenated read set (DESIGN.md section 7).
+ * a single-GPU run over the concatenated read set (DESIGN.md section 6).
  *
  * The communicator is a table of two collectives over buffers in the library's memory space
  * (device memory): abg_rccl_comm_create() fills it with RCCL (stream-ordered, over xGMI);

@@ -149,7 +149,7 @@ def test_partitioned_code_path_on_a_single_rank(name, monkeypatch):
 
 
 def test_pass1_collective_bytes_follow_the_model(monkeypatch):
-    """DESIGN.md section 7's traffic model of the partitioned PASS 1, checked instead of asserted: per k-mer op the
+    """DESIGN.md section 6's traffic model of the partitioned PASS 1, checked instead of asserted: per k-mer op the
     ranks exchange 3 + H bytes through two all_reduces per batch (round 6, FDistPack2: the k-mer's op count, the leader
     bit, H counters, the flags of the shared ones; two bytes with ABG_COSETTLE=0, round 2's rule), plus one byte per op still
     pending in each reservation round, plus -- from three ranks on; two ranks, which share one xGMI link, hash everything

@@ -132,7 +132,7 @@ def test_full_size_results_do_not_depend_on_the_execution_schedule(monkeypatch):
     assert np.array_equal(vis_a, b.visited())
     b.close()
 
-    # and the partitioned code path of the multi-GPU run (DESIGN.md section 7) on one rank: evaluate /
+    # and the partitioned code path of the multi-GPU run (DESIGN.md section 6) on one rank: evaluate /
     # all_reduce / apply rounds with the compacted loser lists, the drain hand-over, split classification,
     # merged walk results -- every collective an identity (abyss_amd.dist.LocalComm)
     from abyss_amd import dist as adist
