@@ -3070,7 +3070,7 @@ class Engine {
 	const Params& params() const { return p_; }
 	uint64_t size() const { return m_; }
 	// (a partitioned run leaves only the rank's own range current until the shards are gathered)
-	uint8_t* counters_dev() { need_whole_filter("direct access to the counters"); gather_counters(); memo_valid_ = false; plane_valid_ = false; /* (the caller may write) */ return cnt_; }
+	uint8_t* counters_dev() { need_whole_filter("direct access to the counters"); gather_counters(); memo_valid_ = false; plane_valid_ = false; arc_valid_ = false; /* (the caller may write: the archived contigs' k-mers may no longer be solid) */ return cnt_; }
 
 	// ---- partitioned multi-GPU run (include/abyss_amd.h, abg_comm): the counting filter is
 	// range-partitioned by position over the ranks of a communicator during PASS 1 -- rank q owns
@@ -3219,9 +3219,10 @@ class Engine {
 		cnt_loaded_ = true;
 		if (!sliced_) { be_.h2d(counters_dev(), in, m_); return; }
 		be_.h2d(cnt_ + own_lo_, in + own_lo_, own_span_);
-		memo_valid_ = false; plane_valid_ = false;
+		memo_valid_ = false; plane_valid_ = false; arc_valid_ = false;
 	}
 	uint8_t* cascade_level_dev(uint32_t l) { return (uint8_t*)(casc_.bits + (uint64_t)l * casc_.level_words); }
+	const uint8_t* visited_dev_ro() const { return vis_; } // (for reading: an export leaves the archive of committed contigs as it is)
 	uint8_t* visited_dev() { arc_valid_ = false; /* (the caller may write: what the archive of committed contigs says may no longer hold) */ return vis_; }
 	uint64_t visited_bytes() const { return m_ / 8; }
 	Counters counters() const { return counters_; }

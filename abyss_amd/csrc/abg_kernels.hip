@@ -931,7 +931,7 @@ int abg_visited_export(abg_ctx* ctx, uint8_t* host_out)
 {
 	if (!ctx || !host_out) return ABG_EINVAL;
 	return guarded(ctx, [&]() -> int {
-		ctx->s.be.d2h(host_out, ctx->s.eng->visited_dev(), ctx->s.eng->visited_bytes());
+		ctx->s.be.d2h(host_out, ctx->s.eng->visited_dev_ro(), ctx->s.eng->visited_bytes());
 		return ABG_OK;
 	});
 }
