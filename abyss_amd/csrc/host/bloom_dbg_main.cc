@@ -388,7 +388,9 @@ int main(int argc, char** argv)
 	if (argc - optind < 1) { fprintf(stderr, PROGRAM ": missing input file arguments\n"); die = true; }
 	if (die) { fprintf(stderr, "Try `%s --help' for more information.\n", PROGRAM); exit(EXIT_FAILURE); }
 	if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-	threads = std::min(threads, 64u);
+	// (parser threads: more than 32 make the run SLOWER -- three runs each on a 256-thread host, the full configs[1] files: 1,176 ms at 32,
+	// 1,191 at 24, 1,221 at 16, 1,277 at 12, 1,414 at 8, ~1,300 at 64 and more: the threads that drive the device wait for a core)
+	threads = std::min(threads, 32u);
 
 	// initGlobals (bloom-dbg.cc:214-233) + SpacedSeed.h:18-75
 	std::string mask;

@@ -1035,7 +1035,7 @@ class Resolver {
 		uint64_t total = 0;
 		for (const std::string& path : opt.readFiles) {
 			if (opt.verbose) fprintf(stderr, "Loading reads from `%s'...\n", path.c_str());
-			abghost::SequenceReader reader(path, raw_reader(), (unsigned)std::max(1, opt.threads));
+			abghost::SequenceReader reader(path, raw_reader(), (unsigned)std::min(32, std::max(1, opt.threads))); // (as in abyss-bloom-dbg: beyond 32 parser threads the run gets slower)
 			std::vector<uint64_t> off;
 			auto count = [&](uint64_t len) { if (len >= lenHist.size()) lenHist.resize(len + 1, 0); lenHist[len]++; total++; };
 			if (reader.has_blocks()) {
