@@ -1546,33 +1546,43 @@ struct FBinCoarseRec { // FBinCoarse over received records: item = a chunk of BI
 		}
 	}
 };
-struct FRouteReply { // one received record per item: what its owner's tiles found out about the op (the two FDistPack bytes)
+struct FRouteReply { // one received record per item: what its owner's tiles found out about THIS pair's counter
+	// [0] 255: the counter is shared with another k-mer of the batch; else the k-mer's op count n (1 .. 126: a counter with 127 pairs
+	//     or more counts as shared on this path, TileEnv::count_max) | 0x80 when the op is the earliest of them
+	// [1] 255 - the counter, shared or not (round 6: what the hashing rank needs for op_verdict's round-4 rule)
 	TileEnv e; const TilePair* recs; uint8_t* rep;
 	ABG_HD void operator()(uint64_t i, uint32_t) const
 	{
 		const TilePair r = recs[i];
-		const uint32_t t = tp_t(r), L = e.lead[t];
-		const bool shared = e.opflag[t] != 0, leader = (L & LEAD_BIT) != 0;
-		rep[2 * i] = (uint8_t)(shared ? 255u : leader ? (L & ~LEAD_BIT) : 0u); // (n < 254: tile_purity)
-		rep[2 * i + 1] = leader ? (uint8_t)(255u - e.cnt[pos_i(e.p, tp_h(r), tp_j(r))]) : (uint8_t)0;
+		const uint32_t t = tp_t(r), j = tp_j(r), L = e.lead[t];
+		const unsigned fl = e.opflag[t];
+		const bool shared = e.p.nh <= 8 ? ((fl >> j) & 1u) != 0 : fl != 0;
+		rep[2 * i] = (uint8_t)(shared ? 255u : ((L & LEAD_BIT) ? 0x80u : 0u) | (L & 0x7Fu));
+		rep[2 * i + 1] = (uint8_t)(255u - e.cnt[pos_i(e.p, tp_h(r), j)]);
 	}
 };
 struct FRouteCombine { // one of the rank's own ops per item: the replies of its nh pairs -> verdict, and the target back out to each pair
-	Params p; const uint32_t* slot; const uint8_t* rep; uint8_t* tgt_out; uint8_t* pendf; // (pendf: [own ops])
+	// op_verdict without the candidates (abg_engine.h, round 4's rule): a k-mer none of whose counters is shared is settled by its
+	// leader; one with shared counters too, when every one of them already holds the target min(m_P + n, 255) -- its ops then
+	// never find a shared counter at their minimum, read nothing another k-mer writes and write nothing another reads; anything
+	// else takes the partitioned reservation rounds.  (benign == 0: round 2's rule -- any shared counter sends the k-mer there.)
+	Params p; const uint32_t* slot; const uint8_t* rep; uint8_t* tgt_out; uint8_t* pendf; uint32_t benign; // (pendf: [own ops])
 	ABG_HD void operator()(uint64_t u, uint32_t) const
 	{
-		unsigned A = 0, B = 0;
+		unsigned n = 0, mp = 256, ms = 256; bool leader = false, any_shared = false;
 		for (unsigned j = 0; j < p.nh; j++) {
 			const uint32_t s = slot[u * p.nh + j];
-			const unsigned a = rep[2ull * s], b = rep[2ull * s + 1];
-			A = a > A ? a : A; B = b > B ? b : B;
+			const unsigned a = rep[2ull * s], c = 255u - rep[2ull * s + 1];
+			if (a == 255u) { any_shared = true; ms = c < ms ? c : ms; }
+			else { n = (a & 0x7Fu) > n ? (a & 0x7Fu) : n; leader = leader || (a & 0x80u) != 0; mp = c < mp ? c : mp; }
 		}
-		const bool shared = A == 255;
-		const unsigned n = A, mn = 255u - B;
-		uint8_t tg = 0;
-		if (!shared && n && mn < 255) tg = (uint8_t)(mn + n > 255 ? 255u : mn + n);
-		pendf[u] = shared ? 1 : 0;
-		for (unsigned j = 0; j < p.nh; j++) tgt_out[slot[u * p.nh + j]] = tg;
+		const unsigned tg = mp + n > 255 ? 255u : mp + n;
+		bool rounds = false;
+		if (any_shared) rounds = !benign || !n || p.nh > 8 || ms < tg;
+		uint8_t out = 0;
+		if (!rounds && leader && n && mp < 255) out = (uint8_t)tg;
+		pendf[u] = rounds ? 1 : 0;
+		for (unsigned j = 0; j < p.nh; j++) tgt_out[slot[u * p.nh + j]] = out;
 	}
 };
 struct FRouteTgt { // one received record per item: the target its op's hashing rank sent back
@@ -4284,7 +4294,7 @@ class Engine {
 		const uint64_t chunk = ((T + R - 1) / R + 7) & ~7ull;
 		const uint64_t a = std::min(T, me * chunk), b = std::min(T, a + chunk), nown = b - a;
 		uint32_t* rflag = rcur_ + MAX_RANKS; // [0] some room ran out on this rank
-		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u, 16u, 254u };
+		TileEnv te{ p_, cnt_, own_lo_, own_lo_ + own_span_, h0_, bins_, tile_cap_, tcur_, lead_, opflag_, tgt_, pendf_, rflag, 0u, 16u, 127u }; // (127: FRouteReply's byte)
 		be_.memset(lead_, 0, T * 4);
 		be_.memset(opflag_, 0, (T + 3) & ~3ull);
 		be_.memset(tcur_, 0, ntiles_ * 4);
@@ -4340,7 +4350,7 @@ class Engine {
 		}
 		if (nrec) { FRouteReply f{ te, rrecv_, rrep_out_ }; be_.launch(nrec, f, "route_reply"); }
 		c_all_to_all_v(rrep_out_, bytes(rc, 2).data(), bytes(rd, 2).data(), rrep_in_, bytes(sc, 2).data(), bytes(sd, 2).data());
-		if (nown) { FRouteCombine f{ p_, rslot_, rrep_in_, rtgt_out_, rpendf_ }; be_.launch(nown, f, "op_target"); }
+		if (nown) { FRouteCombine f{ p_, rslot_, rrep_in_, rtgt_out_, rpendf_, cfg_.benign_sharers ? 1u : 0u }; be_.launch(nown, f, "op_target"); }
 		c_all_to_all_v(rtgt_out_, sc.data(), sd.data(), rtgt_in_, rc.data(), rd.data());
 		if (nrec) {
 			FRouteTgt f{ rrecv_, rtgt_in_, tgt_ };

@@ -190,6 +190,23 @@ def test_partitioned_pass1_settles_what_one_gpu_settles(monkeypatch):
     assert pend["1"][2] == pend["0"][2] > 0 and pend["1"][0] * 4 <= pend["0"][0] and pend["1"][1] <= pend["0"][1], pend
 
 
+def test_routed_pass1_settles_kmers_that_cannot_write_their_shared_counters(monkeypatch):
+    """Round 6: the routed form's replies carry, per pair, whether THAT counter is shared, the k-mer's op count and leader bit, and the
+    counter (FRouteReply: still two bytes), and the hashing rank applies op_verdict's round-4 rule (FRouteCombine): a k-mer whose
+    shared counters already hold its target is settled like one with none.  Same outputs; fewer ops in the partitioned rounds than
+    with round 2's rule (ABG_BENIGN=0: any shared counter sends the k-mer there)."""
+    monkeypatch.setenv("ABG_DIST_ROUTE_MIN", "2")
+    pend = {}
+    for rule in ("1", "0"):
+        monkeypatch.setenv("ABG_BENIGN", rule)
+        out = run_ranks(3, "golden", "k40_mixed")
+        for key in ("filtered_popcount", "fasta", "readlog", "trace", "counters", "ranks_agree"):
+            assert out[key], (rule, key, out)
+        assert out["comm_calls"]["all_to_all_v"] >= 3, out["comm_calls"]
+        pend[rule] = (out["stats"]["tiled_pending"], out["stats"]["tiled_ops"])
+    assert pend["1"][1] == pend["0"][1] > 0 and pend["1"][0] < 0.9 * pend["0"][0], pend
+
+
 # ---- the routed form (Engine::insert_tiles_routed): (op, counter) pairs sent to the ranks that own the counters ----
 @pytest.mark.parametrize("world,args", [(2, ("golden", "k64")), (3, ("golden", "k40_mixed")), (2, ("golden", "k48_K16")), (3, ("tiny_filter",)),
                                         (3, ("saturate_tiled",)), (2, ("kept",)), (3, ("shared",))])
