@@ -37,7 +37,7 @@ class Contig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("insert_rounds", "walk_rounds", "candidates", "walked", "rewalked", "commit_breaks",
-                 "commit_rounds", "generated", "bulk_calls", "bulk_steps", "lin_steps", "guide_slots", "chain_steps", "batch_cuts", "overflows", "memo_hits", "memo_adds", "tiled_ops", "tiled_pending", "tile_overflows", "cls_covered_reads", "archive_bases", "cancelled", "counter_bytes_held")]
+                 "commit_rounds", "generated", "bulk_calls", "bulk_steps", "lin_steps", "guide_slots", "chain_steps", "batch_cuts", "overflows", "memo_hits", "memo_adds", "tiled_ops", "tiled_pending", "tile_overflows", "cls_covered_reads", "archive_bases", "cls_decided_reads", "counter_bytes_held")]
 
 
 CONTIG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Contig))

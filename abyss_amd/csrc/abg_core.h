@@ -1468,6 +1468,7 @@ enum { CB_ACTIVE = 0,    // still a plain chain at (vertex, depth): the guide ha
 enum { WSTAT_BULK_CALLS = 0, WSTAT_BULK_STEPS, WSTAT_LIN_STEPS, WSTAT_CHAIN_STEPS, WSTAT_MEMO_HITS, WSTAT_MEMO_ADDS,
        WSTAT_OVF_POOL, WSTAT_OVF_RECS, // walkers that ran out of contig pool / contig records (the host grows what ran out)
        WSTAT_CLS_COVERED,              // reads whose classification took k-mers from the archive of committed contigs (ContigArchive)
+       WSTAT_CLS_DECIDED,              // ... of which this many got their whole verdict there, look-aheads included (arc_ends_decided)
        WSTAT_N = 16 };
 
 // ------------------------------------------------------- memo of successor()

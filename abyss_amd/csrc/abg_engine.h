@@ -1644,7 +1644,7 @@ struct ContigArchive {
 	uint64_t* used = nullptr; // [1] bytes handed out (from ARC_HEAD; beyond cap: contigs that found no room and are not there)
 	uint64_t* tab = nullptr;  // [mask + 1] bits 40..63 of the k-mer's hash << 40 | archive position of its first base; 0: empty
 	uint64_t mask = 0;
-	uint64_t* nreads = nullptr; // [1] statistics: reads the archive answered for at least one k-mer
+	uint64_t* nreads = nullptr; // [2] statistics: reads the archive answered for at least one k-mer; ... for everything (arc_ends_decided)
 };
 ABG_HD uint64_t arc_slot(uint64_t h, uint64_t mask) { return ((h * 0x9E3779B97F4A7C15ULL) >> 22) & mask; }
 ABG_HD uint64_t arc_entry(uint64_t h, uint64_t pos) { return (h & ~((1ULL << ARC_POS_BITS) - 1)) | pos; }
@@ -1667,7 +1667,7 @@ ABG_HD uint64_t arc_read8(const uint32_t* words, uint64_t woff, uint32_t L, uint
 // past the end of a run is clamped into the archive -- what it yields is only looked at when every base before it matched, and
 // then (a separator ends every run, the first of them at ARC_HEAD - 1) it was not clamped.
 constexpr uint32_t ARC_CHUNK = 8;
-ABG_HD uint32_t arc_cover(const ContigArchive& a, uint64_t P, const uint32_t* words, uint64_t woff, uint32_t L, uint32_t j, unsigned k)
+ABG_HD uint32_t arc_cover(const ContigArchive& a, uint64_t P, const uint32_t* words, uint64_t woff, uint32_t L, uint32_t j, unsigned k, bool* same_strand = nullptr)
 {
 	if (P < ARC_HEAD || P + k > a.cap) return 0;
 	const uint32_t n = L - j;
@@ -1678,6 +1678,7 @@ ABG_HD uint32_t arc_cover(const ContigArchive& a, uint64_t P, const uint32_t* wo
 	const uint32_t first = n < 8 ? n : 8u;
 	const bool fwd = (f0 ? (uint32_t)__builtin_ctzll(f0) >> 3 : 8u) >= first;
 	if (!fwd && (b0 ? (uint32_t)__builtin_ctzll(b0) >> 3 : 8u) < first) return 0;
+	if (same_strand) *same_strand = fwd;
 	uint32_t t = first;
 	while (t < n) {
 		uint64_t d[ARC_CHUNK];
@@ -1700,6 +1701,70 @@ ABG_HD uint32_t arc_cover(const ContigArchive& a, uint64_t P, const uint32_t* wo
 		if (done) break;
 	}
 	return t >= k ? t - k + 1 : 0u;
+}
+
+// ---- hasBluntEnd's two look-aheads answered from the archive (round 6) ----
+// A read that lies on ONE archived contig with at least FP_TRIM more contig bases beyond either end starts both of its
+// look-aheads (bloom-dbg.h:489-532: lookAhead(REVERSE, 5) from its first k-mer and from the reverse complement of its last) on
+// a path of five solid vertices c_1 .. c_5, the contig's own.  That alone does not make the search return true: lookAhead
+// (ExtendPath.h:100-161) shares ONE visited set among its branches and never erases it, and identity is strand-agnostic, so a
+// branch tried earlier that reaches a vertex with the identity of some c_i by another route, and fails from there, blocks the
+// contig's path.  When can that happen?  Suppose the search fails.  Every vertex it entered lies at depth <= 4 (depth 5
+// returns true) and had all its solid neighbours tried, so each of them was entered too, then or earlier.  c_1 is a solid
+// neighbour of the start: something with c_1's identity was entered -- c_1 itself (at whatever depth), or its reverse
+// complement reached within 4 steps (B).  If never (B), c_1 was expanded as itself, so c_2 was entered, ..., so something with
+// c_5's identity was entered at depth d <= 4: c_5 as a d-step shift of the start (A) or its reverse complement (B).  With
+// z(i), i in [-5, k), the start k-mer's bases (i >= 0) and the contig's |i|-th base beyond it (i < 0), as the search sees them:
+//   (A) makes the start's first k - 4 bases periodic with period 5 - d: excluded when for every p in 1..5 some i in [0, 8) has
+//       z(i) != z(i + p);
+//   (B), for c_i and depth d with T = i + d in 1..9, makes z(q) = comp(z(k + 4 - T - ... )) a reverse-palindrome over a range that
+//       always holds q in [k - 12, k - 4): excluded when for every T some u in [0, 8) has z(k - 12 + u) != comp(z(11 - T - u)).
+// Both are properties of 26 bases; where they hold (all but low-complexity and hairpin ends) the search cannot fail, whatever
+// the order it tries the neighbours in.  Where they do not, or the margins are short, the searches are run.
+// z for the first look-ahead: z(i) = r(i); for the second (from the reverse complement of the last k-mer): z(i) = comp(r(L - 1 - i)),
+// with r(j) the read's strand of the contig extended beyond the read: seq[A + j] (same strand, read base 0 at A) or
+// comp(seq[E - j]) (other strand, read base 0 at E).
+ABG_HD bool arc_ends_decided(const ContigArchive& a, bool same, uint64_t anchor, uint32_t L, unsigned k)
+{
+	if (k < 20) return false;
+	// r(j), j in [-5, L + 5): inside the archive?  (the read itself matched, so [0, L) is; a separator or an 'N' fails the tests below)
+	if (same ? (anchor < ARC_HEAD + 5 || anchor + L + 5 > a.cap) : (anchor < ARC_HEAD + L + 4 || anchor + 6 > a.cap)) return false;
+	auto r = [&](int j) -> unsigned { const unsigned c = same ? a.seq[anchor + j] : a.seq[anchor - j]; return c > 3u ? 0x80u : (same ? c : 3u - c); };
+	bool ok = true;
+	for (int end = 0; end < 2; end++) {
+		unsigned zl[18], zh[8]; // z(-5 .. 12], z(k - 12 .. k - 5]
+#pragma unroll
+		for (int q = 0; q < 18; q++) { const int i = q - 5; zl[q] = end ? r((int)L - 1 - i) : r(i); }
+#pragma unroll
+		for (int q = 0; q < 8; q++) { const int i = (int)k - 12 + q; zh[q] = end ? r((int)L - 1 - i) : r(i); }
+		if (end) { // (comp; 0x80 stays out of range)
+#pragma unroll
+			for (int q = 0; q < 18; q++) zl[q] = zl[q] > 3u ? 0x80u : 3u - zl[q];
+#pragma unroll
+			for (int q = 0; q < 8; q++) zh[q] = zh[q] > 3u ? 0x80u : 3u - zh[q];
+		}
+		unsigned bad = 0;
+#pragma unroll
+		for (int q = 0; q < 18; q++) bad |= zl[q];
+#pragma unroll
+		for (int q = 0; q < 8; q++) bad |= zh[q];
+		ok = ok && !(bad & 0x80u); // five contig bases beyond the end, no separator, no 'N' anywhere looked at
+#pragma unroll
+		for (int pp = 1; pp <= 5; pp++) { // (A)
+			bool diff = false;
+#pragma unroll
+			for (int i = 0; i < 8; i++) diff = diff || zl[i + 5] != zl[i + pp + 5];
+			ok = ok && diff;
+		}
+#pragma unroll
+		for (int T = 1; T <= 9; T++) { // (B)
+			bool diff = false;
+#pragma unroll
+			for (int u = 0; u < 8; u++) diff = diff || zh[u] != 3u - zl[11 - T - u + 5];
+			ok = ok && diff;
+		}
+	}
+	return ok;
 }
 
 // (A wave-per-read form of this kernel -- k-mers over the lanes, hashed from scratch, the two
@@ -1737,6 +1802,24 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		v.s = batch_kmer<NW>(b, r, 0, k);
 		vtx_rehash(p, v);
 		Vtx<NW> first_v = v;
+		// A read lying on one archived contig, well inside it: both look-aheads are known to succeed (arc_ends_decided), every k-mer
+		// is solid and visited -- the verdict without a probe.  (Plain builds: under a spaced seed identities ignore the masked bases.)
+		uint32_t cov0 = 0; // k-mers from the read's first that the archive answers for (the sweep below starts behind them)
+		if constexpr (!MASKED_BUILD<NW>) {
+			if (arc.seq && !dbg_skip) {
+				const uint64_t h0 = vtx_hash(p, v), en0 = arc.tab[arc_slot(h0, arc.mask)];
+				if (en0 && !((en0 ^ h0) >> ARC_POS_BITS)) {
+					bool same = true;
+					const uint64_t P0 = en0 & ((1ULL << ARC_POS_BITS) - 1);
+					cov0 = arc_cover(arc, P0, b.words, b.woff[r], L, 0, k, &same);
+					if (cov0 == nk && arc_ends_decided(arc, same, same ? P0 : P0 + k - 1, L, k)) {
+						if (arc.nreads) { wave_count_add(arc.nreads, true); wave_count_add(arc.nreads + 1, true); }
+						result[r] = (uint8_t)RR_ALL_KMERS_VISITED;
+						return;
+					}
+				}
+			}
+		}
 		// (the search in registers, look_ahead_reg; look_ahead_t under a spaced seed and for the rare search whose visited set outgrows them)
 		auto la = [&](const Vtx<NW>& s) -> bool {
 			if constexpr (!MASKED_BUILD<NW>) { const unsigned a = look_ahead_reg(p, cnt, s, REVERSE); if (a != 2) return a != 0; }
@@ -1761,8 +1844,9 @@ struct FClassify { // processRead up to the visited test (bloom-dbg.h:798-828), 
 		const uint64_t rwoff = b.woff[r];
 		uint32_t at = 0; // v is the vertex of k-mer `at` of the read
 		// the archive's entry for the k-mer the sweep stands at (ContigArchive): fetched a round ahead, with the probes of the group before
-		uint64_t en = arc.seq ? arc.tab[arc_slot(vtx_hash(p, v), arc.mask)] : 0;
-		for (uint32_t j0 = 0; j0 < nk && solid;) {
+		uint64_t en = arc.seq && !cov0 ? arc.tab[arc_slot(vtx_hash(p, v), arc.mask)] : 0;
+		if (cov0) covered = true;
+		for (uint32_t j0 = cov0; j0 < nk && solid;) {
 			if (at != j0) { // (after a run the archive answered for: the hashes start over)
 				v.s = batch_kmer<NW>(b, r, j0, k); vtx_rehash(p, v);
 				at = j0;
@@ -3625,7 +3709,7 @@ class Engine {
 	}
 	struct Stats { uint64_t rounds = 0, walked = 0, rewalked = 0, candidates = 0, breaks = 0, insert_rounds = 0, commit_rounds = 0, generated = 0;
 	               uint64_t bulk_calls = 0, bulk_steps = 0, lin_steps = 0, guide_slots = 0, chain_steps = 0, batch_cuts = 0, overflows = 0, memo_hits = 0, memo_adds = 0;
-	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, cls_covered_reads = 0, archive_bases = 0, cancelled = 0; };
+	               uint64_t tiled_ops = 0, tiled_pending = 0, tile_overflows = 0, cls_covered_reads = 0, archive_bases = 0, cls_decided_reads = 0; };
 	Stats stats()
 	{
 		Stats s = stats_;
@@ -3634,7 +3718,7 @@ class Engine {
 			be_.d2h(v, wstats_, sizeof v);
 			s.bulk_calls = v[WSTAT_BULK_CALLS]; s.bulk_steps = v[WSTAT_BULK_STEPS]; s.lin_steps = v[WSTAT_LIN_STEPS]; s.chain_steps = v[WSTAT_CHAIN_STEPS];
 			s.memo_hits = v[WSTAT_MEMO_HITS]; s.memo_adds = v[WSTAT_MEMO_ADDS];
-			s.cls_covered_reads = v[WSTAT_CLS_COVERED];
+			s.cls_covered_reads = v[WSTAT_CLS_COVERED]; s.cls_decided_reads = v[WSTAT_CLS_DECIDED];
 		}
 		if (arc_.seq && arc_valid_) { uint64_t u = 0; be_.d2h(&u, arc_.used, 8); s.archive_bases = std::min(u, arc_.cap) - ARC_HEAD; }
 		s.guide_slots = guide_slots_;

@@ -334,7 +334,7 @@ typedef struct abg_stats {
 	uint64_t tile_overflows; /* ... batches whose bins overflowed (judged through a sort of their pairs instead of the tiles; without memory for that, by the reservation rounds as a whole) */
 	uint64_t cls_covered_reads; /* PASS 2: reads whose classification took k-mers from the archive of committed contigs instead of probing the filters (until round 6: pre_requests, always 0) */
 	uint64_t archive_bases; /* ... bytes of that archive in use (until round 6: pre_adds, always 0) */
-	uint64_t cancelled;     /* always 0 (kept for the layout: several batches in flight are gone) */
+	uint64_t cls_decided_reads; /* ... of which this many got their whole verdict there, both look-aheads included (until round 6: cancelled, always 0) */
 	uint64_t counter_bytes_held; /* bytes of the counting filter this context holds: all of it, or its own range of a sliced filter (abg_params.slice_filter) */
 } abg_stats;
 int abg_get_stats(const abg_ctx* ctx, abg_stats* out);

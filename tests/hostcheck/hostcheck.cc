@@ -278,7 +278,7 @@ void hc_get_stats(void* h, abg_stats* out)
 	out->bulk_calls = s.bulk_calls; out->bulk_steps = s.bulk_steps; out->lin_steps = s.lin_steps; out->guide_slots = s.guide_slots; out->chain_steps = s.chain_steps; out->batch_cuts = s.batch_cuts; out->overflows = s.overflows;
 	out->memo_hits = s.memo_hits; out->memo_adds = s.memo_adds;
 	out->tiled_ops = s.tiled_ops; out->tiled_pending = s.tiled_pending; out->tile_overflows = s.tile_overflows;
-	out->cls_covered_reads = s.cls_covered_reads; out->archive_bases = s.archive_bases; out->cancelled = s.cancelled;
+	out->cls_covered_reads = s.cls_covered_reads; out->archive_bases = s.archive_bases; out->cls_decided_reads = s.cls_decided_reads;
 	out->counter_bytes_held = S(h)->eng->counter_bytes_held();
 }
 uint64_t hc_selftest_kmer(unsigned k, const uint32_t* words, uint32_t len)

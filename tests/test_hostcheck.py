@@ -539,11 +539,17 @@ def test_archive_of_committed_contigs_does_not_change_verdicts(name, monkeypatch
         hc.load(g.buf, g.off)
         results, contigs = hc.assemble(g.buf, g.off)
         st = hc.stats()
-        covered[tag] = (st["cls_covered_reads"], st["archive_bases"])
+        covered[tag] = (st["cls_covered_reads"], st["archive_bases"], st["cls_decided_reads"])
         assert api.format_fasta(contigs, g.ids) == g.fasta, tag
         assert api.format_read_log(results, g.ids) == g.readlog, tag
         assert api.format_trace(contigs, g.ids, g.reads, g.opts["k"], with_length=False) == g.trace, tag
-    assert covered["off"] == (0, 0) and covered["on"][0] > 0 and covered["on"][1] >= covered["tiny"][1] > 0, covered
+    assert covered["off"] == (0, 0, 0) and covered["on"][0] > 0 and covered["on"][1] >= covered["tiny"][1] > 0, covered
+    # ... and reads well inside one archived contig get their whole verdict there, the two blunt-end look-aheads included
+    # (arc_ends_decided: the conditions under which lookAhead cannot fail on a contig's own path) -- not under a spaced seed
+    if name in ("k64", "k40_mixed"):
+        assert covered["on"][2] > 100, covered
+    if name == "k48_K16":
+        assert covered["on"][2] == 0, covered
 
 
 def test_packed_reads_get_their_prefix_sums_and_batches_on_the_device():
