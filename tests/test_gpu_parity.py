@@ -96,6 +96,40 @@ def test_matches_oracle(k, G, cov):
     assert o.assembly_counters() == g.assembly_counters()
 
 
+@pytest.mark.parametrize("trial,k", [(0, 32), (1, 41), (2, 64)])
+def test_archive_verdicts_on_repeats_and_hairpins_match_oracle(trial, k, monkeypatch):
+    """The structure arc_ends_decided's conditions are about (tests/test_stress_logic.py: short-unit tandem repeats, hairpins,
+    self-complementary stretches), on the GPU in many small batches: verdicts, contigs and the visited filter are the oracle's."""
+    from test_stress_logic import _structured_genome
+    rng = np.random.default_rng(9000 + trial)
+    G, L = 60000, 120
+    g = _structured_genome(rng, G)
+    starts = rng.integers(0, G - L, size=int(G * 30 / L))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for i, s in enumerate(starts):
+        r = bytearray(g[s:s + L])
+        for j in np.nonzero(rng.random(L) < 0.003)[0]:
+            r[j] = int(rng.choice(list(b"ACGT")))
+        r = bytes(r)
+        reads.append(r if i % 2 == 0 else r.translate(comp)[::-1])
+    buf, off = api.concat_seqs(reads)
+    monkeypatch.setenv("ABG_P2_FIRST_BATCH", "256")
+    counters = 1 << 22
+    o = ob.Oracle(k, counters=counters)
+    o.load(buf, off)
+    ro, co = o.assemble(buf, off)
+    gg = api.BloomDBG(k, counters=counters)
+    gg.load(buf, off)
+    rg, cg = gg.assemble(buf, off)
+    st = gg.stats()
+    assert st["cls_decided_reads"] > 0 and st["walk_rounds"] > 3, st
+    assert np.array_equal(ro, rg), int(np.sum(ro != rg))
+    assert [contig_tuple(c) for c in co] == [contig_tuple(c) for c in cg]
+    assert np.array_equal(o.visited(), gg.visited())
+    gg.close()
+
+
 def _with_ns(ascii_matrix, rate, seed):
     rng = np.random.default_rng(seed)
     a = ascii_matrix.copy()
