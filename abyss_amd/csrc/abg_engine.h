@@ -3532,20 +3532,33 @@ class Engine {
 	void assemble_packed(const Batch& b, uint8_t* results_host,
 	    const std::function<void(const ContigOut&)>& sink)
 	{
+		// (ABG_HOST_TIMING: where a call's time goes before its first batch -- the marks wait for the device, so the run is a little slower)
+		const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
+		const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t_in = tnow();
+		const auto mark = [&](const char* what) { if (timing) { be_.sync(); fprintf(stderr, "[host] assemble_packed +%.3f s: %s\n", tnow() - t_in, what); } };
 		need_counters();
 		gather_counters();
 		// (PASS 1's bins and claim tables grow with the filter -- 60 GB at B=40G: PASS 2 gets that memory)
 		if (insert_scratch_bytes_ > cfg_.keep_insert_scratch_bytes) free_insert();
+		mark("counters final, PASS 1's scratch given back where it is large");
 		ensure_walk();
+		mark("walkers' pools and tables");
 		ensure_plane();
 		ensure_both();
+		mark("bit plane, two-bit array");
 		ensure_archive(b);
+		mark("archive");
 		build_guide(b);
+		mark("guide");
 		ensure_memo();
+		mark("memo");
 		uint8_t* result_d = (uint8_t*)be_.alloc(b.n ? b.n : 1);
 		dispatch_nw([&](auto nw) { assemble_nw<decltype(nw)::value>(b, result_d, results_host, sink); });
+		mark("batches");
 		deliveries_wait(); // (the last batch's contigs are with the caller)
 		be_.sync_side();
+		mark("last delivery");
 		pre_n_ = 0; prefetch_ = nullptr;
 		guide_.tab = nullptr; // its hints point into this call's reads
 		be_.free(result_d);

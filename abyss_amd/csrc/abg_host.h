@@ -134,6 +134,7 @@ class Session {
 	int load_seqs_v(uint32_t nchunks, const char* const* seqs_v, const uint64_t* const* off_v, const uint64_t* n_v)
 	{
 		const uint32_t k = cfg.k;
+		const double t_call = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 		// longest piece handed to the device as one sequence; longer ACGT runs are cut into
 		// pieces overlapping by k-1 bases, which yields the same k-mers in the same order
 		const uint32_t max_piece = (uint32_t)std::min<uint64_t>(1u << 20, cfg.insert_batch_kmers + k - 1);
@@ -224,7 +225,9 @@ class Session {
 		}
 		st->keeping = keeping; st->kparts = std::move(kparts); st->verdict = std::move(verdict); st->n_reads = base[nchunks];
 		st->t_pack = t1 - t0; st->t_join = tnow() - t1; st->nparts = parts.size();
+		const double t_d0 = tnow();
 		drain();
+		if (timing) fprintf(stderr, "[host] load call: plan %.3f s, pack %.3f s, join + hand-over %.3f s, waited %.3f s for the device's share of the call before\n", t0 - t_call, t1 - t0, t_d0 - t1, tnow() - t_d0);
 		// Only a caller that asked for the pipeline (abg_keep_reads) gets it: otherwise the call does its
 		// device work itself and returns with it done and its errors its own.  A partitioned run's
 		// collectives are the caller's code: they stay on the caller's thread.
@@ -278,20 +281,18 @@ class Session {
 			be.h2d(d.koff, hb.koff.data(), hb.koff.size() * 8);
 			d.b = Batch{ w, (const uint64_t*)d.woff, (const uint32_t*)d.len, (const uint64_t*)d.koff, hb.n() };
 			const double t3 = tnow();
-			eng->load_packed(d.b, hb.koff.data());
+			// (the kept store's book-keeping for these reads -- three numbers a read, tens of milliseconds a chunk -- beside the device's work)
+			std::future<void> book = std::async(std::launch::async, [&]() { keep_book(st, at); });
+			try { eng->load_packed(d.b, hb.koff.data()); } catch (...) { book.wait(); throw; }
+			book.get();
 			be.free(d.woff); be.free(d.len); be.free(d.koff);
 			if (timing) fprintf(stderr, "[host] load: %zu parts, pack %.3f s, join %.3f s, upload %.3f s, device %.3f s\n", st.nparts, st.t_pack, st.t_join, t3 - t2, tnow() - t3);
-		}
+		} else keep_book(st, at);
 		keep_.used = at + hb.words.size();
 		const uint64_t r0 = keep_.n_reads;
 		for (size_t t = 0; t < kparts.size(); t++) {
 			KeptPart& kp = kparts[t];
-			for (size_t j = 0; j < kp.read.size(); j++) {
-				keep_.orig.push_back(r0 + kp.read[j]);
-				keep_.woff.push_back(at + hb.woff[rbase[t] + kp.piece[j]]);
-				keep_.len.push_back(kp.len[j]);
-			}
-			if (kp.extra.n()) { // (reads longer than a piece: a copy of their own behind the batch, in read order with the others)
+			if (kp.extra.n()) { // (reads longer than a piece: a copy of their own behind the batch; assemble_kept puts them back into read order)
 				be.h2d((uint32_t*)keep_.words + keep_.used, kp.extra.words.data(), kp.extra.words.size() * 4);
 				for (size_t j = 0; j < kp.extra.n(); j++) {
 					keep_.orig.push_back(r0 + kp.extra_read[j]);
@@ -302,8 +303,29 @@ class Session {
 				keep_.unordered = true;
 			}
 		}
-		keep_.res.insert(keep_.res.end(), st.verdict.begin(), st.verdict.end());
 		keep_.n_reads += st.n_reads;
+		if (timing) fprintf(stderr, "[host] load: the device's share of the call took %.3f s in all (the kept store's book-keeping included)\n", tnow() - t2);
+	}
+	// the kept store's entries for a call's one-piece reads (words at `at`), and the call's verdicts so far
+	void keep_book(LoadStage& st, uint64_t at)
+	{
+		const HostBatch& hb = st.hb;
+		const uint64_t r0 = keep_.n_reads;
+		uint64_t more = 0;
+		for (const KeptPart& kp : st.kparts) more += kp.read.size();
+		const size_t n0 = keep_.orig.size();
+		keep_.orig.resize(n0 + more); keep_.woff.resize(n0 + more); keep_.len.resize(n0 + more);
+		size_t o = n0;
+		for (size_t t = 0; t < st.kparts.size(); t++) {
+			const KeptPart& kp = st.kparts[t];
+			const uint64_t* w = hb.woff.data() + st.rbase[t];
+			for (size_t j = 0; j < kp.read.size(); j++, o++) {
+				keep_.orig[o] = r0 + kp.read[j];
+				keep_.woff[o] = at + w[kp.piece[j]];
+				keep_.len[o] = kp.len[j];
+			}
+		}
+		keep_.res.insert(keep_.res.end(), st.verdict.begin(), st.verdict.end());
 	}
   public:
 	// ---- reads kept on the device between the passes (include/abyss_amd.h: abg_keep_reads)
@@ -322,6 +344,7 @@ class Session {
 	int assemble_kept(uint8_t* results, abg_contig_cb cb, void* user)
 	{
 		drain();
+		const double t_in = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 		if (!keep_on_) return fail(ABG_EINVAL, "no reads are kept (abg_keep_reads)");
 		if (keep_failed_) return fail(ABG_EAGAIN, "the kept reads were dropped (no device memory for them): read the input again");
 		if (eng->cascade_mode()) return fail(ABG_EINVAL, "assembly is not available on a cascading filter");
@@ -360,9 +383,14 @@ class Session {
 				c.left_code = o.left_code; c.right_code = o.right_code; c.seed_pos = o.seed_pos;
 				cb(user, &c);
 			};
+			const bool timing = getenv("ABG_HOST_TIMING") != nullptr;
+			const auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+			const double ta = tnow();
 			eng->assemble_packed(b, pres.data(), sink);
+			const double tb = tnow();
 			be.free(woff_d); be.free(len_d);
 			for (uint64_t j = 0; j < n2; j++) res[keep_.orig[j]] = pres[j];
+			if (timing) fprintf(stderr, "[host] assemble (kept reads): set-up and upload %.3f s, device passes + callbacks %.3f s, verdicts %.3f s\n", ta - t_in, tb - ta, tnow() - tb);
 		}
 		if (results && n) memcpy(results, res.data(), n);
 		keep_drop(false);

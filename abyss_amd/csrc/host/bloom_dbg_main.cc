@@ -611,6 +611,7 @@ int main(int argc, char** argv)
 	// (the first chunks of a kept-reads run are small, so that the device starts while the parser has
 	// read a fraction of a second's worth; then they double up to CHUNK_BASES)
 	size_t chunk_target = 32u << 20;
+	if (const char* e = getenv("ABG_FIRST_CHUNK_MB")) chunk_target = (size_t)std::max(1, atoi(e)) << 20;
 	auto loaded_v = [&]() {
 		load_done();
 		loading_v = std::move(cur_v);

@@ -517,6 +517,96 @@ class SequenceReader {
 		}
 	}
 
+	// A block of plain four-line FASTQ records parsed where it lies: what FastaReader::read above does for the records of
+	// such a block -- id / comment split, Casava chastity filter and "/1" suffix, masked-end trimming, case folding, -q
+	// trimming, -Q masking -- straight from the block's bytes into the Block's strings (no stream, no string per line:
+	// the stream route reads ~200 MB/s a thread).  Anything else the stream route treats specially -- a '#' line, a
+	// SAM header line, a record that is not '@' ... '+' ..., an empty sequence, sequence and quality of different
+	// lengths, a record cut short by the end of the file -- makes it give up (false; `out` is then rubbish): the caller
+	// parses the block again through FastaReader, which handles it or reports it with its line number.
+	// `nlines`: the block's line count (the getline calls the stream route would have made).
+	static bool parse_fastq_block(const char* p, const char* end, const ReaderOptions& o, Block& out, size_t& nlines)
+	{
+		const auto space = [](unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }; // isspace in the C locale
+		size_t lines = 0;
+		const char* x = p;
+		// the next line [a, b) without its end-of-line characters; false when the block has no bytes left
+		const auto line = [&](const char*& a, const char*& b) -> bool {
+			if (x >= end) return false;
+			a = x;
+			const char* nl = (const char*)memchr(x, '\n', (size_t)(end - x));
+			b = nl ? nl : end;
+			x = nl ? nl + 1 : end;
+			lines++;
+			while (b > a && b[-1] == '\r') b--;
+			return true;
+		};
+		const unsigned qoff = o.qualityOffset > 0 ? (unsigned)o.qualityOffset : 33u;
+		while (x < end) {
+			if (*x != '@') return false;
+			const char *h0, *h1, *s0, *s1, *p0, *p1, *q0, *q1;
+			line(h0, h1);
+			if (h1 - h0 > 3 && isalpha((unsigned char)h0[1]) && isalpha((unsigned char)h0[2]) && h0[3] == '\t') return false;
+			const char* ie = h0 + 1;
+			while (ie < h1 && !space((unsigned char)*ie)) ie++;
+			const char* c0 = ie;
+			while (c0 < h1 && space((unsigned char)*c0)) c0++;
+			const size_t clen = (size_t)(h1 - c0), ilen = (size_t)(ie - (h0 + 1));
+			bool suffix = false;
+			if (clen > 3 && c0[1] == ':' && c0[3] == ':') { // Casava
+				if (o.chastityFilter && c0[2] == 'Y') {
+					const char *a, *b;
+					line(a, b); line(a, b); line(a, b); // (the stream route does not look at them either)
+					continue;
+				}
+				suffix = ilen > 2 && ie[-2] != '/';
+			}
+			if (!line(s0, s1) || !line(p0, p1) || p0 >= end || *p0 != '+') return false;
+			if (!line(q0, q1)) q0 = q1 = end; // (a last record without its quality line: no quality, as the stream route has it)
+			if (s0 == s1) return false;
+			const bool hasq = q1 > q0;
+			if (hasq && q1 - q0 != s1 - s0) return false;
+			if (o.trimMasked) {
+				const char *f = s0, *b = s1;
+				while (f < s1 && *f >= 'a' && *f <= 'z') f++;
+				while (b > s0 && b[-1] >= 'a' && b[-1] <= 'z') b--;
+				if (b < f) b = f;
+				if (hasq) { q1 = q0 + (b - s0); q0 += f - s0; }
+				s0 = f; s1 = b;
+			}
+			bool one = false; // -q found no base worth keeping: the stream route leaves the first base (and its quality)
+			if (o.qualityThreshold > 0 && hasq) {
+				const int good = (int)qoff + o.qualityThreshold;
+				const size_t n = (size_t)(q1 - q0);
+				size_t front = 0, back = n;
+				while (front < n && !((unsigned char)q0[front] >= good && (unsigned char)q0[front] <= '~')) front++;
+				if (front == n) one = true;
+				else {
+					while (!((unsigned char)q0[back - 1] >= good && (unsigned char)q0[back - 1] <= '~')) back--;
+					s1 = s0 + back; s0 += front; q1 = q0 + back; q0 += front;
+				}
+			}
+			const size_t at = out.seqs.size();
+			if (one) { if (s1 - s0 > 1) s1 = s0 + 1; if (q1 - q0 > 1) q1 = q0 + 1; }
+			out.seqs.append(s0, (size_t)(s1 - s0));
+			char* d = &out.seqs[0] + at;
+			const size_t n = (size_t)(s1 - s0);
+			if (o.foldCase) for (size_t i = 0; i < n; i++) { const unsigned char ch = (unsigned char)d[i]; d[i] = (char)(ch - ((ch >= 'a' && ch <= 'z') ? 32 : 0)); }
+			if (o.internalQThreshold > 0 && q1 > q0) {
+				const int good = (int)qoff + o.internalQThreshold;
+				const size_t nq = (size_t)(q1 - q0);
+				for (size_t i = 0; i < nq; i++) if (!((unsigned char)q0[i] >= good && (unsigned char)q0[i] <= '~')) d[i] = 'N';
+			}
+			out.seq_end.push_back(out.seqs.size());
+			out.ids.append(h0 + 1, ilen);
+			if (suffix) { out.ids += '/'; out.ids += c0[0]; }
+			out.id_end.push_back(out.ids.size());
+			out.comments.append(c0, clen);
+			out.com_end.push_back(out.comments.size());
+		}
+		nlines = lines;
+		return true;
+	}
   private:
 	// start of the first record at or after `from` (a line start), or `end` if there is none
 	static size_t next_record(const char* p, size_t from, size_t end)
@@ -633,19 +723,43 @@ class SequenceReader {
 		w.blocks.resize(nb);
 		std::vector<size_t> nlines(nb, 0);
 		std::vector<unsigned> line0(nb, m_lines);
+		std::vector<char> fast(nb, 0);
 		std::vector<std::thread> pool;
-		for (size_t b = 0; b < nb; b++) // line numbers for error messages
-			pool.emplace_back([&, b]() {
-				const char* q = p + start[b];
-				const char* e = p + start[b + 1];
-				size_t n = 0;
-				for (const char* x = q; x < e && (x = (const char*)memchr(x, '\n', (size_t)(e - x))) != nullptr; x++) n++;
-				nlines[b] = n;
-			});
-		for (auto& t : pool) t.join();
-		pool.clear();
+		// every block through parse_fastq_block first ...
+		static const bool fast_on = []() { const char* e = getenv("ABG_READER_FAST"); return !(e && atoi(e) == 0); }();
+		if (fast_on) {
+			for (size_t b = 0; b < nb; b++)
+				pool.emplace_back([&, b]() {
+					const size_t len = start[b + 1] - start[b];
+					Block out; // (filled locally: neighbouring Blocks share cache lines)
+					out.seqs.reserve(len / 2 + 64); out.ids.reserve(len / 16 + 64);
+					out.seq_end.reserve(len / 256 + 16); out.id_end.reserve(len / 256 + 16); out.com_end.reserve(len / 256 + 16);
+					size_t n = 0;
+					if (parse_fastq_block(p + start[b], p + start[b + 1], m_opt, out, n)) { nlines[b] = n; fast[b] = 1; w.blocks[b] = std::move(out); }
+				});
+			for (auto& t : pool) t.join();
+			pool.clear();
+		}
+		// ... and the blocks it gave up on through FastaReader, which wants to know the number of its first line for its messages
+		bool all_fast = true;
+		for (size_t b = 0; b < nb; b++) all_fast = all_fast && fast[b];
+		if (!all_fast) {
+			for (size_t b = 0; b < nb; b++) {
+				if (fast[b]) continue;
+				pool.emplace_back([&, b]() {
+					const char* q = p + start[b];
+					const char* e = p + start[b + 1];
+					size_t n = 0;
+					for (const char* x = q; x < e && (x = (const char*)memchr(x, '\n', (size_t)(e - x))) != nullptr; x++) n++;
+					nlines[b] = n;
+				});
+			}
+			for (auto& t : pool) t.join();
+			pool.clear();
+		}
 		for (size_t b = 1; b < nb; b++) line0[b] = line0[b - 1] + (unsigned)nlines[b - 1];
-		for (size_t b = 0; b < nb; b++)
+		for (size_t b = 0; b < nb && !all_fast; b++) {
+			if (fast[b]) continue;
 			pool.emplace_back([&, b]() {
 				const size_t len = start[b + 1] - start[b];
 				if (!len) return;
@@ -662,6 +776,7 @@ class SequenceReader {
 				}
 				w.blocks[b] = std::move(out);
 			});
+		}
 		for (auto& t : pool) t.join();
 		m_lines = line0[nb - 1] + (unsigned)nlines[nb - 1];
 		// what was not parsed stays for the next window

@@ -30,6 +30,7 @@
 #include "si_bytes.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cassert>
 #include <climits>
 #include <cmath>
@@ -1477,6 +1478,7 @@ class Resolver {
 	void resolve_short() // :1259-1323
 	{
 		if (!determine_read_stats()) return;
+		tmark("read statistics");
 		if (opt.verbose) fprintf(stderr, "\nRunning resolution algorithm...\n");
 		for (size_t bi = 0; bi < readSizes.size(); bi++) {
 			const ReadSize batch = readSizes[bi];
@@ -1485,6 +1487,7 @@ class Resolver {
 				if (rv < (int)opt.k) { fprintf(stderr, "r value %d(%d) is too short - skipping.\n", rv, current.size); continue; }
 				if (opt.verbose) fprintf(stderr, "\nRead size = %d, r = %d ...\n\n", batch.size, rv);
 				build_filters(rv, (size_t)(opt.bfMemFactor * double(opt.bloomSize)));
+				tmark(" filter built");
 				for (int j = 0; j < MAX_SUBITERATIONS; j++) {
 					if (opt.verbose) fprintf(stderr, "\nSubiteration %d...\n", j + 1);
 					const size_t before = unsupportedPaths.size();
@@ -1494,6 +1497,7 @@ class Resolver {
 						assemble_contigs();
 						if (!opt.histPrefix.empty()) write_histograms(res, j);
 					}
+					tmark(" subiteration");
 					if (unsupportedPaths.size() == before) break;
 				}
 			}
@@ -1511,14 +1515,25 @@ class Resolver {
 		if (opt.verbose) fprintf(stderr, "%c%s paths written.\n", toupper(what[0]), what + 1);
 	}
 
+	bool timing_ = false; double tl_ = 0;
+	static double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+	void tmark(const char* what) { if (timing_) { const double t = tnow(); fprintf(stderr, "[host] %-28s %.3f s\n", what, t - tl_); tl_ = t; } }
 	int run() // main after the options, RResolverShort.cpp:378-402
 	{
+		// (ABG_RR_TIMING: where the run's time goes, on stderr)
+		timing_ = getenv("ABG_RR_TIMING") != nullptr;
+		tl_ = tnow();
+		const auto mark = [&](const char* what) { tmark(what); };
 		load_graph();
+		mark("graph read");
 		load_contigs();
+		mark("contigs read");
 		resolve_short();
+		mark("resolved");
 		if (opt.verbose) { fprintf(stderr, "Stats after resolution:\n"); print_graph_stats(stderr, g); }
 		store_contigs(opt.outputContigsPath);
 		store_graph(opt.outputGraphPath);
+		mark("outputs written");
 		if (!opt.outputSupportedPathsPath.empty()) write_paths(opt.outputSupportedPathsPath, supportedPaths, "supported");
 		if (!opt.outputUnsupportedPathsPath.empty()) write_paths(opt.outputUnsupportedPathsPath, unsupportedPaths, "unsupported");
 		return EXIT_SUCCESS;

@@ -169,3 +169,76 @@ def test_compressed_input_inflated_ahead_yields_the_same_records(tmp_path):
         assert run_mine(opts, gz) == want                       # the stream as it comes (one gunzip, sequential reader)
         assert run_mine(opts + ["-j", "4", "--prefetch"], gz) == want
         assert run_mine(opts + ["--prefetch"], gz) == want      # one thread: sequential reader over the inflated buffer
+
+
+def _odd_fastq(rng, n, broken=None):
+    """FASTQ text with everything the block parser (SequenceReader::parse_fastq_block) must either do exactly as
+    FastaReader::read does or hand back to it: CR LF line ends, '#' lines, Casava comments with tabs and runs of
+    blanks, ids that end in /1 already, lower-case ends, empty comments, quality below every threshold, a SAM-like
+    header line; `broken`: one malformed record ("empty", "lengths", "noplus") in the middle."""
+    out = []
+    for i in range(n):
+        L = int(rng.integers(1, 90))
+        seq = "".join(rng.choice(list("ACGTacgtNn"), p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .02], size=L))
+        lo = 33 if rng.random() < 0.8 else 34
+        qual = "".join(chr(int(x)) for x in rng.integers(lo, [36, 74, 127][int(rng.integers(0, 3))], size=L))
+        if qual[0] in "@+":
+            qual = "I" + qual[1:]
+        eol = "\r\n" if rng.random() < 0.3 else "\n"
+        sep = [" ", "\t", "  \t "][int(rng.integers(0, 3))]
+        casava = ["", sep + "1:N:0:ACGT", sep + "2:Y:0:ACGT", sep + "x", sep, sep + "1:N:", sep + "3:N:0"][int(rng.integers(0, 7))]
+        name = ["read%d" % i, "r%d/1" % i, "x", "", "abc"][int(rng.integers(0, 5))]
+        if rng.random() < 0.03:
+            out.append("# a comment line" + eol)
+        if rng.random() < 0.02:
+            out.append("@CO\tsomething" + eol)
+        if broken and i == n // 2:
+            casava = ""
+            if broken == "empty":
+                seq, qual = "", ""
+            elif broken == "lengths":
+                qual = qual + "I"
+            elif broken == "noplus":
+                out.append("@%s%s%s%s%s-%s%s%s" % (name, casava, eol, seq, eol, eol, qual, eol))
+                continue
+        out.append("@%s%s%s%s%s+%s%s%s%s" % (name, casava, eol, seq, eol, "" if rng.random() < 0.7 else name, eol, qual, eol))
+    return "".join(out)
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_block_parser_is_the_stream_reader_on_odd_input(tmp_path, monkeypatch, fast):
+    """The records of the parser threads' blocks (ABG_READER_FAST=1: parsed where they lie; 0: every block through
+    FastaReader over fmemopen) against the sequential FastaReader, record for record; a malformed record ends the run
+    with the sequential reader's message, line number included."""
+    import numpy as np
+    build.build_hostcheck()
+    monkeypatch.setenv("ABG_READER_FAST", fast)
+    allopts = OPTS + [["-q", "15", "-Q", "20", "--no-chastity"], ["-Q", "3"], ["-q", "40"], ["--illumina-quality", "-q", "3"]]
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        text = _odd_fastq(rng, 700)
+        if seed == 1:
+            text = text.rstrip("\r\n")            # no end of line after the last record
+        if seed == 2:
+            text = text[:text.rstrip("\r\n").rfind("\n") + 1]  # ... and no quality line at all
+        p = tmp_path / ("odd%d.fq" % seed)
+        p.write_bytes(text.encode())
+        for opts in allopts:
+            want = run_mine(opts, str(p))
+            assert want.count(b"\n") > 200
+            for window, j in ((None, 2), (None, 8), ("3000", 4), ("700", 3)):
+                if window:
+                    monkeypatch.setenv("ABG_READER_WINDOW", window)
+                else:
+                    monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
+                for extra in ([], ["--blocks"]):
+                    assert run_mine(opts + ["-j", str(j)] + extra, str(p)) == want, (seed, opts, window, j, extra)
+    monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
+    for broken in ("empty", "lengths", "noplus"):
+        rng = np.random.default_rng(7)
+        p = tmp_path / ("broken_%s.fq" % broken)
+        p.write_bytes(_odd_fastq(rng, 300, broken).encode())
+        seq = subprocess.run([build.READER_CHECK, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        par = subprocess.run([build.READER_CHECK, "-j", "4", "--blocks", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert seq.returncode != 0 and par.returncode == seq.returncode, broken
+        assert par.stderr == seq.stderr and b"error" in seq.stderr, (broken, seq.stderr, par.stderr)
