@@ -36,6 +36,16 @@ def test_small_reader_windows_change_nothing(tmp_path):
     assert rr_util.run_case(CHECK, str(tmp_path), "rr_mixed", threads=3, env=env) == rr_util.golden_outputs("rr_mixed")
 
 
+@pytest.mark.parametrize("name", rr_util.CASES)
+def test_contigs_read_block_parallel_change_nothing(name, tmp_path):
+    """load_contigs over a plain FASTA file of a megabyte or more: blocks cut at record starts, a thread each (here forced on the
+    small goldens, 2 .. 16 blocks): the same outputs."""
+    want = rr_util.golden_outputs(name)
+    for j in (2, 5, 16):
+        env = dict(os.environ, ABG_RR_PARALLEL_CONTIGS_MIN="1")
+        assert rr_util.run_case(CHECK, str(tmp_path), name, threads=j, env=env) == want, j
+
+
 @pytest.mark.skipif(not os.path.exists(REF_CHECK), reason="oracle/_ref not built (make -C oracle ref)")
 def test_filter_logic_matches_the_btllib_restatement(tmp_path):
     """abg_rr.h run serially: the array after inserting read prefixes equals bit for bit what oracle/shim/btllib builds (its
