@@ -1092,13 +1092,19 @@ class Resolver {
 			auto count = [&](uint64_t len) { if (len >= lenHist.size()) lenHist.resize(len + 1, 0); lenHist[len]++; total++; };
 			if (reader.has_blocks()) {
 				abghost::SequenceReader::Block b;
+				double t_wait = 0, t_off = 0, t_ins = 0, t0 = tnow();
 				while (reader.next_block(b)) {
+					const double t1 = tnow();
 					const uint64_t n = b.seq_end.size();
 					off.resize(n + 1);
 					off[0] = 0;
 					for (uint64_t i = 0; i < n; i++) { off[i + 1] = b.seq_end[i]; count(off[i + 1] - off[i]); }
+					const double t2 = tnow();
 					filter.insert(b.seqs.data(), off.data(), n, span, wanted.data(), (uint32_t)wanted.size());
+					const double t3 = tnow();
+					t_wait += t1 - t0; t_off += t2 - t1; t_ins += t3 - t2; t0 = t3;
 				}
+				if (timing_) fprintf(stderr, "[host]   `%s': %.3f s waiting for the reader, %.3f s over the lengths, %.3f s in the filter's insert calls\n", path.c_str(), t_wait, t_off, t_ins);
 			} else {
 				std::string id, comment, s, buf;
 				off.assign(1, 0);

@@ -15,8 +15,15 @@ struct GpuFilter : abgrr::ReadFilter {
 	int device;
 	abg_rr* f = nullptr;
 	bool timing;
-	explicit GpuFilter(int device) : device(device), timing(getenv("ABG_RR_TIMING") != nullptr) {}
-	~GpuFilter() override { abg_rr_destroy(f); }
+	// The first HIP call of a process pays for the runtime's start (~0.1 s on the GPU boxes): a filter of a few bytes made and dropped
+	// on a thread of its own while the graph and the contigs are read; create() waits for it.  (What it says does not matter: without
+	// a device the real create() fails and reports.)
+	std::future<void> warm;
+	explicit GpuFilter(int device) : device(device), timing(getenv("ABG_RR_TIMING") != nullptr)
+	{
+		if (!getenv("ABG_RR_NO_WARM")) warm = std::async(std::launch::async, [device]() { abg_rr* t = nullptr; if (abg_rr_create(device, 64, 7, 32, &t) == ABG_OK) abg_rr_destroy(t); });
+	}
+	~GpuFilter() override { if (warm.valid()) warm.wait(); abg_rr_destroy(f); }
 	[[noreturn]] void fail(const char* what)
 	{
 		fprintf(stderr, ABG_RR_PROGRAM ": %s: %s\n", what, abg_rr_last_error(f));
@@ -24,6 +31,7 @@ struct GpuFilter : abgrr::ReadFilter {
 	}
 	void create(uint64_t bytes, unsigned hash_num, unsigned r) override
 	{
+		if (warm.valid()) warm.get();
 		report();
 		abg_rr_destroy(f);
 		f = nullptr;
