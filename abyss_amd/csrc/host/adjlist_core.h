@@ -222,14 +222,8 @@ inline void read_contigs(const std::string& path, const Options& o, Graph& g, st
 	if (o.verbose > 0) fprintf(stderr, "Reading `%s'...\n", path.c_str());
 	abghost::ReaderOptions ro;
 	ro.trimMasked = 0; // AdjList.cpp:387
-	abghost::FastaReader in(path, ro);
 	const unsigned overlap = o.k - 1, W = g.W;
-	std::string id, comment, seq;
-	while (in.read(id, comment, seq)) {
-		if (isdigit((unsigned char)seq[0])) {
-			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': colour-space contigs are not supported\n", path.c_str());
-			exit(EXIT_FAILURE);
-		}
+	const auto flatten = [](std::string& seq) {
 		for (auto& c : seq) { // flattenAmbiguityCodes(seq), N untouched
 			switch (c) {
 			case 'M': case 'R': case 'W': case 'V': case 'H': case 'D': c = 'A'; break;
@@ -237,6 +231,27 @@ inline void read_contigs(const std::string& path, const Options& o, Graph& g, st
 			case 'K': c = 'G'; break;
 			default: break;
 			}
+		}
+	};
+	// (a plain FASTA file of some size is parsed block-parallel -- read_fasta_blocks -- and its records taken in file order below)
+	std::vector<std::vector<abghost::FastaRecord>> parts;
+	const bool blocks = abghost::read_fasta_blocks(path, ro, std::max(1u, std::thread::hardware_concurrency()), parts, [&](abghost::FastaRecord& r) { if (!isdigit((unsigned char)r.seq[0])) flatten(r.seq); });
+	std::unique_ptr<abghost::FastaReader> in;
+	if (!blocks) in.reset(new abghost::FastaReader(path, ro));
+	size_t pb = 0, pi = 0;
+	std::string id, comment, seq;
+	const auto next = [&]() -> bool {
+		if (!blocks) { if (!in->read(id, comment, seq)) return false; if (!isdigit((unsigned char)seq[0])) flatten(seq); return true; }
+		while (pb < parts.size() && pi >= parts[pb].size()) { std::vector<abghost::FastaRecord>().swap(parts[pb]); pb++; pi = 0; }
+		if (pb >= parts.size()) return false;
+		abghost::FastaRecord& r = parts[pb][pi++];
+		id.swap(r.id); comment.swap(r.comment); seq.swap(r.seq);
+		return true;
+	};
+	while (next()) {
+		if (isdigit((unsigned char)seq[0])) {
+			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': colour-space contigs are not supported\n", path.c_str());
+			exit(EXIT_FAILURE);
 		}
 		if (seq.length() <= overlap) { // (an assertion of the reference)
 			fprintf(stderr, ABG_ADJ_PROGRAM ": `%s': contig `%s' is %zu bases long: contigs must be longer than k-1 = %u\n",

@@ -531,7 +531,8 @@ int main(int argc, char** argv)
 	}
 	FILE* out = stdout;
 	if (!outputPath.empty() && !(out = fopen(outputPath.c_str(), "w"))) { fprintf(stderr, "error: `%s': %s\n", outputPath.c_str(), strerror(errno)); exit(EXIT_FAILURE); }
-	const size_t CHUNK_BASES = 256u << 20;
+	size_t CHUNK_BASES = 256u << 20;
+	if (const char* e = getenv("ABG_CHUNK_MB")) CHUNK_BASES = (size_t)std::max(1, atoi(e)) << 20; // (measurements)
 	int first_asm = optind;
 	std::string id, comment, seq;
 	Chunk chunk;

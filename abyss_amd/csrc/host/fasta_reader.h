@@ -14,6 +14,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <future>
 #include <map>
 #include <string>
@@ -386,6 +387,58 @@ class Prefetch {
 	std::atomic<uint64_t> m_inflated{ 0 }; // bytes held by the drain threads
 	uint64_t m_budget = 0;
 };
+
+// A plain FASTA file of a megabyte or more (unitigs: tens of megabytes that AdjList and abyss-rresolver-short read before anything
+// else happens) parsed by several threads: cut at record starts -- a line beginning with '>' -- into a block per thread, every block
+// through the same FastaReader (over fmemopen, with its first line's number for the messages), `hook` run on every record where it
+// was parsed (work that needs nothing but the record).  The records come back per block, in file order.  false: not such a file
+// (compressed, stdin, small, not beginning with '>', one thread) -- the caller reads it with FastaReader as before.
+// (ABG_FASTA_BLOCKS_MIN: the size from which on, tests)
+struct FastaRecord { std::string id, comment, seq, aux; };
+inline bool read_fasta_blocks(const std::string& path, const ReaderOptions& ro, unsigned threads, std::vector<std::vector<FastaRecord>>& parts,
+    const std::function<void(FastaRecord&)>& hook = nullptr)
+{
+	const unsigned T = std::min(16u, threads);
+	const char* prog; const char* flag;
+	struct stat st;
+	const char* e = getenv("ABG_FASTA_BLOCKS_MIN");
+	const long min_bytes = e ? atol(e) : (1L << 20);
+	if (T < 2 || path == "-" || min_bytes < 0 || Prefetch::compressed(path, &prog, &flag) || stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < min_bytes || st.st_size == 0) return false;
+	std::string text((size_t)st.st_size, '\0');
+	FILE* f = fopen(path.c_str(), "rb");
+	const size_t got = f ? fread(&text[0], 1, text.size(), f) : 0;
+	if (f) fclose(f);
+	if (got != text.size() || text[0] != '>') return false;
+	std::vector<size_t> start{ 0 };
+	for (unsigned t = 1; t < T; t++) {
+		const size_t at = text.find("\n>", text.size() / T * t);
+		if (at != std::string::npos && at + 1 > start.back()) start.push_back(at + 1);
+	}
+	start.push_back(text.size());
+	const size_t nb = start.size() - 1;
+	parts.assign(nb, std::vector<FastaRecord>());
+	std::vector<unsigned> line0(nb + 1, 0);
+	std::vector<std::thread> pool;
+	for (size_t b = 0; b < nb; b++)
+		pool.emplace_back([&, b]() { line0[b + 1] = (unsigned)std::count(text.begin() + (ptrdiff_t)start[b], text.begin() + (ptrdiff_t)start[b + 1], '\n'); });
+	for (auto& t : pool) t.join();
+	pool.clear();
+	for (size_t b = 0; b < nb; b++) line0[b + 1] += line0[b];
+	for (size_t b = 0; b < nb; b++)
+		pool.emplace_back([&, b]() {
+			FILE* m = fmemopen((void*)(text.data() + start[b]), start[b + 1] - start[b], "r");
+			if (!m) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
+			FastaReader in(m, path, line0[b], ro);
+			FastaRecord r;
+			while (in.read(r.id, r.comment, r.seq)) {
+				if (hook) hook(r);
+				parts[b].push_back(std::move(r));
+				r = FastaRecord();
+			}
+		});
+	for (auto& t : pool) t.join();
+	return true;
+}
 
 // FASTQ files parsed by several threads.  Parsing is what the host binary spends its time on once
 // the kernels are fast (a single thread reads ~330 MB/s); records are independent, so a window of

@@ -691,53 +691,14 @@ class Resolver {
 			if (rc) { seqs.push_back(std::move(s)); seqs.push_back(std::move(*rc)); }
 			else { std::string r = reverse_complement(s); seqs.push_back(std::move(s)); seqs.push_back(std::move(r)); }
 		};
-		// A plain FASTA file of some size: cut at record starts (a line beginning with '>') into a block per thread, every block
-		// through the same FastaReader (over fmemopen) and its records' reverse complements made there -- one thread reads
-		// ~200 MB/s, and the unitigs of a genome are tens of megabytes the reads' filter waits for.  Records in file order.
+		// (a plain FASTA file of some size: parsed block-parallel, the reverse complements made where the records are parsed --
+		// one thread reads ~200 MB/s, and the unitigs of a genome are tens of megabytes the reads' filter waits for)
 		bool done = false;
-		const unsigned T = (unsigned)std::min(16, std::max(1, opt.threads));
-		if (T > 1 && opt.contigsPath != "-" && !(getenv("ABG_RR_SERIAL_CONTIGS") && atoi(getenv("ABG_RR_SERIAL_CONTIGS")))) {
-			const char* prog; const char* flag;
-			struct stat st;
-			if (!abghost::Prefetch::compressed(opt.contigsPath, &prog, &flag) && stat(opt.contigsPath.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= (getenv("ABG_RR_PARALLEL_CONTIGS_MIN") ? atol(getenv("ABG_RR_PARALLEL_CONTIGS_MIN")) : (1L << 20))) { // (the variable: tests)
-				std::string text((size_t)st.st_size, '\0');
-				FILE* f = fopen(opt.contigsPath.c_str(), "rb");
-				const size_t got = f ? fread(&text[0], 1, text.size(), f) : 0;
-				if (f) fclose(f);
-				if (got == text.size() && text[0] == '>') {
-					std::vector<size_t> start{ 0 };
-					for (unsigned t = 1; t < T; t++) {
-						const size_t at = text.find("\n>", text.size() / T * t);
-						if (at != std::string::npos && at + 1 > start.back()) start.push_back(at + 1);
-					}
-					start.push_back(text.size());
-					const size_t nb = start.size() - 1;
-					struct Rec { std::string id, comment, s, rc; };
-					std::vector<std::vector<Rec>> parts(nb);
-					std::vector<unsigned> line0(nb + 1, 0);
-					std::vector<std::thread> pool;
-					for (size_t b = 0; b < nb; b++)
-						pool.emplace_back([&, b]() { line0[b + 1] = (unsigned)std::count(text.begin() + (ptrdiff_t)start[b], text.begin() + (ptrdiff_t)start[b + 1], '\n'); });
-					for (auto& t : pool) t.join();
-					pool.clear();
-					for (size_t b = 0; b < nb; b++) line0[b + 1] += line0[b];
-					for (size_t b = 0; b < nb; b++)
-						pool.emplace_back([&, b]() {
-							FILE* m = fmemopen((void*)(text.data() + start[b]), start[b + 1] - start[b], "r");
-							if (!m) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
-							abghost::FastaReader in(m, opt.contigsPath, line0[b], ro);
-							Rec r;
-							while (in.read(r.id, r.comment, r.s)) {
-								r.rc = g.index.count(r.id) ? reverse_complement(r.s) : std::string();
-								parts[b].push_back(std::move(r));
-								r = Rec();
-							}
-						});
-					for (auto& t : pool) t.join();
-					for (auto& part : parts) for (Rec& r : part) take(r.id, r.comment, r.s, &r.rc);
-					done = true;
-				}
-			}
+		if (!(getenv("ABG_RR_SERIAL_CONTIGS") && atoi(getenv("ABG_RR_SERIAL_CONTIGS")))) {
+			std::vector<std::vector<abghost::FastaRecord>> parts;
+			done = abghost::read_fasta_blocks(opt.contigsPath, ro, (unsigned)std::max(1, opt.threads), parts,
+			    [&](abghost::FastaRecord& r) { if (g.index.count(r.id)) r.aux = reverse_complement(r.seq); });
+			if (done) for (auto& part : parts) for (abghost::FastaRecord& r : part) take(r.id, r.comment, r.seq, &r.aux);
 		}
 		if (!done) {
 			abghost::FastaReader in(opt.contigsPath, ro);

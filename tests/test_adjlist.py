@@ -235,3 +235,32 @@ def test_random_small_contig_sets_against_the_reference_binary(adjlist_check, tm
         write_fasta(fa, recs, width=rnd.choice([0, 0, 7, 60]))
         for fmt in FORMATS:
             assert run_bin(adjlist_check, k, m, fmt, extra, fa) == run_bin(ao.REF_ADJLIST, k, m, fmt, extra, fa), (case, k, m, extra, fmt)
+
+
+def test_contigs_parsed_block_parallel_change_nothing(adjlist_check, tmp_path, monkeypatch):
+    """read_fasta_blocks (a plain FASTA file of a megabyte or more is cut at record starts and parsed by several threads), forced
+    on small files: the goldens, wrapped and unwrapped synthetic sets with ambiguity codes -- and the reader's complaints, which
+    must name the same line."""
+    outs = {}
+    for force in ("-1", "1"):  # (-1: never)
+        monkeypatch.setenv("ABG_FASTA_BLOCKS_MIN", force)
+        for name in sorted(INDEX):
+            c = INDEX[name]
+            for fmt in ("adj", "dot"):
+                outs[(force, name, fmt)] = run_bin(adjlist_check, c["k"], c["m"], fmt, c["extra"], os.path.join(GOLDEN, c["fasta"]))
+        for seed, width in ((21, 0), (22, 60), (23, 7)):
+            recs = synthetic_contigs(seed, 33, n=900)
+            recs = [(i, c, s.replace(b"AC", b"MY", 1) if n % 5 == 0 else s) for n, (i, c, s) in enumerate(recs)]
+            fa = str(tmp_path / ("c%d.fa" % seed))
+            write_fasta(fa, recs, width=width)
+            outs[(force, seed, "adj")] = run_bin(adjlist_check, 33, 10, "adj", [], fa)
+        # an empty record in the middle: FastaReader's message with the line number
+        recs = synthetic_contigs(31, 25, n=300)
+        fa = str(tmp_path / "broken.fa")
+        write_fasta(fa, recs[:150] + [("x", "", b"")] + recs[150:])
+        r = subprocess.run([adjlist_check, "-k25", fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0 and b"is empty" in r.stderr
+        outs[(force, "broken", "stderr")] = r.stderr
+    for (force, a, b), v in outs.items():
+        if force == "1":
+            assert v == outs[("-1", a, b)], (a, b)

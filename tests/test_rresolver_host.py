@@ -42,7 +42,7 @@ def test_contigs_read_block_parallel_change_nothing(name, tmp_path):
     small goldens, 2 .. 16 blocks): the same outputs."""
     want = rr_util.golden_outputs(name)
     for j in (2, 5, 16):
-        env = dict(os.environ, ABG_RR_PARALLEL_CONTIGS_MIN="1")
+        env = dict(os.environ, ABG_FASTA_BLOCKS_MIN="1")
         assert rr_util.run_case(CHECK, str(tmp_path), name, threads=j, env=env) == want, j
 
 
