@@ -18,12 +18,18 @@ struct GpuFilter : abgrr::ReadFilter {
 	// The first HIP call of a process pays for the runtime's start (~0.1 s on the GPU boxes): a filter of a few bytes made and dropped
 	// on a thread of its own while the graph and the contigs are read; create() waits for it.  (What it says does not matter: without
 	// a device the real create() fails and reports.)
-	std::future<void> warm;
+	// (The reader's error paths leave through exit() like the reference's: exit() then waits for that thread -- wait_for_warm, as
+	// AdjList does -- so that the static destructors never run beside a HIP runtime that is still starting.)
+	static std::future<void>& warm() { static std::future<void> w; return w; }
+	static void wait_for_warm() { if (warm().valid()) warm().wait(); }
 	explicit GpuFilter(int device) : device(device), timing(getenv("ABG_RR_TIMING") != nullptr)
 	{
-		if (!getenv("ABG_RR_NO_WARM")) warm = std::async(std::launch::async, [device]() { abg_rr* t = nullptr; if (abg_rr_create(device, 64, 7, 32, &t) == ABG_OK) abg_rr_destroy(t); });
+		if (getenv("ABG_RR_NO_WARM")) return;
+		(void)warm(); // (made before the handler is registered: destroyed after it has run)
+		atexit(wait_for_warm);
+		warm() = std::async(std::launch::async, [device]() { abg_rr* t = nullptr; if (abg_rr_create(device, 64, 7, 32, &t) == ABG_OK) abg_rr_destroy(t); });
 	}
-	~GpuFilter() override { if (warm.valid()) warm.wait(); abg_rr_destroy(f); }
+	~GpuFilter() override { wait_for_warm(); abg_rr_destroy(f); }
 	[[noreturn]] void fail(const char* what)
 	{
 		fprintf(stderr, ABG_RR_PROGRAM ": %s: %s\n", what, abg_rr_last_error(f));
@@ -31,7 +37,7 @@ struct GpuFilter : abgrr::ReadFilter {
 	}
 	void create(uint64_t bytes, unsigned hash_num, unsigned r) override
 	{
-		if (warm.valid()) warm.get();
+		wait_for_warm();
 		report();
 		abg_rr_destroy(f);
 		f = nullptr;
