@@ -217,6 +217,9 @@ struct HipBackend {
 		if (ticket) free(ticket);
 		if (pin) hipHostFree(pin);
 		for (int i = 0; i < 2; i++) { if (big_pin[i]) hipHostFree(big_pin[i]); if (big_ev[i]) hipEventDestroy(big_ev[i]); }
+		for (int i = 0; i < 2; i++) { if (ahead_pin[i]) hipHostFree(ahead_pin[i]); if (ahead_ev[i]) hipEventDestroy(ahead_ev[i]); if (ahead[i].dev) hipFree(ahead[i].dev); }
+		for (void* q : ahead_old) hipFree(q);
+		if (ahead_stream) hipStreamDestroy(ahead_stream);
 		if (cub_tmp) hipFree(cub_tmp);
 		drop_cache();
 		prof_drain(true);
@@ -376,6 +379,58 @@ struct HipBackend {
 		}
 		check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D");
 		check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+	}
+	// A chunk's arrays uploaded AHEAD (abg_host.h, load_seqs_v): by the CALLING thread while the library's own thread is still busy with
+	// the chunk before -- on a stream, through pinned buffers and into one of two device blocks that belong to this alone (nothing
+	// here shares state with alloc / h2d / the main stream, which that other thread is using meanwhile).  `n` arrays, each placed on
+	// a 256-byte boundary; at[i] = where array i went.  The block is the caller's until the second call after this one.  nullptr:
+	// not available (the caller uploads the ordinary way).
+	struct Ahead { void* dev = nullptr; size_t cap = 0; } ahead[2];
+	std::vector<void*> ahead_old;
+	int ahead_next = 0, ahead_state = 0; // state: 0 untried, 1 ready, -1 unavailable
+	hipStream_t ahead_stream = nullptr; void* ahead_pin[2] = { nullptr, nullptr }; hipEvent_t ahead_ev[2] = { nullptr, nullptr };
+	void* upload_ahead(const void* const* src, const size_t* bytes, int n, void** at)
+	{
+		if (ahead_state < 0 || getenv("ABG_NO_UPLOAD_AHEAD")) return nullptr;
+		(void)hipSetDevice(device);
+		if (ahead_state == 0) {
+			ahead_state = -1;
+			if (hipStreamCreateWithFlags(&ahead_stream, hipStreamNonBlocking) == hipSuccess &&
+			    hipHostMalloc(&ahead_pin[0], BIG_PIN, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&ahead_pin[1], BIG_PIN, hipHostMallocDefault) == hipSuccess &&
+			    hipEventCreateWithFlags(&ahead_ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ahead_ev[1], hipEventDisableTiming) == hipSuccess)
+				ahead_state = 1;
+			else { (void)hipGetLastError(); return nullptr; }
+		}
+		size_t total = 0;
+		for (int i = 0; i < n; i++) total += (bytes[i] + 255) & ~(size_t)255;
+		Ahead& a = ahead[ahead_next];
+		if (total > a.cap) {
+			// (a block that has become too small is kept until the backend goes: hipFree waits for the whole device, which the
+			// other thread is keeping busy -- and the first chunks of a run double in size, so what is kept is less than what is used)
+			const size_t a_cap_was = a.cap;
+			if (a.dev) { ahead_old.push_back(a.dev); a.dev = nullptr; a.cap = 0; }
+			const size_t cap = std::max(total + total / 8, 2 * a_cap_was); // (at least doubled: a handful of blocks ever)
+			if (hipMalloc(&a.dev, cap) != hipSuccess) { (void)hipGetLastError(); a.dev = nullptr; return nullptr; }
+			a.cap = cap;
+		}
+		ahead_next ^= 1;
+		size_t off = 0;
+		int b = 0;
+		for (int i = 0; i < n; i++) {
+			at[i] = (char*)a.dev + off;
+			const char* s = (const char*)src[i];
+			for (size_t done = 0; done < bytes[i]; b ^= 1) {
+				const size_t m = bytes[i] - done < BIG_PIN ? bytes[i] - done : BIG_PIN;
+				check(hipEventSynchronize(ahead_ev[b]), "hipEventSynchronize"); // (the buffer's last copy has left)
+				memcpy(ahead_pin[b], s + done, m);
+				check(hipMemcpyAsync((char*)at[i] + done, ahead_pin[b], m, hipMemcpyHostToDevice, ahead_stream), "hipMemcpy H2D");
+				check(hipEventRecord(ahead_ev[b], ahead_stream), "hipEventRecord");
+				done += m;
+			}
+			off += (bytes[i] + 255) & ~(size_t)255;
+		}
+		check(hipStreamSynchronize(ahead_stream), "hipStreamSynchronize");
+		return a.dev;
 	}
 	static constexpr size_t BIG_PIN = 8u << 20;
 	void* big_pin[2] = { nullptr, nullptr }; hipEvent_t big_ev[2] = { nullptr, nullptr }; int big_state = 0; // 0 untried, 1 ready, -1 unavailable

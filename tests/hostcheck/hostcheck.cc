@@ -51,6 +51,20 @@ struct SerialBackend {
 	void side_scope_end() {}
 	void wait_side_scope() {}
 	void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+	// (the serial backend has one thread's worth of everything: two malloc'ed blocks stand in for the device's)
+	std::vector<char> ahead[2]; int ahead_next = 0;
+	void* upload_ahead(const void* const* src, const size_t* bytes, int n, void** at)
+	{
+		if (getenv("ABG_NO_UPLOAD_AHEAD")) return nullptr;
+		size_t total = 0;
+		for (int i = 0; i < n; i++) total += (bytes[i] + 255) & ~(size_t)255;
+		std::vector<char>& a = ahead[ahead_next];
+		ahead_next ^= 1;
+		if (a.size() < total + 1) a.resize(total + 1);
+		size_t off = 0;
+		for (int i = 0; i < n; i++) { at[i] = a.data() + off; memcpy(at[i], src[i], bytes[i]); off += (bytes[i] + 255) & ~(size_t)255; }
+		return a.data();
+	}
 	void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 	void inclusive_sum_u64(uint64_t* d, uint64_t n) { for (uint64_t i = 1; i < n; i++) d[i] += d[i - 1]; }
 	void sort_pairs_u64_u32(const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n)

@@ -815,12 +815,15 @@ def test_kmer_helpers_and_prefix_xor_hashes_agree_with_the_per_base_forms():
         assert l.hc_selftest_kmer(k, words.ctypes.data, L) == 0, k
 
 
-@pytest.mark.parametrize("k,mask", [(33, None), (40, "k40"), (48, "K16")])
-def test_reads_kept_on_the_device_between_the_passes_assemble_like_the_read_stream(k, mask, monkeypatch):
+@pytest.mark.parametrize("k,mask,ahead", [(33, None, True), (40, "k40", True), (48, "K16", True), (33, None, False)])
+def test_reads_kept_on_the_device_between_the_passes_assemble_like_the_read_stream(k, mask, ahead, monkeypatch):
     """abg_keep_reads / abg_load_seqs_v / abg_assemble_kept against the oracle fed the same stream:
     reads with N, short reads, lower case, a read longer than a PASS-1 piece, empty chunks, several
-    load calls, the packing split over threads."""
+    load calls, the packing split over threads; a call's arrays uploaded ahead by the calling thread (the default) or by the
+    library's thread in front of the chunk's kernels (ABG_NO_UPLOAD_AHEAD)."""
     monkeypatch.setenv("ABG_HOST_SPLIT", "3")
+    if not ahead:
+        monkeypatch.setenv("ABG_NO_UPLOAD_AHEAD", "1")
     m1, m2 = synth.make_read_set(12000, 30.0, err=0.004, genome_seed=k, read_seed=k + 5)
     reads = [bytes(r) for r in synth.codes_to_ascii(np.concatenate([m1, m2]))]
     rng = np.random.default_rng(k)
