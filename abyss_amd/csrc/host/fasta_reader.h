@@ -286,9 +286,24 @@ class FastaReader {
 	}
 	[[noreturn]] void die(const char* msg)
 	{
+		if (m_worker) {
+			// One of several parser threads: exit() would run the static destructors and close every stream beside the threads that
+			// are still parsing (seen once as a crash instead of status 1, on a busy host).  The first complaint is printed, what
+			// the process has written to stdout goes out, and the process ends there and then.
+			static std::atomic<bool> dying{ false };
+			if (dying.exchange(true)) for (;;) pause();
+			fprintf(stderr, "%s:%u: error: %s\n", m_path.c_str(), m_line, msg);
+			fflush(stdout);
+			_exit(EXIT_FAILURE);
+		}
 		fprintf(stderr, "%s:%u: error: %s\n", m_path.c_str(), m_line, msg);
 		exit(EXIT_FAILURE);
 	}
+  public:
+	// this reader runs on one of several parser threads (SequenceReader, read_fasta_blocks): see die()
+	void on_worker_thread() { m_worker = true; }
+  private:
+	bool m_worker = false;
 };
 
 // Compressed inputs decompressed AHEAD: every one by a decompressor child of its own (gunzip -c
@@ -429,6 +444,7 @@ inline bool read_fasta_blocks(const std::string& path, const ReaderOptions& ro, 
 			FILE* m = fmemopen((void*)(text.data() + start[b]), start[b + 1] - start[b], "r");
 			if (!m) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
 			FastaReader in(m, path, line0[b], ro);
+			in.on_worker_thread();
 			FastaRecord r;
 			while (in.read(r.id, r.comment, r.seq)) {
 				if (hook) hook(r);
@@ -819,6 +835,7 @@ class SequenceReader {
 				FILE* f = fmemopen((void*)(p + start[b]), len, "r");
 				if (!f) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
 				FastaReader r(f, m_path, line0[b], m_opt);
+				r.on_worker_thread();
 				Block out; // (filled locally: neighbouring Blocks share cache lines)
 				out.seqs.reserve(len / 2);
 				std::string id, comment, s;
