@@ -214,9 +214,9 @@ def test_block_parser_is_the_stream_reader_on_odd_input(tmp_path, monkeypatch, f
     build.build_hostcheck()
     monkeypatch.setenv("ABG_READER_FAST", fast)
     allopts = OPTS + [["-q", "15", "-Q", "20", "--no-chastity"], ["-Q", "3"], ["-q", "40"], ["--illumina-quality", "-q", "3"]]
-    for seed in range(6):
+    for seed in range(3):
         rng = np.random.default_rng(100 + seed)
-        text = _odd_fastq(rng, 700)
+        text = _odd_fastq(rng, 500)
         if seed == 1:
             text = text.rstrip("\r\n")            # no end of line after the last record
         if seed == 2:
@@ -225,14 +225,14 @@ def test_block_parser_is_the_stream_reader_on_odd_input(tmp_path, monkeypatch, f
         p.write_bytes(text.encode())
         for opts in allopts:
             want = run_mine(opts, str(p))
-            assert want.count(b"\n") > 200
-            for window, j in ((None, 2), (None, 8), ("3000", 4), ("700", 3)):
+            assert want.count(b"\n") > 150
+            for window, j in ((None, 8), ("3000", 4), ("700", 3)):
                 if window:
                     monkeypatch.setenv("ABG_READER_WINDOW", window)
                 else:
                     monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
-                for extra in ([], ["--blocks"]):
-                    assert run_mine(opts + ["-j", str(j)] + extra, str(p)) == want, (seed, opts, window, j, extra)
+                extra = ["--blocks"] if (j + len(opts)) % 2 else []
+                assert run_mine(opts + ["-j", str(j)] + extra, str(p)) == want, (seed, opts, window, j, extra)
     monkeypatch.delenv("ABG_READER_WINDOW", raising=False)
     for broken in ("empty", "lengths", "noplus"):
         rng = np.random.default_rng(7)
