@@ -419,6 +419,8 @@ inline bool read_fasta_blocks(const std::string& path, const ReaderOptions& ro, 
 	const char* e = getenv("ABG_FASTA_BLOCKS_MIN");
 	const long min_bytes = e ? atol(e) : (1L << 20);
 	if (T < 2 || path == "-" || min_bytes < 0 || Prefetch::compressed(path, &prog, &flag) || stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < min_bytes || st.st_size == 0) return false;
+	// (the file and its records are in memory together for a moment: not for a file that is a sizeable part of the host's memory)
+	if ((uint64_t)st.st_size > (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE) / 16) return false;
 	std::string text((size_t)st.st_size, '\0');
 	FILE* f = fopen(path.c_str(), "rb");
 	const size_t got = f ? fread(&text[0], 1, text.size(), f) : 0;
