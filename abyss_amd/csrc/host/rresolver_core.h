@@ -930,14 +930,28 @@ class Resolver {
 	{
 		if (opt.verbose) fprintf(stderr, "Determining read stats...\n");
 		readSizes.clear();
-		for (const std::string& filename : opt.readFiles) {
-			Histogram hist;
-			abghost::FastaReader reader(filename, raw_reader());
+		// (the files' samples are taken side by side when all of them can be opened -- a file that cannot is the sequential loop's to
+		// report -- and merged in file order)
+		std::vector<Histogram> hists(opt.readFiles.size());
+		const auto sample = [&](size_t f, bool worker) {
+			abghost::FastaReader reader(opt.readFiles[f], raw_reader());
+			if (worker) reader.on_worker_thread();
 			std::string id, comment, s;
 			for (long num = 0; num < READ_STATS_SAMPLE_SIZE && reader.read(id, comment, s); num++) {
 				if (s.size() > opt.maxReadSize) continue;
-				hist[(int)s.size()]++;
+				hists[f][(int)s.size()]++;
 			}
+		};
+		bool side_by_side = opt.readFiles.size() > 1 && opt.threads > 1;
+		for (const std::string& filename : opt.readFiles) if (filename == "-" || access(filename.c_str(), R_OK) != 0) side_by_side = false;
+		if (side_by_side) {
+			std::vector<std::thread> pool;
+			for (size_t f = 0; f < opt.readFiles.size(); f++) pool.emplace_back([&, f]() { sample(f, true); });
+			for (auto& t : pool) t.join();
+		} else
+			for (size_t f = 0; f < opt.readFiles.size(); f++) sample(f, false);
+		for (size_t f = 0; f < opt.readFiles.size(); f++) {
+			const Histogram& hist = hists[f];
 			for (const auto& kv : hist) {
 				ReadSize* batch = nullptr;
 				for (auto& b : readSizes) if (b.size == kv.first) { batch = &b; break; }
