@@ -444,7 +444,7 @@ inline bool read_fasta_blocks(const std::string& path, const ReaderOptions& ro, 
 	for (size_t b = 0; b < nb; b++)
 		pool.emplace_back([&, b]() {
 			FILE* m = fmemopen((void*)(text.data() + start[b]), start[b + 1] - start[b], "r");
-			if (!m) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); exit(EXIT_FAILURE); }
+			if (!m) { fprintf(stderr, "error: fmemopen: %s\n", strerror(errno)); fflush(stdout); _exit(EXIT_FAILURE); } // (one of several threads: as FastaReader::die)
 			FastaReader in(m, path, line0[b], ro);
 			in.on_worker_thread();
 			FastaRecord r;

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cassert>
 #include <climits>
 #include <cmath>
@@ -696,7 +697,8 @@ class Resolver {
 		bool done = false;
 		if (!(getenv("ABG_RR_SERIAL_CONTIGS") && atoi(getenv("ABG_RR_SERIAL_CONTIGS")))) {
 			std::vector<std::vector<abghost::FastaRecord>> parts;
-			done = abghost::read_fasta_blocks(opt.contigsPath, ro, (unsigned)std::max(1, opt.threads), parts,
+			if (contigs_ahead_.valid()) { done = contigs_ahead_.get(); parts.swap(contigs_parts_); } // (parsed while the graph was read: run())
+			else done = abghost::read_fasta_blocks(opt.contigsPath, ro, (unsigned)std::max(1, opt.threads), parts,
 			    [&](abghost::FastaRecord& r) { if (g.index.count(r.id)) r.aux = reverse_complement(r.seq); });
 			if (done) for (auto& part : parts) for (abghost::FastaRecord& r : part) take(r.id, r.comment, r.seq, &r.aux);
 		}
@@ -1547,6 +1549,7 @@ class Resolver {
 		if (opt.verbose) fprintf(stderr, "%c%s paths written.\n", toupper(what[0]), what + 1);
 	}
 
+	std::future<bool> contigs_ahead_; std::vector<std::vector<abghost::FastaRecord>> contigs_parts_;
 	bool timing_ = false; double tl_ = 0;
 	static double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 	void tmark(const char* what) { if (timing_) { const double t = tnow(); fprintf(stderr, "[host] %-28s %.3f s\n", what, t - tl_); tl_ = t; } }
@@ -1556,6 +1559,19 @@ class Resolver {
 		timing_ = getenv("ABG_RR_TIMING") != nullptr;
 		tl_ = tnow();
 		const auto mark = [&](const char* what) { tmark(what); };
+		// (the contigs' file is parsed -- nothing more: which records the graph knows is found out afterwards, in file order -- while
+		// the graph is read; a graph file that cannot be opened is load_graph's to report first)
+		if (opt.threads > 1 && opt.graphPath != "-" && access(opt.graphPath.c_str(), R_OK) == 0 && !(getenv("ABG_RR_SERIAL_CONTIGS") && atoi(getenv("ABG_RR_SERIAL_CONTIGS")))) {
+			// (exit() -- a graph file with something wrong in it -- waits for that thread: no static destructors beside it)
+			static std::future<bool>* ahead = nullptr;
+			if (!ahead) { ahead = &contigs_ahead_; atexit([]() { if (ahead && ahead->valid()) ahead->wait(); }); }
+			contigs_ahead_ = std::async(std::launch::async, [this]() {
+				abghost::ReaderOptions ro;
+				ro.foldCase = 0; // (as load_contigs)
+				return abghost::read_fasta_blocks(opt.contigsPath, ro, (unsigned)std::max(1, opt.threads), contigs_parts_,
+				    [](abghost::FastaRecord& r) { r.aux = reverse_complement(r.seq); });
+			});
+		}
 		load_graph();
 		mark("graph read");
 		load_contigs();
