@@ -151,6 +151,7 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
         if r.returncode == 0 and golden and "adjlist" in golden:
             # abyss-pe's next step on the unitigs just written (AdjList $(alopt) --dot, bin/abyss-pe:575-577)
             open(os.path.join(td, "unitigs-1.fa"), "wb").write(r.stdout)
+            time.sleep(gap)
             t0 = time.time()
             ra = subprocess.run([os.path.join(build.BIN_DIR, "AdjList")] + golden["adjlist"]["options"].split() + ["unitigs-1.fa"],
                                 cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ABG_ADJ_TIMING="1"))
@@ -167,6 +168,7 @@ def end_to_end(a, genome_len, read_len, err, device, golden):
                        "-h", "rr", "--dot", "-c", "rr.fa", "-g", "rr.dot", "unitigs-1.fa", "unitigs-1.dot", "r1.fq", "r2.fq"]
                 rwalls, rq = [], None
                 for _ in range(3):
+                    time.sleep(gap)  # (as above: not within a second of another GPU process's exit)
                     t0 = time.time()
                     rq = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ABG_RR_TIMING="1"))
                     rwalls.append(time.time() - t0)
